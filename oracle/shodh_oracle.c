@@ -1,0 +1,909 @@
+/*
+ * shodh_oracle.c -- CPU restatement of the shodh-memory embed-and-recall hot path.
+ * TEST INFRASTRUCTURE ONLY (see shodh_oracle.h). Compile with -ffp-contract=off.
+ * All file:line citations are into /root/reference/src/.
+ */
+#define _GNU_SOURCE
+#include "shodh_oracle.h"
+
+#include <math.h>
+#include <float.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* distance_inline.rs                                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+/* vector_db/distance_inline.rs:157-173  dot_product_scalar_inline
+ *   sum += a[i]*b[i] + a[i+1]*b[i+1] + a[i+2]*b[i+2] + a[i+3]*b[i+3];  (left-assoc, no FMA) */
+float so_dot_scalar4(const float *a, const float *b, size_t n) {
+    size_t un = n & ~(size_t)3;
+    float sum = 0.0f;
+    for (size_t i = 0; i < un; i += 4) {
+        float g = a[i] * b[i];
+        g = g + a[i + 1] * b[i + 1];
+        g = g + a[i + 2] * b[i + 2];
+        g = g + a[i + 3] * b[i + 3];
+        sum = sum + g;
+    }
+    for (size_t j = un; j < n; ++j) sum = sum + a[j] * b[j];
+    return sum;
+}
+
+/* vector_db/distance_inline.rs:67-111  dot_product_avx2_inline, emulated lane by lane with
+ * fmaf (single rounding == _mm256_fmadd_ps).  One 8-lane accumulator; the 2x unrolled loop
+ * feeds the SAME accumulator, so it is equivalent to a plain 8-wide loop. */
+float so_dot_avx2(const float *a, const float *b, size_t n) {
+    size_t sn = n & ~(size_t)7;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < sn; i += 8)
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(a[i + l], b[i + l], acc[l]);
+    float r = acc[0] + acc[1];
+    r = r + acc[2]; r = r + acc[3]; r = r + acc[4]; r = r + acc[5]; r = r + acc[6]; r = r + acc[7];
+    for (size_t j = sn; j < n; ++j) r = r + a[j] * b[j];
+    return r;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma")))
+static float dot_avx2_intrin(const float *a, const float *b, size_t n) {
+    size_t sn = n & ~(size_t)7;
+    __m256 sum = _mm256_setzero_ps();
+    size_t i = 0;
+    while (i + 16 <= sn) {
+        __m256 va1 = _mm256_loadu_ps(a + i), vb1 = _mm256_loadu_ps(b + i);
+        __m256 va2 = _mm256_loadu_ps(a + i + 8), vb2 = _mm256_loadu_ps(b + i + 8);
+        sum = _mm256_fmadd_ps(va1, vb1, sum);
+        sum = _mm256_fmadd_ps(va2, vb2, sum);
+        i += 16;
+    }
+    while (i < sn) {
+        sum = _mm256_fmadd_ps(_mm256_loadu_ps(a + i), _mm256_loadu_ps(b + i), sum);
+        i += 8;
+    }
+    float s[8];
+    _mm256_storeu_ps(s, sum);
+    volatile float r = s[0] + s[1];
+    r = r + s[2]; r = r + s[3]; r = r + s[4]; r = r + s[5]; r = r + s[6]; r = r + s[7];
+    float rr = r;
+    for (size_t j = sn; j < n; ++j) rr = rr + a[j] * b[j];
+    return rr;
+}
+#endif
+
+float so_dot_avx2_native(const float *a, const float *b, size_t n) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return dot_avx2_intrin(a, b, n);
+#endif
+    return so_dot_avx2(a, b, n);
+}
+
+float so_dot(const float *a, const float *b, size_t n, int order) {
+    return order == SO_ORDER_AVX2 ? so_dot_avx2_native(a, b, n) : so_dot_scalar4(a, b, n);
+}
+
+/* :283-305 euclidean_squared_scalar_inline */
+float so_l2sq_scalar4(const float *a, const float *b, size_t n) {
+    size_t un = n & ~(size_t)3;
+    float sum = 0.0f;
+    for (size_t i = 0; i < un; i += 4) {
+        float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        float g = d0 * d0;
+        g = g + d1 * d1;
+        g = g + d2 * d2;
+        g = g + d3 * d3;
+        sum = sum + g;
+    }
+    for (size_t j = un; j < n; ++j) { float d = a[j] - b[j]; sum = sum + d * d; }
+    return sum;
+}
+
+/* :219-253 euclidean_squared_avx2_inline (NOT 2x unrolled) */
+float so_l2sq_avx2(const float *a, const float *b, size_t n) {
+    size_t sn = n & ~(size_t)7;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < sn; i += 8)
+        for (int l = 0; l < 8; ++l) { float d = a[i + l] - b[i + l]; acc[l] = fmaf(d, d, acc[l]); }
+    float r = acc[0] + acc[1];
+    r = r + acc[2]; r = r + acc[3]; r = r + acc[4]; r = r + acc[5]; r = r + acc[6]; r = r + acc[7];
+    for (size_t j = sn; j < n; ++j) { float d = a[j] - b[j]; r = r + d * d; }
+    return r;
+}
+
+float so_l2sq(const float *a, const float *b, size_t n, int order) {
+    return order == SO_ORDER_AVX2 ? so_l2sq_avx2(a, b, n) : so_l2sq_scalar4(a, b, n);
+}
+
+/* :413-431 l2_norm_squared_scalar_inline */
+float so_normsq_scalar4(const float *a, size_t n) { return so_dot_scalar4(a, a, n); }
+
+/* :355-385 l2_norm_squared_avx2_inline */
+float so_normsq_avx2(const float *a, size_t n) {
+    size_t sn = n & ~(size_t)7;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < sn; i += 8)
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(a[i + l], a[i + l], acc[l]);
+    float r = acc[0] + acc[1];
+    r = r + acc[2]; r = r + acc[3]; r = r + acc[4]; r = r + acc[5]; r = r + acc[6]; r = r + acc[7];
+    for (size_t j = sn; j < n; ++j) r = r + a[j] * a[j];
+    return r;
+}
+
+float so_normsq(const float *a, size_t n, int order) {
+    return order == SO_ORDER_AVX2 ? so_normsq_avx2(a, n) : so_normsq_scalar4(a, n);
+}
+
+/* :315-317 */
+float so_l2_norm(const float *a, size_t n, int order) { return sqrtf(so_normsq(a, n, order)); }
+
+/* :444-458 cosine_similarity_inline: dot / sqrt(nsq(a)*nsq(b)); denom < 1e-10 -> 0; no clamp */
+float so_cosine_similarity_inline(const float *a, const float *b, size_t n, int order) {
+    float dot = so_dot(a, b, n, order);
+    float na = so_normsq(a, n, order);
+    float nb = so_normsq(b, n, order);
+    float den = sqrtf(na * nb);
+    if (den < 1e-10f) return 0.0f;
+    return dot / den;
+}
+
+/* :464-466 */
+float so_cosine_distance_inline(const float *a, const float *b, size_t n, int order) {
+    return 1.0f - so_cosine_similarity_inline(a, b, n, order);
+}
+
+/* :479-481 */
+float so_normalized_distance(const float *a, const float *b, size_t n, int order) {
+    return -so_dot(a, b, n, order);
+}
+
+/* :487-490 */
+int so_is_normalized(const float *a, size_t n, float eps, int order) {
+    return fabsf(so_normsq(a, n, order) - 1.0f) < eps;
+}
+
+/* :494-502 (multiplies by the reciprocal) */
+void so_normalize_inplace(float *a, size_t n, int order) {
+    float norm = so_l2_norm(a, n, order);
+    if (norm > 1e-10f) {
+        float inv = 1.0f / norm;
+        for (size_t i = 0; i < n; ++i) a[i] = a[i] * inv;
+    }
+}
+
+/* vector_db/vamana.rs:755-761 VamanaIndex::distance */
+float so_metric_distance(const float *a, const float *b, size_t n, int metric, int order) {
+    switch (metric) {
+        case SO_METRIC_EUCLIDEAN: return so_l2sq(a, b, n, order);
+        case SO_METRIC_COSINE: return 1.0f - so_cosine_similarity_inline(a, b, n, order);
+        default: return so_normalized_distance(a, b, n, order);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* f32::total_cmp                                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+static inline int32_t total_key_i32(float x) {
+    int32_t b;
+    memcpy(&b, &x, 4);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);  /* core::f32::total_cmp */
+    return b;
+}
+
+int so_total_cmp(float a, float b) {
+    int32_t x = total_key_i32(a), y = total_key_i32(b);
+    return (x > y) - (x < y);
+}
+
+uint32_t so_total_order_key(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* similarity.rs                                                                         */
+/* ------------------------------------------------------------------------------------ */
+
+static inline float clampf(float x, float lo, float hi) {
+    /* f32::clamp: NaN stays NaN */
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+/* similarity.rs:10-24 */
+float so_cosine_similarity(const float *a, size_t na, const float *b, size_t nb, int order) {
+    if (na != nb) return 0.0f;
+    float dot = so_dot(a, b, na, order);
+    float norm_a = sqrtf(so_dot(a, a, na, order));
+    float norm_b = sqrtf(so_dot(b, b, na, order));
+    if (norm_a == 0.0f || norm_b == 0.0f) return 0.0f;
+    return clampf(dot / (norm_a * norm_b), -1.0f, 1.0f);
+}
+
+/* OrderedFloat<f32>::cmp : NaN is greatest, NaN == NaN, -0 == +0 */
+static int ordered_float_cmp(float a, float b) {
+    int an = isnan(a), bn = isnan(b);
+    if (an || bn) return an - bn;  /* (1,1)->0, (1,0)->1, (0,1)->-1 */
+    return (a > b) - (a < b);
+}
+
+typedef struct { float s; uint32_t i; } scored_t;
+
+static void merge_sort_scored_desc(scored_t *v, scored_t *tmp, size_t n) {
+    /* stable merge sort, descending on OrderedFloat (slice::sort_by is stable) */
+    if (n < 2) return;
+    size_t h = n / 2;
+    merge_sort_scored_desc(v, tmp, h);
+    merge_sort_scored_desc(v + h, tmp, n - h);
+    size_t i = 0, j = h, k = 0;
+    while (i < h && j < n) {
+        /* comparator: b.0.cmp(&a.0); take left unless right is strictly "less" under it */
+        if (ordered_float_cmp(v[j].s, v[i].s) > 0) tmp[k++] = v[j++]; else tmp[k++] = v[i++];
+    }
+    while (i < h) tmp[k++] = v[i++];
+    while (j < n) tmp[k++] = v[j++];
+    memcpy(v, tmp, n * sizeof(scored_t));
+}
+
+/* similarity.rs:27-48 */
+size_t so_top_k_similar(const float *query, const float *cands, size_t n, size_t dim, size_t k,
+                        int order, float *out_scores, uint32_t *out_index) {
+    if (n == 0) return 0;
+    scored_t *v = (scored_t *)malloc(n * sizeof(scored_t));
+    scored_t *tmp = (scored_t *)malloc(n * sizeof(scored_t));
+    for (size_t i = 0; i < n; ++i) {
+        v[i].s = so_cosine_similarity(query, dim, cands + i * dim, dim, order);
+        v[i].i = (uint32_t)i;
+    }
+    merge_sort_scored_desc(v, tmp, n);
+    size_t m = k < n ? k : n;
+    for (size_t i = 0; i < m; ++i) { out_scores[i] = v[i].s; out_index[i] = v[i].i; }
+    free(v); free(tmp);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* vamana.rs brute_force_search                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { uint32_t id; float d; } idd_t;
+
+static int idd_cmp(const void *pa, const void *pb) {
+    const idd_t *a = (const idd_t *)pa, *b = (const idd_t *)pb;
+    int c = so_total_cmp(a->d, b->d);           /* a.1.total_cmp(&b.1) */
+    if (c) return c;
+    return (a->id > b->id) - (a->id < b->id);   /* .then_with(|| a.0.cmp(&b.0)) */
+}
+
+/* vamana.rs:1167-1188 */
+size_t so_brute_force_search(const float *rows, size_t n, size_t dim, const uint8_t *deleted,
+                             const float *q, size_t k, int metric, int order,
+                             uint32_t *out_ids, float *out_dist) {
+    idd_t *v = (idd_t *)malloc((n ? n : 1) * sizeof(idd_t));
+    float *clone = (float *)malloc((dim ? dim : 1) * sizeof(float));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (deleted && deleted[i]) continue;
+        memcpy(clone, rows + i * dim, dim * sizeof(float));      /* get_vector() clones (:444-451) */
+        v[m].id = (uint32_t)i;
+        v[m].d = so_metric_distance(q, clone, dim, metric, order); /* distance(query, &vec) */
+        ++m;
+    }
+    qsort(v, m, sizeof(idd_t), idd_cmp);   /* keys are unique (id), so stability is moot */
+    size_t out = m < k ? m : k;
+    for (size_t i = 0; i < out; ++i) { out_ids[i] = v[i].id; out_dist[i] = v[i].d; }
+    free(v); free(clone);
+    return out;
+}
+
+/* identical output; keeps the k best in a sorted buffer instead of sorting all n */
+size_t so_brute_force_search_select(const float *rows, size_t n, size_t dim, const uint8_t *deleted,
+                                    const float *q, size_t k, int metric, int order,
+                                    uint32_t *out_ids, float *out_dist) {
+    if (k == 0) return 0;
+    idd_t *best = (idd_t *)malloc(k * sizeof(idd_t));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (deleted && deleted[i]) continue;
+        idd_t c;
+        c.id = (uint32_t)i;
+        c.d = so_metric_distance(q, rows + i * dim, dim, metric, order);
+        if (m == k && idd_cmp(&c, &best[k - 1]) >= 0) continue;
+        size_t p = (m < k) ? m : k - 1;
+        while (p > 0 && idd_cmp(&c, &best[p - 1]) < 0) { best[p] = best[p - 1]; --p; }
+        best[p] = c;
+        if (m < k) ++m;
+    }
+    for (size_t i = 0; i < m; ++i) { out_ids[i] = best[i].id; out_dist[i] = best[i].d; }
+    free(best);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* retrieval.rs search_ids post-processing                                               */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { uint8_t u[16]; float s; } uuid_score_t;
+
+static int uuid_score_cmp_desc(const void *pa, const void *pb) {
+    const uuid_score_t *a = (const uuid_score_t *)pa, *b = (const uuid_score_t *)pb;
+    int c = so_total_cmp(b->s, a->s);   /* b.1.total_cmp(&a.1) */
+    if (c) return c;
+    return memcmp(a->u, b->u, 16);      /* a.0.cmp(&b.0): Uuid orders by its 16 bytes */
+}
+
+/* memory/retrieval.rs:920-963 */
+size_t so_search_ids_postprocess(const uint32_t *vec_ids, const float *dists, size_t n_res,
+                                 const uint8_t *vector_to_memory, size_t n_vectors, size_t limit,
+                                 uint8_t *out_uuid, float *out_sim) {
+    static const uint8_t none[16] = {255, 255, 255, 255, 255, 255, 255, 255,
+                                     255, 255, 255, 255, 255, 255, 255, 255};
+    uuid_score_t *best = (uuid_score_t *)malloc((n_res ? n_res : 1) * sizeof(uuid_score_t));
+    size_t nb = 0;
+    for (size_t r = 0; r < n_res; ++r) {
+        float similarity = -dists[r];
+        if (vec_ids[r] >= n_vectors) continue;
+        const uint8_t *u = vector_to_memory + (size_t)vec_ids[r] * 16;
+        if (memcmp(u, none, 16) == 0) continue;
+        size_t j = 0;
+        for (; j < nb; ++j) if (memcmp(best[j].u, u, 16) == 0) break;
+        if (j == nb) { memcpy(best[nb].u, u, 16); best[nb].s = similarity; ++nb; }
+        else if (similarity > best[j].s) best[j].s = similarity;   /* strict '>' */
+    }
+    qsort(best, nb, sizeof(uuid_score_t), uuid_score_cmp_desc);
+    size_t out = nb < limit ? nb : limit;
+    for (size_t i = 0; i < out; ++i) { memcpy(out_uuid + i * 16, best[i].u, 16); out_sim[i] = best[i].s; }
+    free(best);
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* pq.rs                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+/* vector_db/pq.rs:393-395: a.iter().zip(b).map(|(x,y)| (x-y).powi(2)).sum()  (sequential) */
+float so_squared_l2(const float *a, const float *b, size_t n) {
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) { float d = a[i] - b[i]; s = s + d * d; }
+    return s;
+}
+
+/* pq.rs:220-257 */
+void so_pq_encode(const float *cb, size_t M, size_t ncent, size_t sub, const float *v, uint8_t *codes) {
+    for (size_t m = 0; m < M; ++m) {
+        uint8_t best = 0;
+        float best_dist = FLT_MAX;
+        for (size_t c = 0; c < ncent; ++c) {
+            float d = so_squared_l2(v + m * sub, cb + (m * ncent + c) * sub, sub);
+            if (d < best_dist) { best_dist = d; best = (uint8_t)c; }
+        }
+        codes[m] = best;
+    }
+}
+
+/* pq.rs:259-291 */
+void so_pq_decode(const float *cb, size_t M, size_t ncent, size_t sub, const uint8_t *codes, float *out) {
+    for (size_t m = 0; m < M; ++m) memcpy(out + m * sub, cb + (m * ncent + codes[m]) * sub, sub * sizeof(float));
+}
+
+/* pq.rs:329-351 */
+void so_pq_build_distance_table(const float *cb, size_t M, size_t ncent, size_t sub, const float *q, float *table) {
+    for (size_t m = 0; m < M; ++m)
+        for (size_t c = 0; c < ncent; ++c)
+            table[m * ncent + c] = so_squared_l2(q + m * sub, cb + (m * ncent + c) * sub, sub);
+}
+
+/* pq.rs:358-368 */
+float so_pq_distance_with_table(const float *table, size_t M, size_t ncent, const uint8_t *codes, size_t ncodes) {
+    float total = 0.0f;
+    for (size_t m = 0; m < ncodes; ++m) {
+        if (m >= M || (size_t)codes[m] >= ncent) return FLT_MAX;
+        total = total + table[m * ncent + codes[m]];
+    }
+    return total;
+}
+
+/* pq.rs:297-324 */
+float so_pq_asymmetric_distance(const float *cb, size_t M, size_t ncent, size_t sub, const float *q, const uint8_t *codes) {
+    float total = 0.0f;
+    for (size_t m = 0; m < M; ++m) total = total + so_squared_l2(q + m * sub, cb + (m * ncent + codes[m]) * sub, sub);
+    return total;
+}
+
+/* pq.rs:152-217 (init from a supplied shuffle; no early exit) */
+void so_pq_kmeans(const float *vectors, size_t n, size_t dim, size_t k, size_t iterations,
+                  const uint32_t *init_perm, float *cent) {
+    for (size_t c = 0; c < k; ++c) memcpy(cent + c * dim, vectors + (size_t)init_perm[c % n] * dim, dim * sizeof(float));
+    uint32_t *assign = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    float *newc = (float *)malloc(k * dim * sizeof(float));
+    size_t *counts = (size_t *)malloc(k * sizeof(size_t));
+    for (size_t it = 0; it < iterations; ++it) {
+        for (size_t i = 0; i < n; ++i) {
+            size_t best = 0; float bd = FLT_MAX;
+            for (size_t c = 0; c < k; ++c) {
+                float d = so_squared_l2(vectors + i * dim, cent + c * dim, dim);
+                if (d < bd) { bd = d; best = c; }
+            }
+            assign[i] = (uint32_t)best;
+        }
+        memset(newc, 0, k * dim * sizeof(float));
+        memset(counts, 0, k * sizeof(size_t));
+        for (size_t i = 0; i < n; ++i) {
+            size_t c = assign[i];
+            counts[c] += 1;
+            for (size_t j = 0; j < dim; ++j) newc[c * dim + j] = newc[c * dim + j] + vectors[i * dim + j];
+        }
+        for (size_t c = 0; c < k; ++c) if (counts[c] > 0) {
+            for (size_t j = 0; j < dim; ++j) cent[c * dim + j] = newc[c * dim + j] / (float)counts[c];
+        }
+    }
+    free(assign); free(newc); free(counts);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* spann.rs                                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+/* vector_db/spann.rs:562-571 (strictly sequential iterator sums; NOT distance_inline) */
+float so_spann_compute_distance(const float *a, const float *b, size_t n, int metric) {
+    if (metric == SO_METRIC_EUCLIDEAN) return so_squared_l2(a, b, n);
+    float dot = 0.0f;
+    for (size_t i = 0; i < n; ++i) dot = dot + a[i] * b[i];
+    return 1.0f - dot;
+}
+
+/* spann.rs:545-558 */
+size_t so_spann_find_nearest_centroid(const float *v, const float *centroids, size_t P, size_t dim, int metric) {
+    size_t best = 0; float bd = FLT_MAX;
+    for (size_t i = 0; i < P; ++i) {
+        float d = so_spann_compute_distance(v, centroids + i * dim, dim, metric);
+        if (d < bd) { bd = d; best = i; }
+    }
+    return best;
+}
+
+/* spann.rs:136-139 */
+size_t so_spann_compute_partitions(size_t num_vectors) {
+    size_t p = (size_t)ceil(sqrt((double)num_vectors));
+    return p < 1 ? 1 : p;
+}
+
+/* spann.rs:466-541 */
+size_t so_spann_kmeans(const float *vectors, size_t n, size_t dim, size_t k, size_t iterations,
+                       int metric, const uint32_t *init_perm, float *cent) {
+    for (size_t c = 0; c < k; ++c) memcpy(cent + c * dim, vectors + (size_t)init_perm[c % n] * dim, dim * sizeof(float));
+    uint32_t *assign = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    float *newc = (float *)malloc(k * dim * sizeof(float));
+    size_t *counts = (size_t *)malloc(k * sizeof(size_t));
+    size_t it = 0;
+    for (; it < iterations; ++it) {
+        size_t changed = 0;
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t na = (uint32_t)so_spann_find_nearest_centroid(vectors + i * dim, cent, k, dim, metric);
+            if (na != assign[i]) ++changed;
+            assign[i] = na;
+        }
+        memset(newc, 0, k * dim * sizeof(float));
+        memset(counts, 0, k * sizeof(size_t));
+        for (size_t i = 0; i < n; ++i) {
+            size_t c = assign[i];
+            counts[c] += 1;
+            for (size_t j = 0; j < dim; ++j) newc[c * dim + j] = newc[c * dim + j] + vectors[i * dim + j];
+        }
+        for (size_t c = 0; c < k; ++c) if (counts[c] > 0)
+            for (size_t j = 0; j < dim; ++j) cent[c * dim + j] = newc[c * dim + j] / (float)counts[c];
+        if (changed == 0) { ++it; break; }
+    }
+    free(assign); free(newc); free(counts);
+    return it;
+}
+
+/* max-heap on (OrderedFloat(dist), id) == std BinaryHeap<(OrderedFloat<f32>, u32)> */
+static int heap_less(const idd_t *a, const idd_t *b) {
+    int c = ordered_float_cmp(a->d, b->d);
+    if (c) return c < 0;
+    return a->id < b->id;
+}
+static void heap_push(idd_t *h, size_t *n, idd_t x) {
+    size_t i = (*n)++;
+    h[i] = x;
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (heap_less(&h[p], &h[i])) { idd_t t = h[p]; h[p] = h[i]; h[i] = t; i = p; } else break;
+    }
+}
+static void heap_pop(idd_t *h, size_t *n) {
+    if (*n == 0) return;
+    h[0] = h[--(*n)];
+    size_t i = 0;
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < *n && heap_less(&h[m], &h[l])) m = l;
+        if (r < *n && heap_less(&h[m], &h[r])) m = r;
+        if (m == i) break;
+        idd_t t = h[m]; h[m] = h[i]; h[i] = t; i = m;
+    }
+}
+
+typedef struct { size_t i; float d; } pd_t;
+static int pd_cmp(const void *pa, const void *pb) {
+    const pd_t *a = (const pd_t *)pa, *b = (const pd_t *)pb;
+    int c = so_total_cmp(a->d, b->d);
+    if (c) return c;
+    return (a->i > b->i) - (a->i < b->i);
+}
+
+/* spann.rs:574-693 */
+size_t so_spann_search(const float *centroids, size_t P, size_t dim, int metric,
+                       const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes,
+                       const float *codebook, size_t M, size_t ncent, size_t sub,
+                       size_t num_probes, const float *q, size_t k,
+                       uint32_t *out_ids, float *out_dist) {
+    if (P == 0) return 0;
+    pd_t *pd = (pd_t *)malloc(P * sizeof(pd_t));
+    for (size_t i = 0; i < P; ++i) { pd[i].i = i; pd[i].d = so_spann_compute_distance(q, centroids + i * dim, dim, metric); }
+    qsort(pd, P, sizeof(pd_t), pd_cmp);
+    size_t np = num_probes < P ? num_probes : P;
+    float *table = (float *)malloc(M * ncent * sizeof(float));
+    so_pq_build_distance_table(codebook, M, ncent, sub, q, table);
+    idd_t *heap = (idd_t *)malloc((k + 2) * sizeof(idd_t));
+    size_t hn = 0;
+    for (size_t p = 0; p < np; ++p) {
+        size_t part = pd[p].i;
+        for (uint64_t e = list_off[part]; e < list_off[part + 1]; ++e) {
+            idd_t x;
+            x.d = so_pq_distance_with_table(table, M, ncent, codes + e * M, M);
+            x.id = ids[e];
+            heap_push(heap, &hn, x);
+            if (hn > k) heap_pop(heap, &hn);
+        }
+    }
+    qsort(heap, hn, sizeof(idd_t), idd_cmp);   /* (dist total_cmp asc, id asc) */
+    for (size_t i = 0; i < hn; ++i) { out_ids[i] = heap[i].id; out_dist[i] = heap[i].d; }
+    free(pd); free(table); free(heap);
+    return hn;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* minilm.rs: mean-pool + finalize_pooled, hash embedder                                 */
+/* ------------------------------------------------------------------------------------ */
+
+/* embeddings/minilm.rs:959-978 + :846-878 (native-384 branch: no prenorm, no truncation) */
+void so_mean_pool_finalize(const float *hidden, const int64_t *mask, size_t S, size_t H, float *out) {
+    float mask_sum = 0.0f;
+    for (size_t d = 0; d < H; ++d) out[d] = 0.0f;
+    for (size_t s = 0; s < S; ++s) {
+        if (mask[s] == 1) {
+            for (size_t d = 0; d < H; ++d) out[d] = out[d] + hidden[s * H + d];
+            mask_sum = mask_sum + 1.0f;
+        }
+    }
+    if (mask_sum > 0.0f) for (size_t d = 0; d < H; ++d) out[d] = out[d] / mask_sum;
+    for (size_t d = 0; d < H; ++d) if (isnan(out[d]) || isinf(out[d])) out[d] = 0.0f;
+    float nsq = 0.0f;
+    for (size_t d = 0; d < H; ++d) nsq = nsq + out[d] * out[d];
+    float norm = sqrtf(nsq);
+    if (norm > FLT_EPSILON && !isnan(norm)) for (size_t d = 0; d < H; ++d) out[d] = out[d] / norm;
+}
+
+/* SipHash-1-3, keys (0,0): std::collections::hash_map::DefaultHasher::new() */
+#define ROTL64(x, b) (((x) << (b)) | ((x) >> (64 - (b))))
+#define SIPROUND do { v0 += v1; v1 = ROTL64(v1, 13); v1 ^= v0; v0 = ROTL64(v0, 32); \
+                      v2 += v3; v3 = ROTL64(v3, 16); v3 ^= v2; \
+                      v0 += v3; v3 = ROTL64(v3, 21); v3 ^= v0; \
+                      v2 += v1; v1 = ROTL64(v1, 17); v1 ^= v2; v2 = ROTL64(v2, 32); } while (0)
+
+static uint64_t siphash13(const uint8_t *in, size_t len) {
+    uint64_t k0 = 0, k1 = 0;
+    uint64_t v0 = 0x736f6d6570736575ULL ^ k0, v1 = 0x646f72616e646f6dULL ^ k1;
+    uint64_t v2 = 0x6c7967656e657261ULL ^ k0, v3 = 0x7465646279746573ULL ^ k1;
+    size_t end = len - (len % 8);
+    for (size_t i = 0; i < end; i += 8) {
+        uint64_t m = 0;
+        for (int j = 0; j < 8; ++j) m |= (uint64_t)in[i + j] << (8 * j);
+        v3 ^= m; SIPROUND; v0 ^= m;
+    }
+    uint64_t b = (uint64_t)len << 56;
+    for (size_t j = 0; j < len % 8; ++j) b |= (uint64_t)in[end + j] << (8 * j);
+    v3 ^= b; SIPROUND; v0 ^= b;
+    v2 ^= 0xff; SIPROUND; SIPROUND; SIPROUND;
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+
+/* impl Hash for str: state.write(bytes); state.write_u8(0xff) */
+uint64_t so_siphash13_str(const uint8_t *bytes, size_t len) {
+    uint8_t *buf = (uint8_t *)malloc(len + 1);
+    memcpy(buf, bytes, len);
+    buf[len] = 0xff;
+    uint64_t h = siphash13(buf, len + 1);
+    free(buf);
+    return h;
+}
+
+static size_t utf8_len(uint8_t c) {
+    if (c < 0x80) return 1;
+    if ((c >> 5) == 0x6) return 2;
+    if ((c >> 4) == 0xe) return 3;
+    if ((c >> 3) == 0x1e) return 4;
+    return 1;
+}
+static uint32_t utf8_decode(const uint8_t *p, size_t l) {
+    if (l == 1) return p[0];
+    if (l == 2) return ((p[0] & 0x1f) << 6) | (p[1] & 0x3f);
+    if (l == 3) return ((p[0] & 0x0f) << 12) | ((p[1] & 0x3f) << 6) | (p[2] & 0x3f);
+    return ((p[0] & 0x07) << 18) | ((p[1] & 0x3f) << 12) | ((p[2] & 0x3f) << 6) | (p[3] & 0x3f);
+}
+/* char::is_whitespace (Unicode White_Space) */
+static int is_ws(uint32_t c) {
+    return (c >= 9 && c <= 13) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 ||
+           (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F ||
+           c == 0x205F || c == 0x3000;
+}
+
+/* embeddings/minilm.rs:777-831 generate_embedding_simplified + :749-771 normalize */
+void so_hash_embed(const char *utf8, size_t len, size_t dim, float *e) {
+    const uint8_t *t = (const uint8_t *)utf8;
+    for (size_t j = 0; j < dim; ++j) e[j] = 0.0f;
+    /* words */
+    size_t pos = 0, wi = 0;
+    while (pos < len) {
+        while (pos < len) { size_t l = utf8_len(t[pos]); if (pos + l > len) l = len - pos; if (!is_ws(utf8_decode(t + pos, l))) break; pos += l; }
+        if (pos >= len) break;
+        size_t start = pos;
+        while (pos < len) { size_t l = utf8_len(t[pos]); if (pos + l > len) l = len - pos; if (is_ws(utf8_decode(t + pos, l))) break; pos += l; }
+        uint64_t h = so_siphash13_str(t + start, pos - start);
+        for (size_t j = 0; j < dim; ++j) {
+            size_t index = (wi * 7 + j) % dim;
+            size_t bit = j < 64 ? j : (wi * 7 + j) % 64;
+            e[index] = e[index] + (float)((h >> bit) & 1) * 0.1f;
+        }
+        ++wi;
+    }
+    /* char bigrams */
+    size_t nchars = 0;
+    for (size_t p = 0; p < len;) { size_t l = utf8_len(t[p]); if (p + l > len) l = len - p; p += l; ++nchars; }
+    if (nchars >= 2) {
+        size_t p = 0;
+        for (size_t i = 0; i + 1 < nchars; ++i) {
+            size_t l0 = utf8_len(t[p]); if (p + l0 > len) l0 = len - p;
+            size_t p1 = p + l0;
+            size_t l1 = utf8_len(t[p1]); if (p1 + l1 > len) l1 = len - p1;
+            uint64_t h = so_siphash13_str(t + p, l0 + l1);
+            for (size_t j = 0; j < 32; ++j) {
+                size_t index = (size_t)((h + (uint64_t)j) % (uint64_t)dim);
+                e[index] = e[index] + (float)((h >> (j % 64)) & 1) * 0.05f;
+            }
+            p = p1;
+        }
+    }
+    /* normalize(): scrub, norm = sqrt(sum x*x) sequential, fail if NaN or < EPSILON */
+    for (size_t j = 0; j < dim; ++j) if (isnan(e[j]) || isinf(e[j])) e[j] = 0.0f;
+    float nsq = 0.0f;
+    for (size_t j = 0; j < dim; ++j) nsq = nsq + e[j] * e[j];
+    float norm = sqrtf(nsq);
+    if (isnan(norm) || norm < FLT_EPSILON) { for (size_t j = 0; j < dim; ++j) e[j] = 0.0f; return; }
+    for (size_t j = 0; j < dim; ++j) e[j] = e[j] / norm;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* relevance.rs                                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+/* relevance.rs:64-100, :383-397 */
+void so_weights_default(so_weights *w) {
+    w->semantic = 0.18f; w->entity = 0.17f; w->tag = 0.05f; w->importance = 0.05f;
+    w->momentum = 0.28f; w->access_count = 0.14f; w->graph_strength = 0.13f; w->update_count = 0;
+}
+
+/* relevance.rs:401-418 */
+void so_weights_normalize(so_weights *w) {
+    float sum = w->semantic + w->entity;
+    sum = sum + w->tag; sum = sum + w->importance; sum = sum + w->momentum;
+    sum = sum + w->access_count; sum = sum + w->graph_strength;
+    if (sum > 0.0f) {
+        w->semantic /= sum; w->entity /= sum; w->tag /= sum; w->importance /= sum;
+        w->momentum /= sum; w->access_count /= sum; w->graph_strength /= sum;
+    }
+}
+
+static inline float f32_max(float a, float b) { return fmaxf(a, b); } /* f32::max ignores NaN like fmaxf */
+static inline float f32_min(float a, float b) { return fminf(a, b); }
+
+/* relevance.rs:427-465 */
+void so_weights_apply_feedback(so_weights *w, int sem, int ent, int tag, int helpful) {
+    const float LR = 0.05f, MINW = 0.05f;
+    float direction = helpful ? 1.0f : -1.0f;
+    float delta = LR * direction;
+    if (sem) w->semantic = f32_max(w->semantic + delta, MINW);
+    if (ent) w->entity = f32_max(w->entity + delta, MINW);
+    if (tag) w->tag = f32_max(w->tag + delta, MINW);
+    if (helpful && !sem && !ent && !tag) w->importance = f32_max(w->importance + delta, MINW);
+    float aux = LR * direction * 0.5f;
+    w->momentum = f32_max(w->momentum + aux, MINW);
+    w->access_count = f32_max(w->access_count + aux, MINW);
+    w->graph_strength = f32_max(w->graph_strength + aux, MINW);
+    so_weights_normalize(w);
+    w->update_count += 1;
+}
+
+/* relevance.rs:601-606 */
+float so_calibrate_score(float s) {
+    if (!isfinite(s)) return 0.0f;
+    return 1.0f / (1.0f + expf(-10.0f * (s - 0.5f)));
+}
+
+/* relevance.rs:529-594 */
+float so_fuse_scores_full(const so_weights *w, float sem, float ent, float tag, float imp,
+                          float momentum_ema, uint32_t access_count, float graph_strength) {
+    float c_sem = so_calibrate_score(sem);
+    float c_ent = so_calibrate_score(ent);
+    float c_tag = so_calibrate_score(tag);
+    float c_imp = so_calibrate_score(imp);
+    float nm = (momentum_ema + 1.0f) / 2.0f;
+    float am;
+    if (nm > 0.65f) am = f32_min(nm * 1.5f, 1.0f);
+    else if (nm < 0.40f) am = f32_max(nm * 0.3f, 0.0f);
+    else am = nm;
+    float c_mom = so_calibrate_score(am);
+    float as;
+    if (access_count == 0) as = 0.0f;
+    else { float la = log2f((float)access_count + 1.0f); as = f32_min(la / 4.0f, 1.0f); }
+    float c_acc = so_calibrate_score(as);
+    float c_gr = so_calibrate_score(graph_strength);
+    float r = w->semantic * c_sem + w->entity * c_ent;
+    r = r + w->tag * c_tag;
+    r = r + w->importance * c_imp;
+    r = r + w->momentum * c_mom;
+    r = r + w->access_count * c_acc;
+    r = r + w->graph_strength * c_gr;
+    return isfinite(r) ? r : 0.0f;
+}
+
+/* relevance.rs:471-487 */
+float so_fuse_scores(const so_weights *w, float sem, float ent, float tag, float imp) {
+    return so_fuse_scores_full(w, sem, ent, tag, imp, 0.0f, 0, 0.5f);
+}
+/* relevance.rs:499-517 */
+float so_fuse_scores_with_momentum(const so_weights *w, float sem, float ent, float tag, float imp, float mom) {
+    return so_fuse_scores_full(w, sem, ent, tag, imp, mom, 0, 0.5f);
+}
+
+static char *ascii_lower_dup(const char *s) {
+    /* str::to_lowercase is Unicode-aware; the reference's tests are ASCII. Non-ASCII bytes pass through. */
+    size_t n = strlen(s);
+    char *o = (char *)malloc(n + 1);
+    for (size_t i = 0; i <= n; ++i) o[i] = (s[i] >= 'A' && s[i] <= 'Z') ? (char)(s[i] + 32) : s[i];
+    return o;
+}
+
+/* relevance.rs:680-705 */
+float so_calculate_tag_score(const char *content, const char *const *tags, size_t n_tags) {
+    if (n_tags == 0) return 0.0f;
+    char *ctx = ascii_lower_dup(content);
+    size_t clen = strlen(ctx);
+    int matches = 0;
+    for (size_t t = 0; t < n_tags; ++t) {
+        char *tag = ascii_lower_dup(tags[t]);
+        size_t tl = strlen(tag);
+        if (strstr(ctx, tag) != NULL) { matches += 1; free(tag); continue; }
+        size_t pos = 0;
+        while (pos < clen) {
+            while (pos < clen && is_ws((uint8_t)ctx[pos])) ++pos;
+            if (pos >= clen) break;
+            size_t st = pos;
+            while (pos < clen && !is_ws((uint8_t)ctx[pos])) ++pos;
+            size_t wl = pos - st;
+            int word_starts_with_tag = wl >= tl && memcmp(ctx + st, tag, tl) == 0;
+            int tag_starts_with_word = tl >= wl && memcmp(tag, ctx + st, wl) == 0;
+            if (word_starts_with_tag || tag_starts_with_word) { matches += 1; break; }
+        }
+        free(tag);
+    }
+    free(ctx);
+    return (float)matches / (float)n_tags;
+}
+
+/* relevance.rs:1524-1547 (age_hours = Duration::num_hours() as u64: negative wraps to huge) */
+float so_apply_recency_boost(float base, int64_t age_hours_signed, uint64_t boost_hours, float mult) {
+    if (boost_hours == 0) return base;
+    uint64_t age_hours = (uint64_t)age_hours_signed;
+    if (age_hours <= boost_hours) {
+        float decay = 1.0f - ((float)age_hours / (float)boost_hours);
+        float boost = 1.0f + (mult - 1.0f) * decay;
+        return f32_min(base * boost, 1.0f);
+    }
+    return base;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* hybrid_search.rs RRFusion                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* memory/hybrid_search.rs:536-594 */
+size_t so_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t *uuids,
+                   const size_t *list_len, uint8_t *out_uuid, float *out_score, size_t out_cap) {
+    float *wn = (float *)malloc((n_lists ? n_lists : 1) * sizeof(float));
+    float sum = 0.0f;
+    for (size_t l = 0; l < n_lists; ++l) sum = sum + weights[l];
+    for (size_t l = 0; l < n_lists; ++l) wn[l] = sum > 0.0f ? weights[l] / sum : 1.0f / (float)n_lists;
+    size_t total = 0;
+    for (size_t l = 0; l < n_lists; ++l) total += list_len[l];
+    uuid_score_t *acc = (uuid_score_t *)malloc((total ? total : 1) * sizeof(uuid_score_t));
+    size_t na = 0, base = 0;
+    for (size_t l = 0; l < n_lists; ++l) {
+        for (size_t rank = 0; rank < list_len[l]; ++rank) {
+            const uint8_t *u = uuids + (base + rank) * 16;
+            float contrib = wn[l] / (k + (float)(rank + 1));
+            size_t j = 0;
+            for (; j < na; ++j) if (memcmp(acc[j].u, u, 16) == 0) break;
+            if (j == na) { memcpy(acc[na].u, u, 16); acc[na].s = 0.0f; ++na; }
+            acc[j].s = acc[j].s + contrib;
+        }
+        base += list_len[l];
+    }
+    qsort(acc, na, sizeof(uuid_score_t), uuid_score_cmp_desc);
+    size_t out = na < out_cap ? na : out_cap;
+    for (size_t i = 0; i < out; ++i) { memcpy(out_uuid + i * 16, acc[i].u, 16); out_score[i] = acc[i].s; }
+    free(acc); free(wn);
+    return out;
+}
+
+/* vector_db/vamana_persist.rs:155-163 */
+uint64_t so_fnv1a64(const uint8_t *data, size_t len) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < len; ++i) { h ^= data[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* threaded CPU-baseline driver                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    const float *rows; size_t n, dim; const float *queries; size_t nq, k; int order, full_sort;
+    uint32_t *out_ids; float *out_dist; size_t *next; pthread_mutex_t *mu;
+} bf_job_t;
+
+static void *bf_worker(void *arg) {
+    bf_job_t *j = (bf_job_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        size_t qi = (*j->next)++;
+        pthread_mutex_unlock(j->mu);
+        if (qi >= j->nq) break;
+        const float *q = j->queries + qi * j->dim;
+        if (j->full_sort)
+            so_brute_force_search(j->rows, j->n, j->dim, NULL, q, j->k, SO_METRIC_NDP, j->order,
+                                  j->out_ids + qi * j->k, j->out_dist + qi * j->k);
+        else
+            so_brute_force_search_select(j->rows, j->n, j->dim, NULL, q, j->k, SO_METRIC_NDP, j->order,
+                                         j->out_ids + qi * j->k, j->out_dist + qi * j->k);
+    }
+    return NULL;
+}
+
+double so_bench_brute_force(const float *rows, size_t n, size_t dim, const float *queries,
+                            size_t nq, size_t k, int order, int full_sort, int threads,
+                            uint32_t *out_ids, float *out_dist) {
+    if (threads < 1) threads = 1;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    size_t next = 0;
+    bf_job_t job = {rows, n, dim, queries, nq, k, order, full_sort, out_ids, out_dist, &next, &mu};
+    pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, bf_worker, &job);
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
