@@ -1,0 +1,217 @@
+/*
+ * shodh_hip.h -- C ABI of the MI355X-native embed-and-recall hot path of shodh-memory.
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam on this
+ * path -- MemorySystem owns Arc<MiniLMEmbedder> (src/memory/mod.rs:224) and RetrievalEngine
+ * owns Arc<RwLock<VamanaIndex>> (src/memory/retrieval.rs:50-53) as concrete Rust types -- so the
+ * seam is the METHOD SET of those types.  Each entry point below names the reference method
+ * it replaces (file:line under the reference's src/).  A Rust `extern "C"` shim binding these
+ * symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 (SHODH_OK) or a negative shodh_status; shodh_last_error() gives a
+ *    thread-local UTF-8 message.  No exception or abort crosses the ABI.
+ *  - plain pointers and sizes only.  "host" pointers are ordinary CPU memory; "*_device"
+ *    entry points take HIP device pointers + a hipStream_t passed as void* (NULL = default
+ *    stream) and are asynchronous on that stream.
+ *  - the library owns opaque handles; the caller owns every in/out buffer.
+ *  - thread-safety mirrors the reference's RwLock use (retrieval.rs:680,:712,:912):
+ *    *_search / *_encode may run concurrently on one handle; *_add / *_build /
+ *    *_mark_deleted / *_clear_deleted take the handle exclusively.
+ *  - the library is HIP/gfx950 only.  There is no CPU fallback: without a usable device every
+ *    create call fails with SHODH_ERR_DEVICE.
+ */
+#ifndef SHODH_HIP_H
+#define SHODH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHODH_HIP_ABI_VERSION 1
+
+typedef enum {
+    SHODH_OK = 0,
+    SHODH_ERR_INVALID = -1,    /* bad argument / NULL pointer */
+    SHODH_ERR_DIM = -2,        /* dimension mismatch (spann.rs:586-592 semantics) */
+    SHODH_ERR_DEVICE = -3,     /* HIP error, no device, wrong architecture */
+    SHODH_ERR_OOM = -4,
+    SHODH_ERR_STATE = -5,      /* e.g. IVF-PQ search before trained state is set (spann.rs:612-617) */
+    SHODH_ERR_IO = -6,
+    SHODH_ERR_NONFINITE = -7,  /* NaN/Inf in rows or query: out of contract */
+    SHODH_ERR_UNSUPPORTED = -8
+} shodh_status;
+
+/* DistanceMetric (src/vector_db/vamana.rs; persisted byte in vamana_persist.rs:98-112) */
+enum { SHODH_METRIC_NDP = 0, SHODH_METRIC_EUCLIDEAN = 1, SHODH_METRIC_COSINE = 2 };
+/* which reference build's accumulation order the exact scores reproduce bit-for-bit:
+ * SCALAR4 = dot_product_scalar_inline (distance_inline.rs:157-173; default Linux build),
+ * AVX2    = dot_product_avx2_inline   (distance_inline.rs:67-111; -C target-cpu=native build) */
+enum { SHODH_ORDER_SCALAR4 = 0, SHODH_ORDER_AVX2 = 1 };
+/* index kinds: FLAT = VamanaIndex under SHODH_VECTOR_EXACT (vamana.rs:770-777, :1167-1188);
+ * IVFPQ = SpannIndex (spann.rs:574-693) */
+enum { SHODH_INDEX_FLAT = 0, SHODH_INDEX_IVFPQ = 1 };
+/* scan strategy of the FLAT index. All three return identical results (bit-exact ids+dist):
+ * EXACT = every score computed in reference order on the f32 rows (HBM-bound for nq <= ~16);
+ * MFMA  = fp16 matrix-core pre-scan with a proven error bound + reference-order re-score of the
+ *         surviving candidates; AUTO picks per call. */
+enum { SHODH_SCAN_AUTO = 0, SHODH_SCAN_EXACT = 1, SHODH_SCAN_MFMA = 2 };
+
+typedef struct shodh_index shodh_index;
+typedef struct shodh_embedder shodh_embedder;
+
+typedef struct {
+    uint32_t dim;           /* VamanaConfig.dimension (384; SHODH_TEXT_DIM 128..1024, multiple of 8) */
+    uint32_t metric;        /* FLAT accepts SHODH_METRIC_NDP only, like RetrievalEngine (retrieval.rs:188-193) */
+    uint32_t kind;          /* SHODH_INDEX_* */
+    uint32_t order;         /* SHODH_ORDER_* */
+    int32_t  device;        /* HIP device ordinal */
+    uint32_t scan_mode;     /* SHODH_SCAN_* */
+    uint64_t reserve_rows;  /* rows of HBM to reserve up front (grows by doubling) */
+    uint64_t id_base;       /* global id of local row 0 (row-sharded multi-GPU corpora); ids returned = id_base + local */
+    uint32_t nprobe;        /* IVFPQ: SpannConfig.num_probes (default 10; BackendConfig 20) */
+    uint32_t reserved;
+} shodh_index_cfg;
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char *shodh_last_error(void);
+int shodh_abi_version(void);
+/* number of HIP devices visible; <0 on error */
+int shodh_device_count(void);
+/* fills name (<= cap bytes) and the gcnArchName of device `dev` */
+int shodh_device_info(int dev, char *name, size_t cap, uint64_t *hbm_bytes, uint32_t *compute_units);
+
+/* ---- index: VamanaIndex / VectorIndexBackend method set ------------------------------------- */
+void shodh_index_cfg_default(shodh_index_cfg *cfg);                       /* BackendConfig::default, vector_db/mod.rs:74-86 */
+int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out);    /* VamanaIndex::new vamana.rs:170-172 */
+void shodh_index_destroy(shodh_index *idx);
+/* add_vector (vamana.rs:853-974): appends n rows, ids are dense and sequential; *first_id_out =
+ * id of rows[0] (= len() before the call, + id_base). rows: host [n][dim] row-major f32. */
+int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out);
+int shodh_index_add_device(shodh_index *idx, const float *d_rows, uint64_t n, uint32_t *first_id_out);
+/* build (vamana.rs:200-284) / rebuild_from_vectors (:1363-1462): replaces the contents; ids 0..n-1;
+ * tombstones cleared. */
+int shodh_index_build(shodh_index *idx, const float *rows, uint64_t n);
+int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n);
+/* search (vamana.rs:764-808 under SHODH_VECTOR_EXACT -> brute_force_search :1167-1188;
+ * spann.rs:574-693 for IVFPQ). q: [nq][dim]. ids/dist: [nq][k], row i holds counts[i] valid
+ * entries in ascending (dist by f32::total_cmp, id) order; the rest is filled with
+ * 0xFFFFFFFF / +inf. Empty index -> counts 0, SHODH_OK (vamana.rs:766-768). */
+int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k,
+                       uint32_t *ids, float *dist, uint32_t *counts);
+int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k,
+                              uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
+int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */
+int shodh_index_is_deleted(const shodh_index *idx, uint32_t id);               /* :823-825 (1/0, <0 error) */
+uint64_t shodh_index_len(const shodh_index *idx);                              /* :184-186 */
+uint64_t shodh_index_deleted_count(const shodh_index *idx);                    /* :828-830 */
+float shodh_index_deletion_ratio(const shodh_index *idx);                      /* :834-840 */
+int shodh_index_needs_compaction(const shodh_index *idx);                      /* :843-845 (ratio >= 0.30) */
+int shodh_index_clear_deleted(shodh_index *idx);                               /* :848-850 */
+/* extract_all_vectors (vamana.rs; retrieval.rs:2504-2516: row i is returned bit-for-bit) */
+int shodh_index_extract_rows(const shodh_index *idx, uint64_t first, uint64_t n, float *out_rows);
+/* extract_live_vectors: rows that are not tombstoned, in id order; ids_out may be NULL */
+int shodh_index_extract_live_rows(const shodh_index *idx, float *out_rows, uint32_t *ids_out, uint64_t cap, uint64_t *n_out);
+uint32_t shodh_index_dim(const shodh_index *idx);
+/* last search's device-side stage timings in microseconds (StageTiming.vector_search_us,
+ * memory/mod.rs:3626-3630): scan, select, rerank, total */
+int shodh_index_stage_timings(const shodh_index *idx, float *us4);
+/* mean / min duration (microseconds) of the dominant scan kernel (MFMA emit scan, or the exact
+ * scan) over the searches issued since the last reset, from HIP events recorded on the stream each
+ * search ran on. The caller must have synchronised those streams. Used by bench.py's roofline. */
+int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float *min_us, uint32_t *count);
+/* diagnostics of the last MFMA-path search: [0]=rows pre-scanned, [1]=candidates emitted,
+ * [2]=candidates re-scored exactly, [3]=queries that overflowed to the exact path */
+int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats4);
+
+/* ---- multi-GPU: merge of per-shard results ------------------------------------------------------- */
+/* Row-sharded corpora: every rank searches its shard (ids carry id_base), the
+ * per-shard (ids, dist) blocks are all-gathered (RCCL) into [n_lists][nq][k] and merged here by
+ * (dist total_cmp, id) -- the same comparator as vamana.rs:1185, so the merged list equals a
+ * single-device search of the concatenated corpus. Padding entries have id 0xFFFFFFFF. */
+int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
+                            uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
+
+/* ---- IVF-PQ trained state (SpannIndex given centroids/codebooks/postings) -------------------- */
+/* The reference's k-means is unseeded (spann.rs:472-474, pq.rs:155-157) so parity is defined
+ * GIVEN trained state. centroids [P][dim]; codebook [M][ncent][8] (M = dim/8, ncent <= 256);
+ * postings in CSR form: list_off[P+1], ids[total], codes[total][M] in insertion order. */
+int shodh_index_set_ivfpq(shodh_index *idx, const float *centroids, uint32_t P,
+                          const float *codebook, uint32_t M, uint32_t ncent,
+                          const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes);
+/* SpannIndex::insert (spann.rs:1006-1051): nearest centroid (strict '<') + PQ encode, appended
+ * to that partition's posting list. */
+int shodh_index_ivfpq_insert(shodh_index *idx, uint32_t vector_id, const float *row);
+/* find_nearest_centroid + ProductQuantizer::encode for n rows on the device (spann.rs:545-558,
+ * pq.rs:220-257): assign_out[n], codes_out[n][M] */
+int shodh_index_ivfpq_encode(shodh_index *idx, const float *rows, uint64_t n, uint32_t *assign_out, uint8_t *codes_out);
+/* seeded Lloyd k-means on the device following spann.rs:466-541 / pq.rs:152-217 given the
+ * initial permutations (init_perm_ivf[n], init_perm_pq[M][n]); outputs the trained state */
+int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint32_t dim, uint32_t P, uint32_t ivf_iters,
+                      uint32_t pq_iters, const uint32_t *init_perm_ivf, const uint32_t *init_perm_pq,
+                      float *centroids_out, float *codebook_out);
+
+/* ---- pairwise similarity (src/similarity.rs:10-48) -------------------------------------------- */
+/* cosine_similarity for n pairs: a,b host [n][dim]; out[n]. (reference order, clamp to [-1,1],
+ * 0 on zero norm) */
+int shodh_cosine_similarity_batch(int device, const float *a, const float *b, uint64_t n, uint32_t dim,
+                                  uint32_t order, float *out);
+
+/* ---- embedder: trait Embedder / MiniLMEmbedder (src/embeddings/mod.rs:52-88, minilm.rs) ------- */
+enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1 };
+typedef struct {
+    int32_t  device;
+    uint32_t dtype;          /* GEMM operand type (accumulation is always fp32) */
+    uint32_t max_len;        /* EmbeddingConfig.max_length = 256 (minilm.rs:225) */
+    uint32_t vocab, hidden, layers, heads, intermediate, max_pos, type_vocab;  /* 30522,384,6,12,1536,512,2 */
+    float    ln_eps;         /* 1e-12 */
+    uint32_t compute_padded; /* 0: skip padded positions (exact in fp32/bf16, minilm.rs:153-154); 1: compute all max_len */
+} shodh_embed_cfg;
+void shodh_embed_cfg_default(shodh_embed_cfg *cfg);
+int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out);   /* MiniLMEmbedder::new minilm.rs:652-690 */
+void shodh_embedder_destroy(shodh_embedder *e);
+/* number of f32 parameters expected by shodh_embedder_load_weights, in HF BertModel order
+ * (see DESIGN.md "encoder weight blob") */
+uint64_t shodh_embedder_param_count(const shodh_embedder *e);
+int shodh_embedder_load_weights(shodh_embedder *e, const float *blob, uint64_t n_floats);
+/* deterministic synthetic weights (normal std 0.02, LayerNorm gamma 1 beta 0) from a seed; the
+ * same blob is returned to the host when blob_out != NULL so a checker can mirror it */
+int shodh_embedder_init_synthetic(shodh_embedder *e, uint64_t seed, float *blob_out, uint64_t n_floats);
+uint32_t shodh_embedder_dimension(const shodh_embedder *e);                    /* Embedder::dimension mod.rs:63 */
+/* encode_batch after tokenisation (minilm.rs:996-1115): ids int32 [b][max_len], mask uint8
+ * [b][max_len] (1 = real token). out host [b][hidden]: masked mean-pool, NaN/Inf scrub,
+ * L2-normalise (minilm.rs:959-981, :846-878). A row whose mask is all zero yields zeros
+ * (empty text, minilm.rs:1123-1125). */
+int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out);
+int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b,
+                                     float *d_out, void *stream);
+int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /* StageTiming.embedding_us */
+
+/* ---- fusion: LearnedWeights (src/relevance.rs:343-606) ----------------------------------------- */
+typedef struct {
+    float semantic, entity, tag, importance, momentum, access_count, graph_strength;
+    uint32_t update_count;
+} shodh_weights;
+void  shodh_weights_default(shodh_weights *w);                                  /* relevance.rs:383-397 */
+void  shodh_weights_normalize(shodh_weights *w);                                /* :401-418 */
+void  shodh_weights_apply_feedback(shodh_weights *w, int semantic_contributed, int entity_contributed,
+                                   int tag_contributed, int helpful);           /* :427-465 */
+float shodh_calibrate_score(float score);                                       /* :601-606 */
+float shodh_fuse_scores(const shodh_weights *w, float sem, float ent, float tag, float imp);               /* :471-487 */
+float shodh_fuse_scores_with_momentum(const shodh_weights *w, float sem, float ent, float tag, float imp,
+                                      float momentum_ema);                      /* :499-517 */
+float shodh_fuse_scores_full(const shodh_weights *w, float sem, float ent, float tag, float imp,
+                             float momentum_ema, uint32_t access_count, float graph_strength);              /* :529-594 */
+/* the same for n candidates on the device (signals host arrays [n]); used by the surfacing tail
+ * relevance.rs:847-855 when candidate lists are large */
+int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n, const float *sem, const float *ent,
+                                 const float *tag, const float *imp, const float *momentum_ema,
+                                 const uint32_t *access_count, const float *graph_strength, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHODH_HIP_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of libshodh_hip.so (the C ABI declared in include/shodh_hip.h).
+
+There is no fallback: if the HIP library is missing or fails to load, importing the product
+fails loudly. The oracle (oracle/) is never imported from here.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libshodh_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_DIM, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_IO, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
+METRIC_NDP, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
+ORDER_SCALAR4, ORDER_AVX2 = 0, 1
+INDEX_FLAT, INDEX_IVFPQ = 0, 1
+SCAN_AUTO, SCAN_EXACT, SCAN_MFMA = 0, 1, 2
+DTYPE_FP32, DTYPE_BF16 = 0, 1
+
+
+class ShodhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("shodh_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IndexCfg(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("metric", C.c_uint32), ("kind", C.c_uint32), ("order", C.c_uint32),
+                ("device", C.c_int32), ("scan_mode", C.c_uint32), ("reserve_rows", C.c_uint64),
+                ("id_base", C.c_uint64), ("nprobe", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class EmbedCfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dtype", C.c_uint32), ("max_len", C.c_uint32), ("vocab", C.c_uint32),
+                ("hidden", C.c_uint32), ("layers", C.c_uint32), ("heads", C.c_uint32), ("intermediate", C.c_uint32),
+                ("max_pos", C.c_uint32), ("type_vocab", C.c_uint32), ("ln_eps", C.c_float), ("compute_padded", C.c_uint32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("semantic", C.c_float), ("entity", C.c_float), ("tag", C.c_float), ("importance", C.c_float),
+                ("momentum", C.c_float), ("access_count", C.c_float), ("graph_strength", C.c_float),
+                ("update_count", C.c_uint32)]
+
+
+# every symbol include/shodh_hip.h declares: name -> (restype, argtypes)
+_vp, _fp, _u8p, _u32p, _u64p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+SYMBOLS = {
+    "shodh_last_error": (C.c_char_p, []),
+    "shodh_abi_version": (C.c_int, []),
+    "shodh_device_count": (C.c_int, []),
+    "shodh_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "shodh_index_cfg_default": (None, [C.POINTER(IndexCfg)]),
+    "shodh_index_create": (C.c_int, [C.POINTER(IndexCfg), C.POINTER(C.c_void_p)]),
+    "shodh_index_destroy": (None, [_vp]),
+    "shodh_index_add": (C.c_int, [_vp, _fp, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "shodh_index_add_device": (C.c_int, [_vp, _fp, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "shodh_index_build": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "shodh_index_build_device": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "shodh_index_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "shodh_index_search_device": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
+    "shodh_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
+    "shodh_index_is_deleted": (C.c_int, [_vp, C.c_uint32]),
+    "shodh_index_len": (C.c_uint64, [_vp]),
+    "shodh_index_deleted_count": (C.c_uint64, [_vp]),
+    "shodh_index_deletion_ratio": (C.c_float, [_vp]),
+    "shodh_index_needs_compaction": (C.c_int, [_vp]),
+    "shodh_index_clear_deleted": (C.c_int, [_vp]),
+    "shodh_index_extract_rows": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _fp]),
+    "shodh_index_extract_live_rows": (C.c_int, [_vp, _fp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "shodh_index_dim": (C.c_uint32, [_vp]),
+    "shodh_index_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
+    "shodh_index_kernel_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
+    "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
+    "shodh_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
+    "shodh_index_ivfpq_insert": (C.c_int, [_vp, C.c_uint32, _fp]),
+    "shodh_index_ivfpq_encode": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u8p]),
+    "shodh_ivfpq_train": (C.c_int, [C.c_int, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp]),
+    "shodh_cosine_similarity_batch": (C.c_int, [C.c_int, _fp, _fp, C.c_uint64, C.c_uint32, C.c_uint32, _fp]),
+    "shodh_embed_cfg_default": (None, [C.POINTER(EmbedCfg)]),
+    "shodh_embedder_create": (C.c_int, [C.POINTER(EmbedCfg), C.POINTER(C.c_void_p)]),
+    "shodh_embedder_destroy": (None, [_vp]),
+    "shodh_embedder_param_count": (C.c_uint64, [_vp]),
+    "shodh_embedder_load_weights": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "shodh_embedder_init_synthetic": (C.c_int, [_vp, C.c_uint64, _fp, C.c_uint64]),
+    "shodh_embedder_dimension": (C.c_uint32, [_vp]),
+    "shodh_embedder_encode_ids": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp]),
+    "shodh_embedder_encode_ids_device": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp, _vp]),
+    "shodh_embedder_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 2)]),
+    "shodh_weights_default": (None, [C.POINTER(Weights)]),
+    "shodh_weights_normalize": (None, [C.POINTER(Weights)]),
+    "shodh_weights_apply_feedback": (None, [C.POINTER(Weights), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "shodh_calibrate_score": (C.c_float, [C.c_float]),
+    "shodh_fuse_scores": (C.c_float, [C.POINTER(Weights)] + [C.c_float] * 4),
+    "shodh_fuse_scores_with_momentum": (C.c_float, [C.POINTER(Weights)] + [C.c_float] * 5),
+    "shodh_fuse_scores_full": (C.c_float, [C.POINTER(Weights)] + [C.c_float] * 5 + [C.c_uint32, C.c_float]),
+    "shodh_fuse_scores_full_batch": (C.c_int, [C.c_int, C.POINTER(Weights), C.c_uint64] + [_fp] * 5 + [_u32p, _fp, _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libshodh_hip.so. Raises if it is missing (build it with `python -m shodh_memory_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libshodh_hip.so is not built (%s). Run `python -m shodh_memory_amd.build`; "
+                          "there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)      # AttributeError if the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().shodh_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != OK:
+        raise ShodhError(rc, last_error())
+    return rc

@@ -1,0 +1,619 @@
+// index.hip -- the index object behind the C ABI: VamanaIndex / VectorIndexBackend method set
+// (src/vector_db/vamana.rs:168-1645, src/vector_db/mod.rs:98-266) on one MI355X.
+//
+// HBM layout per index (one device):
+//   rows    f32 [cap][dim]   row-major, the master copy (bit-for-bit what add/build received;
+//                            extract_all_vectors returns it verbatim, retrieval.rs:2504-2516)
+//   rows_h  f16 [cap][dim]   shadow copy fp16(256*x) for the MFMA pre-scan; tombstoned rows zeroed
+//   deleted u32 [cap/32]     tombstone bitmask (vamana.rs:813-849 keeps a HashSet<u32>)
+// ids are dense and sequential exactly like add_vector (vamana.rs:854-855): id = id_base + row.
+#include <algorithm>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace shodh {
+
+// ---- error string ------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ---- kernels living in other translation units ---------------------------------------------------
+uint32_t topk_capacity(uint32_t k);
+size_t exact_partial_bytes(uint32_t nq, uint32_t dim, uint32_t k, uint32_t grid_x);
+uint32_t exact_grid_x(uint64_t n_rows, uint32_t nq, uint32_t k, int cus);
+int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
+                      const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                      uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
+                      const uint32_t *qlist, const uint32_t *qcount, hipStream_t st);
+
+int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
+                       uint32_t *ids, float *dist, uint32_t *counts, hipStream_t st);
+
+struct MfmaPlan {
+    uint32_t passes, n_slots, ksteps;
+    uint32_t tile_stride, n_sel_tiles, J;
+    uint64_t n_tiles;
+    uint32_t cand_cap, fcap, topk_cap;
+    int grid_x;
+};
+bool mfma_supported(uint32_t dim);
+MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus);
+size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs);
+int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
+                         const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
+                         uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1);
+int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
+int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st);
+int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uint32_t *deleted, uint64_t n, uint32_t dim, hipStream_t st);
+
+struct IvfpqState;   // ivfpq.hip
+void ivfpq_destroy(IvfpqState *s);
+int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, uint32_t nq, uint32_t k,
+                 uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st);
+
+// ---- per-search scratch ----------------------------------------------------------------------------
+struct Workspace {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, scan done, select done, end
+    hipEvent_t last_use = nullptr;
+    unsigned char *buf = nullptr;
+    size_t bytes = 0;
+    float *d_q = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr;
+    size_t q_floats = 0, out_elems = 0, nq_cap = 0;
+    // ring of (start, end) events around the dominant scan kernel of each search, for
+    // shodh_index_kernel_timing (bench.py roofline): slot = ring_pos % RING
+    static constexpr uint32_t RING = 256;
+    hipEvent_t ring[RING][2];
+    uint32_t ring_pos = 0;
+
+    int init() {
+        SHODH_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto &e : ev) SHODH_HIP_TRY(hipEventCreate(&e));
+        SHODH_HIP_TRY(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
+        for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }
+        for (auto &r : ring) { SHODH_HIP_TRY(hipEventCreate(&r[0])); SHODH_HIP_TRY(hipEventCreate(&r[1])); }
+        return SHODH_OK;
+    }
+    int reserve(size_t need) {
+        if (need <= bytes) return SHODH_OK;
+        if (buf) SHODH_HIP_TRY(hipFree(buf));
+        buf = nullptr; bytes = 0;
+        SHODH_HIP_TRY(hipMalloc((void **)&buf, need));
+        bytes = need;
+        return SHODH_OK;
+    }
+    int reserve_io(size_t qf, size_t oe, size_t nq) {
+        if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
+        if (oe > out_elems) {
+            if (d_ids) hipFree(d_ids); if (d_dist) hipFree(d_dist); d_ids = nullptr; d_dist = nullptr; out_elems = 0;
+            SHODH_HIP_TRY(hipMalloc((void **)&d_ids, oe * 4)); SHODH_HIP_TRY(hipMalloc((void **)&d_dist, oe * 4)); out_elems = oe;
+        }
+        if (nq > nq_cap) { if (d_counts) hipFree(d_counts); d_counts = nullptr; nq_cap = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_counts, nq * 4)); nq_cap = nq; }
+        return SHODH_OK;
+    }
+    void destroy() {
+        if (buf) hipFree(buf);
+        if (d_q) hipFree(d_q); if (d_ids) hipFree(d_ids); if (d_dist) hipFree(d_dist); if (d_counts) hipFree(d_counts);
+        for (auto &e : ev) if (e) hipEventDestroy(e);
+        if (last_use) hipEventDestroy(last_use);
+        for (auto &r : ring) { if (r[0]) hipEventDestroy(r[0]); if (r[1]) hipEventDestroy(r[1]); }
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace shodh
+
+using namespace shodh;
+
+struct shodh_index {
+    shodh_index_cfg cfg{};
+    int cus = 256;
+    mutable std::shared_mutex mu;        // search: shared; add/build/delete: exclusive
+    float *rows = nullptr;
+    _Float16 *rows_h = nullptr;
+    uint32_t *deleted = nullptr;         // device bitmask, sized for cap_rows
+    uint32_t *stats = nullptr;           // device [4]: max norm^2, max |x|, non-finite count
+    std::vector<uint32_t> deleted_host;  // host mirror of the bitmask
+    uint64_t n = 0, cap_rows = 0, n_deleted = 0;
+    float maxnorm = 0.0f, maxabs = 0.0f;
+    bool quantizable = true;             // fp16 shadow usable (max |x| * 256 < 60000)
+    bool shadow = false;                 // shadow copy maintained (dim supported by the MFMA kernel)
+    std::mutex ws_mu;
+    std::vector<Workspace *> ws_free;
+    mutable std::mutex stat_mu;
+    float last_us[4] = {0, 0, 0, 0};
+    uint64_t last_stats[4] = {0, 0, 0, 0};
+    IvfpqState *ivfpq = nullptr;
+};
+
+namespace shodh {
+
+static int set_device(const shodh_index *idx) {
+    SHODH_HIP_TRY(hipSetDevice(idx->cfg.device));
+    return SHODH_OK;
+}
+
+static int grow(shodh_index *idx, uint64_t need_rows) {
+    if (need_rows <= idx->cap_rows) return SHODH_OK;
+    uint64_t nc = idx->cap_rows ? idx->cap_rows : 1024;
+    while (nc < need_rows) nc *= 2;
+    nc = (nc + 63) & ~63ull;
+    const size_t dim = idx->cfg.dim;
+    float *nr = nullptr; _Float16 *nh = nullptr; uint32_t *nd = nullptr;
+    if (hipMalloc((void **)&nr, nc * dim * 4) != hipSuccess) { set_error("out of HBM growing index to %llu rows", (unsigned long long)nc); return SHODH_ERR_OOM; }
+    if (idx->shadow && hipMalloc((void **)&nh, nc * dim * 2) != hipSuccess) { hipFree(nr); set_error("out of HBM (fp16 shadow)"); return SHODH_ERR_OOM; }
+    if (hipMalloc((void **)&nd, (nc / 32 + 1) * 4) != hipSuccess) { hipFree(nr); if (nh) hipFree(nh); set_error("out of HBM (tombstones)"); return SHODH_ERR_OOM; }
+    SHODH_HIP_TRY(hipMemset(nd, 0, (nc / 32 + 1) * 4));
+    if (idx->n) {
+        SHODH_HIP_TRY(hipMemcpy(nr, idx->rows, idx->n * dim * 4, hipMemcpyDeviceToDevice));
+        if (nh) SHODH_HIP_TRY(hipMemcpy(nh, idx->rows_h, idx->n * dim * 2, hipMemcpyDeviceToDevice));
+        SHODH_HIP_TRY(hipMemcpy(nd, idx->deleted, (idx->cap_rows / 32 + 1) * 4, hipMemcpyDeviceToDevice));
+    }
+    if (idx->rows) hipFree(idx->rows);
+    if (idx->rows_h) hipFree(idx->rows_h);
+    if (idx->deleted) hipFree(idx->deleted);
+    idx->rows = nr; idx->rows_h = nh; idx->deleted = nd; idx->cap_rows = nc;
+    idx->deleted_host.resize(nc / 32 + 1, 0);
+    return SHODH_OK;
+}
+
+// after new rows [first, first+n) are in idx->rows: shadow copy + stats
+static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
+    if (idx->shadow) {
+        SHODH_TRY(launch_convert_rows(idx->rows, first, n, idx->cfg.dim, idx->rows_h, idx->stats, nullptr));
+        uint32_t st[4];
+        SHODH_HIP_TRY(hipMemcpy(st, idx->stats, sizeof(st), hipMemcpyDeviceToHost));
+        float nsq, ma;
+        memcpy(&nsq, &st[0], 4); memcpy(&ma, &st[1], 4);
+        if (st[2] != 0) {
+            // roll back: the rows are not published (n is not advanced by the caller)
+            uint32_t z = 0;
+            hipMemcpy(idx->stats + 2, &z, 4, hipMemcpyHostToDevice);
+            set_error("rows contain %u non-finite values (NaN/Inf are out of contract: MiniLM scrubs them, minilm.rs:847-851)", st[2]);
+            return SHODH_ERR_NONFINITE;
+        }
+        idx->maxnorm = sqrtf(nsq) * 1.00001f;
+        idx->maxabs = ma;
+        idx->quantizable = (ma * 256.0f < 60000.0f);
+    }
+    return SHODH_OK;
+}
+
+static Workspace *ws_acquire(shodh_index *idx) {
+    {
+        std::lock_guard<std::mutex> g(idx->ws_mu);
+        if (!idx->ws_free.empty()) { Workspace *w = idx->ws_free.back(); idx->ws_free.pop_back(); return w; }
+    }
+    Workspace *w = new Workspace();
+    if (w->init() != SHODH_OK) { w->destroy(); delete w; return nullptr; }
+    return w;
+}
+static void ws_release(shodh_index *idx, Workspace *w) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    idx->ws_free.push_back(w);
+}
+
+static bool use_mfma(const shodh_index *idx, uint32_t nq, uint32_t k) {
+    if (idx->cfg.scan_mode == SHODH_SCAN_EXACT) return false;
+    if (!idx->shadow || !idx->quantizable) return false;
+    if (k == 0 || k > 2048) return false;
+    if (idx->n < 16384 || idx->n < 64ull * k) return false;     // pre-scan sampling needs a real corpus
+    if (idx->cfg.scan_mode == SHODH_SCAN_MFMA) return true;
+    return nq >= 4;                                             // AUTO: exact scan is HBM-bound for tiny batches
+}
+
+// enqueue a FLAT search on `st` using workspace w (device in/out pointers)
+static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32_t nq, uint32_t k,
+                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, bool *used_mfma) {
+    const uint32_t dim = idx->cfg.dim;
+    const uint32_t idb = (uint32_t)idx->cfg.id_base;
+    const uint32_t *del = idx->n_deleted ? idx->deleted : nullptr;
+    *used_mfma = use_mfma(idx, nq, k);
+    hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
+    w->ring_pos++;
+    SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
+    if (*used_mfma) {
+        MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
+        size_t offs[11];
+        const size_t ws_bytes = mfma_workspace_bytes(p, dim, offs);
+        const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
+        const size_t part_bytes = exact_partial_bytes(nq, dim, k, gx);
+        SHODH_TRY(w->reserve(ws_bytes + part_bytes + 256));
+        SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
+                                       idx->maxnorm, p, w->buf, offs, d_ids, d_dist, d_counts, st, w->ev[1], w->ev[2], rk[0], rk[1]));
+        // exact scan of whatever the pre-scan could not settle (device-side list; normally empty)
+        const uint32_t *fb_list = (const uint32_t *)(w->buf + offs[6]);
+        const uint32_t *fb_count = (const uint32_t *)(w->buf + offs[7]);
+        uint64_t *partial = (uint64_t *)(w->buf + ((ws_bytes + 255) & ~(size_t)255));
+        SHODH_TRY(launch_flat_exact(idx->rows, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb, partial, gx,
+                                    d_ids, d_dist, d_counts, fb_list, fb_count, st));
+    } else {
+        const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
+        SHODH_TRY(w->reserve(exact_partial_bytes(nq, dim, k, gx) + 256));
+        SHODH_HIP_TRY(hipEventRecord(rk[0], st));
+        SHODH_TRY(launch_flat_exact(idx->rows, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb, (uint64_t *)w->buf, gx,
+                                    d_ids, d_dist, d_counts, nullptr, nullptr, st));
+        SHODH_HIP_TRY(hipEventRecord(rk[1], st));     // scan + merge (the merge is a few microseconds)
+        SHODH_HIP_TRY(hipEventRecord(w->ev[1], st));
+        SHODH_HIP_TRY(hipEventRecord(w->ev[2], st));
+    }
+    SHODH_HIP_TRY(hipEventRecord(w->ev[3], st));
+    return SHODH_OK;
+}
+
+static void collect_timings(shodh_index *idx, Workspace *w, bool used_mfma, const size_t *offs_or_null) {
+    float scan = 0, sel = 0, tot = 0;
+    hipEventElapsedTime(&scan, w->ev[0], w->ev[1]);
+    hipEventElapsedTime(&sel, w->ev[1], w->ev[2]);
+    hipEventElapsedTime(&tot, w->ev[0], w->ev[3]);
+    std::lock_guard<std::mutex> g(idx->stat_mu);
+    idx->last_us[0] = scan * 1000.0f;
+    idx->last_us[1] = sel * 1000.0f;
+    idx->last_us[2] = (tot - scan - sel) * 1000.0f;
+    idx->last_us[3] = tot * 1000.0f;
+    (void)used_mfma; (void)offs_or_null;
+}
+
+}  // namespace shodh
+
+// =====================================================================================================
+extern "C" {
+
+const char *shodh_last_error(void) { return g_err.c_str(); }
+int shodh_abi_version(void) { return SHODH_HIP_ABI_VERSION; }
+
+int shodh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { set_error("hipGetDeviceCount failed (no ROCm device visible)"); return SHODH_ERR_DEVICE; }
+    return n;
+}
+
+int shodh_device_info(int dev, char *name, size_t cap, uint64_t *hbm_bytes, uint32_t *compute_units) {
+    hipDeviceProp_t p;
+    SHODH_HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name && cap) snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    if (compute_units) *compute_units = (uint32_t)p.multiProcessorCount;
+    return SHODH_OK;
+}
+
+void shodh_index_cfg_default(shodh_index_cfg *cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->dim = 384;                       // BackendConfig::default (vector_db/mod.rs:74-86)
+    cfg->metric = SHODH_METRIC_NDP;
+    cfg->kind = SHODH_INDEX_FLAT;
+    cfg->order = SHODH_ORDER_SCALAR4;
+    cfg->device = 0;
+    cfg->scan_mode = SHODH_SCAN_AUTO;
+    cfg->reserve_rows = 0;
+    cfg->id_base = 0;
+    cfg->nprobe = 20;                     // BackendConfig.spann_probes
+}
+
+int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
+    if (!cfg || !out) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->dim == 0 || cfg->dim > 4096) { set_error("dimension %u out of range", cfg->dim); return SHODH_ERR_DIM; }
+    if (cfg->kind != SHODH_INDEX_FLAT && cfg->kind != SHODH_INDEX_IVFPQ) { set_error("unknown index kind %u", cfg->kind); return SHODH_ERR_INVALID; }
+    if (cfg->order > SHODH_ORDER_AVX2) { set_error("unknown accumulation order %u", cfg->order); return SHODH_ERR_INVALID; }
+    if (cfg->kind == SHODH_INDEX_FLAT && cfg->metric != SHODH_METRIC_NDP) {
+        // RetrievalEngine refuses anything else (retrieval.rs:188-193)
+        set_error("FLAT index requires NormalizedDotProduct (vectors are L2-normalised by the embedder)");
+        return SHODH_ERR_INVALID;
+    }
+    if (cfg->kind == SHODH_INDEX_IVFPQ && cfg->dim % 8 != 0) { set_error("IVF-PQ needs dim %% 8 == 0 (pq.rs:43-48)"); return SHODH_ERR_DIM; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libshodh_hip has no CPU fallback"); return SHODH_ERR_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d not present (%d visible)", cfg->device, ndev); return SHODH_ERR_DEVICE; }
+    hipDeviceProp_t prop;
+    SHODH_HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName); return SHODH_ERR_DEVICE; }
+    SHODH_HIP_TRY(hipSetDevice(cfg->device));
+    shodh_index *idx = new shodh_index();
+    idx->cfg = *cfg;
+    idx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    idx->shadow = (cfg->kind == SHODH_INDEX_FLAT) && mfma_supported(cfg->dim);
+    if (hipMalloc((void **)&idx->stats, 16) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
+    hipMemset(idx->stats, 0, 16);
+    if (cfg->kind == SHODH_INDEX_FLAT && cfg->reserve_rows) {
+        int s = grow(idx, cfg->reserve_rows);
+        if (s != SHODH_OK) { shodh_index_destroy(idx); return s; }
+    }
+    *out = idx;
+    return SHODH_OK;
+}
+
+void shodh_index_destroy(shodh_index *idx) {
+    if (!idx) return;
+    hipSetDevice(idx->cfg.device);
+    hipDeviceSynchronize();
+    for (Workspace *w : idx->ws_free) { w->destroy(); delete w; }
+    if (idx->ivfpq) ivfpq_destroy(idx->ivfpq);
+    if (idx->rows) hipFree(idx->rows);
+    if (idx->rows_h) hipFree(idx->rows_h);
+    if (idx->deleted) hipFree(idx->deleted);
+    if (idx->stats) hipFree(idx->stats);
+    delete idx;
+}
+
+static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out, hipMemcpyKind kind) {
+    if (!idx || (!rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.kind != SHODH_INDEX_FLAT) { set_error("add is for FLAT indexes; IVF-PQ uses shodh_index_ivfpq_insert"); return SHODH_ERR_STATE; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    if (idx->n + n + idx->cfg.id_base > 0xFFFFFFFEull) { set_error("vector ids are u32: index full"); return SHODH_ERR_INVALID; }
+    if (first_id_out) *first_id_out = (uint32_t)(idx->cfg.id_base + idx->n);
+    if (n == 0) return SHODH_OK;
+    SHODH_TRY(grow(idx, idx->n + n));
+    SHODH_HIP_TRY(hipMemcpy(idx->rows + idx->n * idx->cfg.dim, rows, n * idx->cfg.dim * 4, kind));
+    if (!idx->shadow && kind == hipMemcpyHostToDevice) {
+        for (uint64_t i = 0; i < n * idx->cfg.dim; ++i)
+            if (!(fabsf(rows[i]) <= 3.0e38f)) { set_error("rows contain non-finite values"); return SHODH_ERR_NONFINITE; }
+    }
+    SHODH_TRY(finish_append(idx, idx->n, n));
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    idx->n += n;
+    return SHODH_OK;
+}
+
+int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out) {
+    return add_impl(idx, rows, n, first_id_out, hipMemcpyHostToDevice);
+}
+int shodh_index_add_device(shodh_index *idx, const float *d_rows, uint64_t n, uint32_t *first_id_out) {
+    return add_impl(idx, d_rows, n, first_id_out, hipMemcpyDeviceToDevice);
+}
+
+static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpyKind kind) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    {
+        std::unique_lock<std::shared_mutex> lk(idx->mu);
+        SHODH_TRY(set_device(idx));
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+        idx->n = 0;
+        idx->n_deleted = 0;
+        idx->maxnorm = 0; idx->maxabs = 0; idx->quantizable = true;
+        if (idx->deleted) SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
+        std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
+        SHODH_HIP_TRY(hipMemset(idx->stats, 0, 16));
+    }
+    return add_impl(idx, rows, n, nullptr, kind);
+}
+int shodh_index_build(shodh_index *idx, const float *rows, uint64_t n) { return build_impl(idx, rows, n, hipMemcpyHostToDevice); }
+int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n) { return build_impl(idx, d_rows, n, hipMemcpyDeviceToDevice); }
+
+static int search_common(shodh_index *idx, const float *q, bool q_on_device, uint32_t nq, uint32_t k,
+                         uint32_t *ids, float *dist, uint32_t *counts, hipStream_t user_stream, bool sync_host) {
+    if (!idx || (nq && (!q || !counts)) || (nq && k && (!ids || !dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (nq == 0) return SHODH_OK;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    const uint32_t dim = idx->cfg.dim;
+    const bool empty = (idx->cfg.kind == SHODH_INDEX_FLAT) ? (idx->n == 0) : (idx->ivfpq == nullptr);
+    if (idx->cfg.kind == SHODH_INDEX_IVFPQ && !idx->ivfpq) {
+        // SpannIndex::search on an unbuilt index: centroids empty -> Ok(vec![]) (spann.rs:575-578)
+    }
+    if (empty || k == 0) {
+        if (sync_host) { for (uint32_t i = 0; i < nq; ++i) counts[i] = 0; for (size_t i = 0; i < (size_t)nq * k; ++i) { ids[i] = 0xFFFFFFFFu; dist[i] = INFINITY; } }
+        else {
+            SHODH_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nq * 4, user_stream));
+            if (k) { SHODH_HIP_TRY(hipMemsetAsync(ids, 0xFF, (size_t)nq * k * 4, user_stream)); SHODH_HIP_TRY(hipMemsetAsync(dist, 0x7F, (size_t)nq * k * 4, user_stream)); }
+        }
+        return SHODH_OK;
+    }
+    if (sync_host) {
+        for (size_t i = 0; i < (size_t)nq * dim; ++i)
+            if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
+    }
+    Workspace *w = ws_acquire(idx);
+    if (!w) return SHODH_ERR_DEVICE;
+    hipStream_t st = sync_host ? w->stream : user_stream;
+    int rc = SHODH_OK;
+    bool used_mfma = false;
+    do {
+        if ((rc = (hipStreamWaitEvent(st, w->last_use, 0) == hipSuccess ? SHODH_OK : SHODH_ERR_DEVICE)) != SHODH_OK) { set_error("hipStreamWaitEvent failed"); break; }
+        const float *d_q = q;
+        uint32_t *d_ids = ids; float *d_dist = dist; uint32_t *d_counts = counts;
+        if (sync_host) {
+            if ((rc = w->reserve_io((size_t)nq * dim, (size_t)nq * k, nq)) != SHODH_OK) break;
+            if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
+            d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
+        }
+        if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma);
+        else {
+            hipEventRecord(w->ev[0], st);
+            rc = ivfpq_search(idx->ivfpq, idx->cfg, d_q, nq, k, d_ids, d_dist, d_counts, st);
+            hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st);
+        }
+        if (rc != SHODH_OK) break;
+        if (sync_host) {
+            if (hipMemcpyAsync(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(dist, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(counts, d_counts, (size_t)nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
+            collect_timings(idx, w, used_mfma, nullptr);
+            if (used_mfma) {
+                uint32_t st4[4] = {0, 0, 0, 0};
+                MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
+                size_t offs[11];
+                mfma_workspace_bytes(p, dim, offs);
+                hipMemcpy(st4, w->buf + offs[8], 16, hipMemcpyDeviceToHost);
+                std::lock_guard<std::mutex> g(idx->stat_mu);
+                idx->last_stats[0] = (uint64_t)p.n_sel_tiles * 64; idx->last_stats[1] = st4[0]; idx->last_stats[2] = st4[1]; idx->last_stats[3] = st4[2];
+            } else {
+                std::lock_guard<std::mutex> g(idx->stat_mu);
+                idx->last_stats[0] = idx->last_stats[1] = idx->last_stats[2] = idx->last_stats[3] = 0;
+            }
+        }
+    } while (0);
+    hipEventRecord(w->last_use, st);
+    ws_release(idx, w);
+    return rc;
+}
+
+int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+    return search_common(idx, q, false, nq, k, ids, dist, counts, nullptr, true);
+}
+int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k, uint32_t *d_ids, float *d_dist,
+                              uint32_t *d_counts, void *stream) {
+    return search_common(idx, d_q, true, nq, k, d_ids, d_dist, d_counts, (hipStream_t)stream, false);
+}
+
+int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    const uint64_t local = (uint64_t)id - idx->cfg.id_base;
+    if (id < idx->cfg.id_base || local >= idx->n) { if (was_valid) *was_valid = 0; return SHODH_OK; }   // vamana.rs:814-819 returns false
+    if (was_valid) *was_valid = 1;
+    uint32_t &word = idx->deleted_host[local >> 5];
+    const uint32_t bit = 1u << (local & 31);
+    if (word & bit) return SHODH_OK;
+    word |= bit;
+    idx->n_deleted++;
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    SHODH_HIP_TRY(hipMemcpy(idx->deleted + (local >> 5), &word, 4, hipMemcpyHostToDevice));
+    if (idx->shadow) { SHODH_TRY(launch_shadow_set_row(idx->rows, idx->rows_h, local, idx->cfg.dim, 1, nullptr)); SHODH_HIP_TRY(hipDeviceSynchronize()); }
+    return SHODH_OK;
+}
+
+int shodh_index_is_deleted(const shodh_index *idx, uint32_t id) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const uint64_t local = (uint64_t)id - idx->cfg.id_base;
+    if (id < idx->cfg.id_base || local >= idx->n) return 0;
+    return (idx->deleted_host[local >> 5] >> (local & 31)) & 1u;
+}
+
+uint64_t shodh_index_len(const shodh_index *idx) {
+    if (!idx) return 0;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    return idx->n;
+}
+uint64_t shodh_index_deleted_count(const shodh_index *idx) {
+    if (!idx) return 0;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    return idx->n_deleted;
+}
+float shodh_index_deletion_ratio(const shodh_index *idx) {
+    if (!idx) return 0.0f;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (idx->n == 0) return 0.0f;
+    return (float)idx->n_deleted / (float)idx->n;    // vamana.rs:834-840
+}
+int shodh_index_needs_compaction(const shodh_index *idx) { return shodh_index_deletion_ratio(idx) >= 0.30f; }   // DELETION_RATIO_THRESHOLD
+
+int shodh_index_clear_deleted(shodh_index *idx) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    if (idx->n_deleted == 0) return SHODH_OK;
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    if (idx->shadow) SHODH_TRY(launch_shadow_restore_deleted(idx->rows, idx->rows_h, idx->deleted, idx->n, idx->cfg.dim, nullptr));
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
+    std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
+    idx->n_deleted = 0;
+    return SHODH_OK;
+}
+
+int shodh_index_extract_rows(const shodh_index *idx, uint64_t first, uint64_t n, float *out_rows) {
+    if (!idx || (!out_rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    if (first + n > idx->n) { set_error("rows [%llu,%llu) out of range (len %llu)", (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)idx->n); return SHODH_ERR_INVALID; }
+    if (n) SHODH_HIP_TRY(hipMemcpy(out_rows, idx->rows + first * idx->cfg.dim, n * idx->cfg.dim * 4, hipMemcpyDeviceToHost));
+    return SHODH_OK;
+}
+
+int shodh_index_extract_live_rows(const shodh_index *idx, float *out_rows, uint32_t *ids_out, uint64_t cap, uint64_t *n_out) {
+    if (!idx || !n_out) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    const uint64_t live = idx->n - idx->n_deleted;
+    *n_out = live;
+    if (!out_rows) return SHODH_OK;
+    if (cap < live) { set_error("buffer holds %llu rows, %llu live", (unsigned long long)cap, (unsigned long long)live); return SHODH_ERR_INVALID; }
+    const uint32_t dim = idx->cfg.dim;
+    uint64_t o = 0, run_start = 0;
+    bool in_run = false;
+    auto flush = [&](uint64_t end) -> int {
+        if (!in_run) return SHODH_OK;
+        SHODH_HIP_TRY(hipMemcpy(out_rows + o * dim, idx->rows + run_start * dim, (end - run_start) * dim * 4, hipMemcpyDeviceToHost));
+        if (ids_out) for (uint64_t r = run_start; r < end; ++r) ids_out[o + (r - run_start)] = (uint32_t)(idx->cfg.id_base + r);
+        o += end - run_start;
+        in_run = false;
+        return SHODH_OK;
+    };
+    for (uint64_t r = 0; r < idx->n; ++r) {
+        const bool del = (idx->deleted_host[r >> 5] >> (r & 31)) & 1u;
+        if (!del && !in_run) { in_run = true; run_start = r; }
+        if (del && in_run) SHODH_TRY(flush(r));
+    }
+    SHODH_TRY(flush(idx->n));
+    return SHODH_OK;
+}
+
+uint32_t shodh_index_dim(const shodh_index *idx) { return idx ? idx->cfg.dim : 0; }
+
+int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
+                            uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream) {
+    if (nq && (!d_in_ids || !d_in_dist || !d_ids || !d_dist || !d_counts)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (k > 8192) { set_error("k too large"); return SHODH_ERR_UNSUPPORTED; }
+    return launch_merge_lists(d_in_ids, d_in_dist, n_lists, nq, k, d_ids, d_dist, d_counts, (hipStream_t)stream);
+}
+
+int shodh_index_stage_timings(const shodh_index *idx, float *us4) {
+    if (!idx || !us4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(idx->stat_mu);
+    memcpy(us4, idx->last_us, sizeof(idx->last_us));
+    return SHODH_OK;
+}
+int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float *min_us, uint32_t *count) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    double sum = 0; float mn = 1e30f; uint32_t n = 0;
+    for (Workspace *w : idx->ws_free) {
+        const uint32_t used = w->ring_pos < Workspace::RING ? w->ring_pos : Workspace::RING;
+        for (uint32_t i = 0; i < used; ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, w->ring[i][0], w->ring[i][1]) == hipSuccess && ms > 0) { sum += ms; if (ms < mn) mn = ms; ++n; }
+        }
+        if (reset) w->ring_pos = 0;
+    }
+    (void)hipGetLastError();
+    if (mean_us) *mean_us = n ? (float)(sum / n * 1000.0) : 0.0f;
+    if (min_us) *min_us = n ? mn * 1000.0f : 0.0f;
+    if (count) *count = n;
+    return SHODH_OK;
+}
+
+int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats4) {
+    if (!idx || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(idx->stat_mu);
+    memcpy(stats4, idx->last_stats, sizeof(idx->last_stats));
+    return SHODH_OK;
+}
+
+}  // extern "C"
+
+// accessors for ivfpq.hip
+namespace shodh {
+IvfpqState *&index_ivfpq_slot(shodh_index *idx) { return idx->ivfpq; }
+const shodh_index_cfg &index_cfg(const shodh_index *idx) { return idx->cfg; }
+std::shared_mutex &index_mutex(shodh_index *idx) { return idx->mu; }
+}  // namespace shodh

@@ -1,0 +1,418 @@
+"""Host-side mirror of the reference's vector-index API over the C ABI.
+
+Mirrors `VamanaIndex` (src/vector_db/vamana.rs:168-1645) and the `VectorIndexBackend` facade
+(src/vector_db/mod.rs:98-266): same method names, argument meaning and error behaviour, so the
+parity tests read like the reference's own tests. Results follow the reference's exact path
+(`SHODH_VECTOR_EXACT`, vamana.rs:770-777): `search` returns `[(id, distance)]`, distance =
+-dot ascending, ties by id.
+
+numpy arrays go through the host entry points; torch CUDA tensors go through the `*_device`
+entry points without leaving HBM.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from enum import Enum
+
+import numpy as np
+
+from . import _lib as L
+
+# vamana.rs:103-117
+REBUILD_THRESHOLD = 10_000
+REPAIR_THRESHOLD = 1_000
+DELETION_RATIO_THRESHOLD = 0.30
+# vector_db/mod.rs:53
+SPANN_AUTO_THRESHOLD = 100_000
+
+
+class DistanceMetric(Enum):
+    NormalizedDotProduct = 0
+    Euclidean = 1
+    Cosine = 2
+
+
+class BackendType(Enum):
+    Vamana = 0
+    Spann = 1
+
+
+@dataclass
+class VamanaConfig:
+    """vamana.rs VamanaConfig (graph parameters are accepted and ignored: the device index is flat)."""
+    dimension: int = 384
+    max_degree: int = 32
+    search_list_size: int = 100
+    alpha: float = 1.2
+    use_mmap: bool = False
+    distance_metric: DistanceMetric = DistanceMetric.NormalizedDotProduct
+    # device-side knobs (not in the reference)
+    device: int = 0
+    order: int = L.ORDER_SCALAR4
+    scan_mode: int = L.SCAN_AUTO
+    reserve_rows: int = 0
+    id_base: int = 0
+
+
+@dataclass
+class BackendConfig:
+    """vector_db/mod.rs:57-86"""
+    dimension: int = 384
+    distance_metric: DistanceMetric = DistanceMetric.NormalizedDotProduct
+    force_backend: "BackendType | None" = None
+    use_pq: bool = True
+    spann_probes: int = 20
+    vamana_max_degree: int = 32
+    vamana_search_list_size: int = 100
+    device: int = 0
+
+
+def _is_torch_cuda(x):
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
+def _as_rows(vectors, dim):
+    a = np.ascontiguousarray(vectors, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.size and a.shape[1] != dim:
+        raise L.ShodhError(L.ERR_DIM, "Vector dimension %d doesn't match config %d" % (a.shape[1], dim))
+    return a.reshape(-1, dim)
+
+
+class _Handle:
+    def __init__(self, cfg: L.IndexCfg):
+        self._h = C.c_void_p()
+        L.check(L.lib().shodh_index_create(C.byref(cfg), C.byref(self._h)))
+        self.dim = cfg.dim
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().shodh_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VamanaIndex:
+    """Flat exact index on one MI355X with the VamanaIndex method set."""
+
+    def __init__(self, config: VamanaConfig = None):
+        self.config = config or VamanaConfig()
+        cfg = L.IndexCfg()
+        L.lib().shodh_index_cfg_default(C.byref(cfg))
+        cfg.dim = self.config.dimension
+        cfg.metric = self.config.distance_metric.value
+        cfg.kind = L.INDEX_FLAT
+        cfg.order = self.config.order
+        cfg.device = self.config.device
+        cfg.scan_mode = self.config.scan_mode
+        cfg.reserve_rows = self.config.reserve_rows
+        cfg.id_base = self.config.id_base
+        self._hd = _Handle(cfg)
+        self._incremental = 0
+
+    # -- VamanaIndex::new / with_storage_path ----------------------------------------------------
+    @classmethod
+    def new(cls, config: VamanaConfig):
+        return cls(config)
+
+    @property
+    def handle(self):
+        return self._hd._h
+
+    def close(self):
+        self._hd.close()
+
+    # -- len / is_empty (vamana.rs:184-191) --------------------------------------------------------
+    def len(self):
+        return int(L.lib().shodh_index_len(self.handle))
+
+    __len__ = len
+
+    def is_empty(self):
+        return self.len() == 0
+
+    # -- build (vamana.rs:200-284) / rebuild_from_vectors (:1363-1462) -------------------------------
+    def build(self, vectors):
+        if _is_torch_cuda(vectors):
+            assert vectors.dtype.is_floating_point and vectors.is_contiguous() and vectors.shape[-1] == self._hd.dim
+            L.check(L.lib().shodh_index_build_device(self.handle, vectors.data_ptr(), vectors.shape[0]))
+        else:
+            a = _as_rows(vectors, self._hd.dim)
+            L.check(L.lib().shodh_index_build(self.handle, a.ctypes.data, a.shape[0]))
+        self._incremental = 0
+
+    rebuild_from_vectors = build
+
+    # -- add_vector (vamana.rs:853-974): returns the new id -------------------------------------------
+    def add_vector(self, vector):
+        a = _as_rows(vector, self._hd.dim)
+        if a.shape[0] != 1:
+            raise L.ShodhError(L.ERR_INVALID, "add_vector takes one vector; use add_vectors")
+        first = C.c_uint32()
+        L.check(L.lib().shodh_index_add(self.handle, a.ctypes.data, 1, C.byref(first)))
+        self._incremental += 1
+        return int(first.value)
+
+    def add_vectors(self, vectors):
+        """n sequential add_vector calls in one transfer; returns the first id."""
+        first = C.c_uint32()
+        if _is_torch_cuda(vectors):
+            assert vectors.is_contiguous() and vectors.shape[-1] == self._hd.dim
+            L.check(L.lib().shodh_index_add_device(self.handle, vectors.data_ptr(), vectors.shape[0], C.byref(first)))
+            self._incremental += int(vectors.shape[0])
+        else:
+            a = _as_rows(vectors, self._hd.dim)
+            L.check(L.lib().shodh_index_add(self.handle, a.ctypes.data, a.shape[0], C.byref(first)))
+            self._incremental += a.shape[0]
+        return int(first.value)
+
+    # -- search (vamana.rs:764-808; exact path :1167-1188) ---------------------------------------------
+    def search(self, query, k):
+        """-> list[(id, distance)] ascending distance, ties by id; at most k; [] on an empty index."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self._hd.dim:
+            raise L.ShodhError(L.ERR_DIM, "Query dimension %d doesn't match index dimension %d" % (q.size, self._hd.dim))
+        ids, dist, counts = self.search_batch(q.reshape(1, -1), k)
+        n = int(counts[0])
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(n)]
+
+    def search_batch(self, queries, k):
+        """queries [nq, dim] -> (ids [nq,k] uint32, dist [nq,k] float32, counts [nq])."""
+        if _is_torch_cuda(queries):
+            return self.search_batch_device(queries, k)
+        q = _as_rows(queries, self._hd.dim)
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        L.check(L.lib().shodh_index_search(self.handle, q.ctypes.data, nq, k, ids.ctypes.data, dist.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], dist[:, :k], counts
+
+    def search_batch_device(self, queries, k, out=None, stream=None):
+        """torch CUDA tensors in, torch CUDA tensors out, asynchronous on the current stream."""
+        import torch
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq = queries.shape[0]
+        if out is None:
+            ids = torch.empty((nq, k), dtype=torch.int32, device=queries.device)     # bit pattern of u32 ids
+            dist = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+            counts = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+        else:
+            ids, dist, counts = out
+        st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
+        L.check(L.lib().shodh_index_search_device(self.handle, queries.data_ptr(), nq, k, ids.data_ptr(), dist.data_ptr(),
+                                                  counts.data_ptr(), C.c_void_p(st)))
+        return ids, dist, counts
+
+    # -- tombstones (vamana.rs:813-850) ------------------------------------------------------------------
+    def mark_deleted(self, vector_id):
+        ok = C.c_int()
+        L.check(L.lib().shodh_index_mark_deleted(self.handle, int(vector_id), C.byref(ok)))
+        return bool(ok.value)
+
+    def is_deleted(self, vector_id):
+        return bool(L.lib().shodh_index_is_deleted(self.handle, int(vector_id)))
+
+    def deleted_count(self):
+        return int(L.lib().shodh_index_deleted_count(self.handle))
+
+    def deletion_ratio(self):
+        return float(L.lib().shodh_index_deletion_ratio(self.handle))
+
+    def needs_compaction(self):
+        return bool(L.lib().shodh_index_needs_compaction(self.handle))
+
+    def clear_deleted(self):
+        L.check(L.lib().shodh_index_clear_deleted(self.handle))
+
+    # -- rebuild bookkeeping (vamana.rs:1190-1340): the flat index never degrades -------------------------
+    def needs_rebuild(self):
+        return self._incremental >= REBUILD_THRESHOLD or self.needs_compaction()
+
+    def incremental_insert_count(self):
+        return self._incremental
+
+    def reset_incremental_counter(self):
+        self._incremental = 0
+
+    def is_rebuilding(self):
+        return False
+
+    def auto_rebuild_if_needed(self):
+        """Compacts tombstoned rows away when the reference would rebuild. Returns True if it did."""
+        if not self.needs_rebuild():
+            return False
+        live = self.extract_live_vectors()
+        self.build(live)
+        return True
+
+    # -- extraction (retrieval.rs:2504-2516: rows come back bit-for-bit) -----------------------------------
+    def extract_all_vectors(self):
+        n = self.len()
+        out = np.empty((n, self._hd.dim), np.float32)
+        if n:
+            L.check(L.lib().shodh_index_extract_rows(self.handle, 0, n, out.ctypes.data))
+        return out
+
+    def extract_live_vectors(self):
+        n = C.c_uint64()
+        L.check(L.lib().shodh_index_extract_live_rows(self.handle, None, None, 0, C.byref(n)))
+        out = np.empty((n.value, self._hd.dim), np.float32)
+        if n.value:
+            L.check(L.lib().shodh_index_extract_live_rows(self.handle, out.ctypes.data, None, n.value, C.byref(n)))
+        return out
+
+    # -- diagnostics -------------------------------------------------------------------------------------------
+    def stage_timings_us(self):
+        a = (C.c_float * 4)()
+        L.check(L.lib().shodh_index_stage_timings(self.handle, C.byref(a)))
+        return dict(scan=a[0], select=a[1], other=a[2], total=a[3])
+
+    def kernel_timing(self, reset=True):
+        """(mean_us, min_us, count) of the dominant scan kernel since the last reset; synchronise first."""
+        m, mn, c = C.c_float(), C.c_float(), C.c_uint32()
+        L.check(L.lib().shodh_index_kernel_timing(self.handle, int(reset), C.byref(m), C.byref(mn), C.byref(c)))
+        return m.value, mn.value, c.value
+
+    def scan_stats(self):
+        a = (C.c_uint64 * 4)()
+        L.check(L.lib().shodh_index_scan_stats(self.handle, C.byref(a)))
+        return dict(sampled_rows=a[0], emitted=a[1], rescored=a[2], overflowed=a[3])
+
+
+class SpannIndex:
+    """IVF-PQ index with the SpannIndex method set (src/vector_db/spann.rs), given trained state."""
+
+    def __init__(self, dimension=384, num_probes=10, distance_metric=DistanceMetric.NormalizedDotProduct, device=0):
+        cfg = L.IndexCfg()
+        L.lib().shodh_index_cfg_default(C.byref(cfg))
+        cfg.dim = dimension
+        cfg.metric = distance_metric.value
+        cfg.kind = L.INDEX_IVFPQ
+        cfg.device = device
+        cfg.nprobe = num_probes
+        self._hd = _Handle(cfg)
+        self._n = 0
+        self.num_probes = num_probes
+
+    @property
+    def handle(self):
+        return self._hd._h
+
+    def close(self):
+        self._hd.close()
+
+    def len(self):
+        return self._n
+
+    def is_empty(self):
+        return self._n == 0
+
+    def set_trained_state(self, centroids, codebook, list_off, ids, codes):
+        c = np.ascontiguousarray(centroids, np.float32)
+        cb = np.ascontiguousarray(codebook, np.float32)
+        lo = np.ascontiguousarray(list_off, np.uint64)
+        i = np.ascontiguousarray(ids, np.uint32)
+        cd = np.ascontiguousarray(codes, np.uint8)
+        M, ncent, sub = cb.shape
+        assert sub == 8
+        L.check(L.lib().shodh_index_set_ivfpq(self.handle, c.ctypes.data, c.shape[0], cb.ctypes.data, M, ncent,
+                                              lo.ctypes.data, i.ctypes.data, cd.ctypes.data))
+        self._n = int(i.size)
+
+    def insert(self, vector_id, vector):
+        v = _as_rows(vector, self._hd.dim)
+        L.check(L.lib().shodh_index_ivfpq_insert(self.handle, int(vector_id), v.ctypes.data))
+        self._n += 1
+
+    def encode(self, vectors):
+        v = _as_rows(vectors, self._hd.dim)
+        assign = np.zeros(v.shape[0], np.uint32)
+        codes = np.zeros((v.shape[0], self._hd.dim // 8), np.uint8)
+        L.check(L.lib().shodh_index_ivfpq_encode(self.handle, v.ctypes.data, v.shape[0], assign.ctypes.data, codes.ctypes.data))
+        return assign, codes
+
+    def search(self, query, k):
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self._hd.dim:
+            raise L.ShodhError(L.ERR_DIM, "Query dimension %d doesn't match index dimension %d" % (q.size, self._hd.dim))
+        ids, dist, counts = self.search_batch(q.reshape(1, -1), k)
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(counts[0]))]
+
+    def search_batch(self, queries, k):
+        q = _as_rows(queries, self._hd.dim)
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        L.check(L.lib().shodh_index_search(self.handle, q.ctypes.data, nq, k, ids.ctypes.data, dist.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], dist[:, :k], counts
+
+
+class VectorIndexBackend:
+    """vector_db/mod.rs:98-266 facade."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    @classmethod
+    def auto(cls, config: BackendConfig, expected_vectors: int):
+        bt = config.force_backend or (BackendType.Spann if expected_vectors >= SPANN_AUTO_THRESHOLD else BackendType.Vamana)
+        return cls.new_vamana(config) if bt == BackendType.Vamana else cls.new_spann(config)
+
+    @classmethod
+    def new_vamana(cls, config: BackendConfig):
+        return cls(VamanaIndex(VamanaConfig(dimension=config.dimension, max_degree=config.vamana_max_degree,
+                                            search_list_size=config.vamana_search_list_size,
+                                            distance_metric=config.distance_metric, device=config.device)))
+
+    @classmethod
+    def new_spann(cls, config: BackendConfig):
+        if not config.use_pq:
+            raise L.ShodhError(L.ERR_STATE, "SPANN requires PQ (use_pq=true): posting lists store only PQ codes")
+        return cls(SpannIndex(config.dimension, config.spann_probes, config.distance_metric, config.device))
+
+    def backend_type(self):
+        return BackendType.Vamana if isinstance(self.inner, VamanaIndex) else BackendType.Spann
+
+    def add_vector(self, vector):
+        if isinstance(self.inner, VamanaIndex):
+            return self.inner.add_vector(vector)
+        vid = self.inner.len()
+        self.inner.insert(vid, vector)
+        return vid
+
+    def search(self, query, k):
+        return self.inner.search(query, k)
+
+    def len(self):
+        return self.inner.len()
+
+    def is_empty(self):
+        return self.len() == 0
+
+    def build(self, vectors):
+        return self.inner.build(vectors)
+
+    def needs_rebuild(self):
+        return self.inner.needs_rebuild() if isinstance(self.inner, VamanaIndex) else False
+
+    def auto_rebuild_if_needed(self):
+        return self.inner.auto_rebuild_if_needed() if isinstance(self.inner, VamanaIndex) else False
+
+    def incremental_insert_count(self):
+        return self.inner.incremental_insert_count() if isinstance(self.inner, VamanaIndex) else 0
+
+    def deleted_count(self):
+        return self.inner.deleted_count() if isinstance(self.inner, VamanaIndex) else 0
+
+    def deletion_ratio(self):
+        return self.inner.deletion_ratio() if isinstance(self.inner, VamanaIndex) else 0.0
+
+    def needs_compaction(self):
+        return self.inner.needs_compaction() if isinstance(self.inner, VamanaIndex) else False
