@@ -6,6 +6,16 @@ fails loudly. The oracle (oracle/) is never imported from here.
 import ctypes as C
 import os
 
+# PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and load them by path. A
+# process must not initialise two HIP runtimes (the second one finds no device), so when torch is
+# installed it is imported FIRST: libshodh_hip.so (DT_NEEDED libamdhip64.so.7) then binds to the
+# runtime already in the process. Without torch the library binds to /opt/rocm/lib as usual. The
+# C library itself has no torch dependency.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:          # standalone use from C/C++/Rust or a torch-free python
+    _torch = None
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libshodh_hip.so")
 

@@ -62,4 +62,7 @@ static inline uint32_t next_pow2(uint32_t v) {
 }
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// raises a kernel's dynamic-LDS limit once (hipFuncSetAttribute costs host time on every call)
+int ensure_dynamic_lds(const void *fn, size_t bytes);
+
 }  // namespace shodh

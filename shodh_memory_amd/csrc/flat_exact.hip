@@ -274,32 +274,22 @@ struct MergeArgs {
 __global__ __launch_bounds__(EX_NT) void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *thr = keys + a.cap;
+    uint64_t *mins = keys + a.cap;
+    uint64_t *thr = mins + EX_NT;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;
     const uint32_t nq_eff = a.qcount ? *a.qcount : a.nq;
     if (slot >= nq_eff) return;
     const uint32_t q = a.qlist ? a.qlist[slot] : slot;
-    if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
-    __syncthreads();
     TopKBuf buf{keys, cnt, thr, a.cap, a.k};
     const uint32_t y = slot / a.qb, qi = slot % a.qb;
     const uint64_t total = (uint64_t)a.nlists * a.k;
-    const uint64_t n_iter = (total + EX_NT - 1) / EX_NT;
-    for (uint64_t it = 0; it < n_iter; ++it) {
-        const uint64_t e = it * EX_NT + tid;
-        if (e < total) {
-            const uint64_t l = e / a.k, i = e % a.k;
-            const uint64_t key = a.lists[((((uint64_t)y * a.nlists + l) * a.qb) + qi) * a.k + i];
-            if (key != KEY_NONE) topk_push(buf, key);
-        }
-        __syncthreads();
-        if (*buf.cnt + EX_NT > a.cap) topk_compact<EX_NT>(buf);
-    }
-    __syncthreads();
-    topk_compact<EX_NT>(buf);
-    const uint32_t m = *buf.cnt;
+    auto key_at = [&](uint64_t e) -> uint64_t {
+        const uint64_t l = e / a.k, i = e % a.k;
+        return a.lists[((((uint64_t)y * a.nlists + l) * a.qb) + qi) * a.k + i];
+    };
+    const uint32_t m = block_select_topk<EX_NT>(key_at, total, buf, mins);
     for (uint32_t i = tid; i < a.k; i += EX_NT) {
         if (i < m) {
             const uint64_t key = buf.keys[i];
@@ -326,29 +316,20 @@ struct MergeListsArgs {
 __global__ __launch_bounds__(EX_NT) void merge_lists_kernel(MergeListsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *thr = keys + a.cap;
+    uint64_t *mins = keys + a.cap;
+    uint64_t *thr = mins + EX_NT;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
-    __syncthreads();
     TopKBuf buf{keys, cnt, thr, a.cap, a.k};
     const uint64_t total = (uint64_t)a.n_lists * a.k;
-    const uint64_t n_iter = (total + EX_NT - 1) / EX_NT;
-    for (uint64_t it = 0; it < n_iter; ++it) {
-        const uint64_t e = it * EX_NT + tid;
-        if (e < total) {
-            const uint64_t l = e / a.k, i = e % a.k;
-            const size_t off = ((size_t)l * a.nq + q) * a.k + i;
-            const uint32_t id = a.in_ids[off];
-            if (id != 0xFFFFFFFFu) topk_push(buf, make_key(a.in_dist[off], id));
-        }
-        __syncthreads();
-        if (*buf.cnt + EX_NT > a.cap) topk_compact<EX_NT>(buf);
-    }
-    __syncthreads();
-    topk_compact<EX_NT>(buf);
-    const uint32_t m = *buf.cnt;
+    auto key_at = [&](uint64_t e) -> uint64_t {
+        const uint64_t l = e / a.k, i = e % a.k;
+        const size_t off = ((size_t)l * a.nq + q) * a.k + i;
+        const uint32_t id = a.in_ids[off];
+        return id == 0xFFFFFFFFu ? KEY_NONE : make_key(a.in_dist[off], id);
+    };
+    const uint32_t m = block_select_topk<EX_NT>(key_at, total, buf, mins);
     for (uint32_t i = tid; i < a.k; i += EX_NT) {
         if (i < m) {
             const uint64_t key = buf.keys[i];
@@ -401,10 +382,10 @@ uint32_t exact_grid_x(uint64_t n_rows, uint32_t nq, uint32_t k, int cus) {
 template <int QB>
 static int launch_fast(const ExactArgs &a, uint32_t order, dim3 grid, size_t lds, hipStream_t st) {
     if (order == SHODH_ORDER_AVX2) {
-        if (lds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)flat_exact_kernel<QB, SHODH_ORDER_AVX2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, SHODH_ORDER_AVX2>, lds));
         hipLaunchKernelGGL((flat_exact_kernel<QB, SHODH_ORDER_AVX2>), grid, dim3(EX_NT), lds, st, a);
     } else {
-        if (lds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)flat_exact_kernel<QB, SHODH_ORDER_SCALAR4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, SHODH_ORDER_SCALAR4>, lds));
         hipLaunchKernelGGL((flat_exact_kernel<QB, SHODH_ORDER_SCALAR4>), grid, dim3(EX_NT), lds, st, a);
     }
     SHODH_HIP_TRY(hipGetLastError());
@@ -443,17 +424,17 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
         const size_t lds = (size_t)((dim + 3) & ~3u) * 4 + (size_t)cap * 8 + 8 + 4 + 16;
         if (lds > 160 * 1024) { set_error("dim/k too large for the generic exact scan"); return SHODH_ERR_UNSUPPORTED; }
         if (order == SHODH_ORDER_AVX2) {
-            if (lds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)flat_exact_generic_kernel<SHODH_ORDER_AVX2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_generic_kernel<SHODH_ORDER_AVX2>, lds));
             hipLaunchKernelGGL((flat_exact_generic_kernel<SHODH_ORDER_AVX2>), grid, dim3(EX_NT), lds, st, a);
         } else {
-            if (lds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)flat_exact_generic_kernel<SHODH_ORDER_SCALAR4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_generic_kernel<SHODH_ORDER_SCALAR4>, lds));
             hipLaunchKernelGGL((flat_exact_generic_kernel<SHODH_ORDER_SCALAR4>), grid, dim3(EX_NT), lds, st, a);
         }
         SHODH_HIP_TRY(hipGetLastError());
     }
     MergeArgs m{partial, grid_x, (uint32_t)qb, k, cap, nq, d_ids, d_dist, d_counts, qlist, qcount};
-    const size_t mlds = (size_t)cap * 8 + 8 + 4 + 16;
-    if (mlds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    const size_t mlds = (size_t)cap * 8 + EX_NT * 8 + 8 + 4 + 16;
+    SHODH_TRY(ensure_dynamic_lds((const void *)merge_topk_kernel, mlds));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(EX_NT), mlds, st, m);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
@@ -464,8 +445,8 @@ int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint32_t n_
     if (nq == 0) return SHODH_OK;
     const uint32_t cap = topk_capacity(k);
     MergeListsArgs a{in_ids, in_dist, n_lists, nq, k, cap, ids, dist, counts};
-    const size_t lds = (size_t)cap * 8 + 8 + 4 + 16;
-    if (lds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)merge_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)cap * 8 + EX_NT * 8 + 8 + 4 + 16;
+    SHODH_TRY(ensure_dynamic_lds((const void *)merge_lists_kernel, lds));
     hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(EX_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;

@@ -28,6 +28,22 @@ void set_error(const char *fmt, ...) {
     g_err = buf;
 }
 
+int ensure_dynamic_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, size_t>> seen;
+    std::lock_guard<std::mutex> g(mu);
+    for (auto &e : seen)
+        if (e.first == fn) {
+            if (e.second >= bytes) return SHODH_OK;
+            SHODH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            e.second = bytes;
+            return SHODH_OK;
+        }
+    SHODH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    seen.emplace_back(fn, bytes);
+    return SHODH_OK;
+}
+
 // ---- kernels living in other translation units ---------------------------------------------------
 uint32_t topk_capacity(uint32_t k);
 size_t exact_partial_bytes(uint32_t nq, uint32_t dim, uint32_t k, uint32_t grid_x);

@@ -25,6 +25,8 @@
 //
 // Thresholds come from a 1/32 strided sample of the tiles (same kernel, BLOCKMAX epilogue): the
 // k-th largest of the per-16-row maxima is a valid lower bound of the k-th best score.
+#include <cstdlib>
+
 #include "common.h"
 #include "topk.h"
 
@@ -36,7 +38,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_NT = 512;
+constexpr int MF_EQ_CAP = 2048;   // LDS emit-queue entries per workgroup
 constexpr int MF_TR = 64;        // corpus rows per tile
 constexpr int MF_BPAD = 256;     // queries per pass
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
@@ -57,16 +59,25 @@ struct MfmaArgs {
     float *blockmax;          // [passes][J][256], J = n_sel_tiles * 4
     uint32_t tile_stride;     // tile index = sel * tile_stride
     uint32_t n_sel_tiles;
+    uint32_t ablate;          // diagnostics only (SHODH_ABLATE): 1 = skip the MFMA phase, 2 = skip the HBM loads
 };
 
-template <int MODE, int KSTEPS>
-__global__ __launch_bounds__(MF_NT, 2) void mfma_scan_kernel(MfmaArgs a) {
+// QB = 32-query blocks per wave: QB=1 -> 8 waves (2 per SIMD, 256 registers each), QB=2 -> 4 waves
+// (1 per SIMD, 512 registers each; every A fragment read from LDS feeds two MFMAs).
+template <int MODE, int KSTEPS, int QB>
+__global__ __launch_bounds__(512 / QB, 2 / QB) void mfma_scan_kernel(MfmaArgs a) {
+    constexpr int NT = 512 / QB;
     constexpr int DIM = KSTEPS * 16;
     constexpr int CPR = KSTEPS * 2;          // 16-B chunks per row
     constexpr int PITCH = DIM * 2;           // bytes per row in LDS
-    constexpr int CPT = KSTEPS / 4;          // chunks per thread per tile
+    constexpr int CPT = MF_TR * CPR / NT;    // chunks per thread per tile
     constexpr int TILE_BYTES = MF_TR * PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: [2 tiles][emit queue: MF_EQ_CAP x (key u64, query u32)][queue counter]
+    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + 2 * TILE_BYTES);
+    uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
+    uint32_t *eq_cnt = eq_q + MF_EQ_CAP;
+    uint32_t *eq_flag = eq_cnt + 1;          // [2] double-buffered "flush now" decision (block-uniform)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,26 +85,28 @@ __global__ __launch_bounds__(MF_NT, 2) void mfma_scan_kernel(MfmaArgs a) {
     const int hi = lane >> 5;
     const int l31 = lane & 31;
     const uint32_t pass = blockIdx.y;
-    const uint32_t q_local = wave * 32 + l31;      // this lane's query within the pass
+    const uint32_t q_base = wave * 32 * QB + l31;       // this lane's queries within the pass: q_base + 32*qb
+    if (tid == 0) *eq_cnt = 0;
 
-    // resident B fragments: query q_local, k = ks*16 + hi*8 .. +8
-    half8 bq[KSTEPS];
-    {
-        const _Float16 *qp = a.q_h + ((size_t)pass * MF_BPAD + q_local) * DIM + hi * 8;
+    // resident B fragments: query q_base + 32*qb, k = ks*16 + hi*8 .. +8
+    half8 bq[QB][KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) bq[ks] = *reinterpret_cast<const half8 *>(qp + ks * 16);
+    for (int qb = 0; qb < QB; ++qb) {
+        const _Float16 *qp = a.q_h + ((size_t)pass * MF_BPAD + q_base + 32 * qb) * DIM + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bq[qb][ks] = *reinterpret_cast<const half8 *>(qp + ks * 16);
     }
-    float thr_l = 0.0f;
-    if (MODE == MF_MODE_EMIT) thr_l = a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE);
+    float thr_l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+        thr_l[qb] = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_base + 32 * qb] * (MF_SCALE * MF_SCALE) : 0.0f;
 
-    const uint64_t n_tiles_total = (a.n_rows + MF_TR - 1) / MF_TR;
-    (void)n_tiles_total;
     u32x4 pre[CPT];
     auto prefetch = [&](uint32_t sel) {
         const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int S = i * MF_NT + tid;
+            const int S = i * NT + tid;
             const int row = S / CPR, c = S % CPR;
             uint64_t r = row0 + row;
             if (r >= a.n_rows) r = a.n_rows - 1;
@@ -103,78 +116,154 @@ __global__ __launch_bounds__(MF_NT, 2) void mfma_scan_kernel(MfmaArgs a) {
     auto stage = [&](unsigned char *buf) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int S = i * MF_NT + tid;
+            const int S = i * NT + tid;
             const int row = S / CPR, c = S % CPR;
             *reinterpret_cast<u32x4 *>(buf + row * PITCH + ((c ^ (row & 15)) << 4)) = pre[i];
         }
+    };
+    // drains the LDS emit queue into the per-query candidate lists (global atomics). Called by the
+    // whole block at points where no prefetch is in flight, so its vmcnt waits cost only themselves.
+    bool eq_overflowed = false;              // block-uniform: entries were dropped at some point
+    auto flush = [&]() {                     // caller: __syncthreads() before, and after before the next push
+        const uint32_t raw = *eq_cnt;
+        eq_overflowed |= raw > (uint32_t)MF_EQ_CAP;
+        const uint32_t n = raw < (uint32_t)MF_EQ_CAP ? raw : (uint32_t)MF_EQ_CAP;
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t key = eq_key[i];
+            const uint32_t row = (uint32_t)key;
+            if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) continue;   // tombstoned (vamana.rs:1175-1177)
+            const size_t qi = (size_t)pass * MF_BPAD + eq_q[i];
+            const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
+            if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
+        }
+        __syncthreads();
+        if (tid == 0) *eq_cnt = 0;
     };
 
     uint32_t sel = blockIdx.x;
     if (sel < a.n_sel_tiles) prefetch(sel);
     if (sel < a.n_sel_tiles) stage(smem);
+    // Everything issued so far (query fragments, thresholds, first tile) must have landed before
+    // the stream starts: otherwise hipcc re-waits for the fragment loads INSIDE the loop with
+    // counted vmcnt(N), which in steady state drains the next tile's prefetch half-way through
+    // the MFMA chain and exposes the HBM latency on every tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    // LDS byte offsets of this lane's A fragments. chunk c = 2*ks + hi; swizzled chunk = c ^ (row&15)
+    // = (c & ~15) | ((c & 15) ^ sw): only 8 distinct low parts per lane, the rest is an immediate.
+    const int sw = l31 & 15;
+    int aoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4);
     int cur = 0;
     for (; sel < a.n_sel_tiles; sel += gridDim.x) {
         const uint32_t nxt = sel + gridDim.x;
         const bool has_next = nxt < a.n_sel_tiles;
-        if (has_next) prefetch(nxt);
+        if (has_next && !(a.ablate & 2)) prefetch(nxt);
         const unsigned char *buf = smem + cur * TILE_BYTES;
         const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
+        floatx16 acc[2][QB];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][qb][r] = 0.0f;
+        if (!(a.ablate & 1)) {
+            // A fragments are read from LDS one group (GS k-steps, 2*GS reads) ahead of the MFMAs that
+            // consume them, in two register sets. Left alone hipcc issues each read right before its
+            // MFMA and the chain runs at LDS latency.
+            constexpr int GS = 2;
+            constexpr int NG = KSTEPS / GS;
+            half8 fa[2][GS][2];
+            auto load_group = [&](int slot, int g) {
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const int ks = g * GS + j;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        fa[slot][j][rb] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
+                }
+            };
+            load_group(0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group((g + 1) & 1, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GS; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            acc[rb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][j][rb], bq[qb][g * GS + j], acc[rb][qb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // C layout (32x32): col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            floatx16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const int row = rb * 32 + l31;
-            const unsigned char *rowp = buf + row * PITCH;
-            const int sw = row & 15;
+            for (int qb = 0; qb < QB; ++qb) {
+                const floatx16 &c = acc[rb][qb];
+                const uint32_t q_local = q_base + 32 * qb;
+                if (MODE == MF_MODE_EMIT) {
+                    float m = c[0];
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const half8 av = *reinterpret_cast<const half8 *>(rowp + (((ks * 2 + hi) ^ sw) << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[ks], acc, 0, 0, 0);
-            }
-            // C layout (32x32): col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            if (MODE == MF_MODE_EMIT) {
-                float m = acc[0];
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
+                    if (m >= thr_l[qb]) {
+                        // rare: survivors go to the workgroup's LDS queue (LDS atomic, no HBM round trip)
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                if (m >= thr_l) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[r] >= thr_l) {
-                            const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            bool live = grow < a.n_rows;
-                            if (live && a.deleted) live = ((a.deleted[grow >> 5] >> (grow & 31)) & 1u) == 0;
-                            if (live) {
-                                const size_t qi = (size_t)pass * MF_BPAD + q_local;
-                                const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
-                                if (slot < a.cand_cap)
-                                    a.cand[qi * a.cand_cap + slot] = make_key(-(acc[r] * MF_INV_SCALE2), (uint32_t)grow);
+                        for (int r = 0; r < 16; ++r) {
+                            if (c[r] >= thr_l[qb]) {
+                                const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                if (grow < a.n_rows) {
+                                    const uint32_t slot = atomicAdd(eq_cnt, 1u);
+                                    if (slot < (uint32_t)MF_EQ_CAP) {
+                                        eq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)grow);
+                                        eq_q[slot] = q_local;
+                                    }
+                                }
                             }
                         }
                     }
-                }
-            } else {
-                float m;
-                if (tile_row0 + MF_TR <= a.n_rows) {
-                    m = acc[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
                 } else {
-                    m = -__builtin_inff();
+                    float m;
+                    if (tile_row0 + MF_TR <= a.n_rows) {
+                        m = c[0];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (grow < a.n_rows) m = fmaxf(m, acc[r]);
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
+                    } else {
+                        m = -__builtin_inff();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (grow < a.n_rows) m = fmaxf(m, c[r]);
+                        }
                     }
+                    const size_t j = ((size_t)sel * 2 + rb) * 2 + hi;
+                    a.blockmax[((size_t)pass * a.n_sel_tiles * 4 + j) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
                 }
-                const size_t j = ((size_t)sel * 2 + rb) * 2 + hi;
-                a.blockmax[((size_t)pass * a.n_sel_tiles * 4 + j) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
             }
         }
         if (has_next) stage(smem + (cur ^ 1) * TILE_BYTES);
+        // Flush the queue early when it is half full. The decision must be block-uniform: thread 0
+        // snapshots it into a double-buffered flag BEFORE the barrier, everyone reads that slot after it
+        // (the slot is rewritten two barriers later). A stale (low) count only delays the flush;
+        // dropped entries are detected by the counter itself (eq_overflowed).
+        if (MODE == MF_MODE_EMIT && tid == 0) eq_flag[cur] = (*eq_cnt > (uint32_t)MF_EQ_CAP / 2) ? 1u : 0u;
         __syncthreads();
+        if (MODE == MF_MODE_EMIT) {
+            if (eq_flag[cur]) { flush(); __syncthreads(); }
+        }
         cur ^= 1;
+    }
+    if (MODE == MF_MODE_EMIT) {
+        __syncthreads();
+        flush();
+        // entries were dropped somewhere: poison every list of this pass so that the final stage sends
+        // those queries to the exact scan (adversarial inputs only, e.g. thousands of identical rows)
+        if (eq_overflowed && tid < MF_BPAD) atomicAdd(a.cand_cnt + (size_t)pass * MF_BPAD + tid, a.cand_cap + 1u);
     }
 }
 
@@ -290,7 +379,8 @@ struct ThrArgs {
 __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *thr = keys + a.cap;
+    uint64_t *mins = keys + a.cap;
+    uint64_t *thr = mins + 256;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;            // pass*256 + q
@@ -301,24 +391,14 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
         return;
     }
-    if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
-    __syncthreads();
     TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-    const uint32_t n_iter = (a.J + 255) / 256;
-    for (uint32_t it = 0; it < n_iter; ++it) {
-        const uint32_t j = it * 256 + tid;
-        if (j < a.J) {
-            const float v = a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql];
-            topk_push(buf, make_key(-v, j));
-        }
-        __syncthreads();
-        if (*buf.cnt + 256 > a.cap) topk_compact<256>(buf);
-    }
-    __syncthreads();
-    topk_compact<256>(buf);
+    auto key_at = [&](uint64_t j) -> uint64_t {
+        return make_key(-a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql], (uint32_t)j);
+    };
+    const uint32_t m = block_select_topk<256>(key_at, a.J, buf, mins);
     if (tid == 0) {
         float t = -__builtin_inff();
-        if (*buf.cnt == a.k && a.k > 0) {
+        if (m == a.k && a.k > 0) {
             const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
             // a positive k-th block max is backed by k LIVE rows (tombstoned rows score exactly 0)
             if (kth > 0.0f) t = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth));
@@ -389,8 +469,10 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);                          // [dim]
     uint64_t *keys = reinterpret_cast<uint64_t *>(qs + a.dim);            // [cap]
-    uint64_t *thr = keys + a.cap;
-    uint32_t *flist = reinterpret_cast<uint32_t *>(thr + 1);              // [fcap]
+    uint64_t *mins = keys + a.cap;                                        // [256]
+    uint64_t *ekeys = mins + 256;                                         // [fcap] exact keys of the window
+    uint64_t *thr = ekeys + a.fcap;
+    uint32_t *flist = reinterpret_cast<uint32_t *>(thr + 1);              // [fcap] rows of the window
     uint32_t *cnt = flist + a.fcap;
     uint32_t *fcnt = cnt + 1;
     const int tid = threadIdx.x;
@@ -400,59 +482,40 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     bool bad = a.fallback[q] != 0 || n > a.cand_cap;
     if (!bad) {
         for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
-        if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; *fcnt = 0; }
-        __syncthreads();
+        if (tid == 0) *fcnt = 0;
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
         const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
-        const uint32_t n_iter = (n + 255) / 256;
         // pass A: k-th best approximate score
-        for (uint32_t it = 0; it < n_iter; ++it) {
-            const uint32_t i = it * 256 + tid;
-            if (i < n) topk_push(buf, list[i]);
-            __syncthreads();
-            if (*buf.cnt + 256 > a.cap) topk_compact<256>(buf);
-        }
-        __syncthreads();
-        topk_compact<256>(buf);
+        auto key_a = [&](uint64_t i) -> uint64_t { return list[i]; };
+        const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
         // window: every candidate with s~ >= kth - 2 eps (all of them if fewer than k exist)
         float lo = -__builtin_inff();
-        if (*buf.cnt == a.k && a.k > 0) {
+        if (ma == a.k && a.k > 0) {
             const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
             lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
         }
         __syncthreads();
-        for (uint32_t it = 0; it < n_iter; ++it) {
-            const uint32_t i = it * 256 + tid;
-            if (i < n) {
-                const uint64_t key = list[i];
-                const float s = -order_key_inv((uint32_t)(key >> 32));
-                if (s >= lo) {
-                    const uint32_t slot = atomicAdd(fcnt, 1u);
-                    if (slot < a.fcap) flist[slot] = (uint32_t)key;
-                }
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t key = list[i];
+            const float s = -order_key_inv((uint32_t)(key >> 32));
+            if (s >= lo) {
+                const uint32_t slot = atomicAdd(fcnt, 1u);
+                if (slot < a.fcap) flist[slot] = (uint32_t)key;
             }
         }
         __syncthreads();
         const uint32_t nf = *fcnt;
         if (nf > a.fcap) bad = true;       // block-uniform
         if (!bad) {
-            // pass B: exact reference-order scores of the window, top-k by (dist, id)
-            if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
-            __syncthreads();
-            const uint32_t f_iter = (nf + 255) / 256;
-            for (uint32_t it = 0; it < f_iter; ++it) {
-                const uint32_t i = it * 256 + tid;
-                if (i < nf) {
-                    const uint32_t row = flist[i];
-                    const float dot = exact_dot_row<ORDER>(qs, a.rows + (size_t)row * a.dim, a.dim);
-                    topk_push(buf, make_key(-dot, a.id_base + row));
-                }
-                __syncthreads();
-                if (*buf.cnt + 256 > a.cap) topk_compact<256>(buf);
+            // pass B: exact reference-order scores of the window, then top-k by (dist, id)
+            for (uint32_t i = tid; i < nf; i += 256) {
+                const uint32_t row = flist[i];
+                const float dot = exact_dot_row<ORDER>(qs, a.rows + (size_t)row * a.dim, a.dim);
+                ekeys[i] = make_key(-dot, a.id_base + row);
             }
             __syncthreads();
-            topk_compact<256>(buf);
-            const uint32_t m = *buf.cnt;
+            auto key_b = [&](uint64_t i) -> uint64_t { return ekeys[i]; };
+            const uint32_t m = block_select_topk<256>(key_b, nf, buf, mins);
             for (uint32_t i = tid; i < a.k; i += 256) {
                 if (i < m) {
                     const uint64_t key = buf.keys[i];
@@ -497,8 +560,9 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     p.n_slots = p.passes * MF_BPAD;
     p.ksteps = dim / 16;
     p.n_tiles = ceil_div(n_rows, MF_TR);
-    // sample: every 32nd tile, but at least 2k block maxima (4 per tile) and at least 64 tiles
-    uint64_t want = p.n_tiles / 32;
+    // sample: every S-th tile (S = 16 unless SHODH_SAMPLE_STRIDE; measured: 32 -> 463, 16 -> 265, 8 -> 150 candidates/query at 1M), but at least 2k block maxima (4 per tile) and 64 tiles
+    static const uint32_t sample_stride = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 16u;
+    uint64_t want = p.n_tiles / (sample_stride ? sample_stride : 16u);
     const uint64_t min_tiles = (uint64_t)k / 2 + 64;
     if (want < min_tiles) want = min_tiles;
     if (want > p.n_tiles) want = p.n_tiles;
@@ -541,14 +605,19 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[11]
 
 template <int MODE>
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st) {
-    const size_t lds = 2ull * MF_TR * a.dim * 2;
+    const size_t lds = 2ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
     if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
+    static const int qb_env = getenv("SHODH_MFMA_QB") ? atoi(getenv("SHODH_MFMA_QB")) : 1;
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
     case KS:                                                                                                       \
-        SHODH_HIP_TRY(hipFuncSetAttribute((const void *)mfma_scan_kernel<MODE, KS>,                                 \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS>), grid, dim3(MF_NT), lds, st, a);                            \
+        if (qb_env == 2) {                                                                                         \
+            SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS, 2>, lds));                        \
+            hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS, 2>), grid, dim3(256), lds, st, a);                       \
+        } else {                                                                                                   \
+            SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS, 1>, lds));                        \
+            hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS, 1>), grid, dim3(512), lds, st, a);                       \
+        }                                                                                                          \
         break;
     switch (p.ksteps) {
         SHODH_LAUNCH_KS(8)
@@ -580,7 +649,8 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
     SHODH_HIP_TRY(hipGetLastError());
 
-    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles};
+    static const uint32_t ablate = getenv("SHODH_ABLATE") ? (uint32_t)atoi(getenv("SHODH_ABLATE")) : 0u;
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u};
     SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
 
     // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
@@ -588,13 +658,14 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     const float eps_rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
     const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f;
     ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps};
-    const size_t tlds = (size_t)p.topk_cap * 8 + 8 + 4 + 16;
-    if (tlds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    const size_t tlds = (size_t)p.topk_cap * 8 + 256 * 8 + 8 + 4 + 16;
+    SHODH_TRY(ensure_dynamic_lds((const void *)threshold_kernel, tlds));
     hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), tlds, st, t);
     SHODH_HIP_TRY(hipGetLastError());
 
     a.tile_stride = 1;
     a.n_sel_tiles = (uint32_t)p.n_tiles;
+    a.ablate = ablate;
     if (ev_emit0) SHODH_HIP_TRY(hipEventRecord(ev_emit0, st));
     SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st));
     if (ev_emit1) SHODH_HIP_TRY(hipEventRecord(ev_emit1, st));
@@ -602,12 +673,12 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 
     FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.cand, w.cand_cnt, p.cand_cap, w.eps, p.fcap, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
-    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 8 + (size_t)p.fcap * 4 + 8 + 16;
+    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 256 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 + 16;
     if (order == SHODH_ORDER_AVX2) {
-        if (flds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_AVX2>), dim3(nq), dim3(256), flds, st, f);
     } else {
-        if (flds > 48 * 1024) SHODH_HIP_TRY(hipFuncSetAttribute((const void *)final_stage_kernel<SHODH_ORDER_SCALAR4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_SCALAR4>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SCALAR4>), dim3(nq), dim3(256), flds, st, f);
     }
     SHODH_HIP_TRY(hipGetLastError());

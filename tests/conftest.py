@@ -4,6 +4,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:
+    import torch  # noqa: F401  must precede libshodh_hip.so: one HIP runtime per process
+except ImportError:
+    pass
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
