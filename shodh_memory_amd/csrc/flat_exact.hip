@@ -24,6 +24,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int EX_NT = 256;            // threads per block (4 waves)
 constexpr int EX_CHUNK = 32;          // floats of a row staged per step (one 128-B line)
 constexpr int EX_PITCH = EX_CHUNK + 4;  // LDS row pitch in floats
+// scoring op of the exact kernels: 0/1 = -dot in SHODH_ORDER_SCALAR4 / SHODH_ORDER_AVX2 order (flat index),
+// 2/3 = SpannIndex::compute_distance (strictly sequential sums): 1 - dot, squared L2
+constexpr int EX_OP_SEQ_ONE_MINUS_DOT = 2;
+constexpr int EX_OP_SEQ_L2 = 3;
 
 struct ExactArgs {
     const float *rows;
@@ -138,6 +142,27 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
                             t = t + w.w * v[g].w;
                             s[q] = s[q] + t;
                         }
+                    } else if (ORDER == EX_OP_SEQ_ONE_MINUS_DOT) {
+                        // spann.rs:566-568: a.iter().zip(b).map(|(x, y)| x * y).sum()  (strictly sequential)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            f32x4 w = *reinterpret_cast<const f32x4 *>(qp + g * 4);
+                            s[q] = s[q] + w.x * v[g].x;
+                            s[q] = s[q] + w.y * v[g].y;
+                            s[q] = s[q] + w.z * v[g].z;
+                            s[q] = s[q] + w.w * v[g].w;
+                        }
+                    } else if (ORDER == EX_OP_SEQ_L2) {
+                        // spann.rs:564: map(|(x, y)| (x - y).powi(2)).sum()
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            f32x4 w = *reinterpret_cast<const f32x4 *>(qp + g * 4);
+                            float d0 = w.x - v[g].x, d1 = w.y - v[g].y, d2 = w.z - v[g].z, d3 = w.w - v[g].w;
+                            s[q] = s[q] + d0 * d0;
+                            s[q] = s[q] + d1 * d1;
+                            s[q] = s[q] + d2 * d2;
+                            s[q] = s[q] + d3 * d3;
+                        }
                     } else {
                         // distance_inline.rs:77-97: one 8-lane FMA accumulator
 #pragma unroll
@@ -162,16 +187,18 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
             if (live) {
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
-                    float dot;
-                    if (ORDER == SHODH_ORDER_SCALAR4) dot = s[q];
+                    float dist;
+                    if (ORDER == SHODH_ORDER_SCALAR4) dist = -s[q];                      // distance_inline.rs:479-481
+                    else if (ORDER == EX_OP_SEQ_ONE_MINUS_DOT) dist = 1.0f - s[q];     // spann.rs:568
+                    else if (ORDER == EX_OP_SEQ_L2) dist = s[q];
                     else {
                         // distance_inline.rs:100-108: lanes summed 0 -> 7
                         float r = acc8[q][0] + acc8[q][1];
                         r = r + acc8[q][2]; r = r + acc8[q][3]; r = r + acc8[q][4];
                         r = r + acc8[q][5]; r = r + acc8[q][6]; r = r + acc8[q][7];
-                        dot = r;
+                        dist = -r;
                     }
-                    if (q0 + q < nq_eff) topk_push(buf[q], make_key(-dot, a.id_base + (uint32_t)row));
+                    if (q0 + q < nq_eff) topk_push(buf[q], make_key(dist, a.id_base + (uint32_t)row));
                 }
             }
         }
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_generic_kernel(ExactArgs a) 
         if (live && a.deleted) live = ((a.deleted[row >> 5] >> (row & 31)) & 1u) == 0;
         if (live) {
             const float *r = a.rows + row * dim;
-            float dot;
+            float dist;
             if (ORDER == SHODH_ORDER_SCALAR4) {
                 const uint32_t un = dim & ~3u;
                 float sum = 0.0f;
@@ -231,7 +258,15 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_generic_kernel(ExactArgs a) 
                     sum = sum + t;
                 }
                 for (uint32_t j = un; j < dim; ++j) sum = sum + qs[j] * r[j];
-                dot = sum;
+                dist = -sum;
+            } else if (ORDER == EX_OP_SEQ_ONE_MINUS_DOT) {
+                float sum = 0.0f;
+                for (uint32_t i = 0; i < dim; ++i) sum = sum + qs[i] * r[i];
+                dist = 1.0f - sum;
+            } else if (ORDER == EX_OP_SEQ_L2) {
+                float sum = 0.0f;
+                for (uint32_t i = 0; i < dim; ++i) { const float d = qs[i] - r[i]; sum = sum + d * d; }
+                dist = sum;
             } else {
                 const uint32_t sn = dim & ~7u;
                 float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -241,9 +276,9 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_generic_kernel(ExactArgs a) 
                 float rr = acc[0] + acc[1];
                 rr = rr + acc[2]; rr = rr + acc[3]; rr = rr + acc[4]; rr = rr + acc[5]; rr = rr + acc[6]; rr = rr + acc[7];
                 for (uint32_t j = sn; j < dim; ++j) rr = rr + qs[j] * r[j];
-                dot = rr;
+                dist = -rr;
             }
-            topk_push(buf, make_key(-dot, a.id_base + (uint32_t)row));
+            topk_push(buf, make_key(dist, a.id_base + (uint32_t)row));
         }
         __syncthreads();
         if (*buf.cnt + EX_NT > a.cap) topk_compact<EX_NT>(buf);
@@ -379,15 +414,26 @@ uint32_t exact_grid_x(uint64_t n_rows, uint32_t nq, uint32_t k, int cus) {
     return (uint32_t)blocks;
 }
 
+template <int QB, int OP>
+static int launch_fast_op(const ExactArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+    SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, OP>, lds));
+    hipLaunchKernelGGL((flat_exact_kernel<QB, OP>), grid, dim3(EX_NT), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
 template <int QB>
-static int launch_fast(const ExactArgs &a, uint32_t order, dim3 grid, size_t lds, hipStream_t st) {
-    if (order == SHODH_ORDER_AVX2) {
-        SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, SHODH_ORDER_AVX2>, lds));
-        hipLaunchKernelGGL((flat_exact_kernel<QB, SHODH_ORDER_AVX2>), grid, dim3(EX_NT), lds, st, a);
-    } else {
-        SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, SHODH_ORDER_SCALAR4>, lds));
-        hipLaunchKernelGGL((flat_exact_kernel<QB, SHODH_ORDER_SCALAR4>), grid, dim3(EX_NT), lds, st, a);
+static int launch_fast(const ExactArgs &a, uint32_t op, dim3 grid, size_t lds, hipStream_t st) {
+    switch (op) {
+        case SHODH_ORDER_AVX2: return launch_fast_op<QB, SHODH_ORDER_AVX2>(a, grid, lds, st);
+        case EX_OP_SEQ_ONE_MINUS_DOT: return launch_fast_op<QB, EX_OP_SEQ_ONE_MINUS_DOT>(a, grid, lds, st);
+        case EX_OP_SEQ_L2: return launch_fast_op<QB, EX_OP_SEQ_L2>(a, grid, lds, st);
+        default: return launch_fast_op<QB, SHODH_ORDER_SCALAR4>(a, grid, lds, st);
     }
+}
+template <int OP>
+static int launch_generic_op(const ExactArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+    SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_generic_kernel<OP>, lds));
+    hipLaunchKernelGGL((flat_exact_generic_kernel<OP>), grid, dim3(EX_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
@@ -423,14 +469,12 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
         dim3 grid(grid_x, gy);
         const size_t lds = (size_t)((dim + 3) & ~3u) * 4 + (size_t)cap * 8 + 8 + 4 + 16;
         if (lds > 160 * 1024) { set_error("dim/k too large for the generic exact scan"); return SHODH_ERR_UNSUPPORTED; }
-        if (order == SHODH_ORDER_AVX2) {
-            SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_generic_kernel<SHODH_ORDER_AVX2>, lds));
-            hipLaunchKernelGGL((flat_exact_generic_kernel<SHODH_ORDER_AVX2>), grid, dim3(EX_NT), lds, st, a);
-        } else {
-            SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_generic_kernel<SHODH_ORDER_SCALAR4>, lds));
-            hipLaunchKernelGGL((flat_exact_generic_kernel<SHODH_ORDER_SCALAR4>), grid, dim3(EX_NT), lds, st, a);
+        switch (order) {
+            case SHODH_ORDER_AVX2: SHODH_TRY(launch_generic_op<SHODH_ORDER_AVX2>(a, grid, lds, st)); break;
+            case EX_OP_SEQ_ONE_MINUS_DOT: SHODH_TRY(launch_generic_op<EX_OP_SEQ_ONE_MINUS_DOT>(a, grid, lds, st)); break;
+            case EX_OP_SEQ_L2: SHODH_TRY(launch_generic_op<EX_OP_SEQ_L2>(a, grid, lds, st)); break;
+            default: SHODH_TRY(launch_generic_op<SHODH_ORDER_SCALAR4>(a, grid, lds, st)); break;
         }
-        SHODH_HIP_TRY(hipGetLastError());
     }
     MergeArgs m{partial, grid_x, (uint32_t)qb, k, cap, nq, d_ids, d_dist, d_counts, qlist, qcount};
     const size_t mlds = (size_t)cap * 8 + EX_NT * 8 + 8 + 4 + 16;

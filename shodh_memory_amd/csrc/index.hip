@@ -77,8 +77,9 @@ int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uin
 
 struct IvfpqState;   // ivfpq.hip
 void ivfpq_destroy(IvfpqState *s);
+size_t ivfpq_scratch_bytes(const IvfpqState *s, const shodh_index_cfg &cfg, uint32_t nq, uint32_t k);
 int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, uint32_t nq, uint32_t k,
-                 uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st);
+                 uint32_t *d_ids, float *d_dist, uint32_t *d_counts, unsigned char *scratch, hipStream_t st);
 
 // ---- per-search scratch ----------------------------------------------------------------------------
 struct Workspace {
@@ -450,8 +451,9 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         }
         if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma);
         else {
+            if ((rc = w->reserve(ivfpq_scratch_bytes(idx->ivfpq, idx->cfg, nq, k) + 256)) != SHODH_OK) break;
             hipEventRecord(w->ev[0], st);
-            rc = ivfpq_search(idx->ivfpq, idx->cfg, d_q, nq, k, d_ids, d_dist, d_counts, st);
+            rc = ivfpq_search(idx->ivfpq, idx->cfg, d_q, nq, k, d_ids, d_dist, d_counts, w->buf, st);
             hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st);
         }
         if (rc != SHODH_OK) break;

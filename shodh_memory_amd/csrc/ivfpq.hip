@@ -1,0 +1,482 @@
+// ivfpq.hip -- SpannIndex (IVF + product quantisation) search / insert / encode on the device,
+// bit-faithful to src/vector_db/spann.rs:545-693 and src/vector_db/pq.rs:220-368 GIVEN trained
+// state (the reference's k-means is unseeded: spann.rs:472-474, pq.rs:155-157).
+//
+// Every distance here is a per-candidate sum in a fixed order with no cross-candidate reduction,
+// so the device reproduces the reference bit-for-bit by running the same order per thread:
+//   probe select  : d_p = 1 - sum_i q_i c_pi (strictly sequential, spann.rs:562-571), the nprobe
+//                   smallest by (d total_cmp, p) (spann.rs:595-607)  -> flat_exact kernels, op SEQ
+//   ADC table     : T[m][c] = sum_{j<8} (q[8m+j] - cb[m][c][j])^2 sequential (pq.rs:329-351), built
+//                   per query straight into LDS (M*ncent*4 = 48 KiB at 384-d)
+//   list scan     : d_e = sum_{m<M} T[m][code_e[m]] sequential from 0 (pq.rs:358-368; a code beyond
+//                   the table gives f32::MAX), candidates over the probed lists in probe order
+//   result        : the k smallest by (d, id) -- identical to the reference's max-heap of size k on
+//                   (OrderedFloat(d), id) followed by the (total_cmp, id) sort (spann.rs:625-690),
+//                   because d is a finite non-negative sum (no NaN, no -0).
+// Roofline: HBM/L2 -- 48-byte codes + 4-byte ids per posting, read coalesced (one entry per lane);
+// the LUT gathers hit LDS.
+#include <algorithm>
+#include <mutex>
+#include <shared_mutex>
+#include <vector>
+
+#include "common.h"
+#include "topk.h"
+
+#pragma clang fp contract(off)
+
+namespace shodh {
+
+constexpr int EX_OP_SEQ_ONE_MINUS_DOT = 2;
+constexpr int EX_OP_SEQ_L2 = 3;
+
+uint32_t topk_capacity(uint32_t k);
+size_t exact_partial_bytes(uint32_t nq, uint32_t dim, uint32_t k, uint32_t grid_x);
+uint32_t exact_grid_x(uint64_t n_rows, uint32_t nq, uint32_t k, int cus);
+int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
+                      const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                      uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
+                      const uint32_t *qlist, const uint32_t *qcount, hipStream_t st);
+
+struct IvfpqState {
+    int device = 0, cus = 256;
+    uint32_t dim = 0, P = 0, M = 0, ncent = 0, metric = 0;
+    float *centroids = nullptr;      // [P][dim]
+    float *codebook = nullptr;       // [M][ncent][8]
+    uint64_t *list_off = nullptr;    // [P+1]
+    uint32_t *ids = nullptr;         // [total]
+    uint8_t *codes = nullptr;        // [total][M]
+    uint64_t total = 0, cap_total = 0;
+    // host mirror of the postings for incremental insert (SpannIndex::insert appends to a Vec)
+    std::vector<std::vector<uint32_t>> h_ids;
+    std::vector<std::vector<uint8_t>> h_codes;
+    bool dirty = false;
+    std::mutex mu;                   // guards the lazy re-upload and the scratch buffers
+    unsigned char *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+void ivfpq_destroy(IvfpqState *s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    hipFree(s->centroids); hipFree(s->codebook); hipFree(s->list_off); hipFree(s->ids); hipFree(s->codes); hipFree(s->scratch);
+    delete s;
+}
+
+static int ensure_scratch(IvfpqState *s, size_t bytes) {
+    if (bytes <= s->scratch_bytes) return SHODH_OK;
+    if (s->scratch) hipFree(s->scratch);
+    s->scratch = nullptr; s->scratch_bytes = 0;
+    SHODH_HIP_TRY(hipMalloc((void **)&s->scratch, bytes));
+    s->scratch_bytes = bytes;
+    return SHODH_OK;
+}
+
+// ---- ADC list scan -------------------------------------------------------------------------------------
+struct AdcArgs {
+    const float *q;            // [nq][dim]
+    const float *codebook;     // [M][ncent][8]
+    const uint64_t *list_off;
+    const uint32_t *ids;
+    const uint8_t *codes;
+    const uint32_t *probes;    // [nq][nprobe_k] partitions in probe order (0xFFFFFFFF = none)
+    const uint32_t *probe_cnt; // [nq]
+    uint32_t nq, dim, M, ncent, nprobe_k, k, cap, split;
+    uint64_t *partial;         // [nq][split][k]
+};
+
+__global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *table = reinterpret_cast<float *>(smem);                              // [M][ncent]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(table + (size_t)a.M * a.ncent);  // [cap]
+    uint64_t *thr = keys + a.cap;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
+    float *qs = reinterpret_cast<float *>(cnt + 1);                              // [dim]
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x, part = blockIdx.y;
+    for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
+    if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
+    __syncthreads();
+    // build_distance_table (pq.rs:329-351): one (m, c) entry per thread-iteration, 8 sequential terms
+    for (uint32_t e = tid; e < a.M * a.ncent; e += 256) {
+        const uint32_t m = e / a.ncent;
+        const float *cb = a.codebook + (size_t)e * 8;
+        const float *qq = qs + m * 8;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = qq[j] - cb[j]; sum = sum + d * d; }
+        table[e] = sum;
+    }
+    __syncthreads();
+    TopKBuf buf{keys, cnt, thr, a.cap, a.k};
+    const uint32_t np = a.probe_cnt[q];
+    // this block's share of every probed list: entries [lo + part*len/split, lo + (part+1)*len/split)
+    for (uint32_t pi = 0; pi < np; ++pi) {
+        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + pi];
+        const uint64_t lo = a.list_off[p], hi = a.list_off[p + 1];
+        const uint64_t len = hi - lo;
+        const uint64_t b0 = lo + len * part / a.split, b1 = lo + len * (part + 1) / a.split;
+        const uint64_t n_iter = (b1 - b0 + 255) / 256;
+        for (uint64_t it = 0; it < n_iter; ++it) {
+            const uint64_t e = b0 + it * 256 + tid;
+            if (e < b1) {
+                const uint8_t *code = a.codes + e * a.M;
+                float total = 0.0f;
+                bool bad = false;
+                // distance_with_table (pq.rs:358-368): strictly m = 0, 1, ... ; a code beyond the table -> f32::MAX
+                if ((a.M & 15u) == 0) {
+                    for (uint32_t w = 0; w < a.M; w += 16) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(code + w);      // entries are M bytes apart, M % 16 == 0
+                        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const uint32_t c = (word[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                            if (c >= a.ncent) bad = true;
+                            if (!bad) total = total + table[(w + j) * a.ncent + c];
+                        }
+                    }
+                } else {
+                    for (uint32_t m = 0; m < a.M; ++m) {
+                        const uint32_t c = code[m];
+                        if (c >= a.ncent) { bad = true; break; }
+                        total = total + table[m * a.ncent + c];
+                    }
+                }
+                if (bad) total = 3.4028234663852886e38f;       // f32::MAX
+                topk_push(buf, make_key(total, a.ids[e]));
+            }
+            __syncthreads();
+            if (*buf.cnt + 256 > a.cap) topk_compact<256>(buf);
+        }
+    }
+    __syncthreads();
+    topk_compact<256>(buf);
+    uint64_t *out = a.partial + ((size_t)q * a.split + part) * a.k;
+    const uint32_t m = *buf.cnt;
+    for (uint32_t i = tid; i < a.k; i += 256) out[i] = (i < m) ? buf.keys[i] : KEY_NONE;
+}
+
+struct AdcMergeArgs {
+    const uint64_t *partial;   // [nq][split][k]
+    uint32_t split, k, cap;
+    uint32_t *ids; float *dist; uint32_t *counts;
+};
+__global__ __launch_bounds__(256) void adc_merge_kernel(AdcMergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *mins = keys + a.cap;
+    uint64_t *thr = mins + 256;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    TopKBuf buf{keys, cnt, thr, a.cap, a.k};
+    const uint64_t *base = a.partial + (size_t)q * a.split * a.k;
+    auto key_at = [&](uint64_t i) -> uint64_t { return base[i]; };
+    const uint32_t m = block_select_topk<256>(key_at, (uint64_t)a.split * a.k, buf, mins);
+    for (uint32_t i = tid; i < a.k; i += 256) {
+        if (i < m) {
+            const uint64_t key = buf.keys[i];
+            a.ids[(size_t)q * a.k + i] = (uint32_t)key;
+            a.dist[(size_t)q * a.k + i] = order_key_inv((uint32_t)(key >> 32));
+        } else {
+            a.ids[(size_t)q * a.k + i] = 0xFFFFFFFFu;
+            a.dist[(size_t)q * a.k + i] = __builtin_inff();
+        }
+    }
+    if (tid == 0) a.counts[q] = m;
+}
+
+// ---- PQ encode (pq.rs:220-257): nearest of ncent centroids per 8-d subvector, first minimum wins ------------
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float *rows, uint64_t n, uint32_t dim, const float *codebook,
+                                                        uint32_t M, uint32_t ncent, uint8_t *codes) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * M) return;
+    const uint64_t row = t / M;
+    const uint32_t m = (uint32_t)(t % M);
+    const float *v = rows + row * dim + m * 8;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = v[j];
+    uint32_t best = 0;
+    float best_dist = 3.4028234663852886e38f;      // f32::MAX
+    const float *cb = codebook + (size_t)m * ncent * 8;
+    for (uint32_t c = 0; c < ncent; ++c) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = x[j] - cb[c * 8 + j]; sum = sum + d * d; }
+        if (sum < best_dist) { best_dist = sum; best = c; }
+    }
+    codes[row * M + m] = (uint8_t)best;
+}
+
+// ---- pairwise cosine (similarity.rs:10-24), one pair per thread ------------------------------------------------
+template <int ORDER>
+__device__ __forceinline__ float ref_dot(const float *a, const float *b, uint32_t n) {
+    if (ORDER == SHODH_ORDER_SCALAR4) {
+        const uint32_t un = n & ~3u;
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < un; i += 4) {
+            float t = a[i] * b[i];
+            t = t + a[i + 1] * b[i + 1];
+            t = t + a[i + 2] * b[i + 2];
+            t = t + a[i + 3] * b[i + 3];
+            sum = sum + t;
+        }
+        for (uint32_t j = un; j < n; ++j) sum = sum + a[j] * b[j];
+        return sum;
+    } else {
+        const uint32_t sn = n & ~7u;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = 0; i < sn; i += 8)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = __builtin_fmaf(a[i + l], b[i + l], acc[l]);
+        float r = acc[0] + acc[1];
+        r = r + acc[2]; r = r + acc[3]; r = r + acc[4]; r = r + acc[5]; r = r + acc[6]; r = r + acc[7];
+        for (uint32_t j = sn; j < n; ++j) r = r + a[j] * b[j];
+        return r;
+    }
+}
+template <int ORDER>
+__global__ void cosine_batch_kernel(const float *a, const float *b, uint64_t n, uint32_t dim, float *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *x = a + i * dim, *y = b + i * dim;
+    const float dot = ref_dot<ORDER>(x, y, dim);
+    const float na = __builtin_sqrtf(ref_dot<ORDER>(x, x, dim));
+    const float nb = __builtin_sqrtf(ref_dot<ORDER>(y, y, dim));
+    float r;
+    if (na == 0.0f || nb == 0.0f) r = 0.0f;
+    else {
+        r = dot / (na * nb);
+        if (r < -1.0f) r = -1.0f;
+        if (r > 1.0f) r = 1.0f;
+    }
+    out[i] = r;
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------
+static int upload_postings(IvfpqState *s) {
+    // flatten the host lists into CSR and upload
+    std::vector<uint64_t> off(s->P + 1, 0);
+    for (uint32_t p = 0; p < s->P; ++p) off[p + 1] = off[p] + s->h_ids[p].size();
+    const uint64_t total = off[s->P];
+    std::vector<uint32_t> ids(total ? total : 1);
+    std::vector<uint8_t> codes((total ? total : 1) * s->M);
+    for (uint32_t p = 0; p < s->P; ++p) {
+        std::copy(s->h_ids[p].begin(), s->h_ids[p].end(), ids.begin() + off[p]);
+        std::copy(s->h_codes[p].begin(), s->h_codes[p].end(), codes.begin() + off[p] * s->M);
+    }
+    if (total > s->cap_total) {
+        hipFree(s->ids); hipFree(s->codes); s->ids = nullptr; s->codes = nullptr;
+        uint64_t nc = total + total / 4 + 1024;
+        SHODH_HIP_TRY(hipMalloc((void **)&s->ids, nc * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&s->codes, nc * s->M));
+        s->cap_total = nc;
+    }
+    SHODH_HIP_TRY(hipMemcpy(s->list_off, off.data(), (s->P + 1) * 8, hipMemcpyHostToDevice));
+    if (total) {
+        SHODH_HIP_TRY(hipMemcpy(s->ids, ids.data(), total * 4, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(s->codes, codes.data(), total * s->M, hipMemcpyHostToDevice));
+    }
+    s->total = total;
+    s->dirty = false;
+    return SHODH_OK;
+}
+
+struct IvfpqLayout { uint32_t nprobe, cap, split, gx; size_t o_probe_ids, o_probe_dist, o_probe_cnt, o_partial, o_flat, bytes; };
+static IvfpqLayout ivfpq_layout(const IvfpqState *s, const shodh_index_cfg &cfg, uint32_t nq, uint32_t k) {
+    IvfpqLayout L{};
+    L.nprobe = cfg.nprobe < s->P ? cfg.nprobe : s->P;     // .take(num_probes)
+    L.cap = topk_capacity(k);
+    // split a query's probed lists over several blocks when the batch alone cannot fill the chip
+    L.split = 1;
+    while ((uint64_t)nq * L.split < (uint64_t)s->cus * 4 && L.split < 32) L.split <<= 1;
+    L.gx = exact_grid_x(s->P, nq, L.nprobe, s->cus);
+    const size_t part_probe = exact_partial_bytes(nq, s->dim, L.nprobe, L.gx);
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t r = o; o += (b + 255) & ~(size_t)255; return r; };
+    L.o_probe_ids = take((size_t)nq * (L.nprobe ? L.nprobe : 1) * 4);
+    L.o_probe_dist = take((size_t)nq * (L.nprobe ? L.nprobe : 1) * 4);
+    L.o_probe_cnt = take((size_t)nq * 4);
+    L.o_partial = take((size_t)nq * L.split * (k ? k : 1) * 8);
+    L.o_flat = take(part_probe + 256);
+    L.bytes = o;
+    return L;
+}
+size_t ivfpq_scratch_bytes(const IvfpqState *s, const shodh_index_cfg &cfg, uint32_t nq, uint32_t k) {
+    return s ? ivfpq_layout(s, cfg, nq, k).bytes : 0;
+}
+
+// scratch: ivfpq_scratch_bytes() bytes of device memory private to this search
+int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, uint32_t nq, uint32_t k,
+                 uint32_t *d_ids, float *d_dist, uint32_t *d_counts, unsigned char *scratch, hipStream_t st) {
+    if (!s || s->P == 0) { set_error("IVF-PQ index has no trained state"); return SHODH_ERR_STATE; }
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (s->dirty) { SHODH_HIP_TRY(hipDeviceSynchronize()); SHODH_TRY(upload_postings(s)); }
+    }
+    const IvfpqLayout L = ivfpq_layout(s, cfg, nq, k);
+    const uint32_t nprobe = L.nprobe, cap = L.cap, split = L.split, gx = L.gx;
+    const size_t o_probe_ids = L.o_probe_ids, o_probe_dist = L.o_probe_dist, o_probe_cnt = L.o_probe_cnt, o_partial = L.o_partial, o_flat = L.o_flat;
+    struct { unsigned char *scratch; } sref{scratch};
+    IvfpqState *const s_ = s;
+    (void)s_;
+#define s_scratch sref.scratch
+    uint32_t *probe_ids = (uint32_t *)(s_scratch + o_probe_ids);
+    float *probe_dist = (float *)(s_scratch + o_probe_dist);
+    uint32_t *probe_cnt = (uint32_t *)(s_scratch + o_probe_cnt);
+    uint64_t *partial = (uint64_t *)(s_scratch + o_partial);
+    // 1. probe selection: the nprobe nearest centroids by (compute_distance, index)
+    const uint32_t op = (s->metric == SHODH_METRIC_EUCLIDEAN) ? EX_OP_SEQ_L2 : EX_OP_SEQ_ONE_MINUS_DOT;
+    SHODH_TRY(launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_q, nq, nprobe, op, 0, (uint64_t *)(s_scratch + o_flat), gx,
+                                probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
+    // 2. ADC table + list scan, 3. merge
+    AdcArgs a{d_q, s->codebook, s->list_off, s->ids, s->codes, probe_ids, probe_cnt, nq, s->dim, s->M, s->ncent, nprobe, k, cap, split, partial};
+    const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 16;
+    if (lds > 160 * 1024) { set_error("IVF-PQ: dim/k too large for LDS (%zu B)", lds); return SHODH_ERR_UNSUPPORTED; }
+    SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel, lds));
+    hipLaunchKernelGGL(adc_scan_kernel, dim3(nq, split), dim3(256), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    AdcMergeArgs m{partial, split, k, cap, d_ids, d_dist, d_counts};
+    const size_t mlds = (size_t)cap * 8 + 256 * 8 + 8 + 4 + 16;
+    SHODH_TRY(ensure_dynamic_lds((const void *)adc_merge_kernel, mlds));
+    hipLaunchKernelGGL(adc_merge_kernel, dim3(nq), dim3(256), mlds, st, m);
+    SHODH_HIP_TRY(hipGetLastError());
+#undef s_scratch
+    return SHODH_OK;
+}
+
+IvfpqState *&index_ivfpq_slot(shodh_index *idx);
+const shodh_index_cfg &index_cfg(const shodh_index *idx);
+std::shared_mutex &index_mutex(shodh_index *idx);
+
+// assign_out / codes_out on the HOST; rows on the host
+static int encode_rows(IvfpqState *s, const float *rows, uint64_t n, uint32_t *assign_out, uint8_t *codes_out) {
+    if (n == 0) return SHODH_OK;
+    std::lock_guard<std::mutex> g(s->mu);
+    const uint32_t gx = exact_grid_x(s->P, 1, 1, s->cus);
+    const uint64_t CH = 65536;     // rows per chunk (each row is one "query" of the nearest-centroid scan)
+    float *d_rows = nullptr; uint8_t *d_codes = nullptr; uint32_t *d_assign = nullptr; float *d_ad = nullptr; uint32_t *d_ac = nullptr; uint64_t *d_part = nullptr;
+    const uint64_t ch = n < CH ? n : CH;
+    const uint32_t gxc = exact_grid_x(s->P, (uint32_t)ch, 1, s->cus);
+    (void)gx;
+    const size_t part_bytes = exact_partial_bytes((uint32_t)ch, s->dim, 1, gxc);
+    SHODH_HIP_TRY(hipMalloc((void **)&d_rows, ch * s->dim * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&d_codes, ch * s->M));
+    SHODH_HIP_TRY(hipMalloc((void **)&d_assign, ch * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&d_ad, ch * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&d_ac, ch * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&d_part, part_bytes + 256));
+    int rc = SHODH_OK;
+    const uint32_t op = (s->metric == SHODH_METRIC_EUCLIDEAN) ? EX_OP_SEQ_L2 : EX_OP_SEQ_ONE_MINUS_DOT;
+    for (uint64_t b = 0; b < n && rc == SHODH_OK; b += ch) {
+        const uint64_t m = (n - b) < ch ? (n - b) : ch;
+        if (hipMemcpy(d_rows, rows + b * s->dim, m * s->dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
+        // find_nearest_centroid (spann.rs:545-558): strict '<' keeps the first minimum == smallest (dist, index)
+        rc = launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_rows, (uint32_t)m, 1, op, 0, d_part, gxc, d_assign, d_ad, d_ac, nullptr, nullptr, nullptr);
+        if (rc != SHODH_OK) break;
+        hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)ceil_div(m * s->M, 256)), dim3(256), 0, nullptr, d_rows, m, s->dim, s->codebook, s->M, s->ncent, d_codes);
+        if (hipGetLastError() != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
+        if (hipMemcpy(assign_out + b, d_assign, m * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(codes_out + b * s->M, d_codes, m * s->M, hipMemcpyDeviceToHost) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
+    }
+    if (rc == SHODH_ERR_DEVICE) set_error("IVF-PQ encode failed on device: %s", hipGetErrorString(hipGetLastError()));
+    hipFree(d_rows); hipFree(d_codes); hipFree(d_assign); hipFree(d_ad); hipFree(d_ac); hipFree(d_part);
+    return rc;
+}
+
+}  // namespace shodh
+
+using namespace shodh;
+
+extern "C" {
+
+int shodh_index_set_ivfpq(shodh_index *idx, const float *centroids, uint32_t P, const float *codebook, uint32_t M, uint32_t ncent,
+                          const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes) {
+    if (!idx || !centroids || !codebook || !list_off || P == 0) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    const shodh_index_cfg &cfg = index_cfg(idx);
+    if (cfg.kind != SHODH_INDEX_IVFPQ) { set_error("not an IVF-PQ index"); return SHODH_ERR_STATE; }
+    if (M * 8 != cfg.dim) { set_error("PQ subvectors %u x 8 != dimension %u", M, cfg.dim); return SHODH_ERR_DIM; }
+    if (ncent == 0 || ncent > 256) { set_error("PQ centroids per subspace must be 1..256"); return SHODH_ERR_INVALID; }
+    std::unique_lock<std::shared_mutex> lk(index_mutex(idx));
+    SHODH_HIP_TRY(hipSetDevice(cfg.device));
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    IvfpqState *&slot = index_ivfpq_slot(idx);
+    if (slot) { ivfpq_destroy(slot); slot = nullptr; }
+    IvfpqState *s = new IvfpqState();
+    hipDeviceProp_t prop;
+    SHODH_HIP_TRY(hipGetDeviceProperties(&prop, cfg.device));
+    s->device = cfg.device; s->cus = prop.multiProcessorCount; s->dim = cfg.dim; s->P = P; s->M = M; s->ncent = ncent; s->metric = cfg.metric;
+    const uint64_t total = list_off[P];
+    if ((total && (!ids || !codes))) { delete s; set_error("null postings"); return SHODH_ERR_INVALID; }
+    SHODH_HIP_TRY(hipMalloc((void **)&s->centroids, (size_t)P * cfg.dim * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&s->codebook, (size_t)M * ncent * 8 * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&s->list_off, (size_t)(P + 1) * 8));
+    SHODH_HIP_TRY(hipMemcpy(s->centroids, centroids, (size_t)P * cfg.dim * 4, hipMemcpyHostToDevice));
+    SHODH_HIP_TRY(hipMemcpy(s->codebook, codebook, (size_t)M * ncent * 8 * 4, hipMemcpyHostToDevice));
+    s->h_ids.resize(P); s->h_codes.resize(P);
+    for (uint32_t p = 0; p < P; ++p) {
+        if (list_off[p + 1] < list_off[p]) { ivfpq_destroy(s); set_error("list_off not monotone"); return SHODH_ERR_INVALID; }
+        s->h_ids[p].assign(ids + list_off[p], ids + list_off[p + 1]);
+        s->h_codes[p].assign(codes + list_off[p] * M, codes + list_off[p + 1] * M);
+    }
+    int rc = upload_postings(s);
+    if (rc != SHODH_OK) { ivfpq_destroy(s); return rc; }
+    slot = s;
+    return SHODH_OK;
+}
+
+int shodh_index_ivfpq_encode(shodh_index *idx, const float *rows, uint64_t n, uint32_t *assign_out, uint8_t *codes_out) {
+    if (!idx || (n && (!rows || !assign_out || !codes_out))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::shared_lock<std::shared_mutex> lk(index_mutex(idx));
+    IvfpqState *s = index_ivfpq_slot(idx);
+    if (!s) { set_error("Cannot insert into empty index - build first"); return SHODH_ERR_STATE; }     // spann.rs:1008-1011
+    SHODH_HIP_TRY(hipSetDevice(s->device));
+    return encode_rows(s, rows, n, assign_out, codes_out);
+}
+
+int shodh_index_ivfpq_insert(shodh_index *idx, uint32_t vector_id, const float *row) {
+    if (!idx || !row) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::unique_lock<std::shared_mutex> lk(index_mutex(idx));
+    IvfpqState *s = index_ivfpq_slot(idx);
+    if (!s) { set_error("Cannot insert into empty index - build first"); return SHODH_ERR_STATE; }
+    SHODH_HIP_TRY(hipSetDevice(s->device));
+    uint32_t part = 0;
+    std::vector<uint8_t> code(s->M);
+    SHODH_TRY(encode_rows(s, row, 1, &part, code.data()));
+    std::lock_guard<std::mutex> g(s->mu);
+    if (part < s->P) {                                   // spann.rs:1040-1046
+        s->h_ids[part].push_back(vector_id);
+        s->h_codes[part].insert(s->h_codes[part].end(), code.begin(), code.end());
+        s->dirty = true;
+    }
+    return SHODH_OK;
+}
+
+int shodh_ivfpq_train(int, const float *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, float *, float *) {
+    // SURVEY.md 8(f) "next" row 4: device k-means is not built yet. Trained state is supplied through
+    // shodh_index_set_ivfpq (parity is defined given trained state; the reference's k-means is unseeded).
+    set_error("shodh_ivfpq_train: device k-means not implemented in this round; pass trained state to shodh_index_set_ivfpq");
+    return SHODH_ERR_UNSUPPORTED;
+}
+
+int shodh_cosine_similarity_batch(int device, const float *a, const float *b, uint64_t n, uint32_t dim, uint32_t order, float *out) {
+    if (n && (!a || !b || !out)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (n == 0) return SHODH_OK;
+    SHODH_HIP_TRY(hipSetDevice(device));
+    float *d = nullptr;
+    SHODH_HIP_TRY(hipMalloc((void **)&d, (2 * n * dim + n) * 4));
+    hipError_t e = hipMemcpy(d, a, n * dim * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n * dim, b, n * dim * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (order == SHODH_ORDER_AVX2) hipLaunchKernelGGL((cosine_batch_kernel<SHODH_ORDER_AVX2>), dim3((uint32_t)ceil_div(n, 64)), dim3(64), 0, nullptr, d, d + n * dim, n, dim, d + 2 * n * dim);
+        else hipLaunchKernelGGL((cosine_batch_kernel<SHODH_ORDER_SCALAR4>), dim3((uint32_t)ceil_div(n, 64)), dim3(64), 0, nullptr, d, d + n * dim, n, dim, d + 2 * n * dim);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n * dim, n * 4, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { set_error("cosine batch failed: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
+    return SHODH_OK;
+}
+
+}  // extern "C"

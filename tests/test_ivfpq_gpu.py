@@ -1,0 +1,144 @@
+"""GPU parity of the IVF-PQ (SpannIndex) path through the C ABI against the oracle's restatement of
+spann.rs:545-693 / pq.rs:220-368, GIVEN the same trained state (the reference's k-means is unseeded)."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def S():
+    from shodh_memory_amd import build
+    build.build()
+    import shodh_memory_amd as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def small_state(oracle):
+    rng = np.random.default_rng(5)
+    rows = synth.corpus(2000, adversarial=False)
+    P = oracle.spann_compute_partitions(2000)                      # 45
+    st = oracle.spann_build(rows, P, rng.permutation(2000).astype(np.uint32),
+                            [rng.permutation(2000).astype(np.uint32) for _ in range(48)], kmeans_iterations=8)
+    return rows, st
+
+
+def check(oracle, idx, st, q, k, nprobe, metric=0):
+    ids, dist, counts = idx.search_batch(q, k)
+    for i in range(len(q)):
+        e_ids, e_dist = oracle.spann_search(st["centroids"], st["list_off"], st["ids"], st["codes"], st["codebook"], nprobe, q[i], k, metric)
+        n = int(counts[i])
+        assert n == len(e_ids)
+        assert ids[i, :n].tolist() == e_ids.tolist(), (i, ids[i, :8], e_ids[:8])
+        assert dist[i, :n].tobytes() == e_dist.tobytes()
+
+
+def test_spann_search_matches_oracle(S, oracle, small_state):
+    rows, st = small_state
+    for nprobe in (1, 10, 20, 45, 1000):
+        idx = S.SpannIndex(384, num_probes=nprobe)
+        assert idx.search(rows[0], 5) == []                          # unbuilt: Ok(vec![]) (spann.rs:575-578)
+        idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+        assert idx.len() == 2000
+        q = np.concatenate([rows[:3], synth.queries(5)])
+        for k in (1, 10, 120):
+            check(oracle, idx, st, q, k, nprobe)
+    idx = S.SpannIndex(384, num_probes=20)
+    idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    res = idx.search(rows[0], 10)                                   # spann.rs:1121-1150: self within the first 3
+    assert len(res) == 10 and 0 in [r[0] for r in res[:3]]
+    from shodh_memory_amd import _lib
+    with pytest.raises(_lib.ShodhError) as e:
+        idx.search(np.zeros(128, f32), 3)                           # spann.rs:1221-1236
+    assert "dimension" in str(e.value)
+    check(oracle, idx, st, synth.queries(300), 10, 20)              # batch > chip-filling split
+
+
+def test_spann_encode_and_insert(S, oracle, small_state):
+    rows, st = small_state
+    idx = S.SpannIndex(384, num_probes=45)
+    idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    new = synth.corpus(300, seed=99, adversarial=False)
+    assign, codes = idx.encode(new)
+    for i in range(300):
+        assert assign[i] == oracle.spann_find_nearest_centroid(new[i], st["centroids"])
+        assert codes[i].tolist() == oracle.pq_encode(st["codebook"], new[i]).tolist()
+    # SpannIndex::insert (spann.rs:1006-1051) keeps insertion order inside the partition
+    lists_i = [st["ids"][int(st["list_off"][p]):int(st["list_off"][p + 1])].tolist() for p in range(len(st["centroids"]))]
+    lists_c = [st["codes"][int(st["list_off"][p]):int(st["list_off"][p + 1])].tolist() for p in range(len(st["centroids"]))]
+    for i in range(40):
+        idx.insert(2000 + i, new[i])
+        lists_i[assign[i]].append(2000 + i); lists_c[assign[i]].append(codes[i].tolist())
+    assert idx.len() == 2040
+    off = np.zeros(len(lists_i) + 1, np.uint64); off[1:] = np.cumsum([len(l) for l in lists_i])
+    st2 = dict(st, list_off=off, ids=np.array(sum(lists_i, []), np.uint32), codes=np.array(sum(lists_c, []), np.uint8))
+    check(oracle, idx, st2, np.concatenate([new[:5], rows[:3]]), 10, 45)
+
+
+def test_spann_small_codebook_bad_codes_and_euclidean(S, oracle):
+    rng = np.random.default_rng(8)
+    rows = synth.corpus(120, adversarial=False)                     # n < 256 -> ncent = 120 (pq.rs:119)
+    st = oracle.spann_build(rows, 11, rng.permutation(120).astype(np.uint32), [rng.permutation(120).astype(np.uint32) for _ in range(48)],
+                            kmeans_iterations=5)
+    assert st["codebook"].shape == (48, 120, 8)
+    idx = S.SpannIndex(384, num_probes=11)
+    idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    check(oracle, idx, st, rows[:6], 10, 11)
+    bad = dict(st, codes=st["codes"].copy())
+    bad["codes"][5, 7] = 200                                        # corrupted code -> f32::MAX, sinks to the bottom
+    idx.set_trained_state(bad["centroids"], bad["codebook"], bad["list_off"], bad["ids"], bad["codes"])
+    check(oracle, idx, bad, rows[:6], 120, 11)
+    ids, dist, counts = idx.search_batch(rows[:1], 120)
+    assert dist[0, counts[0] - 1] == np.finfo(f32).max
+    # Euclidean metric: centroid distance = sequential sum of squared differences
+    st_e = oracle.spann_build(rows, 11, rng.permutation(120).astype(np.uint32), [rng.permutation(120).astype(np.uint32) for _ in range(48)],
+                              kmeans_iterations=5, metric=1)
+    idx_e = S.SpannIndex(384, num_probes=4, distance_metric=S.DistanceMetric.Euclidean)
+    idx_e.set_trained_state(st_e["centroids"], st_e["codebook"], st_e["list_off"], st_e["ids"], st_e["codes"])
+    check(oracle, idx_e, st_e, rows[:6], 10, 4, metric=1)
+    # facade: use_pq=false is rejected like SpannIndex::build (spann.rs:373-379)
+    from shodh_memory_amd import _lib
+    with pytest.raises(_lib.ShodhError) as e:
+        S.VectorIndexBackend.new_spann(S.BackendConfig(use_pq=False))
+    assert "use_pq=true" in str(e.value)
+
+
+def test_spann_larger_given_state(S, oracle):
+    """20k rows, 141 partitions with centroids/codebooks that are simply sampled rows (any trained state
+    is valid input): device encode + search must match the oracle given that state."""
+    rng = np.random.default_rng(3)
+    n, P = 20000, 141
+    rows = synth.corpus(n, adversarial=False)
+    centroids = rows[rng.choice(n, P, replace=False)].copy()
+    codebook = np.stack([rows[rng.choice(n, 256, replace=False), m * 8:(m + 1) * 8] for m in range(48)]).astype(f32)
+    idx = S.SpannIndex(384, num_probes=20)
+    idx.set_trained_state(centroids, codebook, np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 48), np.uint8))
+    assign, codes = idx.encode(rows)
+    sel = rng.choice(n, 200, replace=False)
+    for i in sel:
+        assert assign[i] == oracle.spann_find_nearest_centroid(rows[i], centroids)
+        assert codes[i].tolist() == oracle.pq_encode(codebook, rows[i]).tolist()
+    order = np.argsort(assign, kind="stable")
+    off = np.zeros(P + 1, np.uint64); off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+    st = dict(centroids=centroids, codebook=codebook, list_off=off, ids=order.astype(np.uint32), codes=codes[order])
+    idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    check(oracle, idx, st, synth.queries(48), 10, 20)
+    check(oracle, idx, st, rows[:4], 120, 20)
+
+
+def test_cosine_similarity_batch(S, oracle):
+    import ctypes as C
+    from shodh_memory_amd import _lib
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((500, 384)).astype(f32); b = rng.standard_normal((500, 384)).astype(f32)
+    a[3] = 0; b[4] = 0; b[5] = a[5]; b[6] = -a[6]
+    for order in (0, 1):
+        out = np.zeros(500, f32)
+        _lib.check(_lib.lib().shodh_cosine_similarity_batch(0, a.ctypes.data, b.ctypes.data, 500, 384, order, out.ctypes.data))
+        exp = np.array([oracle.cosine_similarity(a[i], b[i], order) for i in range(500)], f32)
+        assert out.tobytes() == exp.tobytes()
+        assert out[3] == 0 and out[4] == 0 and abs(out[5] - 1) < 1e-6 and abs(out[6] + 1) < 1e-6
