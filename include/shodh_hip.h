@@ -180,6 +180,9 @@ int shodh_embedder_load_weights(shodh_embedder *e, const float *blob, uint64_t n
 /* deterministic synthetic weights (normal std 0.02, LayerNorm gamma 1 beta 0) from a seed; the
  * same blob is returned to the host when blob_out != NULL so a checker can mirror it */
 int shodh_embedder_init_synthetic(shodh_embedder *e, uint64_t seed, float *blob_out, uint64_t n_floats);
+/* host-only helpers (no device needed): parameter count of a configuration and the synthetic blob */
+uint64_t shodh_embed_param_count(const shodh_embed_cfg *cfg);
+int shodh_embedder_synthetic_weights(const shodh_embed_cfg *cfg, uint64_t seed, float *blob_out, uint64_t n_floats);
 uint32_t shodh_embedder_dimension(const shodh_embedder *e);                    /* Embedder::dimension mod.rs:63 */
 /* encode_batch after tokenisation (minilm.rs:996-1115): ids int32 [b][max_len], mask uint8
  * [b][max_len] (1 = real token). out host [b][hidden]: masked mean-pool, NaN/Inf scrub,
@@ -189,6 +192,22 @@ int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8
 int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b,
                                      float *d_out, void *stream);
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /* StageTiming.embedding_us */
+
+/* ---- host-side glue of the same path (string / uuid work: stays on the host by design) ------------------ */
+/* MiniLMEmbedder::new_simplified / generate_embedding_simplified (minilm.rs:777-831): SipHash-1-3
+ * (DefaultHasher, zero keys) over whitespace words and char bigrams -> dim-d unit vector; zeros if
+ * normalisation fails. The reference's unit tests index with this embedder (retrieval.rs:2451-2455). */
+int shodh_hash_embed(const char *utf8, size_t len, uint32_t dim, float *out);
+/* RetrievalEngine::search_ids post-processing (retrieval.rs:920-963): vector ids -> memory ids
+ * (vector_to_memory: [n_vectors][16] uuid bytes, all-0xFF = unmapped), similarity = -distance, per-memory
+ * max over chunks (strict '>'), sort (similarity total_cmp desc, uuid asc), truncate. Returns the count. */
+size_t shodh_search_ids_postprocess(const uint32_t *vec_ids, const float *dists, size_t n_res,
+                                    const uint8_t *vector_to_memory, size_t n_vectors, size_t limit,
+                                    uint8_t *out_uuid /*[limit][16]*/, float *out_sim /*[limit]*/);
+/* RRFusion::new + fuse (memory/hybrid_search.rs:536-594): n_lists ranked uuid lists concatenated in
+ * `uuids` (list l has list_len[l] entries); output sorted (score desc, uuid asc). Returns the count. */
+size_t shodh_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t *uuids, const size_t *list_len,
+                      uint8_t *out_uuid, float *out_score, size_t out_cap);
 
 /* ---- fusion: LearnedWeights (src/relevance.rs:343-606) ----------------------------------------- */
 typedef struct {

@@ -18,6 +18,9 @@ if not (_sys.argv and _sys.argv[0] == "-m"):
 from .index import (BackendConfig, BackendType, DistanceMetric, SpannIndex, VamanaConfig,   # noqa: E402
                     VamanaIndex, VectorIndexBackend)
 from .relevance import LearnedWeights, calibrate_score                                      # noqa: E402
+from .embedder import Embedder, MiniLMEmbedder                                              # noqa: E402
+from .retrieval import IdMapping, RetrievalEngine                                           # noqa: E402
 
 __all__ = ["ShodhError", "lib", "VamanaIndex", "VamanaConfig", "VectorIndexBackend", "BackendConfig", "BackendType",
-           "DistanceMetric", "SpannIndex", "LearnedWeights", "calibrate_score"]
+           "DistanceMetric", "SpannIndex", "LearnedWeights", "calibrate_score", "Embedder", "MiniLMEmbedder",
+           "IdMapping", "RetrievalEngine"]

@@ -93,6 +93,11 @@ SYMBOLS = {
     "shodh_embedder_param_count": (C.c_uint64, [_vp]),
     "shodh_embedder_load_weights": (C.c_int, [_vp, _fp, C.c_uint64]),
     "shodh_embedder_init_synthetic": (C.c_int, [_vp, C.c_uint64, _fp, C.c_uint64]),
+    "shodh_embed_param_count": (C.c_uint64, [C.POINTER(EmbedCfg)]),
+    "shodh_embedder_synthetic_weights": (C.c_int, [C.POINTER(EmbedCfg), C.c_uint64, _fp, C.c_uint64]),
+    "shodh_hash_embed": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, _fp]),
+    "shodh_search_ids_postprocess": (C.c_size_t, [_u32p, _fp, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, _u8p, _fp]),
+    "shodh_rrf_fuse": (C.c_size_t, [C.c_float, _fp, C.c_size_t, _u8p, C.POINTER(C.c_size_t), _u8p, _fp, C.c_size_t]),
     "shodh_embedder_dimension": (C.c_uint32, [_vp]),
     "shodh_embedder_encode_ids": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp]),
     "shodh_embedder_encode_ids_device": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp, _vp]),

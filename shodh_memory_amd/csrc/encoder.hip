@@ -1,0 +1,642 @@
+// encoder.hip -- MiniLM-L6 sentence encoder (BERT: 6 layers, hidden 384, 12 heads x 32, FFN 1536)
+// behind the Embedder seam (src/embeddings/mod.rs:52-88; MiniLMEmbedder, src/embeddings/minilm.rs).
+//
+// The reference runs this function inside ONNX Runtime (minilm.rs:939-949, :1064-1075) and then
+// mean-pools over the attention mask, scrubs NaN/Inf and L2-normalises (minilm.rs:959-981,
+// :846-878). The network itself is the public all-MiniLM-L6-v2 architecture:
+// embeddings sum -> LayerNorm, then per layer  QKV -> softmax(QK^T/sqrt(32)) V -> dense + residual ->
+// LayerNorm -> dense 1536 + GELU(erf) -> dense + residual -> LayerNorm.
+//
+// Device design
+//  * only REAL tokens are computed: sequences are packed back to back ([T, 384], T = sum of
+//    lengths) -- bit-identical in fp32 to computing the 256-padded tensor (minilm.rs:153-154) and
+//    2-4x less work than the reference's fixed 256 positions;
+//  * dense layers: one MFMA kernel (v_mfma_f32_32x32x16_bf16, f32 accumulate), 128x128x32 tiles,
+//    4 waves each 64x64 (2x2 MFMA blocks), LDS double-buffered with XOR-swizzled 16-B chunks;
+//    bias / GELU / residual fused in the epilogue;
+//  * attention: one workgroup per (sequence, head); K and V of the head live in LDS (S <= 256,
+//    d = 32), one query row per thread with an online softmax;
+//  * weights stay resident in HBM as bf16 (45 MB) next to the f32 master copy.
+// dtype FP32 runs the same graph with f32 storage and a plain tiled f32 GEMM (validation path).
+#include <cmath>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+
+namespace shodh {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
+template <class T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2 };
+
+// ---- bf16 MFMA GEMM: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue) ------------------------------------------
+// A, W bf16 row-major; K % 32 == 0, N % 128 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict__ A, const __bf16 *__restrict__ W,
+                                                        const float *__restrict__ bias, const __bf16 *__restrict__ resid,
+                                                        __bf16 *__restrict__ out_b, float *__restrict__ out_f,
+                                                        int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 128 * 64];   // [buf][A|B][128 rows][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    // staging: 512 chunks (128 rows x 4) per operand, 2 per thread
+    int srow[2], sc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int S = i * 256 + tid; srow[i] = S >> 2; sc[i] = S & 3; }
+    u32x4 pa[2], pb[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ra = m0 + srow[i]; if (ra >= M) ra = M - 1;
+            pa[i] = *reinterpret_cast<const u32x4 *>(A + (size_t)ra * K + kt * 32 + sc[i] * 8);
+            pb[i] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + srow[i]) * K + kt * 32 + sc[i] * 8);
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned char *base = lds + buf * (2 * 128 * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cs = sc[i] ^ ((srow[i] >> 2) & 3);      // 16 rows of a read group -> 16 distinct 16-B slots
+            *reinterpret_cast<u32x4 *>(base + srow[i] * 64 + cs * 16) = pa[i];
+            *reinterpret_cast<u32x4 *>(base + 128 * 64 + srow[i] * 64 + cs * 16) = pb[i];
+        }
+    };
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nkt = K / 32;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        const unsigned char *ab = lds + cur * (2 * 128 * 64);
+        const unsigned char *bb = ab + 128 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wr * 64 + i * 32 + l31;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(ab + row * 64 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) << 4));
+                const int col = wc * 64 + i * 32 + l31;
+                fb[i] = *reinterpret_cast<const bf16x8 *>(bb + col * 64 + (((ks * 2 + hi) ^ ((col >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stage(cur ^ 1);
+        __syncthreads();
+    }
+    // C layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*hi (m)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wc * 64 + j * 32 + l31;
+            const float bv = bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                    if (EPI == EPI_BIAS_RESID_F32) out_f[(size_t)m * N + n] = v + (float)resid[(size_t)m * N + n];
+                    else out_b[(size_t)m * N + n] = (__bf16)v;
+                }
+            }
+        }
+}
+
+// ---- plain f32 GEMM (validation dtype): 64x64 tile, 4x4 outputs per thread -------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ resid,
+                                                       float *__restrict__ out, int M, int N, int K) {
+    __shared__ float As[16][65], Ws[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = e & 15;
+            int ra = m0 + r; if (ra >= M) ra = M - 1;
+            As[c][r] = A[(size_t)ra * K + k0 + c];
+            Ws[c][r] = W[(size_t)(n0 + r) * K + k0 + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; w[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            float v = acc[i][j] + bias[n];
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if (EPI == EPI_BIAS_RESID_F32) v += resid[(size_t)m * N + n];
+            out[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+// ---- LayerNorm over the hidden dim (one wave per token), f32 in -> T out --------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, T *__restrict__ out, int ntok, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (tok >= ntok) return;
+    const float *x = in + (size_t)tok * H;
+    float s = 0.0f;
+    for (int i = lane; i < H; i += 64) s += x[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)H;
+    float v = 0.0f;
+    for (int i = lane; i < H; i += 64) { const float d = x[i] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float inv = 1.0f / sqrtf(v / (float)H + eps);
+    for (int i = lane; i < H; i += 64) out[(size_t)tok * H + i] = from_f32<T>((x[i] - mean) * inv * gamma[i] + beta[i]);
+}
+
+// ---- embeddings: word + position + token_type(0), then LayerNorm ------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ tok_seq,
+                                                       const int32_t *__restrict__ tok_pos, const float *__restrict__ word,
+                                                       const float *__restrict__ pos, const float *__restrict__ type0,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       T *__restrict__ out, int ntok, int H, int max_len, int vocab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (tok >= ntok) return;
+    const int sq = tok_seq[tok], p = tok_pos[tok];
+    int id = ids[(size_t)sq * max_len + p];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    float x[16];
+    int cnt = 0;
+    float s = 0.0f;
+    for (int i = lane; i < H; i += 64) { const float v = word[(size_t)id * H + i] + pos[(size_t)p * H + i] + type0[i]; x[cnt++] = v; s += v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)H;
+    float v = 0.0f;
+    for (int c = 0; c < cnt; ++c) { const float d = x[c] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float inv = 1.0f / sqrtf(v / (float)H + eps);
+    cnt = 0;
+    for (int i = lane; i < H; i += 64) { out[(size_t)tok * H + i] = from_f32<T>((x[cnt] - mean) * inv * gamma[i] + beta[i]); ++cnt; }
+}
+
+// ---- attention: one workgroup per (sequence, head); d_head = 32; online softmax per query row ---------------
+template <class T>
+__global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qkv, const int32_t *__restrict__ cu, T *__restrict__ ctx,
+                                                        int H, int heads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    float *Ks = reinterpret_cast<float *>(smem);          // [S][32]
+    float *Vs = Ks + (size_t)S * 32;                       // [S][32]
+    const int H3 = 3 * H;
+    for (int e = threadIdx.x; e < S * 32; e += 128) {
+        const int j = e >> 5, d = e & 31;
+        Ks[e] = to_f32(qkv[(size_t)(t0 + j) * H3 + H + head * 32 + d]);
+        Vs[e] = to_f32(qkv[(size_t)(t0 + j) * H3 + 2 * H + head * 32 + d]);
+    }
+    __syncthreads();
+    const float scale = 0.17677669529663688110f;          // 1/sqrt(32)
+    for (int i = threadIdx.x; i < S; i += 128) {
+        float q[32], o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { q[d] = to_f32(qkv[(size_t)(t0 + i) * H3 + head * 32 + d]) * scale; o[d] = 0.0f; }
+        float mx = -3.0e38f, l = 0.0f;
+        for (int j = 0; j < S; ++j) {
+            const float *kj = Ks + j * 32;
+            float s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s = fmaf(q[d], kj[d], s);
+            const float mn = fmaxf(mx, s);
+            const float corr = __expf(mx - mn), p = __expf(s - mn);
+            l = l * corr + p;
+            const float *vj = Vs + j * 32;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(o[d], corr, p * vj[d]);
+            mx = mn;
+        }
+        const float invl = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) ctx[(size_t)(t0 + i) * H + head * 32 + d] = from_f32<T>(o[d] * invl);
+    }
+}
+
+// ---- masked mean-pool + finalize_pooled (minilm.rs:959-981, :846-878) -------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, const int32_t *__restrict__ cu, float *__restrict__ out, int H) {
+    __shared__ float red[256];
+    const int seq = blockIdx.x;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    float part = 0.0f;
+    float vals[4];
+    int nv = 0;
+    for (int d = threadIdx.x; d < H; d += 256) {
+        float p = 0.0f;
+        for (int s = 0; s < S; ++s) p += to_f32(x[(size_t)(t0 + s) * H + d]);    // s ascending, like the reference loop
+        if (S > 0) p = p / (float)S;
+        if (!(fabsf(p) <= 3.4028235e38f)) p = 0.0f;                                // NaN / Inf scrub
+        vals[nv++] = p;
+        part += p * p;
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float norm = sqrtf(red[0]);
+    const bool ok = norm > 1.1920929e-07f;                                         // f32::EPSILON, !is_nan
+    nv = 0;
+    for (int d = threadIdx.x; d < H; d += 256) { const float p = vals[nv++]; out[(size_t)seq * H + d] = ok ? p / norm : p; }
+}
+
+template <class T>
+__global__ void convert_kernel(const float *in, T *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = from_f32<T>(in[i]);
+}
+
+}  // namespace shodh
+
+using namespace shodh;
+
+struct LayerOff { size_t qw, qb, kw, kb, vw, vb, ow, ob, ln1g, ln1b, iw, ib, dw, db, ln2g, ln2b; };
+
+struct shodh_embedder {
+    shodh_embed_cfg cfg{};
+    std::mutex mu;                       // one inference at a time per handle, like the reference's Mutex<Session>
+    uint64_t n_params = 0;
+    size_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0;
+    std::vector<LayerOff> lo;
+    float *w32 = nullptr;                // all parameters, f32, blob order
+    __bf16 *w16 = nullptr;               // the same as bf16 (dense weights are read from here in BF16 mode)
+    float *bqkv = nullptr;               // [layers][3H] fused q,k,v bias
+    float *wqkv32 = nullptr;             // [layers][3H][H] fused q,k,v weight (the blob interleaves weights and biases)
+    __bf16 *wqkv16 = nullptr;
+    bool loaded = false;
+    // workspace
+    size_t tok_cap = 0, seq_cap = 0;
+    void *X = nullptr, *QKV = nullptr, *CTX = nullptr, *FF = nullptr; float *PRE = nullptr;
+    int32_t *d_ids = nullptr; int32_t *d_tok_seq = nullptr, *d_tok_pos = nullptr, *d_cu = nullptr; float *d_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_us[2] = {0, 0};
+};
+
+namespace shodh {
+
+static void layout(shodh_embedder *e) {
+    const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+    e->o_word = take((size_t)e->cfg.vocab * H);
+    e->o_pos = take((size_t)e->cfg.max_pos * H);
+    e->o_type = take((size_t)e->cfg.type_vocab * H);
+    e->o_eg = take(H); e->o_eb = take(H);
+    e->lo.resize(e->cfg.layers);
+    for (auto &l : e->lo) {
+        l.qw = take(H * H); l.qb = take(H); l.kw = take(H * H); l.kb = take(H); l.vw = take(H * H); l.vb = take(H);
+        l.ow = take(H * H); l.ob = take(H); l.ln1g = take(H); l.ln1b = take(H);
+        l.iw = take(I * H); l.ib = take(I); l.dw = take(H * I); l.db = take(H); l.ln2g = take(H); l.ln2b = take(H);
+    }
+    e->n_params = o;
+}
+
+static int reserve(shodh_embedder *e, size_t ntok, size_t nseq) {
+    const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
+    const size_t es = e->cfg.dtype == SHODH_DTYPE_FP32 ? 4 : 2;
+    if (ntok > e->tok_cap) {
+        hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos);
+        e->X = e->QKV = e->CTX = e->FF = nullptr; e->PRE = nullptr; e->d_tok_seq = e->d_tok_pos = nullptr; e->tok_cap = 0;
+        size_t cap = ntok + ntok / 4 + 256;
+        SHODH_HIP_TRY(hipMalloc(&e->X, cap * H * es));
+        SHODH_HIP_TRY(hipMalloc(&e->QKV, cap * 3 * H * es));
+        SHODH_HIP_TRY(hipMalloc(&e->CTX, cap * H * es));
+        SHODH_HIP_TRY(hipMalloc(&e->FF, cap * I * es));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->PRE, cap * H * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_tok_seq, cap * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_tok_pos, cap * 4));
+        e->tok_cap = cap;
+    }
+    if (nseq > e->seq_cap) {
+        hipFree(e->d_ids); hipFree(e->d_cu); hipFree(e->d_out);
+        e->d_ids = nullptr; e->d_cu = nullptr; e->d_out = nullptr; e->seq_cap = 0;
+        size_t cap = nseq + nseq / 4 + 16;
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_ids, cap * e->cfg.max_len * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_cu, (cap + 1) * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_out, cap * H * 4));
+        e->seq_cap = cap;
+    }
+    return SHODH_OK;
+}
+
+template <int EPI>
+static int gemm_bf16(const __bf16 *A, const __bf16 *W, const float *bias, const __bf16 *resid, __bf16 *out_b, float *out_f,
+                     int M, int N, int K, hipStream_t st) {
+    dim3 grid(N / 128, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, resid, out_b, out_f, M, N, K);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+template <int EPI>
+static int gemm_f32(const float *A, const float *W, const float *bias, const float *resid, float *out, int M, int N, int K, hipStream_t st) {
+    dim3 grid(N / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, resid, out, M, N, K);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+// runs the network on ntok packed tokens (nseq sequences) already described by d_ids / d_tok_* / d_cu
+template <class T>
+static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_out, hipStream_t st) {
+    const int H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
+    const float eps = e->cfg.ln_eps;
+    T *X = (T *)e->X, *QKV = (T *)e->QKV, *CTX = (T *)e->CTX, *FF = (T *)e->FF;
+    const float *w = e->w32;
+    const int tok_blocks = (ntok * 64 + 255) / 256;
+    hipLaunchKernelGGL((embed_ln_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
+                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps);
+    SHODH_HIP_TRY(hipGetLastError());
+    const size_t att_lds = (size_t)max_seq * 32 * 4 * 2;
+    SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<T>, att_lds));
+    for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+        const LayerOff &l = e->lo[li];
+        const float *bqkv = e->bqkv + (size_t)li * 3 * H;
+        if constexpr (std::is_same<T, float>::value) {
+            SHODH_TRY(gemm_f32<EPI_BIAS>(X, e->wqkv32 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, ntok, 3 * H, H, st));
+        } else {
+            SHODH_TRY(gemm_bf16<EPI_BIAS>(X, e->wqkv16 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, nullptr, ntok, 3 * H, H, st));
+        }
+        hipLaunchKernelGGL((attention_kernel<T>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads);
+        SHODH_HIP_TRY(hipGetLastError());
+        if constexpr (std::is_same<T, float>::value) {
+            SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(CTX, w + l.ow, w + l.ob, X, e->PRE, ntok, H, H, st));
+        } else {
+            SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(CTX, e->w16 + l.ow, w + l.ob, X, nullptr, e->PRE, ntok, H, H, st));
+        }
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
+        SHODH_HIP_TRY(hipGetLastError());
+        if constexpr (std::is_same<T, float>::value) {
+            SHODH_TRY(gemm_f32<EPI_BIAS_GELU>(X, w + l.iw, w + l.ib, nullptr, FF, ntok, I, H, st));
+            SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(FF, w + l.dw, w + l.db, X, e->PRE, ntok, H, I, st));
+        } else {
+            SHODH_TRY(gemm_bf16<EPI_BIAS_GELU>(X, e->w16 + l.iw, w + l.ib, nullptr, FF, nullptr, ntok, I, H, st));
+            SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(FF, e->w16 + l.dw, w + l.db, X, nullptr, e->PRE, ntok, H, I, st));
+        }
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
+        SHODH_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL((pool_kernel<T>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+static int finish_weights(shodh_embedder *e) {
+    const size_t H = e->cfg.hidden;
+    hipLaunchKernelGGL((convert_kernel<__bf16>), dim3((uint32_t)ceil_div(e->n_params, 256)), dim3(256), 0, nullptr, e->w32, e->w16, (size_t)e->n_params);
+    SHODH_HIP_TRY(hipGetLastError());
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    // q, k, v weights sit back to back in the blob as [H,H] blocks separated by their biases, so the
+    // fused [3H, H] operand needs a contiguous copy; reuse the blob layout by compacting in place is
+    // not possible -> keep a fused copy at the q slot's position in a side buffer.
+    for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+        const LayerOff &l = e->lo[li];
+        const size_t offs[3] = {l.qw, l.kw, l.vw};
+        for (int j = 0; j < 3; ++j) {
+            SHODH_HIP_TRY(hipMemcpy(e->wqkv32 + ((size_t)li * 3 + j) * H * H, e->w32 + offs[j], H * H * 4, hipMemcpyDeviceToDevice));
+            SHODH_HIP_TRY(hipMemcpy(e->wqkv16 + ((size_t)li * 3 + j) * H * H, e->w16 + offs[j], H * H * 2, hipMemcpyDeviceToDevice));
+        }
+        SHODH_HIP_TRY(hipMemcpy(e->bqkv + (size_t)li * 3 * H, e->w32 + l.qb, H * 4, hipMemcpyDeviceToDevice));
+        SHODH_HIP_TRY(hipMemcpy(e->bqkv + (size_t)li * 3 * H + H, e->w32 + l.kb, H * 4, hipMemcpyDeviceToDevice));
+        SHODH_HIP_TRY(hipMemcpy(e->bqkv + (size_t)li * 3 * H + 2 * H, e->w32 + l.vb, H * 4, hipMemcpyDeviceToDevice));
+    }
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    e->loaded = true;
+    return SHODH_OK;
+}
+
+}  // namespace shodh
+
+extern "C" {
+
+void shodh_embed_cfg_default(shodh_embed_cfg *cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0;
+    cfg->dtype = SHODH_DTYPE_BF16;
+    cfg->max_len = 256;             // EmbeddingConfig.max_length (minilm.rs:225, pinned by the test at :1393-1395)
+    cfg->vocab = 30522; cfg->hidden = 384; cfg->layers = 6; cfg->heads = 12; cfg->intermediate = 1536;
+    cfg->max_pos = 512; cfg->type_vocab = 2;
+    cfg->ln_eps = 1e-12f;
+    cfg->compute_padded = 0;
+}
+
+int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
+    if (!cfg || !out) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->hidden % 128 != 0 || cfg->intermediate % 128 != 0 || cfg->heads * 32 != cfg->hidden) {
+        set_error("encoder kernels need hidden %% 128 == 0, intermediate %% 128 == 0 and 32-wide heads (got hidden %u, heads %u)", cfg->hidden, cfg->heads);
+        return SHODH_ERR_UNSUPPORTED;
+    }
+    if (cfg->max_len == 0 || cfg->max_len > cfg->max_pos || cfg->max_len > 512) { set_error("max_len %u out of range", cfg->max_len); return SHODH_ERR_INVALID; }
+    if (cfg->compute_padded) { set_error("compute_padded=1 only matters for the INT8 graph, which is not built; fp32/bf16 results are identical without padding"); return SHODH_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libshodh_hip has no CPU fallback"); return SHODH_ERR_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d not present", cfg->device); return SHODH_ERR_DEVICE; }
+    SHODH_HIP_TRY(hipSetDevice(cfg->device));
+    shodh_embedder *e = new shodh_embedder();
+    e->cfg = *cfg;
+    layout(e);
+    if (hipMalloc((void **)&e->w32, e->n_params * 4) != hipSuccess || hipMalloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
+        hipMalloc((void **)&e->bqkv, (size_t)cfg->layers * 3 * cfg->hidden * 4) != hipSuccess ||
+        hipMalloc((void **)&e->wqkv32, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 4) != hipSuccess ||
+        hipMalloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess) {
+        shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
+    }
+    SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    SHODH_HIP_TRY(hipEventCreate(&e->ev0));
+    SHODH_HIP_TRY(hipEventCreate(&e->ev1));
+    *out = e;
+    return SHODH_OK;
+}
+
+void shodh_embedder_destroy(shodh_embedder *e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    hipDeviceSynchronize();
+    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
+    hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+uint64_t shodh_embedder_param_count(const shodh_embedder *e) { return e ? e->n_params : 0; }
+uint32_t shodh_embedder_dimension(const shodh_embedder *e) { return e ? e->cfg.hidden : 0; }
+
+int shodh_embedder_load_weights(shodh_embedder *e, const float *blob, uint64_t n_floats) {
+    if (!e || !blob) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (n_floats != e->n_params) { set_error("weight blob has %llu floats, expected %llu", (unsigned long long)n_floats, (unsigned long long)e->n_params); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(e->mu);
+    SHODH_HIP_TRY(hipSetDevice(e->cfg.device));
+    SHODH_HIP_TRY(hipMemcpy(e->w32, blob, n_floats * 4, hipMemcpyHostToDevice));
+    return finish_weights(e);
+}
+
+// host-only: the parameter layout and the synthetic generator need no device
+static void layout_cfg(const shodh_embed_cfg &cfg, size_t &o_word, size_t &o_pos, size_t &o_type, size_t &o_eg, size_t &o_eb,
+                       std::vector<LayerOff> &lo, uint64_t &n_params) {
+    shodh_embedder tmp;
+    tmp.cfg = cfg;
+    layout(&tmp);
+    o_word = tmp.o_word; o_pos = tmp.o_pos; o_type = tmp.o_type; o_eg = tmp.o_eg; o_eb = tmp.o_eb; lo = tmp.lo; n_params = tmp.n_params;
+}
+
+uint64_t shodh_embed_param_count(const shodh_embed_cfg *cfg) {
+    if (!cfg) return 0;
+    size_t a, b, c, d, f; std::vector<LayerOff> lo; uint64_t n = 0;
+    layout_cfg(*cfg, a, b, c, d, f, lo, n);
+    return n;
+}
+
+int shodh_embedder_synthetic_weights(const shodh_embed_cfg *cfg, uint64_t seed, float *blob, uint64_t n_floats) {
+    if (!cfg || !blob) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    size_t o_word, o_pos, o_type, o_eg, o_eb; std::vector<LayerOff> lo; uint64_t n_params = 0;
+    layout_cfg(*cfg, o_word, o_pos, o_type, o_eg, o_eb, lo, n_params);
+    if (n_floats != n_params) { set_error("blob has %llu floats, expected %llu", (unsigned long long)n_floats, (unsigned long long)n_params); return SHODH_ERR_INVALID; }
+    // splitmix64 -> Box-Muller; weights and biases ~ N(0, 0.02), LayerNorm gamma 1 / beta 0
+    uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto normal = [&]() { const double u1 = ((next() >> 11) + 1.0) / 9007199254740993.0, u2 = (next() >> 11) / 9007199254740992.0; return (float)(0.02 * std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2)); };
+    auto fill_n = [&](size_t off, size_t n) { for (size_t i = 0; i < n; ++i) blob[off + i] = normal(); };
+    auto fill_c = [&](size_t off, size_t n, float v) { for (size_t i = 0; i < n; ++i) blob[off + i] = v; };
+    const size_t H = cfg->hidden, I = cfg->intermediate;
+    fill_n(o_word, (size_t)cfg->vocab * H); fill_n(o_pos, (size_t)cfg->max_pos * H); fill_n(o_type, (size_t)cfg->type_vocab * H);
+    fill_c(o_eg, H, 1.0f); fill_c(o_eb, H, 0.0f);
+    for (auto &l : lo) {
+        fill_n(l.qw, H * H); fill_n(l.qb, H); fill_n(l.kw, H * H); fill_n(l.kb, H); fill_n(l.vw, H * H); fill_n(l.vb, H);
+        fill_n(l.ow, H * H); fill_n(l.ob, H); fill_c(l.ln1g, H, 1.0f); fill_c(l.ln1b, H, 0.0f);
+        fill_n(l.iw, I * H); fill_n(l.ib, I); fill_n(l.dw, H * I); fill_n(l.db, H); fill_c(l.ln2g, H, 1.0f); fill_c(l.ln2b, H, 0.0f);
+    }
+    return SHODH_OK;
+}
+
+int shodh_embedder_init_synthetic(shodh_embedder *e, uint64_t seed, float *blob_out, uint64_t n_floats) {
+    if (!e) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (blob_out && n_floats != e->n_params) { set_error("blob_out has %llu floats, expected %llu", (unsigned long long)n_floats, (unsigned long long)e->n_params); return SHODH_ERR_INVALID; }
+    std::vector<float> blob(e->n_params);
+    SHODH_TRY(shodh_embedder_synthetic_weights(&e->cfg, seed, blob.data(), e->n_params));
+    if (blob_out) memcpy(blob_out, blob.data(), e->n_params * 4);
+    return shodh_embedder_load_weights(e, blob.data(), e->n_params);
+}
+
+static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, bool device_io, hipStream_t user_st) {
+    if (!e || (b && (!ids || !mask || !out))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (b == 0) return SHODH_OK;
+    if (!e->loaded) { set_error("encoder weights not loaded (shodh_embedder_load_weights / shodh_embedder_init_synthetic)"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> g(e->mu);
+    SHODH_HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint32_t ML = e->cfg.max_len, H = e->cfg.hidden;
+    std::vector<uint8_t> hmask;
+    std::vector<int32_t> hids;
+    const uint8_t *m = mask;
+    const int32_t *idp = ids;
+    hipStream_t st = device_io ? user_st : e->stream;
+    if (device_io) {
+        // lengths are needed on the host to size the launches: one small synchronous read of the mask
+        SHODH_HIP_TRY(hipStreamSynchronize(st));
+        hmask.resize((size_t)b * ML);
+        SHODH_HIP_TRY(hipMemcpy(hmask.data(), mask, (size_t)b * ML, hipMemcpyDeviceToHost));
+        m = hmask.data();
+    }
+    std::vector<int32_t> cu(b + 1, 0), tok_seq, tok_pos;
+    int max_seq = 1;
+    for (uint32_t s = 0; s < b; ++s) {
+        int len = 0;
+        for (uint32_t p = 0; p < ML; ++p) {
+            if (m[(size_t)s * ML + p] == 1) {
+                if ((int)p != len) { set_error("attention mask of row %u is not a prefix of ones (tokenizers pad on the right, minilm.rs:912-921)", s); return SHODH_ERR_UNSUPPORTED; }
+                ++len;
+            }
+        }
+        cu[s + 1] = cu[s] + len;
+        if (len > max_seq) max_seq = len;
+        for (int p = 0; p < len; ++p) { tok_seq.push_back((int32_t)s); tok_pos.push_back(p); }
+    }
+    const int ntok = cu[b];
+    SHODH_TRY(reserve(e, (size_t)(ntok ? ntok : 1), b));
+    if (device_io) SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyDeviceToDevice, st));
+    else SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyHostToDevice, st));
+    SHODH_HIP_TRY(hipMemcpyAsync(e->d_cu, cu.data(), (size_t)(b + 1) * 4, hipMemcpyHostToDevice, st));
+    if (ntok) {
+        SHODH_HIP_TRY(hipMemcpyAsync(e->d_tok_seq, tok_seq.data(), (size_t)ntok * 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(e->d_tok_pos, tok_pos.data(), (size_t)ntok * 4, hipMemcpyHostToDevice, st));
+    }
+    // the host vectors must outlive the async copies: synchronise before leaving (pageable memory copies are staged, but be explicit)
+    SHODH_HIP_TRY(hipEventRecord(e->ev0, st));
+    float *d_out = device_io ? out : e->d_out;
+    int rc;
+    if (ntok == 0) { rc = (hipMemsetAsync(d_out, 0, (size_t)b * H * 4, st) == hipSuccess) ? SHODH_OK : SHODH_ERR_DEVICE; }
+    else if (e->cfg.dtype == SHODH_DTYPE_FP32) rc = forward<float>(e, ntok, (int)b, max_seq, d_out, st);
+    else rc = forward<__bf16>(e, ntok, (int)b, max_seq, d_out, st);
+    if (rc != SHODH_OK) return rc;
+    SHODH_HIP_TRY(hipEventRecord(e->ev1, st));
+    if (!device_io) SHODH_HIP_TRY(hipMemcpyAsync(out, e->d_out, (size_t)b * H * 4, hipMemcpyDeviceToHost, st));
+    hipError_t er = hipStreamSynchronize(st);
+    if (er != hipSuccess) { set_error("encode failed on device: %s", hipGetErrorString(er)); return SHODH_ERR_DEVICE; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) { e->last_us[0] = ms * 1000.0f; e->last_us[1] = (float)ntok; }
+    return SHODH_OK;
+}
+
+int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out) {
+    return encode_impl(e, ids, mask, b, out, false, nullptr);
+}
+int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b, float *d_out, void *stream) {
+    return encode_impl(e, d_ids, d_mask, b, d_out, true, (hipStream_t)stream);
+}
+int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2) {
+    if (!e || !us2) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    us2[0] = e->last_us[0]; us2[1] = e->last_us[1];
+    return SHODH_OK;
+}
+
+}  // extern "C"

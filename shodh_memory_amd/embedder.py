@@ -1,0 +1,238 @@
+"""Host-side mirror of the reference's `Embedder` trait and `MiniLMEmbedder`
+(src/embeddings/mod.rs:52-88, src/embeddings/minilm.rs) over the C ABI.
+
+Tokenisation (HF `tokenizers`, WordPiece, truncation pinned to 128: minilm.rs:112-117) stays on the
+host exactly as in the reference; the device takes token ids. No tokenizer.json / weights ship with
+the reference tree (downloaded at first run, embeddings/downloader.rs:29-53), so the caller supplies
+them: a `tokenizers.Tokenizer` and either a weight blob or a synthetic seed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+MODEL_TOKEN_WINDOW = 128        # embeddings/chunking.rs:60
+SPECIAL_TOKEN_OVERHEAD = 2      # embeddings/chunking.rs:63  ([CLS] + [SEP])
+
+
+def embed_cfg(**kw):
+    cfg = L.EmbedCfg()
+    L.lib().shodh_embed_cfg_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def param_count(cfg=None):
+    cfg = cfg or embed_cfg()
+    return int(L.lib().shodh_embed_param_count(C.byref(cfg)))
+
+
+def synthetic_weights(seed, cfg=None):
+    """The deterministic synthetic parameter blob (HF BertModel order). Host only."""
+    cfg = cfg or embed_cfg()
+    n = param_count(cfg)
+    blob = np.empty(n, np.float32)
+    L.check(L.lib().shodh_embedder_synthetic_weights(C.byref(cfg), int(seed), blob.ctypes.data, n))
+    return blob
+
+
+def blob_to_state_dict(blob, cfg=None):
+    """Splits a blob into HF `BertModel` parameter names -> arrays (for checkers / weight import)."""
+    cfg = cfg or embed_cfg()
+    H, I = cfg.hidden, cfg.intermediate
+    out, o = {}, 0
+
+    def take(name, *shape):
+        nonlocal o
+        n = int(np.prod(shape))
+        out[name] = blob[o:o + n].reshape(shape)
+        o += n
+    take("embeddings.word_embeddings.weight", cfg.vocab, H)
+    take("embeddings.position_embeddings.weight", cfg.max_pos, H)
+    take("embeddings.token_type_embeddings.weight", cfg.type_vocab, H)
+    take("embeddings.LayerNorm.weight", H); take("embeddings.LayerNorm.bias", H)
+    for l in range(cfg.layers):
+        p = "encoder.layer.%d." % l
+        for nm in ("query", "key", "value"):
+            take(p + "attention.self.%s.weight" % nm, H, H); take(p + "attention.self.%s.bias" % nm, H)
+        take(p + "attention.output.dense.weight", H, H); take(p + "attention.output.dense.bias", H)
+        take(p + "attention.output.LayerNorm.weight", H); take(p + "attention.output.LayerNorm.bias", H)
+        take(p + "intermediate.dense.weight", I, H); take(p + "intermediate.dense.bias", I)
+        take(p + "output.dense.weight", H, I); take(p + "output.dense.bias", H)
+        take(p + "output.LayerNorm.weight", H); take(p + "output.LayerNorm.bias", H)
+    assert o == blob.size
+    return out
+
+
+def state_dict_to_blob(sd, cfg=None):
+    """Inverse of blob_to_state_dict: accepts HF `BertModel` tensors/arrays (e.g. from model.safetensors)."""
+    cfg = cfg or embed_cfg()
+    ref = blob_to_state_dict(np.zeros(param_count(cfg), np.float32), cfg)
+    parts = []
+    for name, z in ref.items():
+        a = sd[name]
+        a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        assert a.shape == z.shape, (name, a.shape, z.shape)
+        parts.append(np.ascontiguousarray(a, np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
+class Embedder:
+    """trait Embedder (embeddings/mod.rs:52-88)"""
+
+    def encode(self, text):
+        raise NotImplementedError
+
+    def encode_query(self, text):
+        return self.encode(text)
+
+    def dimension(self):
+        raise NotImplementedError
+
+    def encode_batch(self, texts):
+        return [self.encode(t) for t in texts]
+
+    def count_tokens(self, text):
+        return max(1, len(text) // 4) + SPECIAL_TOKEN_OVERHEAD
+
+    def chunk_budget_tokens(self):
+        return MODEL_TOKEN_WINDOW
+
+
+class MiniLMEmbedder(Embedder):
+    def __init__(self, tokenizer=None, weights=None, synthetic_seed=None, dtype=L.DTYPE_BF16, device=0,
+                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384):
+        self._dim = dim
+        self.simplified_mode = simplified
+        self.query_prefix, self.doc_prefix = query_prefix, doc_prefix
+        self.max_length = max_length
+        self.tokenizer = tokenizer
+        self._h = C.c_void_p()
+        if simplified:
+            return
+        if tokenizer is not None:
+            # minilm.rs:112-117: truncation pinned to the model window; padding is done by the embedder
+            tokenizer.enable_truncation(max_length=MODEL_TOKEN_WINDOW)
+            tokenizer.no_padding()
+        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim)
+        L.check(L.lib().shodh_embedder_create(C.byref(cfg), C.byref(self._h)))
+        if weights is not None:
+            w = np.ascontiguousarray(weights, np.float32).reshape(-1)
+            L.check(L.lib().shodh_embedder_load_weights(self._h, w.ctypes.data, w.size))
+        elif synthetic_seed is not None:
+            L.check(L.lib().shodh_embedder_init_synthetic(self._h, int(synthetic_seed), None, 0))
+        self._cfg = cfg
+
+    @classmethod
+    def new_simplified(cls, dim=384):
+        """MiniLMEmbedder::new_simplified (minilm.rs:721-747): hash embeddings, no model."""
+        return cls(simplified=True, dim=dim)
+
+    def close(self):
+        if self._h and self._h.value:
+            L.lib().shodh_embedder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dimension(self):
+        return self._dim
+
+    # -- device entry points -------------------------------------------------------------------
+    def encode_ids(self, ids, mask):
+        """ids int32 [b, max_len], mask uint8 [b, max_len] -> float32 [b, dim] unit rows (zeros if mask empty)."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, self.max_length)
+        mask = np.ascontiguousarray(mask, np.uint8).reshape(-1, self.max_length)
+        out = np.zeros((ids.shape[0], self._dim), np.float32)
+        L.check(L.lib().shodh_embedder_encode_ids(self._h, ids.ctypes.data, mask.ctypes.data, ids.shape[0], out.ctypes.data))
+        return out
+
+    def encode_ids_device(self, ids, mask, out=None, stream=None):
+        import torch
+        b = ids.shape[0]
+        if out is None:
+            out = torch.empty((b, self._dim), dtype=torch.float32, device=ids.device)
+        st = stream if stream is not None else torch.cuda.current_stream(ids.device).cuda_stream
+        L.check(L.lib().shodh_embedder_encode_ids_device(self._h, ids.data_ptr(), mask.data_ptr(), b, out.data_ptr(), C.c_void_p(st)))
+        return out
+
+    def stage_timings_us(self):
+        a = (C.c_float * 2)()
+        L.check(L.lib().shodh_embedder_stage_timings(self._h, C.byref(a)))
+        return dict(embedding_us=a[0], tokens=int(a[1]))
+
+    # -- trait Embedder --------------------------------------------------------------------------
+    def _tokenize(self, texts):
+        ids = np.zeros((len(texts), self.max_length), np.int32)
+        mask = np.zeros((len(texts), self.max_length), np.uint8)
+        for i, enc in enumerate(self.tokenizer.encode_batch(list(texts), add_special_tokens=True)):
+            n = min(len(enc.ids), self.max_length)                     # minilm.rs:912-921
+            ids[i, :n] = enc.ids[:n]
+            mask[i, :n] = enc.attention_mask[:n]
+        return ids, mask
+
+    def _hash_embed(self, text):
+        b = text.encode("utf-8")
+        out = np.zeros(self._dim, np.float32)
+        L.check(L.lib().shodh_hash_embed(b, len(b), self._dim, out.ctypes.data))
+        return out
+
+    def _encode_prefixed(self, text, prefix):                          # minilm.rs:1122-1192
+        if text == "":
+            return np.zeros(self._dim, np.float32)
+        if self.simplified_mode:
+            return self._hash_embed(prefix + text if prefix else text)
+        if self.tokenizer is None:
+            raise L.ShodhError(L.ERR_STATE, "no tokenizer: pass token ids to encode_ids or construct with a tokenizers.Tokenizer")
+        ids, mask = self._tokenize([prefix + text if prefix else text])
+        return self.encode_ids(ids, mask)[0]
+
+    def encode(self, text):
+        return self._encode_prefixed(text, self.doc_prefix)
+
+    def encode_query(self, text):
+        return self._encode_prefixed(text, self.query_prefix)
+
+    def encode_batch(self, texts):                                     # minilm.rs:1247-1376
+        texts = list(texts)
+        if not texts:
+            return []
+        out = [np.zeros(self._dim, np.float32) for _ in texts]
+        idx = [i for i, t in enumerate(texts) if t != ""]              # empty positions keep zero vectors (:1319-1350)
+        if not idx:
+            return out
+        full = [(self.doc_prefix + texts[i]) if self.doc_prefix else texts[i] for i in idx]
+        if self.simplified_mode:
+            for i, t in zip(idx, full):
+                out[i] = self._hash_embed(t)
+            return out
+        if self.tokenizer is None:
+            raise L.ShodhError(L.ERR_STATE, "no tokenizer")
+        ids, mask = self._tokenize(full)
+        emb = self.encode_ids(ids, mask)
+        for j, i in enumerate(idx):
+            out[i] = emb[j]
+        return out
+
+    def count_tokens(self, text):                                      # minilm.rs:1216-1229
+        if text == "":
+            return SPECIAL_TOKEN_OVERHEAD
+        if not self.simplified_mode and self.tokenizer is not None:
+            self.tokenizer.no_truncation()
+            try:
+                return len(self.tokenizer.encode(text, add_special_tokens=True).ids)
+            finally:
+                self.tokenizer.enable_truncation(max_length=MODEL_TOKEN_WINDOW)
+        return max(1, len(text) // 4) + SPECIAL_TOKEN_OVERHEAD
+
+    def chunk_budget_tokens(self):                                     # minilm.rs:1236-1245
+        if not self.doc_prefix:
+            return MODEL_TOKEN_WINDOW
+        prefix_tokens = max(0, self.count_tokens(self.doc_prefix) - SPECIAL_TOKEN_OVERHEAD)
+        return max(0, MODEL_TOKEN_WINDOW - prefix_tokens)

@@ -1,0 +1,93 @@
+"""Hot subset of `RetrievalEngine` (src/memory/retrieval.rs): IdMapping, index_memory, search_ids,
+search_by_embedding -- the glue between the embedder, the vector index and memory ids. The storage
+engine (RocksDB), chunker and event buffer of the reference are out of scope; an in-memory mapping
+stands in for `update_vector_mapping`.
+"""
+import uuid as _uuid
+
+import numpy as np
+
+from . import _lib as L
+from .index import VamanaConfig, VamanaIndex
+
+VECTOR_SEARCH_CANDIDATE_MULTIPLIER = 2      # src/constants.rs:350
+
+
+class IdMapping:
+    """retrieval.rs:70-142: vector_id (u32) <-> MemoryId (uuid); several chunk vectors may map to one memory."""
+
+    def __init__(self):
+        self.vector_to_memory = {}
+        self.memory_to_vectors = {}
+
+    def insert(self, memory_id, vector_id):
+        if self.vector_to_memory.get(vector_id) == memory_id:
+            return                                      # idempotent (retrieval.rs:2160-2178)
+        self.vector_to_memory[vector_id] = memory_id
+        self.memory_to_vectors.setdefault(memory_id, []).append(vector_id)
+
+    def get_memory_id(self, vector_id):
+        return self.vector_to_memory.get(vector_id)
+
+    def get_vector_ids(self, memory_id):
+        return list(self.memory_to_vectors.get(memory_id, []))
+
+    def remove_all(self, memory_id):
+        for v in self.memory_to_vectors.pop(memory_id, []):
+            self.vector_to_memory.pop(v, None)
+
+    def len(self):
+        return len(self.memory_to_vectors)
+
+
+class RetrievalEngine:
+    def __init__(self, embedder, dimension=384, device=0, scan_mode=L.SCAN_AUTO):
+        # retrieval.rs:174-193: NormalizedDotProduct only
+        self.embedder = embedder
+        self.vector_index = VamanaIndex(VamanaConfig(dimension=dimension, device=device, scan_mode=scan_mode))
+        self.id_mapping = IdMapping()
+
+    def index_memory(self, memory_id, content=None, embedding=None, chunks=None):
+        """retrieval.rs:646-730. `chunks`: pre-chunked texts (the structural chunker is host text logic and out
+        of scope); short memories reuse `embedding` (:704-705)."""
+        assert isinstance(memory_id, _uuid.UUID)
+        if chunks:
+            vecs = self.embedder.encode_batch(chunks)
+        else:
+            vecs = [np.asarray(embedding, np.float32) if embedding is not None else self.embedder.encode(content)]
+        ids = []
+        for v in vecs:
+            vid = self.vector_index.add_vector(v)
+            self.id_mapping.insert(memory_id, vid)
+            ids.append(vid)
+        return ids
+
+    def _postprocess(self, results, limit, exclude=None):
+        if not results:
+            return []
+        n_vec = self.vector_index.len()
+        v2m = np.full((n_vec, 16), 0xFF, np.uint8)
+        for vid, mid in self.id_mapping.vector_to_memory.items():
+            if vid < n_vec and (exclude is None or mid != exclude):
+                v2m[vid] = np.frombuffer(mid.bytes, np.uint8)
+        vec_ids = np.array([r[0] for r in results], np.uint32)
+        dists = np.array([r[1] for r in results], np.float32)
+        out_u = np.zeros((max(limit, 1), 16), np.uint8)
+        out_s = np.zeros(max(limit, 1), np.float32)
+        m = L.lib().shodh_search_ids_postprocess(vec_ids.ctypes.data, dists.ctypes.data, len(results), v2m.ctypes.data, n_vec, limit,
+                                                 out_u.ctypes.data, out_s.ctypes.data)
+        return [(_uuid.UUID(bytes=bytes(out_u[i])), float(out_s[i])) for i in range(m)]
+
+    def search_ids(self, query_text=None, query_embedding=None, limit=10):
+        """retrieval.rs:872-964 -> [(MemoryId, similarity)]"""
+        if query_embedding is None:
+            if query_text is None:
+                return []
+            query_embedding = self.embedder.encode(query_text)
+        res = self.vector_index.search(query_embedding, limit * VECTOR_SEARCH_CANDIDATE_MULTIPLIER * 2)   # :913-918
+        return self._postprocess(res, limit)
+
+    def search_by_embedding(self, embedding, limit, exclude_id=None):
+        """retrieval.rs:980-1031 (dedup / interference check of remember, memory/mod.rs:1252-1256)"""
+        res = self.vector_index.search(embedding, limit * VECTOR_SEARCH_CANDIDATE_MULTIPLIER * 2)
+        return self._postprocess(res, limit, exclude=exclude_id)

@@ -1,0 +1,140 @@
+"""GPU tests of the HIP MiniLM encoder through the C ABI: against the committed golden vectors
+(transformers.BertModel with the seed-1234 synthetic weights) and against the plain-torch fp32
+restatement on fresh random batches. Tolerances: fp32 path 1e-4 absolute on unit vectors; bf16 path
+cosine >= 0.999. Parity with the real all-MiniLM-L6-v2 checkpoint is UNPINNED: no
+weights are available offline."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import bert_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP32_TOL = 1e-4
+BF16_COS = 0.999
+
+
+@pytest.fixture(scope="module")
+def S():
+    from shodh_memory_amd import build
+    build.build()
+    import shodh_memory_amd as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def ref_sd():
+    from shodh_memory_amd import embedder as E
+    b = E.synthetic_weights(1234)
+    return {k: torch.from_numpy(v.copy()).cuda() for k, v in E.blob_to_state_dict(b).items()}
+
+
+def cos(a, b):
+    return (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_golden_vectors(S, dtype):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz"))
+    e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+    assert e.dimension() == 384
+    for name in ("b1", "b4", "edge"):
+        emb = e.encode_ids(g[name + "_ids"], g[name + "_mask"])
+        exp = g[name + "_emb"]
+        lens = g[name + "_mask"].sum(1)
+        assert (emb[lens == 0] == 0).all()                                 # empty text -> zero vector (minilm.rs:1123-1125)
+        if dtype == 0:
+            assert np.abs(emb - exp).max() < FP32_TOL, (name, np.abs(emb - exp).max())
+        else:
+            assert cos(emb[lens > 0], exp[lens > 0]).min() > BF16_COS, (name, cos(emb[lens > 0], exp[lens > 0]))
+        assert np.allclose(np.linalg.norm(emb[lens > 0], axis=1), 1, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_random_batches_vs_torch_reference(S, ref_sd, dtype):
+    e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+    for b, seed in ((1, 1), (7, 2), (64, 3), (130, 4)):
+        ids, mask = bert_ref.synth_batch(b, 256, seed=seed)
+        with torch.no_grad():
+            exp = bert_ref.encode(ref_sd, ids.cuda(), mask.cuda()).cpu().numpy()
+        emb = e.encode_ids(ids.numpy().astype(np.int32), mask.numpy().astype(np.uint8))
+        if dtype == 0:
+            assert np.abs(emb - exp).max() < FP32_TOL, (b, np.abs(emb - exp).max())
+        else:
+            assert cos(emb, exp).min() > BF16_COS, (b, cos(emb, exp).min())
+    t = e.stage_timings_us()
+    assert t["embedding_us"] > 0 and t["tokens"] > 0
+
+
+def test_full_length_and_device_api(S, ref_sd):
+    e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=0)
+    ids, mask = bert_ref.synth_batch(3, 256, seed=9, lengths=[256, 200, 129])    # beyond the tokenizer's 128 cut: the ABI allows max_len
+    with torch.no_grad():
+        exp = bert_ref.encode(ref_sd, ids.cuda(), mask.cuda()).cpu().numpy()
+    d_ids = ids.to(torch.int32).cuda().contiguous(); d_mask = mask.to(torch.uint8).cuda().contiguous()
+    out = e.encode_ids_device(d_ids, d_mask)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - exp).max() < FP32_TOL
+    from shodh_memory_amd import _lib
+    bad = mask.numpy().astype(np.uint8).copy(); bad[0, 5] = 0                     # hole in the mask: rejected
+    with pytest.raises(_lib.ShodhError):
+        e.encode_ids(ids.numpy().astype(np.int32), bad)
+    e2 = S.MiniLMEmbedder()                                                       # no weights loaded
+    with pytest.raises(_lib.ShodhError):
+        e2.encode_ids(ids.numpy().astype(np.int32), mask.numpy().astype(np.uint8))
+
+
+def test_embedder_trait_with_a_tokenizer(S):
+    """Embedder::encode / encode_query / encode_batch semantics (mod.rs:52-70, minilm.rs:1195-1377) with a
+    small in-memory WordPiece tokenizer (the real tokenizer.json is not shipped)."""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    vocab = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102}
+    for i, w in enumerate("the quick brown fox jumps over lazy dog memory recall vector search rust gpu hello world query passage :".split()):
+        vocab[w] = 1000 + i
+    tok = Tokenizer(models.WordPiece(vocab, unk_token="[UNK]"))
+    tok.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", 101), ("[SEP]", 102)])
+    e = S.MiniLMEmbedder(tokenizer=tok, synthetic_seed=1234, dtype=0)
+    a = e.encode("The quick brown fox")
+    assert a.shape == (384,) and abs(np.linalg.norm(a) - 1) < 1e-4
+    assert np.array_equal(e.encode_query("The quick brown fox"), a)              # symmetric model: same path
+    assert not e.encode("").any()
+    batch = e.encode_batch(["hello world", "", "the lazy dog"])
+    assert len(batch) == 3 and not batch[1].any()
+    assert np.abs(batch[0] - e.encode("hello world")).max() < 1e-5
+    assert e.count_tokens("") == 2 and e.count_tokens("hello world") == 4 and e.chunk_budget_tokens() == 128
+    long_text = " ".join(["fox"] * 400)
+    assert e.count_tokens(long_text) == 402                                       # counted without truncation
+    v = e.encode(long_text)                                                       # truncated to 128 tokens by the tokenizer
+    assert abs(np.linalg.norm(v) - 1) < 1e-4 and e.stage_timings_us()["tokens"] == 128
+    # asymmetric prefixes (SHODH_EMBEDDER=e5: minilm.rs:279-300)
+    e5 = S.MiniLMEmbedder(tokenizer=tok, synthetic_seed=1234, dtype=0, query_prefix="query: ", doc_prefix="passage: ")
+    assert not np.array_equal(e5.encode("hello world"), e5.encode_query("hello world"))
+    assert e5.chunk_budget_tokens() < 128
+
+
+def test_retrieval_engine_with_simplified_embedder(S):
+    """retrieval.rs:2446-2535 shape: simplified (hash) embedder + deterministic vectors through
+    index_memory / search_ids, chunk dedup keeps the best chunk per memory."""
+    import uuid
+    from tests.test_oracle_kats import ref_test_vector
+    eng = S.RetrievalEngine(S.MiniLMEmbedder.new_simplified(), dimension=384, scan_mode=1)
+    mids = [uuid.UUID(int=1000 + i) for i in range(25)]
+    for i, m in enumerate(mids):
+        eng.index_memory(m, embedding=ref_test_vector(i, 384))
+    for i, m in enumerate(mids):
+        res = eng.search_ids(query_embedding=ref_test_vector(i, 384), limit=3)
+        assert res[0][0] == m and abs(res[0][1] - 1.0) < 1e-5 and len(res) == 3
+    # a chunked memory: three vectors -> one id, max similarity kept
+    big = uuid.UUID(int=5)
+    eng.index_memory(big, chunks=["alpha beta", "gamma delta", "epsilon"])
+    assert len(eng.id_mapping.get_vector_ids(big)) == 3
+    q = eng.embedder.encode("gamma delta")
+    res = eng.search_ids(query_embedding=q, limit=5)
+    assert res[0][0] == big and abs(res[0][1] - 1.0) < 1e-5 and [r[0] for r in res].count(big) == 1
+    assert eng.search_by_embedding(q, 5, exclude_id=big)[0][0] != big
+    assert eng.search_ids() == []
