@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Secondary measurements (NOT the driver's contract line; that is bench.py): the other
+BASELINE.json configurations and a few diagnostics, one JSON object per line.
+
+  python bench_extra.py flat10m | k120 | pcie | latency | encoder | ivfpq [--rows N]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+import bench          # noqa: E402
+import shodh_memory_amd as S   # noqa: E402
+from shodh_memory_amd import _lib as L   # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, steps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps
+
+
+def flat(rows_n, nq, k, steps=20, scan=L.SCAN_AUTO, tag="flat"):
+    rows = bench.synth_rows(torch, rows_n, 384, 1, dev)
+    q = bench.synth_rows(torch, nq, 384, 2, dev)
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=384, scan_mode=scan, reserve_rows=rows_n))
+    idx.build(rows)
+    del rows
+    out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq,), dtype=torch.int32, device=dev))
+    idx.kernel_timing(True)
+    dt = timed(lambda: idx.search_batch_device(q, k, out=out), steps)
+    km, kmin, kn = idx.kernel_timing(True)
+    alg = rows_n * 384 * 4
+    print(json.dumps({"bench": tag, "rows": rows_n, "nq": nq, "k": k, "ms_per_step": round(dt * 1e3, 4), "qps": round(nq / dt, 1),
+                      "scan_kernel_us_mean": round(km, 1), "scan_kernel_algorithmic_GBs": round(alg * ((nq + 255) // 256 if nq > 4 else 1) / (km * 1e-6) / 1e9 / max(1, (nq + 255) // 256 if nq > 4 else 1), 1),
+                      "hbm_frac_of_8TBs": round(alg / (km * 1e-6) / 8e12, 4)}), flush=True)
+    return idx, q
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("flat10m", "all"):
+        flat(10_000_000, 256, 10, steps=10, tag="flat 10M x 384, batch 256, top-10")
+        flat(10_000_000, 1024, 10, steps=5, tag="flat 10M x 384, batch 1024, top-10")
+        flat(10_000_000, 1, 10, steps=20, tag="flat 10M x 384, single query (exact-order scan)")
+    if what in ("k120", "all"):
+        flat(1_000_000, 256, 120, steps=20, tag="flat 1M, batch 256, k=120 (the index-level k of a top-10 recall, retrieval.rs:913-918)")
+        flat(1_000_000, 64, 10, steps=20, tag="flat 1M, batch 64, top-10")
+        flat(1_000_000, 1024, 10, steps=10, tag="flat 1M, batch 1024, top-10")
+    if what in ("latency", "all"):
+        for mode, name in ((L.SCAN_EXACT, "exact-order f32 scan"), (L.SCAN_MFMA, "fp16 MFMA pre-scan + re-score")):
+            idx, q = flat(1_000_000, 1, 10, steps=50, scan=mode, tag="flat 1M single query: " + name)
+    if what in ("pcie", "all"):
+        rows = bench.synth_rows(torch, 1_000_000, 384, 1, dev)
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=384, reserve_rows=1_000_000))
+        idx.build(rows)
+        qh = bench.synth_rows(torch, 256, 384, 2, dev).cpu().numpy()
+        for _ in range(3):
+            idx.search_batch(qh, 10)
+        t = time.perf_counter()
+        for _ in range(20):
+            idx.search_batch(qh, 10)
+        dt = (time.perf_counter() - t) / 20
+        print(json.dumps({"bench": "flat 1M, batch 256, top-10, HOST pointers (PCIe H2D queries + D2H results + sync per call)",
+                          "ms_per_step": round(dt * 1e3, 4), "qps": round(256 / dt, 1), "stage_us": idx.stage_timings_us()}), flush=True)
+    if what in ("encoder", "all"):
+        from tests import bert_ref
+        for dtype, name in ((L.DTYPE_BF16, "bf16"), (L.DTYPE_FP32, "fp32")):
+            e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+            b = 4096 if dtype == L.DTYPE_BF16 else 512
+            ids, mask = bert_ref.synth_batch(b, 256, seed=5)
+            d_ids = ids.to(torch.int32).cuda().contiguous(); d_mask = mask.to(torch.uint8).cuda().contiguous()
+            out = torch.empty((b, 384), dtype=torch.float32, device=dev)
+            dt = timed(lambda: e.encode_ids_device(d_ids, d_mask, out=out), 5, warmup=2)
+            tokens = int(mask.sum())
+            lens = mask.sum(1).double()
+            flop = float(tokens * 2 * (3 * 384 * 384 + 384 * 384 + 2 * 384 * 1536) * 6 + (lens ** 2).sum() * 4 * 384 * 6)
+            print(json.dumps({"bench": "MiniLM-L6 encode, %s, batch %d texts, lengths U[8,128] (real tokens only)" % (name, b),
+                              "ms_per_batch": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1),
+                              "tflops": round(flop / dt / 1e12, 2), "device_us": e.stage_timings_us()}), flush=True)
+    if what in ("ivfpq", "all"):
+        n = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 10_000_000
+        P, nprobe, nq, k = 4096, 32, 1024, 10
+        rows = bench.synth_rows(torch, n, 384, 1, dev)
+        g = torch.Generator(device=dev).manual_seed(3)
+        cent = rows[torch.randperm(n, generator=g, device=dev)[:P]].contiguous()
+        # a few Lloyd steps in torch (any trained state is valid input; parity is defined given the state)
+        sample = rows[torch.randperm(n, generator=g, device=dev)[:min(n, 400_000)]]
+        for _ in range(4):
+            a = (sample @ cent.T).argmax(1)
+            cent = torch.zeros_like(cent).index_add_(0, a, sample)
+            cnt = torch.bincount(a, minlength=P).clamp(min=1)[:, None]
+            cent = torch.nn.functional.normalize(cent / cnt, dim=1)
+        sub = sample[:65536].view(-1, 48, 8)
+        codebook = torch.stack([sub[torch.randperm(sub.shape[0], generator=g, device=dev)[:256], m] for m in range(48)]).contiguous()
+        idx = S.SpannIndex(384, num_probes=nprobe)
+        idx.set_trained_state(cent.cpu().numpy(), codebook.cpu().numpy(), np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 48), np.uint8))
+        t = time.perf_counter()
+        h_rows = rows.cpu().numpy()
+        assign, codes = idx.encode(h_rows)
+        t_enc = time.perf_counter() - t
+        order = np.argsort(assign, kind="stable")
+        off = np.zeros(P + 1, np.uint64); off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+        idx.set_trained_state(cent.cpu().numpy(), codebook.cpu().numpy(), off, order.astype(np.uint32), codes[order])
+        qh = bench.synth_rows(torch, nq, 384, 2, dev).cpu().numpy()
+        for _ in range(2):
+            idx.search_batch(qh, k)
+        t = time.perf_counter()
+        for _ in range(5):
+            ids, dist, counts = idx.search_batch(qh, k)
+        dt = (time.perf_counter() - t) / 5
+        lens = np.diff(off.astype(np.int64))
+        print(json.dumps({"bench": "IVF-PQ %d rows, nlist %d, nprobe %d, batch %d, top-%d (host API)" % (n, P, nprobe, nq, k),
+                          "ms_per_batch": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "encode_s_for_all_rows": round(t_enc, 2),
+                          "list_len_mean": float(lens.mean()), "list_len_max": int(lens.max()),
+                          "algorithmic_bytes_per_query": float(nprobe * lens.mean() * 52)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

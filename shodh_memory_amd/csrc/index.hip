@@ -228,8 +228,10 @@ static bool use_mfma(const shodh_index *idx, uint32_t nq, uint32_t k) {
     if (!idx->shadow || !idx->quantizable) return false;
     if (k == 0 || k > 2048) return false;
     if (idx->n < 16384 || idx->n < 64ull * k) return false;     // pre-scan sampling needs a real corpus
-    if (idx->cfg.scan_mode == SHODH_SCAN_MFMA) return true;
-    return nq >= 4;                                             // AUTO: exact scan is HBM-bound for tiny batches
+    (void)nq;
+    // AUTO == MFMA whenever the shadow copy is usable: measured at 1M rows a single query takes 260 us on the
+    // fp16 pre-scan path (half the bytes) vs 346 us on the exact-order f32 scan; batches only widen the gap.
+    return true;
 }
 
 // enqueue a FLAT search on `st` using workspace w (device in/out pointers)

@@ -89,8 +89,9 @@ class ShardedFlatIndex:
         self.index.search_batch_device(queries, k, out=(b["ids"], b["dist"], b["counts"]))
         if self.world == 1:
             return b["ids"], b["dist"], b["counts"]
-        self.dist.all_gather_into_tensor(b["ids_all"], b["ids"], group=self.group)
-        self.dist.all_gather_into_tensor(b["dist_all"], b["dist"], group=self.group)
+        # concatenation form [world*nq, k] (accepted by both RCCL and gloo); same memory as [world, nq, k]
+        self.dist.all_gather_into_tensor(b["ids_all"].view(self.world * nq, k), b["ids"], group=self.group)
+        self.dist.all_gather_into_tensor(b["dist_all"].view(self.world * nq, k), b["dist"], group=self.group)
         st = torch.cuda.current_stream(queries.device).cuda_stream
         L.check(L.lib().shodh_topk_merge_device(b["ids_all"].data_ptr(), b["dist_all"].data_ptr(), self.world, nq, k,
                                                 b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_counts"].data_ptr(),

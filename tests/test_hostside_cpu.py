@@ -1,0 +1,73 @@
+"""Host-side glue exported by the C ABI (no device): hash embedder, search_ids post-processing and
+RRF must equal the oracle's restatement bit-for-bit."""
+import ctypes as C
+import uuid
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def L():
+    from shodh_memory_amd import build
+    build.build()
+    from shodh_memory_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def test_hash_embed_matches_oracle(L, oracle):
+    texts = ["Hello world", "", "a", "ab", "  leading and   trailing  ", "café olé 😀 naïve", "x" * 500,
+             "The quick brown fox jumps over the lazy dog " * 5, "tab\tnew\nline　ideographic space"]
+    for t in texts:
+        b = t.encode("utf-8")
+        for dim in (384, 128, 1024):
+            out = np.zeros(dim, np.float32)
+            assert L.lib().shodh_hash_embed(b, len(b), dim, out.ctypes.data) == 0
+            assert out.tobytes() == oracle.hash_embed(t, dim).tobytes(), (t[:20], dim)
+    v = np.zeros(384, np.float32)
+    L.lib().shodh_hash_embed(b"Hello world", 11, 384, v.ctypes.data)          # minilm.rs:1399-1417
+    assert abs(float(np.linalg.norm(v)) - 1.0) < 1e-5
+
+
+def test_search_ids_postprocess_matches_oracle(L, oracle):
+    rng = np.random.default_rng(4)
+    n_vec = 500
+    mem = [uuid.UUID(int=int(x)).bytes for x in rng.integers(1, 2 ** 62, 120)]
+    v2m = np.frombuffer(b"".join(mem[int(i)] if rng.random() > 0.1 else b"\xff" * 16 for i in rng.integers(0, 120, n_vec)), np.uint8).reshape(-1, 16).copy()
+    for trial in range(20):
+        n = int(rng.integers(0, 200))
+        vec_ids = rng.integers(0, n_vec + 20, n).astype(np.uint32)
+        dists = (-rng.random(n)).astype(np.float32)
+        dists[rng.random(n) < 0.2] = np.float32(-0.5)                       # ties -> uuid order decides
+        limit = int(rng.integers(1, 40))
+        ou = np.zeros((limit, 16), np.uint8); os_ = np.zeros(limit, np.float32)
+        m = L.lib().shodh_search_ids_postprocess(vec_ids.ctypes.data, dists.ctypes.data, n, v2m.ctypes.data, n_vec, limit, ou.ctypes.data, os_.ctypes.data)
+        eu, es = oracle.search_ids_postprocess(vec_ids, dists, v2m, limit)
+        assert m == len(eu) and ou[:m].tobytes() == eu.tobytes() and os_[:m].tobytes() == es.tobytes()
+
+
+def test_rrf_matches_oracle_and_reference_kats(L, oracle):
+    id1, id2, id3 = (uuid.UUID(int=i).bytes for i in (1, 2, 3))
+
+    def fuse(k, w, lists):
+        w = np.asarray(w, np.float32)
+        flat = np.frombuffer(b"".join(b"".join(l) for l in lists) or b"\0" * 16, np.uint8).copy()
+        lens = (C.c_size_t * len(lists))(*[len(l) for l in lists])
+        cap = max(sum(len(l) for l in lists), 1)
+        ou = np.zeros((cap, 16), np.uint8); os_ = np.zeros(cap, np.float32)
+        m = L.lib().shodh_rrf_fuse(k, w.ctypes.data, len(lists), flat.ctypes.data, lens, ou.ctypes.data, os_.ctypes.data, cap)
+        return [bytes(ou[i]) for i in range(m)], os_[:m].copy()
+    ids, sc = fuse(60.0, [0.5, 0.5], [[id1, id2, id3], [id2, id1, id3]])     # hybrid_search.rs:970-1029
+    assert abs(dict(zip(ids, sc))[id1] - dict(zip(ids, sc))[id2]) < 1e-4 and ids[2] == id3
+    lo, hi = uuid.UUID(int=5).bytes, uuid.UUID(int=9).bytes
+    ids, sc = fuse(60.0, [0.5, 0.5], [[hi], [lo]])                           # :1031-1056 ties -> lower MemoryId first
+    assert ids == [lo, hi]
+    rng = np.random.default_rng(0)
+    pool = [uuid.UUID(int=int(x)).bytes for x in rng.integers(1, 2 ** 60, 50)]
+    for _ in range(10):
+        lists = [[pool[int(i)] for i in rng.permutation(50)[:int(rng.integers(0, 30))]] for _ in range(3)]
+        w = rng.random(3).astype(np.float32)
+        a_ids, a_sc = fuse(60.0, w, lists)
+        e_ids, e_sc = oracle.rrf_fuse(60.0, w, lists)
+        assert a_ids == e_ids and a_sc.tobytes() == e_sc.tobytes()
