@@ -131,13 +131,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     rows_local = hi - lo
     alg_bytes = rows_local * args.dim * 4                 # corpus read once per batch at f32
+    # HBM traffic of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE doubled per the
+    # gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc in separate runs, not live)
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if (pm["config"]["rows"], pm["config"]["dim"], pm["config"]["nq"]) == (rows_local, args.dim, args.nq) and args.scan != "exact":
+            traffic = [v["traffic_bytes_per_launch"] for kk, v in pm["kernels"].items() if "mfma_scan_kernel<1" in kk][0]
+    except Exception:
+        traffic = None
     roof = None
     if kern_n:
         ach = alg_bytes / (kern_mean_us * 1e-6) / 1e9
         flops = 2.0 * rows_local * args.dim * 256         # the pre-scan always multiplies a 256-query pass
-        roof = {"bound": "hbm", "kernel": "mfma_scan_kernel<EMIT>" if args.nq >= 4 and args.scan != "exact" else "flat_exact_kernel",
+        roof = {"bound": "hbm", "kernel": "mfma_scan_kernel<EMIT>" if args.scan != "exact" else "flat_exact_kernel",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
+                "traffic": traffic, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
                 "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_moved_fp16_shadow_per_launch": rows_local * args.dim * 2,
                 "mfma_tflops": round(flops / (kern_mean_us * 1e-6) / 1e12, 1), "mfma_frac": round(flops / (kern_mean_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
