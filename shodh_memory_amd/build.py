@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libshodh_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact-order kernels must not fuse a*b+c (rustc never does)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("SHODH_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(EX_NT) void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *mins = keys + a.cap;
-    uint64_t *thr = mins + EX_NT;
+    uint64_t *thr = mins + 2 * EX_NT;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(EX_NT) void merge_lists_kernel(MergeListsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *mins = keys + a.cap;
-    uint64_t *thr = mins + EX_NT;
+    uint64_t *thr = mins + 2 * EX_NT;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
@@ -477,7 +477,7 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
         }
     }
     MergeArgs m{partial, grid_x, (uint32_t)qb, k, cap, nq, d_ids, d_dist, d_counts, qlist, qcount};
-    const size_t mlds = (size_t)cap * 8 + EX_NT * 8 + 8 + 4 + 16;
+    const size_t mlds = (size_t)cap * 8 + 2 * EX_NT * 8 + 8 + 4 + 16;
     SHODH_TRY(ensure_dynamic_lds((const void *)merge_topk_kernel, mlds));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(EX_NT), mlds, st, m);
     SHODH_HIP_TRY(hipGetLastError());
@@ -489,7 +489,7 @@ int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint32_t n_
     if (nq == 0) return SHODH_OK;
     const uint32_t cap = topk_capacity(k);
     MergeListsArgs a{in_ids, in_dist, n_lists, nq, k, cap, ids, dist, counts};
-    const size_t lds = (size_t)cap * 8 + EX_NT * 8 + 8 + 4 + 16;
+    const size_t lds = (size_t)cap * 8 + 2 * EX_NT * 8 + 8 + 4 + 16;
     SHODH_TRY(ensure_dynamic_lds((const void *)merge_lists_kernel, lds));
     hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(EX_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());

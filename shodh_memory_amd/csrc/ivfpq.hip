@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void adc_merge_kernel(AdcMergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *mins = keys + a.cap;
-    uint64_t *thr = mins + 256;
+    uint64_t *thr = mins + 512;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
@@ -338,7 +338,7 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
     hipLaunchKernelGGL(adc_scan_kernel, dim3(nq, split), dim3(256), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     AdcMergeArgs m{partial, split, k, cap, d_ids, d_dist, d_counts};
-    const size_t mlds = (size_t)cap * 8 + 256 * 8 + 8 + 4 + 16;
+    const size_t mlds = (size_t)cap * 8 + 512 * 8 + 8 + 4 + 16;
     SHODH_TRY(ensure_dynamic_lds((const void *)adc_merge_kernel, mlds));
     hipLaunchKernelGGL(adc_merge_kernel, dim3(nq), dim3(256), mlds, st, m);
     SHODH_HIP_TRY(hipGetLastError());

@@ -23,8 +23,8 @@
 // top-k filter is a register compare against a per-lane threshold; survivors (rare) are appended
 // to per-query candidate lists with one atomic each.
 //
-// Thresholds come from a 1/32 strided sample of the tiles (same kernel, BLOCKMAX epilogue): the
-// k-th largest of the per-16-row maxima is a valid lower bound of the k-th best score.
+// Thresholds come from a 1/16 strided sample of the tiles (same kernel, BLOCKMAX epilogue): the
+// k-th largest of the per-tile maxima is a valid lower bound of the k-th best score.
 #include <cstdlib>
 
 #include "common.h"
@@ -38,13 +38,24 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_EQ_CAP = 2048;   // LDS emit-queue entries per workgroup
+constexpr int MF_EQ_CAP = 1024;   // LDS emit-queue entries per workgroup
 constexpr int MF_TR = 64;        // corpus rows per tile
 constexpr int MF_BPAD = 256;     // queries per pass
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
 constexpr float MF_INV_SCALE2 = 1.0f / 65536.0f;   // acc -> score
 
 enum { MF_MODE_BLOCKMAX = 0, MF_MODE_EMIT = 1 };
+
+// build with SHODH_EXTRA_FLAGS=-DSHODH_PROF to print per-section wave cycles (s_memtime) of the scan kernel
+#ifdef SHODH_PROF
+#define PROF_DECL long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64();
+#define PROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
+#define PROF_N(i) pt_[i] += 1;
+#else
+#define PROF_DECL
+#define PROF_T(i)
+#define PROF_N(i)
+#endif
 
 struct MfmaArgs {
     const _Float16 *rows_h;   // [n_rows][dim] fp16(256*x); tombstoned rows are zero
@@ -56,75 +67,116 @@ struct MfmaArgs {
     uint64_t *cand;           // [passes][256][cand_cap]  key = (order_key(-s~) << 32) | local row
     uint32_t *cand_cnt;       // [passes][256]
     uint32_t cand_cap;
-    float *blockmax;          // [passes][J][256], J = n_sel_tiles * 4
+    float *blockmax;          // [passes][J][256], J = n_sel_tiles (one maximum per sampled 64-row tile and query)
     uint32_t tile_stride;     // tile index = sel * tile_stride
     uint32_t n_sel_tiles;
     uint32_t ablate;          // diagnostics only (SHODH_ABLATE): 1 = skip the MFMA phase, 2 = skip the HBM loads
 };
 
-// QB = 32-query blocks per wave: QB=1 -> 8 waves (2 per SIMD, 256 registers each), QB=2 -> 4 waves
-// (1 per SIMD, 512 registers each; every A fragment read from LDS feeds two MFMAs).
-template <int MODE, int KSTEPS, int QB>
-__global__ __launch_bounds__(512 / QB, 2 / QB) void mfma_scan_kernel(MfmaArgs a) {
-    constexpr int NT = 512 / QB;
+// LDS-DMA: 16 bytes per lane from each lane's own global address (uniform base + per-lane byte offset) to
+// LDS [m0 + lane*16]. hipcc neither counts nor waits for it (inline asm): completion is tracked by hand with
+// s_waitcnt vmcnt(N) below. M0 is compiler-reserved, so it is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void *gbase, uint32_t voff_bytes, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int KSTEPS>
+__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + 64 <= 160 * 1024) ? 3 : 2; }
+
+// 8 waves per workgroup (2 per SIMD), wave w owns queries [32w, 32w+32) as resident B fragments (dim/16 x 4 VGPRs).
+// Every wave runs ONE software-pipelined instruction stream per 64-row tile: 2*KSTEPS MFMAs (row block 0 into acc0 for all
+// k-steps, then row block 1 into acc1), and in their shadows (the matrix pipe is busy 32 cycles per MFMA; the wave
+// is free to issue other work meanwhile)
+//   - one ds_read_b128 per MFMA: the A fragment D steps ahead;
+//   - the running maximum of the accumulator that is NOT being written (acc1 of the previous tile during the acc0
+//     chain, acc0 during the acc1 chain), one v_max per MFMA; only when a lane's maximum reaches its threshold --
+//     rare -- are the 16 values walked;
+//   - the LDS-DMA (global_load_lds_dwordx4) of this thread's share of the tile NBUF-1 ahead: no staging registers,
+//     no ds_write pass, and two tile periods for the data to land (NBUF = 3 where the LDS allows it).
+// The LDS image of a tile is row-major with the 16-B chunks of a row XOR-swizzled by row&15 (conflict-free
+// ds_read_b128 for the 32x32x16 A fragment). LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE
+// address: the lane that owns LDS chunk (row, p) fetches global chunk (row, p ^ (row&15)) -- a permutation inside one
+// 256-B segment, still whole cache lines per wave.
+// One s_barrier per tile hands the buffers over (raw barrier + lgkmcnt(0): a __syncthreads() would not wait for
+// the DMA anyway, the counted vmcnt before it does).
+// History, cycles per tile at 1M x 384, 256 queries (s_memtime; matrix-pipe floor 2 waves x 48 x 32 = 3072):
+//   register staging, all phases in sequence, waves in lock-step: 5190; two wave groups half a tile out of phase
+//   (one group multiplies while the other stages): 5390 including the profiling reads -- the two groups' MFMA phases
+//   ended up serialised by the two barriers per tile.
+template <int MODE, int KSTEPS>
+__global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
+    constexpr int NT = 512;
     constexpr int DIM = KSTEPS * 16;
     constexpr int CPR = KSTEPS * 2;          // 16-B chunks per row
     constexpr int PITCH = DIM * 2;           // bytes per row in LDS
     constexpr int CPT = MF_TR * CPR / NT;    // chunks per thread per tile
     constexpr int TILE_BYTES = MF_TR * PITCH;
+    constexpr int NS = 2 * KSTEPS;           // MFMAs per wave and tile (step s: row block s / KSTEPS, k-step s % KSTEPS)
+    constexpr int D = 6;                     // A fragments in flight
+    constexpr int NBUF = mfma_scan_nbuf<KSTEPS>();
+    constexpr int PF = NBUF - 1;             // tiles the DMA runs ahead
+    static_assert(8 * CPT <= NS, "DMA issue slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: [2 tiles][emit queue: MF_EQ_CAP x (key u64, query u32)][queue counter]
-    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + 2 * TILE_BYTES);
+    // LDS: [NBUF tiles][emit queue: MF_EQ_CAP x (key u64, query u32)][queue counter][flush flags]
+    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + NBUF * TILE_BYTES);
     uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
     uint32_t *eq_cnt = eq_q + MF_EQ_CAP;
     uint32_t *eq_flag = eq_cnt + 1;          // [2] double-buffered "flush now" decision (block-uniform)
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
     const uint32_t pass = blockIdx.y;
-    const uint32_t q_base = wave * 32 * QB + l31;       // this lane's queries within the pass: q_base + 32*qb
-    if (tid == 0) *eq_cnt = 0;
+    const uint32_t q_local = wave * 32 + l31;      // this lane's query within the pass
+    if (tid == 0) { *eq_cnt = 0; eq_flag[0] = 0; eq_flag[1] = 0; }
+#ifdef SHODH_PROF
+    const long long wc0_ = wall_clock64();
+#endif
 
-    // resident B fragments: query q_base + 32*qb, k = ks*16 + hi*8 .. +8
-    half8 bq[QB][KSTEPS];
+    // source byte offsets inside a tile for this thread's LDS chunks p = i*NT + tid (see the swizzle note above).
+    // No row clamp: the shadow slab is allocated in multiples of 64 rows, rows >= n_rows are never reported.
+    uint32_t srcoff[CPT];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const _Float16 *qp = a.q_h + ((size_t)pass * MF_BPAD + q_base + 32 * qb) * DIM + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) bq[qb][ks] = *reinterpret_cast<const half8 *>(qp + ks * 16);
+    for (int i = 0; i < CPT; ++i) {
+        const int p = i * NT + tid;
+        const int row = p / CPR, slot = p % CPR;
+        const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
+        srcoff[i] = (uint32_t)(row * PITCH + c * 16);
     }
-    float thr_l[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-        thr_l[qb] = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_base + 32 * qb] * (MF_SCALE * MF_SCALE) : 0.0f;
+    const size_t tile_bytes_g = (size_t)a.tile_stride * MF_TR * DIM * 2;
+    const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
+    const uint32_t wave_lds = smem_lds + (uint32_t)wave * 1024u;     // this wave's 64 x 16 B window inside each NT-chunk slab
 
-    u32x4 pre[CPT];
-    auto prefetch = [&](uint32_t sel) {
-        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR;
+    uint32_t sel = blockIdx.x;
+    const uint32_t step = gridDim.x;
+    // prologue DMA: tiles 0 .. PF-1 of this workgroup (clamped to a valid tile: a harmless extra read, no branch)
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int S = i * NT + tid;
-            const int row = S / CPR, c = S % CPR;
-            uint64_t r = row0 + row;
-            if (r >= a.n_rows) r = a.n_rows - 1;
-            pre[i] = *reinterpret_cast<const u32x4 *>(a.rows_h + r * DIM + c * 8);
-        }
-    };
-    auto stage = [&](unsigned char *buf) {
+    for (int b = 0; b < PF; ++b) {
+        const uint32_t tsel = sel + b * step < a.n_sel_tiles ? sel + b * step : (sel < a.n_sel_tiles ? sel : 0u);
+        const unsigned char *src = rows_b + (size_t)tsel * tile_bytes_g;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int S = i * NT + tid;
-            const int row = S / CPR, c = S % CPR;
-            *reinterpret_cast<u32x4 *>(buf + row * PITCH + ((c ^ (row & 15)) << 4)) = pre[i];
-        }
-    };
-    // drains the LDS emit queue into the per-query candidate lists (global atomics). Called by the
-    // whole block at points where no prefetch is in flight, so its vmcnt waits cost only themselves.
+        for (int i = 0; i < CPT; ++i) glds16(src, srcoff[i], wave_lds + b * TILE_BYTES + i * NT * 16);
+    }
+
+    // resident B fragments: query q_local, k = ks*16 + hi*8 .. +8
+    half8 bq[KSTEPS];
+    {
+        const _Float16 *qp = a.q_h + ((size_t)pass * MF_BPAD + q_local) * DIM + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bq[ks] = *reinterpret_cast<const half8 *>(qp + ks * 16);
+    }
+    float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
+    if (a.ablate & 8u) thr_l = __builtin_inff();   // diagnostics: nothing is emitted
+
     bool eq_overflowed = false;              // block-uniform: entries were dropped at some point
-    auto flush = [&]() {                     // caller: __syncthreads() before, and after before the next push
+    auto flush = [&]() {                     // caller: barrier before, and after before the next push
         const uint32_t raw = *eq_cnt;
         eq_overflowed |= raw > (uint32_t)MF_EQ_CAP;
         const uint32_t n = raw < (uint32_t)MF_EQ_CAP ? raw : (uint32_t)MF_EQ_CAP;
@@ -140,131 +192,177 @@ __global__ __launch_bounds__(512 / QB, 2 / QB) void mfma_scan_kernel(MfmaArgs a)
         if (tid == 0) *eq_cnt = 0;
     };
 
-    uint32_t sel = blockIdx.x;
-    if (sel < a.n_sel_tiles) prefetch(sel);
-    if (sel < a.n_sel_tiles) stage(smem);
-    // Everything issued so far (query fragments, thresholds, first tile) must have landed before
-    // the stream starts: otherwise hipcc re-waits for the fragment loads INSIDE the loop with
-    // counted vmcnt(N), which in steady state drains the next tile's prefetch half-way through
-    // the MFMA chain and exposes the HBM latency on every tile.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    __syncthreads();
     // LDS byte offsets of this lane's A fragments. chunk c = 2*ks + hi; swizzled chunk = c ^ (row&15)
     // = (c & ~15) | ((c & 15) ^ sw): only 8 distinct low parts per lane, the rest is an immediate.
     const int sw = l31 & 15;
     int aoff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4);
-    int cur = 0;
-    for (; sel < a.n_sel_tiles; sel += gridDim.x) {
-        const uint32_t nxt = sel + gridDim.x;
-        const bool has_next = nxt < a.n_sel_tiles;
-        if (has_next && !(a.ablate & 2)) prefetch(nxt);
+
+    // one score against this lane's threshold. C layout (32x32): col = lane&31 (query), value r of a lane is
+    // row (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-row block. Survivors (rare) go to the workgroup's LDS queue
+    // (LDS atomic, no HBM round trip).
+    auto test_push = [&](float v, float thr, uint64_t grow) {
+        if (v >= thr) {
+            if (grow < a.n_rows) {
+                const uint32_t slot = atomicAdd(eq_cnt, 1u);
+                if (slot < (uint32_t)MF_EQ_CAP) {
+                    eq_key[slot] = make_key(-(v * MF_INV_SCALE2), (uint32_t)grow);
+                    eq_q[slot] = q_local;
+                }
+            }
+        }
+    };
+    // the survivors of one 32-row block (entered when some lane's maximum reached its threshold)
+    auto emit_block = [&](const floatx16 &c, uint64_t brow0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) test_push(c[r], thr_l, brow0 + (r & 3) + 8 * (r >> 2));
+    };
+    const int grp = wave >> 2;               // the two waves of a SIMD issue their DMA in alternate slots
+
+    // the pipeline is primed: everything issued so far (DMA, query fragments, thresholds) lands before the stream starts
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): hipcc's own loads, so that it does not re-wait for them inside the loop
+    __syncthreads();
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool have_prev = false;                 // acc1 of the previous tile waits for its epilogue
+    uint32_t prev_sel = 0;
+    uint32_t cur = 0;                       // LDS buffer of the current tile
+    uint32_t fl = 0;
+    PROF_DECL
+#ifdef SHODH_PROF
+    const long long wc1_ = wall_clock64();
+#endif
+    for (; sel < a.n_sel_tiles; sel += step) {
         const unsigned char *buf = smem + cur * TILE_BYTES;
-        const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
-        floatx16 acc[2][QB];
+        const uint32_t pfb = cur + PF >= NBUF ? cur + PF - NBUF : cur + PF;      // buffer the DMA fills during this tile
+        const uint32_t psel = sel + PF * step < a.n_sel_tiles ? sel + PF * step : sel;
+        const unsigned char *psrc = rows_b + (size_t)psel * tile_bytes_g;
+        const uint32_t pdst = wave_lds + pfb * TILE_BYTES;
+
+        half8 ring[8];
+        auto rd = [&](int st) {
+            const int rb = st / KSTEPS, ks = st % KSTEPS;
+            ring[st & 7] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
+        };
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int st = 0; st < D; ++st) rd(st);
+        PROF_T(0)
+        constexpr int PER1 = (16 + KSTEPS - 1) / KSTEPS;          // accumulator values folded into the maximum per step
+        constexpr int PER0 = (16 + KSTEPS - 3) / (KSTEPS - 2);
+        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + 4 * hi;
+        const uint64_t prow1 = (uint64_t)prev_sel * a.tile_stride * MF_TR + 32 + 4 * hi;
+        float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+        // row block 0 -> acc0; in the shadows: maximum of the previous tile's acc1, DMA issue
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
+        for (int st = 0; st < KSTEPS; ++st) {
+            rd(st + D);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st & 7], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
+            if (MODE == MF_MODE_EMIT) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rb][qb][r] = 0.0f;
-        if (!(a.ablate & 1)) {
-            // A fragments are read from LDS one group (GS k-steps, 2*GS reads) ahead of the MFMAs that
-            // consume them, in two register sets. Left alone hipcc issues each read right before its
-            // MFMA and the chain runs at LDS latency.
-            constexpr int GS = 2;
-            constexpr int NG = KSTEPS / GS;
-            half8 fa[2][GS][2];
-            auto load_group = [&](int slot, int g) {
-#pragma unroll
-                for (int j = 0; j < GS; ++j) {
-                    const int ks = g * GS + j;
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        fa[slot][j][rb] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
-                }
-            };
-            load_group(0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) load_group((g + 1) & 1, g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < GS; ++j)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int qb = 0; qb < QB; ++qb)
-                            acc[rb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][j][rb], bq[qb][g * GS + j], acc[rb][qb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < PER1; ++u) if (st * PER1 + u < 16) m1 = fmaxf(m1, acc1[st * PER1 + u]);
             }
-        }
-        // C layout (32x32): col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const floatx16 &c = acc[rb][qb];
-                const uint32_t q_local = q_base + 32 * qb;
-                if (MODE == MF_MODE_EMIT) {
-                    float m = c[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
-                    if (m >= thr_l[qb]) {
-                        // rare: survivors go to the workgroup's LDS queue (LDS atomic, no HBM round trip)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (c[r] >= thr_l[qb]) {
-                                const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                                if (grow < a.n_rows) {
-                                    const uint32_t slot = atomicAdd(eq_cnt, 1u);
-                                    if (slot < (uint32_t)MF_EQ_CAP) {
-                                        eq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)grow);
-                                        eq_q[slot] = q_local;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                } else {
-                    float m;
-                    if (tile_row0 + MF_TR <= a.n_rows) {
-                        m = c[0];
-#pragma unroll
-                        for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
-                    } else {
-                        m = -__builtin_inff();
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const uint64_t grow = tile_row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            if (grow < a.n_rows) m = fmaxf(m, c[r]);
-                        }
-                    }
-                    const size_t j = ((size_t)sel * 2 + rb) * 2 + hi;
-                    a.blockmax[((size_t)pass * a.n_sel_tiles * 4 + j) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
-                }
+            if ((st & 3) == 2 && (st >> 3) < CPT) {
+                if (((st >> 2) & 1) == grp) glds16(psrc, srcoff[st >> 3], pdst + (st >> 3) * NT * 16);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (has_next) stage(smem + (cur ^ 1) * TILE_BYTES);
-        // Flush the queue early when it is half full. The decision must be block-uniform: thread 0
-        // snapshots it into a double-buffered flag BEFORE the barrier, everyone reads that slot after it
-        // (the slot is rewritten two barriers later). A stale (low) count only delays the flush;
-        // dropped entries are detected by the counter itself (eq_overflowed).
-        if (MODE == MF_MODE_EMIT && tid == 0) eq_flag[cur] = (*eq_cnt > (uint32_t)MF_EQ_CAP / 2) ? 1u : 0u;
-        __syncthreads();
+        PROF_T(1)
         if (MODE == MF_MODE_EMIT) {
-            if (eq_flag[cur]) { flush(); __syncthreads(); }
+            if (have_prev && m1 >= thr_l) emit_block(acc1, prow1);
         }
-        cur ^= 1;
+        PROF_T(2)
+        // row block 1 -> acc1; in the shadows: maximum of acc0 (from two steps in: its last MFMA has to retire first)
+#pragma unroll
+        for (int st = KSTEPS; st < NS; ++st) {
+            if (st + D < NS) rd(st + D);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st & 7], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+            if (MODE == MF_MODE_EMIT && st >= KSTEPS + 2) {
+#pragma unroll
+                for (int u = 0; u < PER0; ++u) if ((st - KSTEPS - 2) * PER0 + u < 16) m0 = fmaxf(m0, acc0[(st - KSTEPS - 2) * PER0 + u]);
+            }
+            if ((st & 3) == 2 && (st >> 3) < CPT) {
+                if (((st >> 2) & 1) == grp) glds16(psrc, srcoff[st >> 3], pdst + (st >> 3) * NT * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PROF_T(3)
+        if (MODE == MF_MODE_EMIT) {
+            if (m0 >= thr_l) emit_block(acc0, row0);
+        }
+        PROF_T(3)
+        if (MODE == MF_MODE_EMIT) {
+            have_prev = true;
+            prev_sel = sel;
+            // Flush the queue early when it is half full. The decision must be block-uniform: thread 0
+            // snapshots it into a double-buffered flag BEFORE the barrier, everyone reads that slot after it
+            // (the slot is rewritten two barriers later). A stale (low) count only delays the flush;
+            // dropped entries are detected by the counter itself (eq_overflowed).
+            if (tid == 0) eq_flag[fl] = (*eq_cnt > (uint32_t)MF_EQ_CAP / 2) ? 1u : 0u;
+        } else {
+            // sample pass: the maximum score of this query over the whole 64-row tile
+            const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
+            float m = -__builtin_inff();
+            if (tile_row0 + MF_TR <= a.n_rows) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(acc0[r], acc1[r]));
+            } else {                                 // the last, partial tile: rows past the end do not count
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t g0 = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (g0 < a.n_rows) m = fmaxf(m, acc0[r]);
+                    if (g0 + 32 < a.n_rows) m = fmaxf(m, acc1[r]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));        // the two half-waves hold different rows of the same query
+            if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
+        }
+        // hand-over: the tile after this one must have landed (the DMA issued during this tile may stay in flight
+        // when there are three buffers); all LDS traffic of this wave done; then the workgroup barrier
+        PROF_T(4)
+        if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROF_T(5)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PROF_T(6)
+        PROF_N(7)
+        if (MODE == MF_MODE_EMIT) {
+            if (eq_flag[fl]) { flush(); __syncthreads(); }
+            fl ^= 1;
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
+#ifdef SHODH_PROF
+    if (MODE == MF_MODE_EMIT && blockIdx.x == 200 && blockIdx.y == 0 && lane == 0 && pt_[7])
+        printf("wave %d tiles %lld | per tile: top %lld chain0 %lld emit1 %lld chain1 %lld emit0 %lld vmcnt %lld barrier %lld\n", wave, pt_[7],
+               pt_[0] / pt_[7], pt_[1] / pt_[7], pt_[2] / pt_[7], pt_[3] / pt_[7], pt_[4] / pt_[7], pt_[5] / pt_[7], pt_[6] / pt_[7]);
+#endif
+#ifdef SHODH_PROF
+    const long long wc2_ = wall_clock64();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the clamped tail DMA before the LDS is released
     if (MODE == MF_MODE_EMIT) {
+        if (have_prev) {
+            const uint64_t prow1 = (uint64_t)prev_sel * a.tile_stride * MF_TR + 32 + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) test_push(acc1[j], thr_l, prow1 + (j & 3) + 8 * (j >> 2));   // (block-final: no maximum was folded)
+        }
         __syncthreads();
         flush();
         // entries were dropped somewhere: poison every list of this pass so that the final stage sends
         // those queries to the exact scan (adversarial inputs only, e.g. thousands of identical rows)
         if (eq_overflowed && tid < MF_BPAD) atomicAdd(a.cand_cnt + (size_t)pass * MF_BPAD + tid, a.cand_cap + 1u);
     }
+#ifdef SHODH_PROF
+    if (MODE == MF_MODE_EMIT && (blockIdx.x == 100 || blockIdx.x == 200) && blockIdx.y == 0 && tid == 0)
+        printf("block %u: prologue %lld loop %lld epilogue %lld (10 ns ticks)\n", blockIdx.x, wc1_ - wc0_, wc2_ - wc1_, (long long)wall_clock64() - wc2_);
+#endif
 }
 
 // ---- conversions ------------------------------------------------------------------------------------
@@ -377,11 +475,7 @@ struct ThrArgs {
     float *eps;              // [n_slots]
 };
 __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *mins = keys + a.cap;
-    uint64_t *thr = mins + 256;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
+    __shared__ uint32_t scratch[KTH_SCRATCH_U32];
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;            // pass*256 + q
     const uint32_t pass = slot / MF_BPAD, ql = slot % MF_BPAD;
@@ -391,16 +485,15 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
         return;
     }
-    TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-    auto key_at = [&](uint64_t j) -> uint64_t {
-        return make_key(-a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql], (uint32_t)j);
-    };
-    const uint32_t m = block_select_topk<256>(key_at, a.J, buf, mins);
+    // k-th LARGEST tile maximum == k-th smallest order_key(-max)
+    auto key_at = [&](uint32_t j) -> uint32_t { return order_key(-a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql]); };
+    bool ovf = false;
+    const uint32_t kk = a.k ? block_kth_u32<256>(key_at, a.J, a.k, scratch, &ovf) : 0xFFFFFFFFu;
     if (tid == 0) {
         float t = -__builtin_inff();
-        if (m == a.k && a.k > 0) {
-            const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
-            // a positive k-th block max is backed by k LIVE rows (tombstoned rows score exactly 0)
+        if (kk != 0xFFFFFFFFu) {
+            const float kth = -order_key_inv(kk);
+            // a positive k-th tile max is backed by k LIVE rows (tombstoned rows score exactly 0)
             if (kth > 0.0f) t = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth));
         }
         a.thr[slot] = t;   // -inf => emit everything => list overflow => exact fallback
@@ -464,58 +557,183 @@ __device__ __forceinline__ float exact_dot_row(const float *__restrict__ q_lds, 
     }
 }
 
+constexpr int FS_CH = 16;     // AVX2 order: rows of the re-score window staged raw in LDS at a time
+constexpr int FS_TC = 64;     // scalar-4 order: rows whose per-group partial sums are staged at a time
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim) {
+    const size_t a = (size_t)FS_TC * (dim / 4 + 1) * 4;
+    const size_t b = (size_t)FS_CH * (dim + 8) * 4 + (size_t)FS_CH * 8 * 4;
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);                          // [dim]
     uint64_t *keys = reinterpret_cast<uint64_t *>(qs + a.dim);            // [cap]
-    uint64_t *mins = keys + a.cap;                                        // [256]
-    uint64_t *ekeys = mins + 256;                                         // [fcap] exact keys of the window
+    uint64_t *mins = keys + a.cap;                                        // [512]
+    uint64_t *ekeys = mins + 512;                                         // [fcap] exact keys of the window
     uint64_t *thr = ekeys + a.fcap;
     uint32_t *flist = reinterpret_cast<uint32_t *>(thr + 1);              // [fcap] rows of the window
     uint32_t *cnt = flist + a.fcap;
     uint32_t *fcnt = cnt + 1;
+    float *region = reinterpret_cast<float *>(fcnt + 1);                  // 16-B aligned: thr sits at a 16-B boundary
+    uint32_t *sel32 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(region) + final_stage_region_bytes(a.dim));   // [KTH_SCRATCH_U32]
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (q >= a.nq) return;
     const uint32_t n = a.cand_cnt[q];
     bool bad = a.fallback[q] != 0 || n > a.cand_cap;
+    PROF_DECL
     if (!bad) {
         for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
         if (tid == 0) *fcnt = 0;
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
         const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
-        // pass A: k-th best approximate score
-        auto key_a = [&](uint64_t i) -> uint64_t { return list[i]; };
-        const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
-        // window: every candidate with s~ >= kth - 2 eps (all of them if fewer than k exist)
+        // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
+        PROF_T(0)
         float lo = -__builtin_inff();
-        if (ma == a.k && a.k > 0) {
-            const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
-            lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
+        if (a.k > 0 && a.k <= 128) {
+            auto key32 = [&](uint32_t i) -> uint32_t { return (uint32_t)(list[i] >> 32); };
+            bool ovf = false;
+            const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
+            if (ovf) bad = true;        // block-uniform
+            else if (kk != 0xFFFFFFFFu) {
+                const float kth = -order_key_inv(kk);
+                lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
+            }
+        } else if (a.k > 0) {
+            auto key_a = [&](uint64_t i) -> uint64_t { return list[i]; };
+            const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
+            if (ma == a.k) {
+                const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
+                lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
+            }
         }
+        PROF_T(1)
+        // window: every candidate with s~ >= kth - 2 eps (all of them if fewer than k exist)
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t key = list[i];
-            const float s = -order_key_inv((uint32_t)(key >> 32));
-            if (s >= lo) {
-                const uint32_t slot = atomicAdd(fcnt, 1u);
-                if (slot < a.fcap) flist[slot] = (uint32_t)key;
+        if (!bad) {
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint64_t key = list[i];
+                const float s = -order_key_inv((uint32_t)(key >> 32));
+                if (s >= lo) {
+                    const uint32_t slot = atomicAdd(fcnt, 1u);
+                    if (slot < a.fcap) flist[slot] = (uint32_t)key;
+                }
             }
         }
         __syncthreads();
         const uint32_t nf = *fcnt;
+        PROF_T(2)
         if (nf > a.fcap) bad = true;       // block-uniform
         if (!bad) {
-            // pass B: exact reference-order scores of the window, then top-k by (dist, id)
-            for (uint32_t i = tid; i < nf; i += 256) {
-                const uint32_t row = flist[i];
-                const float dot = exact_dot_row<ORDER>(qs, a.rows + (size_t)row * a.dim, a.dim);
-                ekeys[i] = make_key(-dot, a.id_base + row);
+            // pass B: exact reference-order scores of the window, then top-k by (dist, id).
+            // The f32 rows of the window are cold in HBM, so every load of a chunk is put in flight at once
+            // (coalesced float4) and only then reduced in the reference order:
+            //   scalar-4: each float4 group is reduced straight out of its register to the group sum t_g
+            //             (distance_inline.rs:165-168 inner expression) and parked in LDS; one thread per row then adds
+            //             the dim/4 group sums sequentially, as the reference's `sum += t` does;
+            //   AVX2:     raw rows are staged; eight FMA chains per row (:77-97), lanes 0..7 summed in order (:100-108).
+            const uint32_t dim = a.dim, d4 = dim >> 2;
+            const f32x4 *qs4 = reinterpret_cast<const f32x4 *>(qs);
+            if (ORDER == SHODH_ORDER_SCALAR4) {
+                float *tbuf = region;
+                const uint32_t tp = d4 + 1;
+                const uint32_t wv = tid >> 6, ln = tid & 63;
+                for (uint32_t c0 = 0; c0 < nf; c0 += FS_TC) {
+                    const uint32_t nc = (nf - c0) < (uint32_t)FS_TC ? (nf - c0) : (uint32_t)FS_TC;
+                    // wave w takes rows w, w+4, ...; its lanes take float4 groups ln, ln+64, ... (one row = one
+                    // coalesced d4*16-byte read); four rows' loads are in flight per wave before any is reduced
+                    for (uint32_t cb = wv; cb < nc; cb += 16) {
+                        for (uint32_t g0 = 0; g0 < d4; g0 += 128) {
+                            f32x4 r[4][2];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t c = cb + 4 * u;
+                                if (c < nc) {
+                                    const float *rp_ = a.rows + (size_t)flist[c0 + c] * dim;
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const uint32_t g = g0 + h * 64 + ln;
+                                        if (g < d4) r[u][h] = *reinterpret_cast<const f32x4 *>(rp_ + g * 4);
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t c = cb + 4 * u;
+                                if (c < nc) {
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const uint32_t g = g0 + h * 64 + ln;
+                                        if (g < d4) {
+                                            const f32x4 w = qs4[g];
+                                            float t = w.x * r[u][h].x;
+                                            t = t + w.y * r[u][h].y;
+                                            t = t + w.z * r[u][h].z;
+                                            t = t + w.w * r[u][h].w;
+                                            tbuf[c * tp + g] = t;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < nc) {
+                        float sum = 0.0f;
+                        const float *tr = tbuf + tid * tp;
+                        uint32_t g = 0;
+                        for (; g + 8 <= d4; g += 8) {
+                            float t8[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) t8[u] = tr[g + u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) sum = sum + t8[u];
+                        }
+                        for (; g < d4; ++g) sum = sum + tr[g];
+                        for (uint32_t j = d4 * 4; j < dim; ++j) sum = sum + qs[j] * a.rows[(size_t)flist[c0 + tid] * dim + j];
+                        ekeys[c0 + tid] = make_key(-sum, a.id_base + flist[c0 + tid]);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                const uint32_t rp = dim + 8;
+                float *rowbuf = region;
+                f32x4 *rowbuf4 = reinterpret_cast<f32x4 *>(rowbuf);
+                float *tbuf = rowbuf + (size_t)FS_CH * rp;
+                for (uint32_t c0 = 0; c0 < nf; c0 += FS_CH) {
+                    const uint32_t nc = (nf - c0) < (uint32_t)FS_CH ? (nf - c0) : (uint32_t)FS_CH;
+                    for (uint32_t e = tid; e < nc * d4; e += 256) {
+                        const uint32_t c = e / d4, j = e % d4;
+                        rowbuf4[c * (rp >> 2) + j] = *reinterpret_cast<const f32x4 *>(a.rows + (size_t)flist[c0 + c] * dim + j * 4);
+                    }
+                    __syncthreads();
+                    if (tid < nc * 8) {
+                        const uint32_t c = tid >> 3, l = tid & 7;
+                        float acc = 0.0f;
+                        for (uint32_t i = 0; i < dim; i += 8) acc = __builtin_fmaf(qs[i + l], rowbuf[c * rp + i + l], acc);
+                        tbuf[c * 8 + l] = acc;
+                    }
+                    __syncthreads();
+                    if (tid < nc) {
+                        const float *p8 = tbuf + tid * 8;
+                        float r = p8[0] + p8[1];
+                        r = r + p8[2]; r = r + p8[3]; r = r + p8[4]; r = r + p8[5]; r = r + p8[6]; r = r + p8[7];
+                        ekeys[c0 + tid] = make_key(-r, a.id_base + flist[c0 + tid]);
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
+            PROF_T(3)
             auto key_b = [&](uint64_t i) -> uint64_t { return ekeys[i]; };
             const uint32_t m = block_select_topk<256>(key_b, nf, buf, mins);
+            PROF_T(4)
+#ifdef SHODH_PROF
+            if (tid == 0 && (q % 37) == 0) printf("final q %u n %u nf %u | load-q %lld selectA %lld window %lld rescore %lld selectB %lld\n", q, n, nf, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4]);
+#endif
             for (uint32_t i = tid; i < a.k; i += 256) {
                 if (i < m) {
                     const uint64_t key = buf.keys[i];
@@ -563,13 +781,13 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     // sample: every S-th tile (S = 16 unless SHODH_SAMPLE_STRIDE; measured: 32 -> 463, 16 -> 265, 8 -> 150 candidates/query at 1M), but at least 2k block maxima (4 per tile) and 64 tiles
     static const uint32_t sample_stride = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 16u;
     uint64_t want = p.n_tiles / (sample_stride ? sample_stride : 16u);
-    const uint64_t min_tiles = (uint64_t)k / 2 + 64;
+    const uint64_t min_tiles = (uint64_t)k * 2 + 64;
     if (want < min_tiles) want = min_tiles;
     if (want > p.n_tiles) want = p.n_tiles;
     p.tile_stride = (uint32_t)(p.n_tiles / want);
     if (p.tile_stride < 1) p.tile_stride = 1;
     p.n_sel_tiles = (uint32_t)ceil_div(p.n_tiles, p.tile_stride);
-    p.J = p.n_sel_tiles * 4;
+    p.J = p.n_sel_tiles;
     uint32_t cc = 192u * (k ? k : 1);
     if (cc < 4096) cc = 4096;
     p.cand_cap = next_pow2(cc);
@@ -605,19 +823,14 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[11]
 
 template <int MODE>
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st) {
-    const size_t lds = 2ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 32;
+    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 64 <= 160 * 1024) ? 3 : 2;
+    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
     if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
-    static const int qb_env = getenv("SHODH_MFMA_QB") ? atoi(getenv("SHODH_MFMA_QB")) : 1;
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
     case KS:                                                                                                       \
-        if (qb_env == 2) {                                                                                         \
-            SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS, 2>, lds));                        \
-            hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS, 2>), grid, dim3(256), lds, st, a);                       \
-        } else {                                                                                                   \
-            SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS, 1>, lds));                        \
-            hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS, 1>), grid, dim3(512), lds, st, a);                       \
-        }                                                                                                          \
+        SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS>, lds));                               \
+        hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS>), grid, dim3(512), lds, st, a);                              \
         break;
     switch (p.ksteps) {
         SHODH_LAUNCH_KS(8)
@@ -658,9 +871,9 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     const float eps_rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
     const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f;
     ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps};
-    const size_t tlds = (size_t)p.topk_cap * 8 + 256 * 8 + 8 + 4 + 16;
-    SHODH_TRY(ensure_dynamic_lds((const void *)threshold_kernel, tlds));
-    hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), tlds, st, t);
+    const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
+    (void)tlds;
+    hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), 0, st, t);
     SHODH_HIP_TRY(hipGetLastError());
 
     a.tile_stride = 1;
@@ -673,7 +886,9 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 
     FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.cand, w.cand_cnt, p.cand_cap, w.eps, p.fcap, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
-    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 256 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 + 16;
+    // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32   (every part a multiple of 8 B; region at 16 B)
+    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 +
+                        final_stage_region_bytes(dim) + (size_t)KTH_SCRATCH_U32 * 4 + 16;
     if (order == SHODH_ORDER_AVX2) {
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_AVX2>), dim3(nq), dim3(256), flds, st, f);

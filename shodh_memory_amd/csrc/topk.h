@@ -71,20 +71,62 @@ __device__ __forceinline__ void topk_push(TopKBuf &b, uint64_t key) {
     }
 }
 
+// ranks the first n (<= 2*NT) keys among themselves by counting (keys are unique; duplicates -- only KEY_NONE
+// padding -- are ordered by position): n broadcast LDS reads per key, one barrier, no sorting network.
+// Writes the keys in ascending order to `out` (2*NT entries).
+template <int NT>
+__device__ __forceinline__ void rank_sort_lds(const uint64_t *in, uint64_t *out, uint32_t n) {
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (uint32_t e = 0; e < 2; ++e) {
+        const uint32_t i = tid + e * NT;
+        if (i < n) {
+            const uint64_t v = in[i];
+            // keys are distinct except for KEY_NONE padding, which never reaches this function's callers with
+            // n counting it -- so plain '<' ranks; 8 LDS reads in flight per step (a dependent read per
+            // iteration costs the full LDS latency)
+            uint32_t r = 0;
+            uint32_t j = 0;
+            for (; j + 8 <= n; j += 8) {
+                uint64_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = in[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r += (w[u] < v) || (w[u] == v && (j + u) < i);
+            }
+            for (; j < n; ++j) { const uint64_t w = in[j]; r += (w < v) || (w == v && j < i); }
+            out[r] = v;
+        }
+    }
+    __syncthreads();
+}
+
 // k smallest of the keys key_at(0..n) (KEY_NONE entries are skipped). Result: b.keys[0..m) sorted
-// ascending, m = min(k, #valid) returned and left in *b.cnt. `mins` is NT u64 of LDS scratch.
+// ascending, m = min(k, #valid) returned and left in *b.cnt. `mins` is 2*NT u64 of LDS scratch.
 // Every thread of the block must call this with the same arguments.
 template <int NT, class KeyFn>
 __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, TopKBuf &b, uint64_t *mins) {
     const uint32_t tid = threadIdx.x;
     uint64_t T = KEY_NONE;
-    if (b.k > 0 && b.k <= NT && n > (uint64_t)b.cap / 2) {
+    if (b.k > 0 && b.k <= NT && n > (uint64_t)2 * NT) {
+        // pass 1: the k-th smallest of the NT per-thread minima bounds the k-th smallest key from above
         uint64_t tmin = KEY_NONE;
         for (uint64_t i = tid; i < n; i += NT) { const uint64_t key = key_at(i); tmin = key < tmin ? key : tmin; }
         mins[tid] = tmin;
         __syncthreads();
-        bitonic_sort_lds<NT>(mins, NT, NT);
-        T = mins[b.k - 1];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < NT; j += 8) {
+            uint64_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = mins[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (w[u] < tmin) || (w[u] == tmin && (j + u) < tid);
+        }
+        if (tid == 0) *b.thr = KEY_NONE;
+        __syncthreads();
+        if (r == b.k - 1) *b.thr = tmin;          // exactly one thread holds rank k-1
+        __syncthreads();
+        T = *b.thr;
         __syncthreads();
     }
     if (tid == 0) { *b.cnt = 0; *b.thr = b.k ? (T == KEY_NONE ? KEY_NONE : T + 1) : 0; }
@@ -99,8 +141,111 @@ __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, 
         }
     }
     __syncthreads();
-    topk_compact<NT>(b);
+    const uint32_t cnt = *b.cnt;
+    if (cnt <= 2 * NT) {
+        // the usual case (about k survivors): order them by counting instead of a sorting network
+        __syncthreads();
+        rank_sort_lds<NT>(b.keys, mins, cnt);
+        if (tid < cnt) b.keys[tid] = mins[tid];
+        if (tid + NT < cnt) b.keys[tid + NT] = mins[tid + NT];
+        if (tid == 0) {
+            const uint32_t m = cnt < b.k ? cnt : b.k;
+            *b.cnt = m;
+            if (b.k == 0) *b.thr = 0;
+            else if (m == b.k) { const uint64_t t = mins[b.k - 1]; if (t < *b.thr) *b.thr = t; }
+        }
+        __syncthreads();
+    } else {
+        topk_compact<NT>(b);
+    }
     return *b.cnt;
+}
+
+// k-th smallest (k >= 1) of n 32-bit keys key_at(0..n) -- the VALUE only, duplicates allowed. Returns
+// 0xFFFFFFFF if fewer than k keys exist, and sets *overflow if the bounded gather buffer (1024) was too small
+// (pathological inputs: thousands of equal keys) so that the caller can take another route.
+//   1. filter: the keys are dealt round-robin into k groups; the k-th smallest key is <= the LARGEST of the k
+//      group minima (k distinct keys are <= it), and only ~k*H(k) keys pass that bound on random input;
+//   2. the survivors are gathered into LDS;
+//   3. few survivors: rank counting (O(c) per thread); many: 4 x 8-bit radix select over the LDS copy.
+// A rank loop over c keys costs ~25 cycles * c per thread (wave64 VALU ops issue over 4 cycles), which is why
+// the first two steps exist. scratch: KTH_SCRATCH_U32 u32 of LDS. Block-uniform arguments; every thread calls.
+constexpr int KTH_BUF = 1024;
+constexpr int KTH_SCRATCH_U32 = 128 + KTH_BUF + 256 + 8;
+template <int NT, class KeyFn>
+__device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint32_t k, uint32_t *scratch, bool *overflow) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t *gmin = scratch, *buf = scratch + 128, *hist = buf + KTH_BUF, *cnt = hist + 256, *res = cnt + 1, *sel = cnt + 2;
+    uint32_t T = 0xFFFFFFFFu;
+    const bool filt = k <= 128 && n >= 4u * k;
+    if (tid == 0) { *cnt = 0; *res = 0xFFFFFFFFu; }
+    if (filt && tid < k) gmin[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (filt) {
+        const uint32_t step = NT % k;
+        uint32_t g = tid % k;
+        for (uint32_t i = tid; i < n; i += NT) {
+            atomicMin(&gmin[g], key_at(i));
+            g += step;
+            if (g >= k) g -= k;
+        }
+        __syncthreads();
+        uint32_t m = 0;
+        for (uint32_t j = 0; j < k; ++j) { const uint32_t v = gmin[j]; m = v > m ? v : m; }
+        T = m;
+    }
+    for (uint32_t i = tid; i < n; i += NT) {
+        const uint32_t key = key_at(i);
+        if (key <= T && key != 0xFFFFFFFFu) { const uint32_t slot = atomicAdd(cnt, 1u); if (slot < (uint32_t)KTH_BUF) buf[slot] = key; }
+    }
+    __syncthreads();
+    const uint32_t c = *cnt;
+    *overflow = c > (uint32_t)KTH_BUF;
+    if (c > (uint32_t)KTH_BUF || c < k) return 0xFFFFFFFFu;
+    if (c <= 128u) {
+        if (tid < c) {
+            const uint32_t v = buf[tid];
+            uint32_t r = 0, j = 0;
+            for (; j + 8 <= c; j += 8) {
+                uint32_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = buf[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r += (w[u] < v) || (w[u] == v && (j + u) < tid);
+            }
+            for (; j < c; ++j) { const uint32_t w = buf[j]; r += (w < v) || (w == v && j < tid); }
+            if (r == k - 1) *res = v;
+        }
+        __syncthreads();
+        return *res;
+    }
+    uint32_t prefix = 0, mask = 0, kk = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < c; i += NT) {
+            const uint32_t v = buf[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t sum = h0 + h1 + h2 + h3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)tid >= o) incl += t; }
+            const uint32_t excl = incl - sum;
+            if (excl < kk && kk <= incl) {
+                uint32_t r = kk - excl, d = 0;
+                if (r > h0) { r -= h0; d = 1; if (r > h1) { r -= h1; d = 2; if (r > h2) { r -= h2; d = 3; } } }
+                sel[0] = 4 * tid + d; sel[1] = r;
+            }
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift; mask |= 255u << shift; kk = sel[1];
+    }
+    return prefix;
 }
 
 }  // namespace shodh

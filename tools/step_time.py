@@ -12,8 +12,10 @@ for _ in range(3): idx.search_batch_device(q, k)
 torch.cuda.synchronize(); idx.kernel_timing(True)
 t = time.perf_counter()
 for _ in range(30): idx.search_batch_device(q, k)
+t_enq = (time.perf_counter() - t) / 30
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 30
+print("host enqueue per step %.1f us" % (t_enq * 1e6))
 qh = q.cpu().numpy()
 idx.search_batch(qh, k)
 print("step %.1f us | emit kernel mean/min us: %s | stats %s" % (dt * 1e6, idx.kernel_timing(True)[:2], idx.scan_stats()))
