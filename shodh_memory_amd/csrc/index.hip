@@ -86,6 +86,8 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, scan done, select done, end
     hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the most recent search that used this workspace
+    bool pending = false;                // ... and whether that search may still be running (device-pointer calls)
     unsigned char *buf = nullptr;
     size_t bytes = 0;
     float *d_q = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr;
@@ -209,10 +211,21 @@ static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
     return SHODH_OK;
 }
 
-static Workspace *ws_acquire(shodh_index *idx) {
+// A workspace that was last used on the same stream needs no synchronisation at all (stream order); one coming from
+// another stream gets an event recorded on that stream now and waited for by the new one. (Recording an event after
+// every search and waiting for it before the next cost ~5 us per search: every record is a packet between kernels.)
+static Workspace *ws_acquire(shodh_index *idx, hipStream_t st, bool own_stream) {
     {
         std::lock_guard<std::mutex> g(idx->ws_mu);
-        if (!idx->ws_free.empty()) { Workspace *w = idx->ws_free.back(); idx->ws_free.pop_back(); return w; }
+        if (!idx->ws_free.empty()) {
+            size_t pick = idx->ws_free.size() - 1;
+            if (!own_stream)
+                for (size_t i = idx->ws_free.size(); i-- > 0;)
+                    if (!idx->ws_free[i]->pending || idx->ws_free[i]->last_stream == st) { pick = i; break; }
+            Workspace *w = idx->ws_free[pick];
+            idx->ws_free.erase(idx->ws_free.begin() + (long)pick);
+            return w;
+        }
     }
     Workspace *w = new Workspace();
     if (w->init() != SHODH_OK) { w->destroy(); delete w; return nullptr; }
@@ -236,23 +249,29 @@ static bool use_mfma(const shodh_index *idx, uint32_t nq, uint32_t k) {
 
 // enqueue a FLAT search on `st` using workspace w (device in/out pointers)
 static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32_t nq, uint32_t k,
-                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, bool *used_mfma) {
+                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, bool *used_mfma, bool stage_events) {
+    // events: the per-stage ones only for host-pointer calls (their timings are read back after the call's own
+    // synchronisation); the pair around the scan kernel unless SHODH_KERNEL_EVENTS=0. Each record is a packet in the
+    // stream between two kernels.
+    static const bool kernel_events = !(getenv("SHODH_KERNEL_EVENTS") && atoi(getenv("SHODH_KERNEL_EVENTS")) == 0);
     const uint32_t dim = idx->cfg.dim;
     const uint32_t idb = (uint32_t)idx->cfg.id_base;
     const uint32_t *del = idx->n_deleted ? idx->deleted : nullptr;
     *used_mfma = use_mfma(idx, nq, k);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
-    w->ring_pos++;
-    SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
+    hipEvent_t rk0 = nullptr, rk1 = nullptr;
+    if (kernel_events) { rk0 = rk[0]; rk1 = rk[1]; w->ring_pos++; }
+    if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
     if (*used_mfma) {
         MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-        size_t offs[11];
+        size_t offs[12];
         const size_t ws_bytes = mfma_workspace_bytes(p, dim, offs);
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
         const size_t part_bytes = exact_partial_bytes(nq, dim, k, gx);
         SHODH_TRY(w->reserve(ws_bytes + part_bytes + 256));
         SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
-                                       idx->maxnorm, p, w->buf, offs, d_ids, d_dist, d_counts, st, w->ev[1], w->ev[2], rk[0], rk[1]));
+                                       idx->maxnorm, p, w->buf, offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
+                                       stage_events ? w->ev[2] : nullptr, rk0, rk1));
         // exact scan of whatever the pre-scan could not settle (device-side list; normally empty)
         const uint32_t *fb_list = (const uint32_t *)(w->buf + offs[6]);
         const uint32_t *fb_count = (const uint32_t *)(w->buf + offs[7]);
@@ -262,14 +281,13 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     } else {
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
         SHODH_TRY(w->reserve(exact_partial_bytes(nq, dim, k, gx) + 256));
-        SHODH_HIP_TRY(hipEventRecord(rk[0], st));
+        if (rk0) SHODH_HIP_TRY(hipEventRecord(rk0, st));
         SHODH_TRY(launch_flat_exact(idx->rows, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb, (uint64_t *)w->buf, gx,
                                     d_ids, d_dist, d_counts, nullptr, nullptr, st));
-        SHODH_HIP_TRY(hipEventRecord(rk[1], st));     // scan + merge (the merge is a few microseconds)
-        SHODH_HIP_TRY(hipEventRecord(w->ev[1], st));
-        SHODH_HIP_TRY(hipEventRecord(w->ev[2], st));
+        if (rk1) SHODH_HIP_TRY(hipEventRecord(rk1, st));     // scan + merge (the merge is a few microseconds)
+        if (stage_events) { SHODH_HIP_TRY(hipEventRecord(w->ev[1], st)); SHODH_HIP_TRY(hipEventRecord(w->ev[2], st)); }
     }
-    SHODH_HIP_TRY(hipEventRecord(w->ev[3], st));
+    if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[3], st));
     return SHODH_OK;
 }
 
@@ -437,13 +455,19 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         for (size_t i = 0; i < (size_t)nq * dim; ++i)
             if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
     }
-    Workspace *w = ws_acquire(idx);
+    Workspace *w = ws_acquire(idx, user_stream, sync_host);
     if (!w) return SHODH_ERR_DEVICE;
     hipStream_t st = sync_host ? w->stream : user_stream;
     int rc = SHODH_OK;
     bool used_mfma = false;
     do {
-        if ((rc = (hipStreamWaitEvent(st, w->last_use, 0) == hipSuccess ? SHODH_OK : SHODH_ERR_DEVICE)) != SHODH_OK) { set_error("hipStreamWaitEvent failed"); break; }
+        if (w->pending && w->last_stream != st) {
+            // the previous user may still be running on another stream
+            if (hipEventRecord(w->last_use, w->last_stream) != hipSuccess || hipStreamWaitEvent(st, w->last_use, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipDeviceSynchronize() != hipSuccess) { set_error("cannot order the workspace after its previous use"); rc = SHODH_ERR_DEVICE; break; }
+            }
+        }
         const float *d_q = q;
         uint32_t *d_ids = ids; float *d_dist = dist; uint32_t *d_counts = counts;
         if (sync_host) {
@@ -451,12 +475,12 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
             d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
         }
-        if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma);
+        if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma, sync_host);
         else {
             if ((rc = w->reserve(ivfpq_scratch_bytes(idx->ivfpq, idx->cfg, nq, k) + 256)) != SHODH_OK) break;
-            hipEventRecord(w->ev[0], st);
+            if (sync_host) hipEventRecord(w->ev[0], st);
             rc = ivfpq_search(idx->ivfpq, idx->cfg, d_q, nq, k, d_ids, d_dist, d_counts, w->buf, st);
-            hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st);
+            if (sync_host) { hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st); }
         }
         if (rc != SHODH_OK) break;
         if (sync_host) {
@@ -469,7 +493,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (used_mfma) {
                 uint32_t st4[4] = {0, 0, 0, 0};
                 MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-                size_t offs[11];
+                size_t offs[12];
                 mfma_workspace_bytes(p, dim, offs);
                 hipMemcpy(st4, w->buf + offs[8], 16, hipMemcpyDeviceToHost);
                 std::lock_guard<std::mutex> g(idx->stat_mu);
@@ -480,7 +504,8 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             }
         }
     } while (0);
-    hipEventRecord(w->last_use, st);
+    w->last_stream = st;
+    w->pending = !(sync_host && rc == SHODH_OK);       // successful host-pointer calls end with a stream synchronisation
     ws_release(idx, w);
     return rc;
 }

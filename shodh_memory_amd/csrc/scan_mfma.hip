@@ -38,7 +38,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_EQ_CAP = 1024;   // LDS emit-queue entries per workgroup
+constexpr int MF_WQ_CAP = 128;    // LDS emit-queue entries per WAVE (8 private queues per workgroup)
+constexpr int MF_EQ_CAP = 8 * MF_WQ_CAP;
+constexpr int MF_SLOTS = 4;       // private candidate slots per (query, workgroup); the rest goes to the shared overflow list
 constexpr int MF_TR = 64;        // corpus rows per tile
 constexpr int MF_BPAD = 256;     // queries per pass
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
@@ -64,7 +66,8 @@ struct MfmaArgs {
     const _Float16 *q_h;      // [passes][256][dim]
     const float *thr;         // [passes][256] emit threshold on the true score scale
     const uint32_t *deleted;  // bitmask or nullptr
-    uint64_t *cand;           // [passes][256][cand_cap]  key = (order_key(-s~) << 32) | local row
+    uint64_t *slots;          // [passes][256][gridDim.x][MF_SLOTS] private (query, workgroup) candidate slots, KEY_NONE = empty
+    uint64_t *cand;           // [passes][256][cand_cap]  shared overflow list, key = (order_key(-s~) << 32) | local row
     uint32_t *cand_cnt;       // [passes][256]
     uint32_t cand_cap;
     float *blockmax;          // [passes][J][256], J = n_sel_tiles (one maximum per sampled 64-row tile and query)
@@ -76,6 +79,11 @@ struct MfmaArgs {
 // LDS-DMA: 16 bytes per lane from each lane's own global address (uniform base + per-lane byte offset) to
 // LDS [m0 + lane*16]. hipcc neither counts nor waits for it (inline asm): completion is tracked by hand with
 // s_waitcnt vmcnt(N) below. M0 is compiler-reserved, so it is saved and restored inside the statement.
+__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p) {   // provably wave-uniform for the "s" constraint
+    const uint64_t v = (uint64_t)p;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);   // (the builtin returns int: no sign extension)
+    return (const unsigned char *)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 __device__ __forceinline__ void glds16(const void *gbase, uint32_t voff_bytes, uint32_t lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -85,7 +93,7 @@ __device__ __forceinline__ void glds16(const void *gbase, uint32_t voff_bytes, u
 }
 
 template <int KSTEPS>
-__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + 64 <= 160 * 1024) ? 3 : 2; }
+__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2; }
 
 // 8 waves per workgroup (2 per SIMD), wave w owns queries [32w, 32w+32) as resident B fragments (dim/16 x 4 VGPRs).
 // Every wave runs ONE software-pipelined instruction stream per 64-row tile: 2*KSTEPS MFMAs (row block 0 into acc0 for all
@@ -116,16 +124,16 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     constexpr int CPT = MF_TR * CPR / NT;    // chunks per thread per tile
     constexpr int TILE_BYTES = MF_TR * PITCH;
     constexpr int NS = 2 * KSTEPS;           // MFMAs per wave and tile (step s: row block s / KSTEPS, k-step s % KSTEPS)
-    constexpr int D = 6;                     // A fragments in flight
+    constexpr int D = 6;                     // A fragments in flight (10 measured the same)
+    constexpr int RING = 8;
     constexpr int NBUF = mfma_scan_nbuf<KSTEPS>();
     constexpr int PF = NBUF - 1;             // tiles the DMA runs ahead
-    static_assert(8 * CPT <= NS, "DMA issue slots");
+    static_assert(4 * 2 * CPT <= NS, "DMA issue slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: [NBUF tiles][emit queue: MF_EQ_CAP x (key u64, query u32)][queue counter][flush flags]
+    // LDS: [NBUF tiles][8 wave-private emit queues: MF_WQ_CAP x (key u64, query u32)][per-query slot counters]
     uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + NBUF * TILE_BYTES);
     uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
-    uint32_t *eq_cnt = eq_q + MF_EQ_CAP;
-    uint32_t *eq_flag = eq_cnt + 1;          // [2] double-buffered "flush now" decision (block-uniform)
+    uint32_t *qcount = eq_q + MF_EQ_CAP;     // [MF_BPAD] entries this workgroup has written per query
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x;
@@ -135,24 +143,35 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const int l31 = lane & 31;
     const uint32_t pass = blockIdx.y;
     const uint32_t q_local = wave * 32 + l31;      // this lane's query within the pass
-    if (tid == 0) { *eq_cnt = 0; eq_flag[0] = 0; eq_flag[1] = 0; }
+    if (MODE == MF_MODE_EMIT && tid < MF_BPAD) {
+        qcount[tid] = 0;
+        // this workgroup's private candidate slots of query tid start out empty (nobody else writes them)
+        uint64_t *sl = a.slots + (((size_t)blockIdx.y * MF_BPAD + tid) * gridDim.x + blockIdx.x) * MF_SLOTS;
+#pragma unroll
+        for (int j = 0; j < MF_SLOTS; ++j) sl[j] = KEY_NONE;
+    }
 #ifdef SHODH_PROF
     const long long wc0_ = wall_clock64();
 #endif
 
     // source byte offsets inside a tile for this thread's LDS chunks p = i*NT + tid (see the swizzle note above).
     // No row clamp: the shadow slab is allocated in multiples of 64 rows, rows >= n_rows are never reported.
-    uint32_t srcoff[CPT];
+    // The DMA is issued by waves 0-3 only (2*CPT pieces of 256 x 16 B each per tile): the SIMD arbiter favours the
+    // older wave of a SIMD, so waves 0-3 reach the end of a tile long before their partners 4-7 and have the slack to
+    // absorb the ~100-150 cycles an LDS-DMA instruction stalls its wave at issue; on waves 4-7 the same stalls were
+    // fully exposed (measured per tile: waves 0-3 2800 cycles busy + 2000 waiting at the barrier, waves 4-7 4600 busy).
+    constexpr int NPC = 2 * CPT;             // DMA pieces per issuing thread and tile
+    uint32_t srcoff[NPC];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int p = i * NT + tid;
+    for (int i = 0; i < NPC; ++i) {
+        const int p = i * 256 + (tid & 255);
         const int row = p / CPR, slot = p % CPR;
         const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
         srcoff[i] = (uint32_t)(row * PITCH + c * 16);
     }
     const size_t tile_bytes_g = (size_t)a.tile_stride * MF_TR * DIM * 2;
     const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
-    const uint32_t wave_lds = smem_lds + (uint32_t)wave * 1024u;     // this wave's 64 x 16 B window inside each NT-chunk slab
+    const uint32_t wave_lds = smem_lds + (uint32_t)(wave & 3) * 1024u;     // this wave's 64 x 16 B window inside each 256-chunk slab
 
     uint32_t sel = blockIdx.x;
     const uint32_t step = gridDim.x;
@@ -160,9 +179,11 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #pragma unroll
     for (int b = 0; b < PF; ++b) {
         const uint32_t tsel = sel + b * step < a.n_sel_tiles ? sel + b * step : (sel < a.n_sel_tiles ? sel : 0u);
-        const unsigned char *src = rows_b + (size_t)tsel * tile_bytes_g;
+        const unsigned char *src = uniform_ptr(rows_b + (size_t)tsel * tile_bytes_g);
+        if (wave < 4) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) glds16(src, srcoff[i], wave_lds + b * TILE_BYTES + i * NT * 16);
+            for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * TILE_BYTES + i * 4096);
+        }
     }
 
     // resident B fragments: query q_local, k = ks*16 + hi*8 .. +8
@@ -175,23 +196,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
     if (a.ablate & 8u) thr_l = __builtin_inff();   // diagnostics: nothing is emitted
 
-    bool eq_overflowed = false;              // block-uniform: entries were dropped at some point
-    auto flush = [&]() {                     // caller: barrier before, and after before the next push
-        const uint32_t raw = *eq_cnt;
-        eq_overflowed |= raw > (uint32_t)MF_EQ_CAP;
-        const uint32_t n = raw < (uint32_t)MF_EQ_CAP ? raw : (uint32_t)MF_EQ_CAP;
-        for (uint32_t i = tid; i < n; i += NT) {
-            const uint64_t key = eq_key[i];
-            const uint32_t row = (uint32_t)key;
-            if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) continue;   // tombstoned (vamana.rs:1175-1177)
-            const size_t qi = (size_t)pass * MF_BPAD + eq_q[i];
-            const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
-            if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
-        }
-        __syncthreads();
-        if (tid == 0) *eq_cnt = 0;
-    };
-
     // LDS byte offsets of this lane's A fragments. chunk c = 2*ks + hi; swizzled chunk = c ^ (row&15)
     // = (c & ~15) | ((c & 15) ^ sw): only 8 distinct low parts per lane, the rest is an immediate.
     const int sw = l31 & 15;
@@ -199,32 +203,66 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4);
 
-    // one score against this lane's threshold. C layout (32x32): col = lane&31 (query), value r of a lane is
-    // row (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-row block. Survivors (rare) go to the workgroup's LDS queue
-    // (LDS atomic, no HBM round trip).
-    auto test_push = [&](float v, float thr, uint64_t grow) {
-        if (v >= thr) {
-            if (grow < a.n_rows) {
-                const uint32_t slot = atomicAdd(eq_cnt, 1u);
-                if (slot < (uint32_t)MF_EQ_CAP) {
-                    eq_key[slot] = make_key(-(v * MF_INV_SCALE2), (uint32_t)grow);
-                    eq_q[slot] = q_local;
-                }
+    // ---- survivors -------------------------------------------------------------------------------------
+    // Each wave appends to its OWN LDS queue; the fill count is a wave-uniform register, slots come from a
+    // ballot + mbcnt (no atomic, nothing to wait for). The queue is drained by the wave itself (no workgroup
+    // barrier): entry -> slot s = qcount[q]++ (LDS atomic) of this workgroup's private MF_SLOTS slots of query q,
+    // a plain store nobody else writes to; only s >= MF_SLOTS takes the shared overflow list and its global atomic.
+    // (With one shared list per query all 256 workgroups drained at the end of the launch into the same 256
+    // counters: 14 us of serialised device-scope atomics.)
+    uint64_t *wq_key = eq_key + wave * MF_WQ_CAP;
+    uint32_t *wq_q = eq_q + wave * MF_WQ_CAP;
+    uint32_t wq_n = 0;                       // wave-uniform
+    bool wq_dropped = false;                 // wave-uniform: the queue overflowed at some point
+    uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;   // + q * gridDim.x * MF_SLOTS
+    auto drain = [&]() {
+        const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint64_t key = wq_key[i];
+            const uint32_t row = (uint32_t)key;
+            if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) continue;   // tombstoned (vamana.rs:1175-1177)
+            const uint32_t ql = wq_q[i];
+            const uint32_t s_ = atomicAdd(qcount + ql, 1u);
+            if (s_ < (uint32_t)MF_SLOTS) {
+                my_slots[(size_t)ql * gridDim.x * MF_SLOTS + s_] = key;
+            } else {
+                const size_t qi = (size_t)pass * MF_BPAD + ql;
+                const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
+                if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
             }
         }
+        wq_n = 0;
     };
-    // the survivors of one 32-row block (entered when some lane's maximum reached its threshold)
-    auto emit_block = [&](const floatx16 &c, uint64_t brow0) {
+    // the survivors of one 32-row block (entered BY THE WHOLE WAVE when some lane's maximum reached its threshold: the
+    // queue bookkeeping below is wave-uniform). C layout (32x32):
+    // col = lane&31 (query), value r of a lane is row (r&3) + 8*(r>>2) + 4*(lane>>5) of the block.
+    auto emit_block = [&](const floatx16 &c, uint64_t brow0 /* first row of the block */) {
+        const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
+        const uint32_t lim = left < 64 ? (uint32_t)left : 64u;      // this lane's values with row offset < lim exist
 #pragma unroll
-        for (int r = 0; r < 16; ++r) test_push(c[r], thr_l, brow0 + (r & 3) + 8 * (r >> 2));
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t roff = (r & 3) + 8 * (r >> 2);
+            const bool hit = c[r] >= thr_l && roff < lim;
+            const uint64_t b = __builtin_amdgcn_ballot_w64(hit);
+            if (__builtin_expect(b != 0, 0)) {
+                const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (hit && slot < (uint32_t)MF_WQ_CAP) {
+                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    wq_q[slot] = q_local;
+                }
+                wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
+            }
+        }
+        if (wq_n > (uint32_t)MF_WQ_CAP) { wq_dropped = true; wq_n = MF_WQ_CAP; }
     };
-    const int grp = wave >> 2;               // the two waves of a SIMD issue their DMA in alternate slots
 
     // the pipeline is primed: everything issued so far (DMA, query fragments, thresholds) lands before the stream starts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): hipcc's own loads, so that it does not re-wait for them inside the loop
     __syncthreads();
 
+    if (a.ablate & 16u) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }
+    if (a.ablate & 32u) { if (wave & 1) __builtin_amdgcn_s_setprio(3); }
     floatx16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -232,7 +270,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     bool have_prev = false;                 // acc1 of the previous tile waits for its epilogue
     uint32_t prev_sel = 0;
     uint32_t cur = 0;                       // LDS buffer of the current tile
-    uint32_t fl = 0;
     PROF_DECL
 #ifdef SHODH_PROF
     const long long wc1_ = wall_clock64();
@@ -241,68 +278,69 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         const unsigned char *buf = smem + cur * TILE_BYTES;
         const uint32_t pfb = cur + PF >= NBUF ? cur + PF - NBUF : cur + PF;      // buffer the DMA fills during this tile
         const uint32_t psel = sel + PF * step < a.n_sel_tiles ? sel + PF * step : sel;
-        const unsigned char *psrc = rows_b + (size_t)psel * tile_bytes_g;
-        const uint32_t pdst = wave_lds + pfb * TILE_BYTES;
+        const unsigned char *psrc = uniform_ptr(rows_b + (size_t)psel * tile_bytes_g);
+        const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * TILE_BYTES));
 
-        half8 ring[8];
+        half8 ring[RING];
         auto rd = [&](int st) {
             const int rb = st / KSTEPS, ks = st % KSTEPS;
-            ring[st & 7] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
+            ring[st % RING] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
         };
 #pragma unroll
         for (int st = 0; st < D; ++st) rd(st);
         PROF_T(0)
         constexpr int PER1 = (16 + KSTEPS - 1) / KSTEPS;          // accumulator values folded into the maximum per step
         constexpr int PER0 = (16 + KSTEPS - 3) / (KSTEPS - 2);
-        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + 4 * hi;
-        const uint64_t prow1 = (uint64_t)prev_sel * a.tile_stride * MF_TR + 32 + 4 * hi;
+        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR;
+        const uint64_t prow1 = (uint64_t)prev_sel * a.tile_stride * MF_TR + 32;
         float m0 = -__builtin_inff(), m1 = -__builtin_inff();
         // row block 0 -> acc0; in the shadows: maximum of the previous tile's acc1, DMA issue
 #pragma unroll
         for (int st = 0; st < KSTEPS; ++st) {
             rd(st + D);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st & 7], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
             if (MODE == MF_MODE_EMIT) {
 #pragma unroll
                 for (int u = 0; u < PER1; ++u) if (st * PER1 + u < 16) m1 = fmaxf(m1, acc1[st * PER1 + u]);
             }
-            if ((st & 3) == 2 && (st >> 3) < CPT) {
-                if (((st >> 2) & 1) == grp) glds16(psrc, srcoff[st >> 3], pdst + (st >> 3) * NT * 16);
+            if ((st & 3) == 2 && (st >> 2) < NPC) {
+                if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         PROF_T(1)
         if (MODE == MF_MODE_EMIT) {
-            if (have_prev && m1 >= thr_l) emit_block(acc1, prow1);
+            if (have_prev && __builtin_amdgcn_ballot_w64(m1 >= thr_l) != 0) emit_block(acc1, prow1);   // wave-uniform entry
         }
         PROF_T(2)
         // row block 1 -> acc1; in the shadows: maximum of acc0 (from two steps in: its last MFMA has to retire first)
 #pragma unroll
         for (int st = KSTEPS; st < NS; ++st) {
             if (st + D < NS) rd(st + D);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st & 7], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
             if (MODE == MF_MODE_EMIT && st >= KSTEPS + 2) {
 #pragma unroll
                 for (int u = 0; u < PER0; ++u) if ((st - KSTEPS - 2) * PER0 + u < 16) m0 = fmaxf(m0, acc0[(st - KSTEPS - 2) * PER0 + u]);
             }
-            if ((st & 3) == 2 && (st >> 3) < CPT) {
-                if (((st >> 2) & 1) == grp) glds16(psrc, srcoff[st >> 3], pdst + (st >> 3) * NT * 16);
+            if ((st & 3) == 2 && (st >> 2) < NPC) {
+                if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         PROF_T(3)
         if (MODE == MF_MODE_EMIT) {
-            if (m0 >= thr_l) emit_block(acc0, row0);
+            if (__builtin_amdgcn_ballot_w64(m0 >= thr_l) != 0) emit_block(acc0, row0);
         }
         PROF_T(3)
         if (MODE == MF_MODE_EMIT) {
             have_prev = true;
             prev_sel = sel;
-            // Flush the queue early when it is half full. The decision must be block-uniform: thread 0
-            // snapshots it into a double-buffered flag BEFORE the barrier, everyone reads that slot after it
-            // (the slot is rewritten two barriers later). A stale (low) count only delays the flush;
-            // dropped entries are detected by the counter itself (eq_overflowed).
-            if (tid == 0) eq_flag[fl] = (*eq_cnt > (uint32_t)MF_EQ_CAP / 2) ? 1u : 0u;
+            // drain early when the queue is half full (wave-local; the stores and atomics share the VM counter with
+            // the DMA and may complete out of order with it, so everything is drained before the counted wait below)
+            if (wq_n >= (uint32_t)MF_WQ_CAP / 2) {
+                drain();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else {
             // sample pass: the maximum score of this query over the whole 64-row tile
             const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
@@ -324,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         // hand-over: the tile after this one must have landed (the DMA issued during this tile may stay in flight
         // when there are three buffers); all LDS traffic of this wave done; then the workgroup barrier
         PROF_T(4)
-        if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CPT) : "memory");
+        if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PROF_T(5)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -332,10 +370,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         PROF_T(6)
         PROF_N(7)
-        if (MODE == MF_MODE_EMIT) {
-            if (eq_flag[fl]) { flush(); __syncthreads(); }
-            fl ^= 1;
-        }
         cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
 #ifdef SHODH_PROF
@@ -348,16 +382,11 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the clamped tail DMA before the LDS is released
     if (MODE == MF_MODE_EMIT) {
-        if (have_prev) {
-            const uint64_t prow1 = (uint64_t)prev_sel * a.tile_stride * MF_TR + 32 + 4 * hi;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) test_push(acc1[j], thr_l, prow1 + (j & 3) + 8 * (j >> 2));   // (block-final: no maximum was folded)
-        }
-        __syncthreads();
-        flush();
+        if (have_prev) emit_block(acc1, (uint64_t)prev_sel * a.tile_stride * MF_TR + 32);   // (no maximum was folded for the last tile)
+        drain();
         // entries were dropped somewhere: poison every list of this pass so that the final stage sends
         // those queries to the exact scan (adversarial inputs only, e.g. thousands of identical rows)
-        if (eq_overflowed && tid < MF_BPAD) atomicAdd(a.cand_cnt + (size_t)pass * MF_BPAD + tid, a.cand_cap + 1u);
+        if (wq_dropped && lane < 32) atomicAdd(a.cand_cnt + (size_t)pass * MF_BPAD + q_local, a.cand_cap + 1u);
     }
 #ifdef SHODH_PROF
     if (MODE == MF_MODE_EMIT && (blockIdx.x == 100 || blockIdx.x == 200) && blockIdx.y == 0 && tid == 0)
@@ -507,7 +536,9 @@ struct FinalArgs {
     uint32_t dim;
     const float *q;           // [nq][dim] f32 queries
     uint32_t nq, k, cap;      // cap: TopKBuf capacity
-    const uint64_t *cand;     // [n_slots][cand_cap]
+    const uint64_t *slots;    // [n_slots][nb][MF_SLOTS] private (query, workgroup) slots of the pre-scan, KEY_NONE = empty
+    uint32_t nb;              // workgroups of the pre-scan launch
+    const uint64_t *cand;     // [n_slots][cand_cap] shared overflow list
     const uint32_t *cand_cnt;
     uint32_t cand_cap;
     const float *eps;         // [n_slots]
@@ -583,19 +614,25 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (q >= a.nq) return;
-    const uint32_t n = a.cand_cnt[q];
-    bool bad = a.fallback[q] != 0 || n > a.cand_cap;
+    // candidates of query q: the workgroups' private slots (mostly empty: KEY_NONE) followed by the shared overflow list
+    const uint32_t n_ovf = a.cand_cnt[q];
+    bool bad = a.fallback[q] != 0 || n_ovf > a.cand_cap;
+    const uint32_t n_main = a.nb * MF_SLOTS;
+    const uint32_t n = n_main + (bad ? 0u : n_ovf);
+    uint32_t *ecnt = sel32 + KTH_SCRATCH_U32 - 1;    // number of real candidates (statistics)
     PROF_DECL
     if (!bad) {
         for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
-        if (tid == 0) *fcnt = 0;
+        if (tid == 0) { *fcnt = 0; *ecnt = 0; }
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
+        const uint64_t *slots_q = a.slots + (size_t)q * n_main;
         const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
+        auto key_at = [&](uint32_t i) -> uint64_t { return i < n_main ? slots_q[i] : list[i - n_main]; };
         // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
         PROF_T(0)
         float lo = -__builtin_inff();
         if (a.k > 0 && a.k <= 128) {
-            auto key32 = [&](uint32_t i) -> uint32_t { return (uint32_t)(list[i] >> 32); };
+            auto key32 = [&](uint32_t i) -> uint32_t { return (uint32_t)(key_at(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
             bool ovf = false;
             const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
             if (ovf) bad = true;        // block-uniform
@@ -604,9 +641,9 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                 lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
             }
         } else if (a.k > 0) {
-            auto key_a = [&](uint64_t i) -> uint64_t { return list[i]; };
+            auto key_a = [&](uint64_t i) -> uint64_t { return key_at((uint32_t)i); };
             const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
-            if (ma == a.k) {
+            if (ma == a.k && buf.keys[a.k - 1] != KEY_NONE) {
                 const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
                 lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
             }
@@ -615,14 +652,18 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
         // window: every candidate with s~ >= kth - 2 eps (all of them if fewer than k exist)
         __syncthreads();
         if (!bad) {
+            uint32_t real = 0;
             for (uint32_t i = tid; i < n; i += 256) {
-                const uint64_t key = list[i];
+                const uint64_t key = key_at(i);
+                if (key == KEY_NONE) continue;
+                ++real;
                 const float s = -order_key_inv((uint32_t)(key >> 32));
                 if (s >= lo) {
                     const uint32_t slot = atomicAdd(fcnt, 1u);
                     if (slot < a.fcap) flist[slot] = (uint32_t)key;
                 }
             }
+            if (real) atomicAdd(ecnt, real);
         }
         __syncthreads();
         const uint32_t nf = *fcnt;
@@ -746,7 +787,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             }
             if (tid == 0) {
                 a.counts[q] = m;
-                atomicAdd(a.stats + 0, n);
+                atomicAdd(a.stats + 0, *ecnt);
                 atomicAdd(a.stats + 1, nf);
             }
         }
@@ -801,10 +842,10 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
 
 struct MfmaWorkspace {
     _Float16 *q_h; float *qnorm; float *thr; float *eps; uint32_t *cand_cnt; uint32_t *fallback; uint32_t *fb_list;
-    uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand;
+    uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand; uint64_t *slots;
 };
 
-size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[11]*/) {
+size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[12]*/) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     offs[0] = take((size_t)p.n_slots * dim * 2);         // q_h
@@ -817,14 +858,15 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[11]
     offs[7] = take(256);                                 // fb_count
     offs[8] = take(256);                                 // stats
     offs[9] = take((size_t)p.passes * p.J * MF_BPAD * 4);  // blockmax
-    offs[10] = take((size_t)p.n_slots * p.cand_cap * 8);   // cand
+    offs[10] = take((size_t)p.n_slots * p.cand_cap * 8);   // cand (shared overflow lists)
+    offs[11] = take((size_t)p.n_slots * p.grid_x * MF_SLOTS * 8);   // slots (private per query and workgroup)
     return o;
 }
 
 template <int MODE>
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st) {
-    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 64 <= 160 * 1024) ? 3 : 2;
-    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + 32;
+    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
+    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
     if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
@@ -856,14 +898,14 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     w.q_h = (_Float16 *)(ws_base + offs[0]); w.qnorm = (float *)(ws_base + offs[1]); w.thr = (float *)(ws_base + offs[2]);
     w.eps = (float *)(ws_base + offs[3]); w.cand_cnt = (uint32_t *)(ws_base + offs[4]); w.fallback = (uint32_t *)(ws_base + offs[5]);
     w.fb_list = (uint32_t *)(ws_base + offs[6]); w.fb_count = (uint32_t *)(ws_base + offs[7]); w.stats = (uint32_t *)(ws_base + offs[8]);
-    w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]);
+    w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]); w.slots = (uint64_t *)(ws_base + offs[11]);
 
     QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
     SHODH_HIP_TRY(hipGetLastError());
 
     static const uint32_t ablate = getenv("SHODH_ABLATE") ? (uint32_t)atoi(getenv("SHODH_ABLATE")) : 0u;
-    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u};
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u};
     SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
 
     // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
@@ -884,7 +926,8 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     if (ev_emit1) SHODH_HIP_TRY(hipEventRecord(ev_emit1, st));
     if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
 
-    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.cand, w.cand_cnt, p.cand_cap, w.eps, p.fcap, order, id_base,
+    const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
+    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, p.fcap, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32   (every part a multiple of 8 B; region at 16 B)
     const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 +

@@ -11,10 +11,11 @@ idx.build(rows)
 for _ in range(3): idx.search_batch_device(q, k)
 torch.cuda.synchronize(); idx.kernel_timing(True)
 t = time.perf_counter()
-for _ in range(30): idx.search_batch_device(q, k)
-t_enq = (time.perf_counter() - t) / 30
+ITERS = int(os.environ.get('ITERS', 30))
+for _ in range(ITERS): idx.search_batch_device(q, k)
+t_enq = (time.perf_counter() - t) / ITERS
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t) / 30
+dt = (time.perf_counter() - t) / ITERS
 print("host enqueue per step %.1f us" % (t_enq * 1e6))
 qh = q.cpu().numpy()
 idx.search_batch(qh, k)
