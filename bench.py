@@ -11,8 +11,8 @@ A step = one recall pass: one batch of `--nq` (256) query vectors against the wh
 
 N > 1: the corpus is row-sharded over the ranks (shodh_memory_amd/distributed.py): every rank scans
 its shard for the same query batch, the per-shard top-k are all-gathered over RCCL and merged.
---scaling strong (default) keeps the total corpus at --rows; --scaling weak holds --rows PER GPU
-(BASELINE.json configs[4] shape: 10M x 8).
+--scaling weak (default) holds --rows PER GPU, so the corpus grows with N (BASELINE.json configs[4] shape, 10M x 8:
+the ideal is a constant queries/s while the corpus grows N-fold); --scaling strong keeps the total corpus at --rows.
 
 Besides the driver's fields the JSON line carries
   roofline     -- dominant kernel (MFMA emit scan): algorithmic bytes (live rows x dim x 4) / its mean
@@ -59,8 +59,13 @@ def main():
     ap.add_argument("--nq", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--scan", choices=["auto", "exact", "mfma"], default="auto")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
+                    help="N > 1: weak = --rows per GPU (the corpus grows with N, BASELINE configs[4] shape: ideal is constant queries/s), strong = --rows in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency section (keeps a rocprof kernel summary to the batch launches)")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed recall steps for this long BEFORE the contract's warm-up: the GPU idles at ~100 MHz while the corpus is "
+                         "generated and needs a few hundred ms of load to reach its sustained clocks")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -103,6 +108,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    for _ in range(int(args.prewarm_ms * 3)):      # ~0.3 ms per step; a fixed count, so that every rank issues the same collectives
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         res = step()
     torch.cuda.synchronize()
@@ -153,7 +161,7 @@ def main():
 
     # single-query latency (recall(k) on one query: the reference's own bench shape, benches/memory_benchmarks.rs:228-253)
     lat = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_latency:
         q1 = queries[:1].contiguous()
         o1 = (torch.empty((1, args.k), dtype=torch.int32, device=dev), torch.empty((1, args.k), dtype=torch.float32, device=dev),
               torch.empty((1,), dtype=torch.int32, device=dev))

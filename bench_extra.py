@@ -54,7 +54,7 @@ def main():
     if what in ("flat10m", "all"):
         flat(10_000_000, 256, 10, steps=10, tag="flat 10M x 384, batch 256, top-10")
         flat(10_000_000, 1024, 10, steps=5, tag="flat 10M x 384, batch 1024, top-10")
-        flat(10_000_000, 1, 10, steps=20, tag="flat 10M x 384, single query (exact-order scan)")
+        flat(10_000_000, 1, 10, steps=20, tag="flat 10M x 384, single query")
     if what in ("k120", "all"):
         flat(1_000_000, 256, 120, steps=20, tag="flat 1M, batch 256, k=120 (the index-level k of a top-10 recall, retrieval.rs:913-918)")
         flat(1_000_000, 64, 10, steps=20, tag="flat 1M, batch 64, top-10")

@@ -63,7 +63,7 @@ struct MfmaArgs {
     const _Float16 *rows_h;   // [n_rows][dim] fp16(256*x); tombstoned rows are zero
     uint64_t n_rows;
     uint32_t dim;
-    const _Float16 *q_h;      // [passes][256][dim]
+    const _Float16 *q_h;      // [passes][8 waves][dim/16 k-steps][64 lanes][8] fragment-major fp16(256*q), zero padded
     const float *thr;         // [passes][256] emit threshold on the true score scale
     const uint32_t *deleted;  // bitmask or nullptr
     uint64_t *slots;          // [passes][256][gridDim.x][MF_SLOTS] private (query, workgroup) candidate slots, KEY_NONE = empty
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     // resident B fragments: query q_local, k = ks*16 + hi*8 .. +8
     half8 bq[KSTEPS];
     {
-        const _Float16 *qp = a.q_h + ((size_t)pass * MF_BPAD + q_local) * DIM + hi * 8;
+        const half8 *qp = reinterpret_cast<const half8 *>(a.q_h) + ((size_t)pass * 8 + wave) * KSTEPS * 64 + lane;   // fragment-major (convert_queries_kernel)
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) bq[ks] = *reinterpret_cast<const half8 *>(qp + ks * 16);
+        for (int ks = 0; ks < KSTEPS; ++ks) bq[ks] = qp[ks * 64];
     }
     float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
     if (a.ablate & 8u) thr_l = __builtin_inff();   // diagnostics: nothing is emitted
@@ -455,7 +455,7 @@ __global__ void shadow_restore_deleted_kernel(const float *rows, _Float16 *rows_
 struct QueryPrep {
     const float *q;          // [nq][dim]
     uint32_t nq, dim, n_slots;
-    _Float16 *q_h;           // [n_slots][dim]
+    _Float16 *q_h;           // [n_slots * dim] fragment-major, see the kernel
     float *qnorm;            // [n_slots]
     uint32_t *cand_cnt;      // [n_slots]
     uint32_t *fallback;      // [n_slots] 1 = must go through the exact scan
@@ -476,7 +476,14 @@ __global__ __launch_bounds__(256) void convert_queries_kernel(QueryPrep p) {
         if (!(__builtin_fabsf(x) <= 3.0e38f)) bad++;
         mx = fmaxf(mx, __builtin_fabsf(x));
         ss = __builtin_fmaf(x, x, ss);
-        p.q_h[(size_t)slot * p.dim + i] = (_Float16)(x * MF_SCALE);
+        // fragment-major: [pass][wave = q/32][k-step = i/16][lane = ((i%16)/8)*32 + q%32][i%8], so that the scan kernel's
+        // 32x32x16 B fragment of one k-step is ONE contiguous 1 KiB wave load (row-major made every load instruction touch 32
+        // different 128-B lines for 32 B each: ~9 us of prologue per launch)
+        {
+            const uint32_t ql = slot % MF_BPAD, ps = slot / MF_BPAD;
+            const size_t frag = (((size_t)ps * 8 + ql / 32) * (p.dim / 16) + i / 16) * 64 + ((i % 16) / 8) * 32 + ql % 32;
+            p.q_h[frag * 8 + i % 8] = (_Float16)(x * MF_SCALE);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         ss += __shfl_xor(ss, off);
@@ -503,8 +510,10 @@ struct ThrArgs {
     float *thr;              // [n_slots] emit threshold
     float *eps;              // [n_slots]
 };
+constexpr int THR_STAGE = 4096;
 __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     __shared__ uint32_t scratch[KTH_SCRATCH_U32];
+    __shared__ uint32_t staged[THR_STAGE];
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;            // pass*256 + q
     const uint32_t pass = slot / MF_BPAD, ql = slot % MF_BPAD;
@@ -514,8 +523,19 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
         return;
     }
-    // k-th LARGEST tile maximum == k-th smallest order_key(-max)
-    auto key_at = [&](uint32_t j) -> uint32_t { return order_key(-a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql]); };
+    // k-th LARGEST tile maximum == k-th smallest order_key(-max). The maxima of one query are 1 KiB apart in memory and
+    // are needed twice (filter, gather): the first THR_STAGE of them are staged in LDS.
+    auto key_glb = [&](uint32_t j) -> uint32_t { return order_key(-a.blockmax[((size_t)pass * a.J + j) * MF_BPAD + ql]); };
+    const uint32_t n_st = a.J < (uint32_t)THR_STAGE ? a.J : (uint32_t)THR_STAGE;
+    for (uint32_t j0 = 0; j0 < n_st; j0 += 1024) {      // four unconditional loads in flight per thread (clamped index)
+        uint32_t kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * 256 + tid; kv[u] = key_glb(j < n_st ? j : 0); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * 256 + tid; if (j < n_st) staged[j] = kv[u]; }
+    }
+    __syncthreads();
+    auto key_at = [&](uint32_t j) -> uint32_t { return j < n_st ? staged[j] : key_glb(j); };
     bool ovf = false;
     const uint32_t kk = a.k ? block_kth_u32<256>(key_at, a.J, a.k, scratch, &ovf) : 0xFFFFFFFFu;
     if (tid == 0) {
@@ -590,6 +610,8 @@ __device__ __forceinline__ float exact_dot_row(const float *__restrict__ q_lds, 
 
 constexpr int FS_CH = 16;     // AVX2 order: rows of the re-score window staged raw in LDS at a time
 constexpr int FS_TC = 64;     // scalar-4 order: rows whose per-group partial sums are staged at a time
+constexpr int FS_RW = 16;      // scalar-4 order: rows in flight per wave (FS_TC / 4 waves)
+constexpr int FS_STAGE = 2048; // candidate keys staged in LDS (the rest, if any, is re-read from global)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim) {
@@ -614,25 +636,51 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (q >= a.nq) return;
-    // candidates of query q: the workgroups' private slots (mostly empty: KEY_NONE) followed by the shared overflow list
+    // candidates of query q: the workgroups' private slots (mostly empty: KEY_NONE) followed by the shared overflow list.
+    // Everything the block needs first is requested in one go (unconditional loads on clamped indices: a load behind a
+    // runtime condition makes hipcc wait for each one separately -- measured as 4 + 2 + 2 dependent round trips here).
+    const uint32_t n_main = a.nb * MF_SLOTS;
+    const uint64_t *slots_q = a.slots + (size_t)q * n_main;
+    uint64_t kv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; kv[j] = slots_q[i < n_main ? i : 0]; }
+    float qv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const uint32_t i = j * 256 + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 512 on this path
     const uint32_t n_ovf = a.cand_cnt[q];
     bool bad = a.fallback[q] != 0 || n_ovf > a.cand_cap;
-    const uint32_t n_main = a.nb * MF_SLOTS;
     const uint32_t n = n_main + (bad ? 0u : n_ovf);
     uint32_t *ecnt = sel32 + KTH_SCRATCH_U32 - 1;    // number of real candidates (statistics)
+    uint32_t *skey = sel32 + KTH_SCRATCH_U32;        // [FS_STAGE] score keys (high words) of the candidates, staged once
+    uint32_t *srow = skey + FS_STAGE;                // [FS_STAGE] their rows (low words)
     PROF_DECL
     if (!bad) {
-        for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const uint32_t i = j * 256 + tid; if (i < a.dim) qs[i] = qv[j]; }
         if (tid == 0) { *fcnt = 0; *ecnt = 0; }
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-        const uint64_t *slots_q = a.slots + (size_t)q * n_main;
         const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
-        auto key_at = [&](uint32_t i) -> uint64_t { return i < n_main ? slots_q[i] : list[i - n_main]; };
+        auto key_glb = [&](uint32_t i) -> uint64_t { return i < n_main ? slots_q[i] : list[i - n_main]; };
+        // the candidate keys are read three times (filter, gather, window): stage them in LDS once
+        const uint32_t n_st = n < (uint32_t)FS_STAGE ? n : (uint32_t)FS_STAGE;
+        const uint32_t st_main = n_main < n_st ? n_main : n_st;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; if (i < st_main) { skey[i] = (uint32_t)(kv[j] >> 32); srow[i] = (uint32_t)kv[j]; } }
+        for (uint32_t i0 = 1024; i0 < st_main; i0 += 1024) {      // more than 256 workgroups in the pre-scan
+            uint64_t kw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * 256 + tid; kw[j] = slots_q[i < st_main ? i : 0]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * 256 + tid; if (i < st_main) { skey[i] = (uint32_t)(kw[j] >> 32); srow[i] = (uint32_t)kw[j]; } }
+        }
+        for (uint32_t i = n_main + tid; i < n_st; i += 256) { const uint64_t key = list[i - n_main]; skey[i] = (uint32_t)(key >> 32); srow[i] = (uint32_t)key; }
+        __syncthreads();
+        auto key_at = [&](uint32_t i) -> uint64_t { return i < n_st ? (((uint64_t)skey[i] << 32) | srow[i]) : key_glb(i); };
         // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
         PROF_T(0)
         float lo = -__builtin_inff();
         if (a.k > 0 && a.k <= 128) {
-            auto key32 = [&](uint32_t i) -> uint32_t { return (uint32_t)(key_at(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
+            auto key32 = [&](uint32_t i) -> uint32_t { return i < n_st ? skey[i] : (uint32_t)(key_glb(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
             bool ovf = false;
             const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
             if (ovf) bad = true;        // block-uniform
@@ -686,24 +734,24 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                 for (uint32_t c0 = 0; c0 < nf; c0 += FS_TC) {
                     const uint32_t nc = (nf - c0) < (uint32_t)FS_TC ? (nf - c0) : (uint32_t)FS_TC;
                     // wave w takes rows w, w+4, ...; its lanes take float4 groups ln, ln+64, ... (one row = one
-                    // coalesced d4*16-byte read); four rows' loads are in flight per wave before any is reduced
-                    for (uint32_t cb = wv; cb < nc; cb += 16) {
+                    // coalesced d4*16-byte read); FS_RW rows' loads are in flight per wave before any is reduced (the rows are
+                    // cold in HBM: every round trip is ~2 us)
+                    for (uint32_t cb = wv; cb < nc; cb += 4 * FS_RW) {
                         for (uint32_t g0 = 0; g0 < d4; g0 += 128) {
-                            f32x4 r[4][2];
+                            f32x4 r[FS_RW][2];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t c = cb + 4 * u;
-                                if (c < nc) {
-                                    const float *rp_ = a.rows + (size_t)flist[c0 + c] * dim;
+                            for (int u = 0; u < FS_RW; ++u) {
+                                // unconditional loads on clamped indices (see the staging loop above): all FS_RW x 2 in flight
+                                const uint32_t c = cb + 4 * u < nc ? cb + 4 * u : nc - 1;
+                                const float *rp_ = a.rows + (size_t)flist[c0 + c] * dim;
 #pragma unroll
-                                    for (int h = 0; h < 2; ++h) {
-                                        const uint32_t g = g0 + h * 64 + ln;
-                                        if (g < d4) r[u][h] = *reinterpret_cast<const f32x4 *>(rp_ + g * 4);
-                                    }
+                                for (int h = 0; h < 2; ++h) {
+                                    const uint32_t g = g0 + h * 64 + ln;
+                                    r[u][h] = *reinterpret_cast<const f32x4 *>(rp_ + (g < d4 ? g : d4 - 1) * 4);
                                 }
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < FS_RW; ++u) {
                                 const uint32_t c = cb + 4 * u;
                                 if (c < nc) {
 #pragma unroll
@@ -811,7 +859,7 @@ struct MfmaPlan {
 
 uint32_t topk_capacity(uint32_t k);   // flat_exact.hip
 
-bool mfma_supported(uint32_t dim) { return dim == 128 || dim == 256 || dim == 384 || dim == 512; }
+bool mfma_supported(uint32_t dim) { return dim == 128 || dim == 256 || dim == 384 || dim == 512; }   // (final_stage_kernel loads the query with two loads per thread: dim <= 512)
 
 MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus) {
     MfmaPlan p{};
@@ -931,7 +979,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32   (every part a multiple of 8 B; region at 16 B)
     const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 +
-                        final_stage_region_bytes(dim) + (size_t)KTH_SCRATCH_U32 * 4 + 16;
+                        final_stage_region_bytes(dim) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)FS_STAGE * 8 + 16;
     if (order == SHODH_ORDER_AVX2) {
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_AVX2>), dim3(nq), dim3(256), flds, st, f);

@@ -164,8 +164,8 @@ __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, 
 // k-th smallest (k >= 1) of n 32-bit keys key_at(0..n) -- the VALUE only, duplicates allowed. Returns
 // 0xFFFFFFFF if fewer than k keys exist, and sets *overflow if the bounded gather buffer (1024) was too small
 // (pathological inputs: thousands of equal keys) so that the caller can take another route.
-//   1. filter: the keys are dealt round-robin into k groups; the k-th smallest key is <= the LARGEST of the k
-//      group minima (k distinct keys are <= it), and only ~k*H(k) keys pass that bound on random input;
+//   1. filter: the keys are dealt into k groups (by owning thread, tid % k); the k-th smallest key is <= the LARGEST
+//      of the k group minima (k distinct keys are <= it), and only ~k*H(k) keys pass that bound on random input;
 //   2. the survivors are gathered into LDS;
 //   3. few survivors: rank counting (O(c) per thread); many: 4 x 8-bit radix select over the LDS copy.
 // A rank loop over c keys costs ~25 cycles * c per thread (wave64 VALU ops issue over 4 cycles), which is why
@@ -182,17 +182,14 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
     if (filt && tid < k) gmin[tid] = 0xFFFFFFFFu;
     __syncthreads();
     if (filt) {
-        const uint32_t step = NT % k;
-        uint32_t g = tid % k;
-        for (uint32_t i = tid; i < n; i += NT) {
-            atomicMin(&gmin[g], key_at(i));
-            g += step;
-            if (g >= k) g -= k;
-        }
+        // group g = the keys of the threads with tid % k == g: one LDS atomic per thread, none for empty threads
+        uint32_t tmin = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < n; i += NT) { const uint32_t key = key_at(i); tmin = key < tmin ? key : tmin; }
+        if (tmin != 0xFFFFFFFFu) atomicMin(&gmin[tid % k], tmin);
         __syncthreads();
         uint32_t m = 0;
         for (uint32_t j = 0; j < k; ++j) { const uint32_t v = gmin[j]; m = v > m ? v : m; }
-        T = m;
+        T = m;      // 0xFFFFFFFF if some group is empty: nothing is filtered, still correct
     }
     for (uint32_t i = tid; i < n; i += NT) {
         const uint32_t key = key_at(i);
