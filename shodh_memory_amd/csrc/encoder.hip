@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "glds.h"
 
 namespace shodh {
 
@@ -38,95 +39,292 @@ template <> __device__ __forceinline__ float from_f32<float>(float x) { return x
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float x) { return (__bf16)x; }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's 2^-9) -- 14 VALU instead of ~40 for
+// erff; in the FFN-up GEMM the exact erff epilogue cost three times the MFMA time of the tile
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = 1.0f - p * t * e;
+    return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
+}
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2 };
 
 // ---- bf16 MFMA GEMM: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue) ------------------------------------------
-// A, W bf16 row-major; K % 32 == 0, N % 128 == 0.
+// A, W bf16 row-major; K % 64 == 0, N % 128 == 0. 128 x 128 x 64 tiles, 4 waves x (2 x 2) 32x32 blocks,
+// register-staged double-buffered LDS (64 KiB, rows of 128 B with the 16-B chunks XOR-swizzled by (row>>1)&7:
+// the 16 rows of a ds_read_b128 lane group land on 16 distinct slots).
+// The MFMA computes C^T (A operand = the W tile, B operand = the activation tile), so a lane owns ONE token
+// (col = lane&31) and its registers run along n: four consecutive registers are four consecutive output features,
+// which makes the epilogue 8-byte (bf16) / 16-byte (f32) stores and float4 bias loads instead of 2-byte scatters.
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict__ A, const __bf16 *__restrict__ W,
                                                         const float *__restrict__ bias, const __bf16 *__restrict__ resid,
                                                         __bf16 *__restrict__ out_b, float *__restrict__ out_f,
                                                         int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 128 * 64];   // [buf][A|B][128 rows][64 B]
+    constexpr int TB = 128 * 128;                       // bytes of one operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TB];   // [buf][A|W][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    // staging: 512 chunks (128 rows x 4) per operand, 2 per thread
-    int srow[2], sc[2];
+    // staging: 1024 chunks (128 rows x 8) per operand, 4 per thread
+    u32x4 pa[4], pb[4];
+    const __bf16 *ga[4], *gb[4];
+    int loff[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int S = i * 256 + tid; srow[i] = S >> 2; sc[i] = S & 3; }
-    u32x4 pa[2], pb[2];
+    for (int i = 0; i < 4; ++i) {
+        const int S = i * 256 + tid, row = S >> 3, c = S & 7;
+        int ra = m0 + row; if (ra >= M) ra = M - 1;
+        ga[i] = A + (size_t)ra * K + c * 8;
+        gb[i] = W + (size_t)(n0 + row) * K + c * 8;
+        loff[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    }
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int ra = m0 + srow[i]; if (ra >= M) ra = M - 1;
-            pa[i] = *reinterpret_cast<const u32x4 *>(A + (size_t)ra * K + kt * 32 + sc[i] * 8);
-            pb[i] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + srow[i]) * K + kt * 32 + sc[i] * 8);
-        }
+        for (int i = 0; i < 4; ++i) { pa[i] = *reinterpret_cast<const u32x4 *>(ga[i] + kt * 64); pb[i] = *reinterpret_cast<const u32x4 *>(gb[i] + kt * 64); }
     };
     auto stage = [&](int buf) {
-        unsigned char *base = lds + buf * (2 * 128 * 64);
+        unsigned char *base = lds + buf * (2 * TB);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cs = sc[i] ^ ((srow[i] >> 2) & 3);      // 16 rows of a read group -> 16 distinct 16-B slots
-            *reinterpret_cast<u32x4 *>(base + srow[i] * 64 + cs * 16) = pa[i];
-            *reinterpret_cast<u32x4 *>(base + 128 * 64 + srow[i] * 64 + cs * 16) = pb[i];
-        }
+        for (int i = 0; i < 4; ++i) { *reinterpret_cast<u32x4 *>(base + loff[i]) = pa[i]; *reinterpret_cast<u32x4 *>(base + TB + loff[i]) = pb[i]; }
     };
-    floatx16 acc[2][2];
+    floatx16 acc[2][2];      // [n block j][m block i]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int nkt = K / 32;
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+    // fragment offsets: row (l31) part + swizzle; the k-step chunk (2*ks + hi) is XORed in
+    int fo_a[2], fo_b[2], sw_a[2], sw_b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+        fo_a[i] = ra * 128; sw_a[i] = (ra >> 1) & 7;
+        fo_b[i] = TB + rb * 128; sw_b[i] = (rb >> 1) & 7;
+    }
+    const int nkt = K / 64;
     gload(0);
     stage(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
-        const unsigned char *ab = lds + cur * (2 * 128 * 64);
-        const unsigned char *bb = ab + 128 * 64;
+        const unsigned char *tb = lds + cur * (2 * TB);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = wr * 64 + i * 32 + l31;
-                fa[i] = *reinterpret_cast<const bf16x8 *>(ab + row * 64 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) << 4));
-                const int col = wc * 64 + i * 32 + l31;
-                fb[i] = *reinterpret_cast<const bf16x8 *>(bb + col * 64 + (((ks * 2 + hi) ^ ((col >> 2) & 3)) << 4));
+                fa[i] = *reinterpret_cast<const bf16x8 *>(tb + fo_a[i] + (((ks * 2 + hi) ^ sw_a[i]) << 4));
+                fb[i] = *reinterpret_cast<const bf16x8 *>(tb + fo_b[i] + (((ks * 2 + hi) ^ sw_b[i]) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
         if (kt + 1 < nkt) stage(cur ^ 1);
         __syncthreads();
     }
-    // C layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*hi (m)
+    // C^T layout: col = lane&31 -> token m, value r -> feature n = (r&3) + 8*(r>>2) + 4*hi of the 32-wide n block
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wr * 64 + i * 32 + l31;
+        if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wc * 64 + j * 32 + l31;
-            const float bv = bias[n];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                    if (EPI == EPI_BIAS_RESID_F32) out_f[(size_t)m * N + n] = v + (float)resid[(size_t)m * N + n];
-                    else out_b[(size_t)m * N + n] = (__bf16)v;
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
+                const f32x4e bv = *reinterpret_cast<const f32x4e *>(bias + nb);
+                f32x4e v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[j][i][4 * g + e] + bv[e];
+                    if (EPI == EPI_BIAS_GELU) x = gelu_erf_fast(x);
+                    v[e] = x;
+                }
+                if (EPI == EPI_BIAS_RESID_F32) {
+                    const bf16x4e rv = *reinterpret_cast<const bf16x4e *>(resid + (size_t)m * N + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    *reinterpret_cast<f32x4e *>(out_f + (size_t)m * N + nb) = v;
+                } else {
+                    bf16x4e o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4e *>(out_b + (size_t)m * N + nb) = o;
                 }
             }
+    }
+}
+
+// ---- weight-stationary streaming GEMM for K = 384 (QKV, attention output, FFN up) -------------------------------
+// With K = 384 a tiled GEMM spends its time in prologues: six K-tiles per output tile, every one a dependent HBM/L2
+// round trip (measured: 15 us per 128x128 tile for 1.5 us of MFMA work). So the small operand stays put and the big
+// one streams, exactly like the corpus scan (scan_mfma.hip):
+//   - persistent workgroups, 8 waves; wave w holds the 32 output features [32*(8*g+w), +32) of W as resident MFMA
+//     fragments for the whole launch (24 x 4 VGPRs, read from a fragment-major copy packed once at weight load);
+//   - the activations X[M,384] stream through LDS in 64-token tiles by LDS-DMA, three buffers, two tiles ahead,
+//     issued by waves 0-3 (the older wave of each SIMD has the slack), one s_barrier per tile;
+//   - per tile and wave: 24 MFMAs into acc0 (tokens 0-31), 24 into acc1 (32-63), weights as the A operand so that a
+//     lane owns a token and four consecutive registers are four consecutive features (8/16-byte stores);
+//   - bias / GELU / residual in the epilogue of each tile (the SIMD's other wave multiplies meanwhile).
+constexpr int GS_TR = 64, GS_KSTEPS = 24, GS_DIM = 384, GS_PITCH = 768, GS_TILE = GS_TR * GS_PITCH, GS_NBUF = 3;
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ Wp /* fragment-major */,
+                                                                   const float *__restrict__ bias, const __bf16 *__restrict__ resid,
+                                                                   __bf16 *__restrict__ out_b, float *__restrict__ out_f, int M, int N, int n_groups) {
+    constexpr int NT = 512, CPR = 48, KSTEPS = GS_KSTEPS, NS = 2 * KSTEPS, D = 6, PF = GS_NBUF - 1;
+    constexpr int NPC = 2 * (GS_TR * CPR / NT);      // DMA pieces per issuing thread (waves 0-3) and tile = 12
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x % n_groups, worker = blockIdx.x / n_groups, n_workers = gridDim.x / n_groups;
+    const int nblk = grp * 8 + wave;                 // this wave's 32-feature block
+    const bool active = nblk * 32 < N;               // wave-uniform
+    const int nblk_c = active ? nblk : 0;
+
+    uint32_t srcoff[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int p = i * 256 + (tid & 255);
+        const int row = p / CPR, slot = p % CPR;
+        const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
+        srcoff[i] = (uint32_t)(row * GS_PITCH + c * 16);
+    }
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(X);
+    const uint32_t wave_lds = smem_lds + (uint32_t)(wave & 3) * 1024u;
+    const int n_tiles = (M + GS_TR - 1) / GS_TR;     // the last tile may read up to 63 rows past M (the buffer is padded); they are not stored
+    int t = worker;
+#pragma unroll
+    for (int b = 0; b < PF; ++b) {
+        const int tt = t + b * n_workers < n_tiles ? t + b * n_workers : (t < n_tiles ? t : 0);
+        const unsigned char *src = uniform_ptr(xb + (size_t)tt * GS_TILE);
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * GS_TILE + i * 4096);
         }
+    }
+    // resident weight fragments (A operand: row = feature l31 of the block, k = 16*ks + 8*hi ..)
+    bf16x8 bw[KSTEPS];
+    {
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(Wp) + (size_t)nblk_c * KSTEPS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bw[ks] = wp[ks * 64];
+    }
+    // this lane's 16 features: n = 32*nblk + (r&3) + 8*(r>>2) + 4*hi
+    float bv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4e b4 = *reinterpret_cast<const f32x4e *>(bias + nblk_c * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[4 * g + e] = b4[e];
+    }
+    const int sw = l31 & 15;
+    int aoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aoff[j] = l31 * GS_PITCH + (((2 * j + hi) ^ sw) << 4);
+
+    auto epilogue = [&](const floatx16 &c, int m) {
+        if (m >= M) return;
+        f32x4e rv[4];
+        if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4e r4 = *reinterpret_cast<const bf16x4e *>(resid + (size_t)m * N + nblk * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[g][e] = (float)r4[e];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4e v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = c[4 * g + e] + bv[4 * g + e];
+                if (EPI == EPI_BIAS_GELU) x = gelu_erf_fast(x);
+                v[e] = x;
+            }
+            const size_t o = (size_t)m * N + nblk * 32 + 8 * g + 4 * hi;
+            if (EPI == EPI_BIAS_RESID_F32) {
+                *reinterpret_cast<f32x4e *>(out_f + o) = v + rv[g];
+            } else {
+                bf16x4e ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ob[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4e *>(out_b + o) = ob;
+            }
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) for hipcc's own loads (weights, bias): not re-waited inside the loop
+    __syncthreads();
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 acc0 = zero16, acc1 = zero16;
+    uint32_t cur = 0;
+    for (; t < n_tiles; t += n_workers) {
+        const unsigned char *buf = smem + cur * GS_TILE;
+        const uint32_t pfb = cur + PF >= GS_NBUF ? cur + PF - GS_NBUF : cur + PF;
+        const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
+        const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * GS_TILE);
+        const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * GS_TILE));
+        bf16x8 ring[8];
+        auto rd = [&](int st) {
+            const int rb = st / KSTEPS, ks = st % KSTEPS;
+            ring[st & 7] = *reinterpret_cast<const bf16x8 *>(buf + rb * 32 * GS_PITCH + aoff[ks & 7] + (ks >> 3) * 256);
+        };
+#pragma unroll
+        for (int st = 0; st < D; ++st) rd(st);
+#pragma unroll
+        for (int st = 0; st < KSTEPS; ++st) {
+            rd(st + D);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[st], ring[st & 7], st == 0 ? zero16 : acc0, 0, 0, 0);
+            if ((st & 3) == 2 && (st >> 2) < NPC) { if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int st = KSTEPS; st < NS; ++st) {
+            if (st + D < NS) rd(st + D);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[st - KSTEPS], ring[st & 7], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+            if ((st & 3) == 2 && (st >> 2) < NPC) { if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // The next tile must have landed before the barrier. Counted wait BEFORE this tile's stores are issued: the only
+        // VM operations younger than that tile's DMA are the previous tile's stores (issued a whole tile ago) and the NPC
+        // pieces issued during this tile, so "at most NPC outstanding" implies it is complete whether or not stores retire
+        // in order with loads.
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+        if (active) {
+            epilogue(acc0, t * GS_TR + l31);
+            epilogue(acc1, t * GS_TR + 32 + l31);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == GS_NBUF ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// W[N][K] row-major bf16 -> fragment-major [N/32][K/16][64 lanes][8]: lane = ((k%16)/8)*32 + n%32
+__global__ void pack_frag_kernel(const __bf16 *__restrict__ W, __bf16 *__restrict__ out, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const size_t frag = ((size_t)(n / 32) * (K / 16) + k / 16) * 64 + ((k % 16) / 8) * 32 + n % 32;
+    out[frag * 8 + k % 8] = W[i];
 }
 
 // ---- plain f32 GEMM (validation dtype): 64x64 tile, 4x4 outputs per thread -------------------------------
@@ -173,23 +371,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     }
 }
 
-// ---- LayerNorm over the hidden dim (one wave per token), f32 in -> T out --------------------------------
+// ---- LayerNorm over the hidden dim, f32 in -> T out. Half a wave per token: lane l owns the float4 groups l, l+32, ...
+// (512 contiguous bytes per load instruction); the row is read once and stays in registers. H % 128 == 0, H <= 512.
 template <class T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, T *__restrict__ out, int ntok, int H, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int l = threadIdx.x & 31;
+    const int tok = (blockIdx.x * 256 + threadIdx.x) >> 5;
     if (tok >= ntok) return;
-    const float *x = in + (size_t)tok * H;
+    const f32x4e *x4 = reinterpret_cast<const f32x4e *>(in + (size_t)tok * H);
+    const int ng = H >> 7;                  // float4 groups per lane (3 at H = 384)
+    f32x4e xv[4];
     float s = 0.0f;
-    for (int i = lane; i < H; i += 64) s += x[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < ng) { xv[j] = x4[j * 32 + l]; s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]); }
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)H;
     float v = 0.0f;
-    for (int i = lane; i < H; i += 64) { const float d = x[i] - mean; v += d * d; }
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < ng) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
+    }
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const float inv = 1.0f / sqrtf(v / (float)H + eps);
-    for (int i = lane; i < H; i += 64) out[(size_t)tok * H + i] = from_f32<T>((x[i] - mean) * inv * gamma[i] + beta[i]);
+    const f32x4e *g4 = reinterpret_cast<const f32x4e *>(gamma), *b4 = reinterpret_cast<const f32x4e *>(beta);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < ng) {
+        const f32x4e g = g4[j * 32 + l], b = b4[j * 32 + l];
+        T o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>((xv[j][e] - mean) * inv * g[e] + b[e]);
+        T *dst = out + (size_t)tok * H + (size_t)(j * 32 + l) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = o4[e];
+    }
 }
 
 // ---- embeddings: word + position + token_type(0), then LayerNorm ------------------------------------------
@@ -261,6 +477,110 @@ __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qk
     }
 }
 
+// ---- attention on the matrix cores (bf16 path): one workgroup per (sequence, head), d_head = 32 -----------------
+// Everything is computed TRANSPOSED so that a lane owns one query for the whole kernel:
+//   S^T[key, q] = K[key, :] . Q[q, :]      A = K block (LDS, rows = keys), B = Q fragments (registers, straight from HBM)
+//   softmax over keys = over the lane's own 16 registers + one exchange with the other half-wave (online, per lane)
+//   O^T[d, q]  = V^T[d, key] . P^T[key, q]  A = V^T (LDS, staged transposed), B = P^T = the lane's own registers
+// P never leaves the registers: the MFMA k-index of the second product is DEFINED as the order in which the first
+// product's C layout hands the keys to a lane (register r of half-wave h is key (r&3) + 8*(r>>2) + 4*h of the block), and
+// V^T is staged in that same order (position 16*(r>>3) + 8*h + (r&7)), so both operands agree without any shuffle.
+// Wave w takes the query blocks w, w+4, ... of the sequence; keys go in blocks of 32.
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const __bf16 *__restrict__ qkv, const int32_t *__restrict__ cu,
+                                                             __bf16 *__restrict__ ctx, int H, int heads, int s_pad /* multiple of 32 */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int H3 = 3 * H;
+    const int nkb = (S + 31) >> 5;
+    unsigned char *Ks = smem;                                   // [nkb*32 keys][64 B], 16-B chunks XOR-swizzled by (key>>2)&3
+    const int vt_pitch = s_pad * 2 + 16;                        // bytes per d row of V^T (+16: rows start 4 banks apart)
+    unsigned char *Vt = smem + (size_t)s_pad * 64;              // [32 d][s_pad keys, block-permuted]
+    // stage K (row-major, zero beyond S) and V^T
+    for (int e = tid; e < nkb * 32 * 4; e += 256) {
+        const int key = e >> 2, c = e & 3;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (key < S) v = *reinterpret_cast<const u32x4 *>(qkv + (size_t)(t0 + key) * H3 + H + head * 32 + c * 8);
+        *reinterpret_cast<u32x4 *>(Ks + key * 64 + ((c ^ ((key >> 2) & 3)) << 4)) = v;
+    }
+    for (int e = tid; e < nkb * 32 * 4; e += 256) {
+        const int key = e >> 2, c = e & 3;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < S) v = *reinterpret_cast<const bf16x8 *>(qkv + (size_t)(t0 + key) * H3 + 2 * H + head * 32 + c * 8);
+        // key -> (register r, half h) of the S^T layout -> position inside its 32-key block
+        const int kb = key >> 5, kk = key & 31;
+        const int h = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        const int pos = kb * 32 + 16 * (r >> 3) + 8 * h + (r & 7);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<__bf16 *>(Vt + (c * 8 + j) * vt_pitch + pos * 2) = v[j];
+    }
+    __syncthreads();
+    const float sc = 0.17677669529663688110f * 1.44269504088896340736f;      // 1/sqrt(32) * log2(e): softmax in base 2
+    for (int qb = wave; qb * 32 < S; qb += 4) {
+        const int q = qb * 32 + l31;
+        const int qc = q < S ? q : S - 1;
+        bf16x8 bq[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bq[ks] = *reinterpret_cast<const bf16x8 *>(qkv + (size_t)(t0 + qc) * H3 + head * 32 + ks * 16 + hi * 8);
+        floatx16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        float mx = -3.0e38f, l = 0.0f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            floatx16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+            const int krow = kb * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ak = *reinterpret_cast<const bf16x8 *>(Ks + krow * 64 + (((ks * 2 + hi) ^ ((krow >> 2) & 3)) << 4));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, bq[ks], st, 0, 0, 0);
+            }
+            // this lane: query q, keys kb*32 + (r&3) + 8*(r>>2) + 4*hi
+            float bm = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                st[r] = key < S ? st[r] * sc : -3.0e38f;
+                bm = fmaxf(bm, st[r]);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = fmaxf(mx, bm);
+            const float corr = __builtin_amdgcn_exp2f(mx - mn);
+            float ps = 0.0f;
+            bf16x8 pb[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(st[r] - mn);     // masked keys: exp2(-3e38 - mn) = 0
+                ps += pv;
+                pb[r >> 3][r & 7] = (__bf16)pv;
+            }
+            ps += __shfl_xor(ps, 32);
+            l = l * corr + ps;
+            mx = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= corr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(Vt + l31 * vt_pitch + (kb * 32 + ks * 16 + hi * 8) * 2);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[ks], o, 0, 0, 0);
+            }
+        }
+        if (q < S) {
+            const float invl = 1.0f / l;
+            // O^T layout: this lane = query q, value r = feature d = (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4e ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (__bf16)(o[4 * g + e] * invl);
+                *reinterpret_cast<bf16x4e *>(ctx + (size_t)(t0 + q) * H + head * 32 + 8 * g + 4 * hi) = ov;
+            }
+        }
+    }
+}
+
 // ---- masked mean-pool + finalize_pooled (minilm.rs:959-981, :846-878) -------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, const int32_t *__restrict__ cu, float *__restrict__ out, int H) {
@@ -310,7 +630,9 @@ struct shodh_embedder {
     float *bqkv = nullptr;               // [layers][3H] fused q,k,v bias
     float *wqkv32 = nullptr;             // [layers][3H][H] fused q,k,v weight (the blob interleaves weights and biases)
     __bf16 *wqkv16 = nullptr;
+    __bf16 *wp16 = nullptr;              // [layers][3H + H + I][H] fragment-major copies of the K = H weights (streaming GEMM), H == 384 only
     bool loaded = false;
+    int cus = 256;
     // workspace
     size_t tok_cap = 0, seq_cap = 0;
     void *X = nullptr, *QKV = nullptr, *CTX = nullptr, *FF = nullptr; float *PRE = nullptr;
@@ -375,6 +697,21 @@ static int gemm_bf16(const __bf16 *A, const __bf16 *W, const float *bias, const 
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
+// K == 384 only; Wp = fragment-major weights
+template <int EPI>
+static int gemm_k384_stream(const __bf16 *X, const __bf16 *Wp, const float *bias, const __bf16 *resid, __bf16 *out_b, float *out_f,
+                            int M, int N, int cus, hipStream_t st) {
+    const int n_groups = (N + 255) / 256;
+    int n_workers = cus / n_groups;
+    if (n_workers < 1) n_workers = 1;
+    const int n_tiles = (M + GS_TR - 1) / GS_TR;
+    if (n_workers > n_tiles) n_workers = n_tiles > 0 ? n_tiles : 1;
+    const size_t lds = (size_t)GS_NBUF * GS_TILE;
+    SHODH_TRY(ensure_dynamic_lds((const void *)gemm_k384_stream_kernel<EPI>, lds));
+    hipLaunchKernelGGL((gemm_k384_stream_kernel<EPI>), dim3(n_groups * n_workers), dim3(512), lds, st, X, Wp, bias, resid, out_b, out_f, M, N, n_groups);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
 template <int EPI>
 static int gemm_f32(const float *A, const float *W, const float *bias, const float *resid, float *out, int M, int N, int K, hipStream_t st) {
     dim3 grid(N / 64, (M + 63) / 64);
@@ -391,36 +728,51 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
     T *X = (T *)e->X, *QKV = (T *)e->QKV, *CTX = (T *)e->CTX, *FF = (T *)e->FF;
     const float *w = e->w32;
     const int tok_blocks = (ntok * 64 + 255) / 256;
+    const int ln_blocks = (ntok * 32 + 255) / 256;
     hipLaunchKernelGGL((embed_ln_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
                        w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_seq * 32 * 4 * 2;
     SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<T>, att_lds));
+    const int s_pad = (max_seq + 31) & ~31;
+    const size_t att_mfma_lds = (size_t)s_pad * 64 + 32 * ((size_t)s_pad * 2 + 16);
+    if constexpr (!std::is_same<T, float>::value) SHODH_TRY(ensure_dynamic_lds((const void *)attention_mfma_kernel, att_mfma_lds));
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
         const float *bqkv = e->bqkv + (size_t)li * 3 * H;
+        const __bf16 *wp = e->wp16 + (size_t)li * (4 * H + I) * H;      // fragment-major [qkv | o | ffn-up]
+        const bool stream_gemm = (H == GS_DIM) && !(getenv("SHODH_ENC_TILED") && atoi(getenv("SHODH_ENC_TILED")));
+        (void)wp; (void)stream_gemm;
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS>(X, e->wqkv32 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, ntok, 3 * H, H, st));
         } else {
-            SHODH_TRY(gemm_bf16<EPI_BIAS>(X, e->wqkv16 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, nullptr, ntok, 3 * H, H, st));
+            if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS>(X, wp, bqkv, nullptr, QKV, nullptr, ntok, 3 * H, e->cus, st));
+            else SHODH_TRY(gemm_bf16<EPI_BIAS>(X, e->wqkv16 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, nullptr, ntok, 3 * H, H, st));
         }
-        hipLaunchKernelGGL((attention_kernel<T>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads);
+        if constexpr (std::is_same<T, float>::value) {
+            hipLaunchKernelGGL((attention_kernel<T>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads);
+        } else {
+            if (H / heads != 32) { set_error("the MFMA attention kernel needs head size 32"); return SHODH_ERR_UNSUPPORTED; }
+            hipLaunchKernelGGL(attention_mfma_kernel, dim3(nseq * heads), dim3(256), att_mfma_lds, st, QKV, e->d_cu, CTX, H, heads, s_pad);
+        }
         SHODH_HIP_TRY(hipGetLastError());
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(CTX, w + l.ow, w + l.ob, X, e->PRE, ntok, H, H, st));
         } else {
-            SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(CTX, e->w16 + l.ow, w + l.ob, X, nullptr, e->PRE, ntok, H, H, st));
+            if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_RESID_F32>(CTX, wp + (size_t)3 * H * H, w + l.ob, X, nullptr, e->PRE, ntok, H, e->cus, st));
+            else SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(CTX, e->w16 + l.ow, w + l.ob, X, nullptr, e->PRE, ntok, H, H, st));
         }
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
         SHODH_HIP_TRY(hipGetLastError());
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS_GELU>(X, w + l.iw, w + l.ib, nullptr, FF, ntok, I, H, st));
             SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(FF, w + l.dw, w + l.db, X, e->PRE, ntok, H, I, st));
         } else {
-            SHODH_TRY(gemm_bf16<EPI_BIAS_GELU>(X, e->w16 + l.iw, w + l.ib, nullptr, FF, nullptr, ntok, I, H, st));
+            if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_GELU>(X, wp + (size_t)4 * H * H, w + l.ib, nullptr, FF, nullptr, ntok, I, e->cus, st));
+            else SHODH_TRY(gemm_bf16<EPI_BIAS_GELU>(X, e->w16 + l.iw, w + l.ib, nullptr, FF, nullptr, ntok, I, H, st));
             SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(FF, e->w16 + l.dw, w + l.db, X, nullptr, e->PRE, ntok, H, I, st));
         }
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
         SHODH_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((pool_kernel<T>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H);
@@ -448,6 +800,18 @@ static int finish_weights(shodh_embedder *e) {
         SHODH_HIP_TRY(hipMemcpy(e->bqkv + (size_t)li * 3 * H + 2 * H, e->w32 + l.vb, H * 4, hipMemcpyDeviceToDevice));
     }
     SHODH_HIP_TRY(hipDeviceSynchronize());
+    {   // fragment-major copies for the streaming GEMM: per layer [qkv 3H | attention output H | FFN up I] rows of K = H
+        const size_t I = e->cfg.intermediate, per_layer = (4 * H + I) * H;
+        for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+            const LayerOff &l = e->lo[li];
+            __bf16 *dst = e->wp16 + (size_t)li * per_layer;
+            hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(3 * H * H, 256)), dim3(256), 0, nullptr, e->wqkv16 + (size_t)li * 3 * H * H, dst, (int)(3 * H), (int)H);
+            hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(H * H, 256)), dim3(256), 0, nullptr, e->w16 + l.ow, dst + 3 * H * H, (int)H, (int)H);
+            hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(I * H, 256)), dim3(256), 0, nullptr, e->w16 + l.iw, dst + 4 * H * H, (int)I, (int)H);
+        }
+        SHODH_HIP_TRY(hipGetLastError());
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+    }
     e->loaded = true;
     return SHODH_OK;
 }
@@ -471,8 +835,8 @@ void shodh_embed_cfg_default(shodh_embed_cfg *cfg) {
 int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     if (!cfg || !out) { set_error("null argument"); return SHODH_ERR_INVALID; }
     *out = nullptr;
-    if (cfg->hidden % 128 != 0 || cfg->intermediate % 128 != 0 || cfg->heads * 32 != cfg->hidden) {
-        set_error("encoder kernels need hidden %% 128 == 0, intermediate %% 128 == 0 and 32-wide heads (got hidden %u, heads %u)", cfg->hidden, cfg->heads);
+    if (cfg->hidden % 128 != 0 || cfg->hidden > 512 || cfg->intermediate % 128 != 0 || cfg->heads * 32 != cfg->hidden) {
+        set_error("encoder kernels need hidden %% 128 == 0 and <= 512, intermediate %% 128 == 0 and 32-wide heads (got hidden %u, heads %u)", cfg->hidden, cfg->heads);
         return SHODH_ERR_UNSUPPORTED;
     }
     if (cfg->max_len == 0 || cfg->max_len > cfg->max_pos || cfg->max_len > 512) { set_error("max_len %u out of range", cfg->max_len); return SHODH_ERR_INVALID; }
@@ -483,11 +847,13 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     SHODH_HIP_TRY(hipSetDevice(cfg->device));
     shodh_embedder *e = new shodh_embedder();
     e->cfg = *cfg;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);
     if (hipMalloc((void **)&e->w32, e->n_params * 4) != hipSuccess || hipMalloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
         hipMalloc((void **)&e->bqkv, (size_t)cfg->layers * 3 * cfg->hidden * 4) != hipSuccess ||
         hipMalloc((void **)&e->wqkv32, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 4) != hipSuccess ||
-        hipMalloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess) {
+        hipMalloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess ||
+        hipMalloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
     SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -501,7 +867,7 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     hipDeviceSynchronize();
-    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
+    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->wp16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
     hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
