@@ -2,7 +2,7 @@
 """Secondary measurements (NOT the driver's contract line; that is bench.py): the other
 BASELINE.json configurations and a few diagnostics, one JSON object per line.
 
-  python bench_extra.py flat10m | k120 | pcie | latency | encoder | ivfpq [--rows N]
+  python bench_extra.py flat10m | k120 | pcie | latency | encoder | pipeline [--texts N] | ivfpq [--rows N]
 """
 import json
 import os
@@ -90,6 +90,54 @@ def main():
             print(json.dumps({"bench": "MiniLM-L6 encode, %s, batch %d texts, lengths U[8,128] (real tokens only)" % (name, b),
                               "ms_per_batch": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1),
                               "tflops": round(flop / dt / 1e12, 2), "device_us": e.stage_timings_us()}), flush=True)
+    if what in ("pipeline",):
+        # BASELINE.json configs[2]: on-GPU embed + insert + recall end to end (benches/pipeline_benchmarks.rs shape):
+        # token ids (synthetic, lengths U[8,128], [CLS] .. [SEP], padded to 256) -> MiniLM bf16 -> add_vectors -> recall
+        n_texts = int(sys.argv[sys.argv.index("--texts") + 1]) if "--texts" in sys.argv else 1_000_000
+        bsz, ML = 4096, 256
+        e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=L.DTYPE_BF16)
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=384, reserve_rows=n_texts))
+        g = torch.Generator(device=dev).manual_seed(11)
+        pos = torch.arange(ML, device=dev)[None, :]
+
+        def synth_ids(b):
+            lens = torch.randint(8, 129, (b,), generator=g, device=dev)
+            ids = torch.randint(1000, 30522, (b, ML), generator=g, device=dev, dtype=torch.int32)
+            mask = (pos < lens[:, None])
+            ids = torch.where(mask, ids, torch.zeros_like(ids))
+            ids[:, 0] = 101
+            ids[torch.arange(b, device=dev), lens - 1] = 102
+            return ids.contiguous(), mask.to(torch.uint8).contiguous(), int(lens.sum())
+
+        emb = torch.empty((bsz, 384), dtype=torch.float32, device=dev)
+        ids, mask, _ = synth_ids(bsz)
+        e.encode_ids_device(ids, mask, out=emb); torch.cuda.synchronize()          # warm-up (weights, workspaces)
+        done, tokens, t_enc, t_add = 0, 0, 0.0, 0.0
+        t0 = time.perf_counter()
+        while done < n_texts:
+            b = min(bsz, n_texts - done)
+            ids, mask, nt = synth_ids(b)
+            torch.cuda.synchronize(); a = time.perf_counter()
+            e.encode_ids_device(ids, mask, out=emb[:b])
+            torch.cuda.synchronize(); c = time.perf_counter()
+            idx.add_vectors(emb[:b])
+            torch.cuda.synchronize(); d = time.perf_counter()
+            t_enc += c - a; t_add += d - c; tokens += nt; done += b
+        t_ingest = time.perf_counter() - t0
+        # recall: 256 query texts -> encode -> top-10
+        qids, qmask, _ = synth_ids(256)
+        qemb = torch.empty((256, 384), dtype=torch.float32, device=dev)
+        out = (torch.empty((256, 10), dtype=torch.int32, device=dev), torch.empty((256, 10), dtype=torch.float32, device=dev), torch.empty((256,), dtype=torch.int32, device=dev))
+
+        def recall():
+            e.encode_ids_device(qids, qmask, out=qemb)
+            idx.search_batch_device(qemb, 10, out=out)
+        dt = timed(recall, 50, warmup=20)
+        dt_s = timed(lambda: idx.search_batch_device(qemb, 10, out=out), 50, warmup=5)
+        print(json.dumps({"bench": "pipeline (configs[2]): %d synthetic texts, MiniLM-L6 bf16 encode -> add_vectors -> recall top-10, batch 256 query texts" % n_texts,
+                          "ingest_s": round(t_ingest, 3), "ingest_texts_per_s": round(n_texts / t_ingest, 1), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
+                          "tokens": tokens, "index_rows": idx.len(), "recall_ms_per_batch_incl_query_encode": round(dt * 1e3, 4),
+                          "recall_qps_incl_query_encode": round(256 / dt, 1), "search_only_ms_per_batch": round(dt_s * 1e3, 4), "scan_stats": idx.scan_stats()}), flush=True)
     if what in ("ivfpq", "all"):
         n = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 10_000_000
         P, nprobe, nq, k = 4096, 32, 1024, 10

@@ -85,6 +85,8 @@ struct AdcArgs {
     uint64_t *partial;         // [nq][split][k]
 };
 
+constexpr int ADC_U = 2;        // postings per thread and iteration
+constexpr int ADC_MAXP = 256;   // probed lists per query (nprobe is capped at P and at this)
 __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *table = reinterpret_cast<float *>(smem);                              // [M][ncent]
@@ -92,6 +94,8 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     uint64_t *thr = keys + a.cap;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
     float *qs = reinterpret_cast<float *>(cnt + 1);                              // [dim]
+    uint64_t *seg_base = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(qs + a.dim) + 7) & ~(uintptr_t)7);   // [ADC_MAXP] first posting of each segment
+    uint32_t *seg_start = reinterpret_cast<uint32_t *>(seg_base + ADC_MAXP);        // [ADC_MAXP + 1] start of each segment in the block's posting space
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x, part = blockIdx.y;
     for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
@@ -109,45 +113,96 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     }
     __syncthreads();
     TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-    const uint32_t np = a.probe_cnt[q];
-    // this block's share of every probed list: entries [lo + part*len/split, lo + (part+1)*len/split)
-    for (uint32_t pi = 0; pi < np; ++pi) {
-        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + pi];
-        const uint64_t lo = a.list_off[p], hi = a.list_off[p + 1];
-        const uint64_t len = hi - lo;
+    const uint32_t np = a.probe_cnt[q] < ADC_MAXP ? a.probe_cnt[q] : (uint32_t)ADC_MAXP;
+    // This block's share of every probed list, [lo + part*len/split, lo + (part+1)*len/split), laid end to end as one
+    // posting space [0, total): segment starts in LDS, a posting index is mapped back by binary search. Every iteration
+    // is then full (ADC_U postings per thread) whatever the list lengths are, and the codes of the NEXT iteration are
+    // requested before the current one is scored (the loads used to be issued and awaited inside every 256-posting
+    // iteration: 122 exposed round trips per block at 4M rows). Scoring order does not matter: the result is the k
+    // smallest (distance, id) keys and every distance is its own fixed-order sum.
+    if (tid < np) {
+        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + tid];
+        const uint64_t lo = a.list_off[p], len = a.list_off[p + 1] - lo;
         const uint64_t b0 = lo + len * part / a.split, b1 = lo + len * (part + 1) / a.split;
-        const uint64_t n_iter = (b1 - b0 + 255) / 256;
-        for (uint64_t it = 0; it < n_iter; ++it) {
-            const uint64_t e = b0 + it * 256 + tid;
-            if (e < b1) {
-                const uint8_t *code = a.codes + e * a.M;
-                float total = 0.0f;
+        seg_base[tid] = b0;
+        seg_start[tid] = (uint32_t)(b1 - b0);       // length for now; scanned below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < np; ++i) { const uint32_t l = seg_start[i]; seg_start[i] = acc; acc += l; }
+        seg_start[np] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = seg_start[np];
+    auto locate = [&](uint32_t g) -> uint64_t {      // posting g of the block's space -> index into codes / ids
+        uint32_t lo_ = 0, hi_ = np;                   // largest i with seg_start[i] <= g
+        while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (seg_start[mid] <= g) lo_ = mid; else hi_ = mid; }
+        return seg_base[lo_] + (g - seg_start[lo_]);
+    };
+    const bool wide = (a.M == 48);                   // 384-d: 3 x 16-byte code loads per posting
+    uint4 cw[ADC_U][3];
+    uint32_t idv[ADC_U];
+    uint64_t ev[ADC_U];
+    auto fetch = [&](uint32_t g0) {
+#pragma unroll
+        for (int u = 0; u < ADC_U; ++u) {
+            const uint32_t g = g0 + u * 256 + tid;
+            const uint64_t e = locate(g < total ? g : (total ? total - 1 : 0));      // clamped: unconditional loads
+            ev[u] = e;
+            if (wide) {
+                const uint4 *cp = reinterpret_cast<const uint4 *>(a.codes + e * 48);
+                cw[u][0] = cp[0]; cw[u][1] = cp[1]; cw[u][2] = cp[2];
+            }
+            idv[u] = a.ids[e];
+        }
+    };
+    if (total) fetch(0);
+    for (uint32_t g0 = 0; g0 < total; g0 += 256 * ADC_U) {
+        uint4 cc[ADC_U][3];
+        uint32_t idc[ADC_U];
+        uint64_t ec[ADC_U];
+#pragma unroll
+        for (int u = 0; u < ADC_U; ++u) { cc[u][0] = cw[u][0]; cc[u][1] = cw[u][1]; cc[u][2] = cw[u][2]; idc[u] = idv[u]; ec[u] = ev[u]; }
+        if (g0 + 256 * ADC_U < total) fetch(g0 + 256 * ADC_U);
+#pragma unroll
+        for (int u = 0; u < ADC_U; ++u) {
+            const uint32_t g = g0 + u * 256 + tid;
+            if (g < total) {
+                float totald = 0.0f;
                 bool bad = false;
                 // distance_with_table (pq.rs:358-368): strictly m = 0, 1, ... ; a code beyond the table -> f32::MAX
-                if ((a.M & 15u) == 0) {
-                    for (uint32_t w = 0; w < a.M; w += 16) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(code + w);      // entries are M bytes apart, M % 16 == 0
-                        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+                if (wide) {
+                    // all 16 table reads of a code word are issued before the first add (a read behind the `bad` branch was
+                    // one exposed LDS round trip per sub-quantiser: 48 per posting); the adds stay strictly in m order
+                    const uint32_t cmax = a.ncent - 1;
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const uint32_t word[4] = {cc[u][w].x, cc[u][w].y, cc[u][w].z, cc[u][w].w};
+                        float tv[16];
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             const uint32_t c = (word[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                            if (c >= a.ncent) bad = true;
-                            if (!bad) total = total + table[(w + j) * a.ncent + c];
+                            bad |= c > cmax;
+                            tv[j] = table[(w * 16 + j) * a.ncent + (c > cmax ? cmax : c)];
                         }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) totald = totald + tv[j];
                     }
                 } else {
+                    const uint8_t *code = a.codes + ec[u] * a.M;
                     for (uint32_t m = 0; m < a.M; ++m) {
                         const uint32_t c = code[m];
                         if (c >= a.ncent) { bad = true; break; }
-                        total = total + table[m * a.ncent + c];
+                        totald = totald + table[m * a.ncent + c];
                     }
                 }
-                if (bad) total = 3.4028234663852886e38f;       // f32::MAX
-                topk_push(buf, make_key(total, a.ids[e]));
+                if (bad) totald = 3.4028234663852886e38f;       // f32::MAX
+                topk_push(buf, make_key(totald, idc[u]));
             }
-            __syncthreads();
-            if (*buf.cnt + 256 > a.cap) topk_compact<256>(buf);
         }
+        __syncthreads();
+        if (*buf.cnt + 256 * ADC_U > a.cap) topk_compact<256>(buf);
     }
     __syncthreads();
     topk_compact<256>(buf);
@@ -332,8 +387,9 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
                                 probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
     // 2. ADC table + list scan, 3. merge
     AdcArgs a{d_q, s->codebook, s->list_off, s->ids, s->codes, probe_ids, probe_cnt, nq, s->dim, s->M, s->ncent, nprobe, k, cap, split, partial};
-    const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 16;
+    const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
     if (lds > 160 * 1024) { set_error("IVF-PQ: dim/k too large for LDS (%zu B)", lds); return SHODH_ERR_UNSUPPORTED; }
+    if (nprobe > (uint32_t)ADC_MAXP) { set_error("IVF-PQ: nprobe %u > %d", nprobe, ADC_MAXP); return SHODH_ERR_UNSUPPORTED; }
     SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel, lds));
     hipLaunchKernelGGL(adc_scan_kernel, dim3(nq, split), dim3(256), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
