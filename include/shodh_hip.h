@@ -209,6 +209,37 @@ size_t shodh_search_ids_postprocess(const uint32_t *vec_ids, const float *dists,
 size_t shodh_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t *uuids, const size_t *list_len,
                       uint8_t *out_uuid, float *out_score, size_t out_cap);
 
+/* ---- on-disk index formats of the reference (host code; both little-endian, FNV-1a-64 over everything after the header) --- */
+/* VAMA v1: src/vector_db/vamana_persist.rs:6-34 layout, :98-112 header bytes, :175-284 save_to_file, :290-391 load_from_file */
+typedef struct {
+    uint64_t num_vectors;
+    uint32_t dimension, max_degree, medoid, deleted_count;
+    uint64_t incremental_inserts;
+    uint64_t graph_edges;          /* sum of the per-node neighbour counts (size of the `neighbors` array) */
+    uint8_t  distance_metric;      /* 0 NormalizedDotProduct, 1 Euclidean, 2 Cosine (:87-91) */
+} shodh_vama_info;
+int shodh_vama_info_read(const char *path, shodh_vama_info *out);   /* validates magic, version and checksum (verify_index_file, :410-424) */
+/* any output may be NULL; sizes come from shodh_vama_info_read: vectors [num_vectors*dimension], deleted [deleted_count],
+ * degree [num_vectors], neighbors [graph_edges] */
+int shodh_vama_load(const char *path, float *vectors, uint32_t *deleted, uint16_t *degree, uint32_t *neighbors);
+/* degree == NULL writes an empty adjacency for every node (this library searches exactly; the graph is not built) */
+int shodh_vama_save(const char *path, const float *vectors, uint64_t n, uint32_t dim, uint32_t max_degree, uint32_t medoid,
+                    uint8_t metric, const uint32_t *deleted, uint32_t deleted_count, uint64_t incremental_inserts,
+                    const uint16_t *degree, const uint32_t *neighbors);
+/* SPAN v1: src/vector_db/spann.rs:13-52 layout, :221-252 header bytes, :750-876 save_to_file, :879-1003 load_from_file */
+typedef struct {
+    uint64_t num_vectors, total_postings;
+    uint32_t num_partitions, dimension, pq_subvectors, pq_num_centroids, pq_subvec_dim;
+    uint8_t  pq_enabled, distance_metric;
+} shodh_span_info;
+int shodh_span_info_read(const char *path, shodh_span_info *out);
+/* outputs (any may be NULL): centroids [P*dim], codebook [M*256*8], list_off [P+1] (CSR), ids [total_postings],
+ * codes [total_postings*M] -- exactly the arrays shodh_index_set_ivfpq takes */
+int shodh_span_load(const char *path, float *centroids, float *codebook, uint64_t *list_off, uint32_t *ids, uint8_t *codes);
+/* codebook == NULL writes a PQ-less file (ids only) */
+int shodh_span_save(const char *path, uint64_t num_vectors, uint32_t num_partitions, uint32_t dim, uint32_t pq_subvectors, uint8_t metric,
+                    const float *centroids, const float *codebook, const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes);
+
 /* ---- fusion: LearnedWeights (src/relevance.rs:343-606) ----------------------------------------- */
 typedef struct {
     float semantic, entity, tag, importance, momentum, access_count, graph_strength;

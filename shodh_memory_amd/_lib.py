@@ -54,6 +54,17 @@ class Weights(C.Structure):
 
 # every symbol include/shodh_hip.h declares: name -> (restype, argtypes)
 _vp, _fp, _u8p, _u32p, _u64p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+class VamaInfo(C.Structure):
+    _fields_ = [("num_vectors", C.c_uint64), ("dimension", C.c_uint32), ("max_degree", C.c_uint32), ("medoid", C.c_uint32),
+                ("deleted_count", C.c_uint32), ("incremental_inserts", C.c_uint64), ("graph_edges", C.c_uint64), ("distance_metric", C.c_uint8)]
+
+
+class SpanInfo(C.Structure):
+    _fields_ = [("num_vectors", C.c_uint64), ("total_postings", C.c_uint64), ("num_partitions", C.c_uint32), ("dimension", C.c_uint32),
+                ("pq_subvectors", C.c_uint32), ("pq_num_centroids", C.c_uint32), ("pq_subvec_dim", C.c_uint32),
+                ("pq_enabled", C.c_uint8), ("distance_metric", C.c_uint8)]
+
+
 SYMBOLS = {
     "shodh_last_error": (C.c_char_p, []),
     "shodh_abi_version": (C.c_int, []),
@@ -97,6 +108,12 @@ SYMBOLS = {
     "shodh_embedder_synthetic_weights": (C.c_int, [C.POINTER(EmbedCfg), C.c_uint64, _fp, C.c_uint64]),
     "shodh_hash_embed": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, _fp]),
     "shodh_search_ids_postprocess": (C.c_size_t, [_u32p, _fp, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, _u8p, _fp]),
+    "shodh_vama_info_read": (C.c_int, [C.c_char_p, C.POINTER(VamaInfo)]),
+    "shodh_vama_load": (C.c_int, [C.c_char_p, _fp, _u32p, C.c_void_p, _u32p]),
+    "shodh_vama_save": (C.c_int, [C.c_char_p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _u32p, C.c_uint32, C.c_uint64, C.c_void_p, _u32p]),
+    "shodh_span_info_read": (C.c_int, [C.c_char_p, C.POINTER(SpanInfo)]),
+    "shodh_span_load": (C.c_int, [C.c_char_p, _fp, _fp, _u64p, _u32p, _u8p]),
+    "shodh_span_save": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _fp, _fp, _u64p, _u32p, _u8p]),
     "shodh_rrf_fuse": (C.c_size_t, [C.c_float, _fp, C.c_size_t, _u8p, C.POINTER(C.c_size_t), _u8p, _fp, C.c_size_t]),
     "shodh_embedder_dimension": (C.c_uint32, [_vp]),
     "shodh_embedder_encode_ids": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp]),

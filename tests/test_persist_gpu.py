@@ -1,0 +1,65 @@
+"""A persisted reference index (VAMA v1 / SPAN v1) loaded straight into the GPU indexes answers exactly like the oracle
+on the same data. The five-vector file is the reference's own test_save_and_load fixture
+(vamana_persist.rs:432-470)."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from shodh_memory_amd import build
+    build.build()
+    import shodh_memory_amd as s
+    return s
+
+
+def test_vamana_file_save_load_search(S, oracle, tmp_path):
+    from shodh_memory_amd import persist as P
+    vectors = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [0.5, 0.5, 0, 0]], np.float32)
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=4, max_degree=8))
+    idx.build(vectors)
+    path = tmp_path / "test.vamana"
+    P.save_vamana(idx, path)
+    assert P.verify_index_file(path)
+    loaded = P.load_vamana(path)
+    assert loaded.len() == 5
+    res = loaded.search(np.array([1, 0, 0, 0], np.float32), 3)
+    assert res and res[0][0] == 0                                       # "Should find vector 0 first" (:469)
+
+
+def test_vamana_file_with_tombstones_matches_oracle(S, oracle, tmp_path):
+    from shodh_memory_amd import persist as P
+    rows = synth.corpus(3000, adversarial=True)
+    q = synth.queries(7)
+    deleted = [5, 17, 1999, 2500]
+    path = tmp_path / "big.vamana"
+    P.write_vamana(path, rows, max_degree=32, medoid=3, deleted=deleted, incremental_inserts=9)
+    idx = P.load_vamana(path)
+    assert idx.len() == 3000 and idx.deleted_count() == 4 and idx.incremental_insert_count() == 9
+    ids, dist, counts = idx.search_batch(q, 10)
+    mask = np.zeros(3000, np.uint8)
+    mask[deleted] = 1
+    for i in range(len(q)):
+        e_ids, e_dist = oracle.brute_force_search(rows, q[i], 10, deleted=mask)
+        assert ids[i].tolist() == e_ids.tolist() and dist[i].tobytes() == e_dist.tobytes()
+
+
+def test_spann_file_load_search(S, oracle, tmp_path):
+    from shodh_memory_amd import persist as P
+    rng = np.random.default_rng(5)
+    rows = synth.corpus(2000, adversarial=False)
+    Pn = oracle.spann_compute_partitions(2000)
+    st = oracle.spann_build(rows, Pn, rng.permutation(2000).astype(np.uint32), [rng.permutation(2000).astype(np.uint32) for _ in range(48)], kmeans_iterations=4)
+    path = tmp_path / "idx.spann"
+    P.write_spann(path, 2000, st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    idx = P.load_spann(path, num_probes=6)
+    q = synth.queries(5)
+    ids, dist, counts = idx.search_batch(q, 10)
+    for i in range(len(q)):
+        e_ids, e_dist = oracle.spann_search(st["centroids"], st["list_off"], st["ids"], st["codes"], st["codebook"], 6, q[i], 10, 0)
+        n = int(counts[i])
+        assert n == len(e_ids) and ids[i, :n].tolist() == e_ids.tolist() and dist[i, :n].tobytes() == e_dist.tobytes()
