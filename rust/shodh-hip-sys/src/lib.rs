@@ -1,0 +1,298 @@
+//! Reference-shaped wrappers over the C ABI of `libshodh_hip.so` (`include/shodh_hip.h`; raw bindings in `ffi`,
+//! generated from the header by `tools/gen_rust_ffi.py`).
+//!
+//! The types below carry the METHOD SETS of the reference's own types on this path, so that the two field swaps of
+//! INTEGRATION.md are the whole integration:
+//!   `HipIndex`      <-> `VamanaIndex`      (src/vector_db/vamana.rs:168-1645; exact path of :770-777 / :1167-1188)
+//!   `HipSpannIndex` <-> `SpannIndex`       (src/vector_db/spann.rs:574-693, :879-1003)
+//!   `HipEmbedder`   <-> `MiniLMEmbedder`   (`impl Embedder`, src/embeddings/mod.rs:52-88; minilm.rs:1122-1376)
+//! Not compiled in this repository's image (no Rust toolchain there); the same entry points are exercised through
+//! ctypes by tests/.
+pub mod ffi;
+
+use anyhow::{anyhow, Result};
+use std::ffi::{CStr, CString};
+use std::path::Path;
+
+fn check(rc: i32) -> Result<()> {
+    if rc == ffi::SHODH_OK {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(ffi::shodh_last_error()) }.to_string_lossy().into_owned();
+    Err(anyhow!("shodh_hip error {rc}: {msg}"))
+}
+
+fn cpath(p: &Path) -> Result<CString> {
+    CString::new(p.to_string_lossy().as_bytes()).map_err(|e| anyhow!("path contains NUL: {e}"))
+}
+
+/// `VamanaConfig` (vamana.rs:120-166). Graph parameters are accepted and ignored: the device index is flat and exact.
+#[derive(Clone, Debug)]
+pub struct VamanaConfig {
+    pub dimension: usize,
+    pub max_degree: usize,
+    pub search_list_size: usize,
+    pub alpha: f32,
+    pub use_mmap: bool,
+    pub device: i32,
+}
+impl Default for VamanaConfig {
+    fn default() -> Self {
+        Self { dimension: 384, max_degree: 32, search_list_size: 75, alpha: 1.2, use_mmap: false, device: 0 }
+    }
+}
+
+/// Same method set as `VamanaIndex`. `search` returns ids and distances bit-identical to `brute_force_search`.
+pub struct HipIndex {
+    h: *mut ffi::shodh_index,
+    dim: usize,
+    max_degree: usize,
+    incremental: std::sync::atomic::AtomicUsize,
+}
+// search may run concurrently on one handle; add / build / delete take the library's own lock
+unsafe impl Send for HipIndex {}
+unsafe impl Sync for HipIndex {}
+
+impl HipIndex {
+    pub fn new(config: VamanaConfig) -> Result<Self> {
+        let mut cfg = ffi::shodh_index_cfg::default();
+        unsafe { ffi::shodh_index_cfg_default(&mut cfg) };
+        cfg.dim = config.dimension as u32; // metric stays NormalizedDotProduct (retrieval.rs:188-193)
+        cfg.device = config.device;
+        let mut h = std::ptr::null_mut();
+        check(unsafe { ffi::shodh_index_create(&cfg, &mut h) })?;
+        Ok(Self { h, dim: config.dimension, max_degree: config.max_degree, incremental: Default::default() })
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::shodh_index_len(self.h) as usize } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+
+    /// vamana.rs:200-284 (ids 0..n-1, tombstones cleared)
+    pub fn build(&mut self, vectors: Vec<Vec<f32>>) -> Result<()> {
+        for v in &vectors {
+            if v.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, v.len())); }
+        }
+        let flat: Vec<f32> = vectors.into_iter().flatten().collect();
+        check(unsafe { ffi::shodh_index_build(self.h, flat.as_ptr(), (flat.len() / self.dim.max(1)) as u64) })?;
+        self.incremental.store(0, std::sync::atomic::Ordering::Release);
+        Ok(())
+    }
+    pub fn rebuild_from_vectors(&mut self, vectors: Vec<Vec<f32>>) -> Result<()> { self.build(vectors) }
+
+    /// vamana.rs:853-974: returns the new vector id (dense, sequential)
+    pub fn add_vector(&mut self, vector: Vec<f32>) -> Result<u32> {
+        if vector.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, vector.len())); }
+        let mut id = 0u32;
+        check(unsafe { ffi::shodh_index_add(self.h, vector.as_ptr(), 1, &mut id) })?;
+        self.incremental.fetch_add(1, std::sync::atomic::Ordering::AcqRel);
+        Ok(id)
+    }
+    /// n sequential `add_vector` calls in one transfer; returns the first id
+    pub fn add_vectors(&mut self, flat: &[f32]) -> Result<u32> {
+        let mut id = 0u32;
+        check(unsafe { ffi::shodh_index_add(self.h, flat.as_ptr(), (flat.len() / self.dim.max(1)) as u64, &mut id) })?;
+        self.incremental.fetch_add(flat.len() / self.dim.max(1), std::sync::atomic::Ordering::AcqRel);
+        Ok(id)
+    }
+
+    /// vamana.rs:764-808 under SHODH_VECTOR_EXACT: `(id, distance)` ascending by `(distance.total_cmp, id)`
+    pub fn search(&self, query: &[f32], k: usize) -> Result<Vec<(u32, f32)>> {
+        if query.len() != self.dim { return Err(anyhow!("Query dimension mismatch: expected {}, got {}", self.dim, query.len())); }
+        if k == 0 || self.is_empty() { return Ok(Vec::new()); }
+        let (mut ids, mut dist, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        check(unsafe { ffi::shodh_index_search(self.h, query.as_ptr(), 1, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), &mut n) })?;
+        Ok(ids.into_iter().zip(dist).take(n as usize).collect())
+    }
+    /// `nq` queries in one pass over the corpus (what makes the GPU worth having): rows of `(id, distance)`
+    pub fn search_batch(&self, queries: &[f32], k: usize) -> Result<Vec<Vec<(u32, f32)>>> {
+        let nq = queries.len() / self.dim.max(1);
+        if nq == 0 || k == 0 { return Ok(vec![Vec::new(); nq]); }
+        let (mut ids, mut dist, mut n) = (vec![0u32; nq * k], vec![0f32; nq * k], vec![0u32; nq]);
+        check(unsafe { ffi::shodh_index_search(self.h, queries.as_ptr(), nq as u32, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), n.as_mut_ptr()) })?;
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], dist[q * k + i])).collect()).collect())
+    }
+
+    pub fn mark_deleted(&self, id: u32) -> bool {
+        let mut ok = 0;
+        unsafe { ffi::shodh_index_mark_deleted(self.h, id, &mut ok) };
+        ok != 0
+    }
+    pub fn is_deleted(&self, id: u32) -> bool { unsafe { ffi::shodh_index_is_deleted(self.h, id) == 1 } }
+    pub fn deleted_count(&self) -> usize { unsafe { ffi::shodh_index_deleted_count(self.h) as usize } }
+    pub fn deletion_ratio(&self) -> f32 { unsafe { ffi::shodh_index_deletion_ratio(self.h) } }
+    pub fn needs_compaction(&self) -> bool { unsafe { ffi::shodh_index_needs_compaction(self.h) == 1 } }
+    pub fn clear_deleted(&self) { unsafe { ffi::shodh_index_clear_deleted(self.h) }; }
+
+    // the flat index never degrades with inserts: nothing to rebuild or repair (vamana.rs:985-1236)
+    pub fn needs_rebuild(&self) -> bool { false }
+    pub fn needs_repair(&self) -> bool { false }
+    pub fn incremental_repair(&self) -> Result<usize> { Ok(0) }
+    pub fn quality_degraded(&self) -> Result<bool> { Ok(false) }
+    pub fn estimate_recall(&self, _sample_size: usize, _k: usize) -> Result<f32> { Ok(1.0) }   // exact search
+    pub fn auto_maintain(&self) -> Result<String> { Ok("exact index: no maintenance needed".to_string()) }
+    pub fn auto_rebuild_if_needed(&self) -> Result<bool> { Ok(false) }
+    pub fn is_rebuilding(&self) -> bool { false }
+    pub fn incremental_insert_count(&self) -> usize { self.incremental.load(std::sync::atomic::Ordering::Acquire) }
+    pub fn reset_incremental_counter(&self) { self.incremental.store(0, std::sync::atomic::Ordering::Release) }
+
+    /// row i bit-for-bit what `add_vector` / `build` received (retrieval.rs:2504-2516)
+    pub fn extract_all_vectors(&self) -> Vec<Vec<f32>> {
+        let n = self.len();
+        let mut flat = vec![0f32; n * self.dim];
+        unsafe { ffi::shodh_index_extract_rows(self.h, 0, n as u64, flat.as_mut_ptr()) };
+        flat.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect()
+    }
+    pub fn extract_live_vectors(&self) -> Vec<Vec<f32>> {
+        let n = self.len();
+        let (mut flat, mut m) = (vec![0f32; n * self.dim], 0u64);
+        unsafe { ffi::shodh_index_extract_live_rows(self.h, flat.as_mut_ptr(), std::ptr::null_mut(), n as u64, &mut m) };
+        flat.truncate(m as usize * self.dim);
+        flat.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect()
+    }
+
+    /// `save_to_file` (vamana_persist.rs:175-284): VAMA v1 with empty adjacency lists (the graph is not built here)
+    pub fn save_to_file(&self, path: &Path) -> Result<()> {
+        let n = self.len();
+        let mut flat = vec![0f32; n * self.dim];
+        check(unsafe { ffi::shodh_index_extract_rows(self.h, 0, n as u64, flat.as_mut_ptr()) })?;
+        let deleted: Vec<u32> = (0..n as u32).filter(|&i| self.is_deleted(i)).collect();
+        let p = cpath(path)?;
+        check(unsafe {
+            ffi::shodh_vama_save(p.as_ptr(), flat.as_ptr(), n as u64, self.dim as u32, self.max_degree as u32, 0, 0,
+                                 if deleted.is_empty() { std::ptr::null() } else { deleted.as_ptr() }, deleted.len() as u32,
+                                 self.incremental_insert_count() as u64, std::ptr::null(), std::ptr::null())
+        })
+    }
+    /// `load_from_file` (vamana_persist.rs:290-391): vectors and tombstones of a persisted index, straight into HBM
+    pub fn load_from_file(path: &Path) -> Result<Self> {
+        let p = cpath(path)?;
+        let mut info = ffi::shodh_vama_info::default();
+        check(unsafe { ffi::shodh_vama_info_read(p.as_ptr(), &mut info) })?;
+        let (n, d) = (info.num_vectors as usize, info.dimension as usize);
+        let (mut flat, mut deleted) = (vec![0f32; n * d], vec![0u32; info.deleted_count as usize]);
+        check(unsafe { ffi::shodh_vama_load(p.as_ptr(), flat.as_mut_ptr(), deleted.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) })?;
+        let idx = Self::new(VamanaConfig { dimension: d, max_degree: info.max_degree as usize, ..Default::default() })?;
+        if n > 0 { check(unsafe { ffi::shodh_index_build(idx.h, flat.as_ptr(), n as u64) })?; }
+        for id in deleted { idx.mark_deleted(id); }
+        idx.incremental.store(info.incremental_inserts as usize, std::sync::atomic::Ordering::Release);
+        Ok(idx)
+    }
+    pub fn verify_index_file(path: &Path) -> Result<bool> {
+        let p = cpath(path)?;
+        let mut info = ffi::shodh_vama_info::default();
+        Ok(unsafe { ffi::shodh_vama_info_read(p.as_ptr(), &mut info) } == ffi::SHODH_OK)
+    }
+}
+impl Drop for HipIndex {
+    fn drop(&mut self) { unsafe { ffi::shodh_index_destroy(self.h) } }
+}
+
+/// `SpannIndex` search side (spann.rs:574-693) on a trained state (`load_from_file`, :879-1003, or `set_trained_state`).
+pub struct HipSpannIndex { h: *mut ffi::shodh_index, dim: usize }
+unsafe impl Send for HipSpannIndex {}
+unsafe impl Sync for HipSpannIndex {}
+impl HipSpannIndex {
+    pub fn new(dimension: usize, num_probes: usize, device: i32) -> Result<Self> {
+        let mut cfg = ffi::shodh_index_cfg::default();
+        unsafe { ffi::shodh_index_cfg_default(&mut cfg) };
+        cfg.dim = dimension as u32;
+        cfg.kind = ffi::SHODH_INDEX_IVFPQ as u32;
+        cfg.nprobe = num_probes as u32;
+        cfg.device = device;
+        let mut h = std::ptr::null_mut();
+        check(unsafe { ffi::shodh_index_create(&cfg, &mut h) })?;
+        Ok(Self { h, dim: dimension })
+    }
+    #[allow(clippy::too_many_arguments)]
+    pub fn set_trained_state(&mut self, centroids: &[f32], codebook: &[f32], list_off: &[u64], ids: &[u32], codes: &[u8]) -> Result<()> {
+        let p = (list_off.len() - 1) as u32;
+        let m = (self.dim / 8) as u32;
+        check(unsafe { ffi::shodh_index_set_ivfpq(self.h, centroids.as_ptr(), p, codebook.as_ptr(), m, 256, list_off.as_ptr(), ids.as_ptr(), codes.as_ptr()) })
+    }
+    pub fn load_from_file(path: &Path, num_probes: usize, device: i32) -> Result<Self> {
+        let p = cpath(path)?;
+        let mut info = ffi::shodh_span_info::default();
+        check(unsafe { ffi::shodh_span_info_read(p.as_ptr(), &mut info) })?;
+        if info.pq_enabled != 1 { return Err(anyhow!("PQ-less SPANN files carry no codes to scan")); }
+        let (pn, d, m, t) = (info.num_partitions as usize, info.dimension as usize, info.pq_subvectors as usize, info.total_postings as usize);
+        let mut cent = vec![0f32; pn * d];
+        let mut cb = vec![0f32; m * info.pq_num_centroids as usize * info.pq_subvec_dim as usize];
+        let (mut off, mut ids, mut codes) = (vec![0u64; pn + 1], vec![0u32; t], vec![0u8; t * m]);
+        check(unsafe { ffi::shodh_span_load(p.as_ptr(), cent.as_mut_ptr(), cb.as_mut_ptr(), off.as_mut_ptr(), ids.as_mut_ptr(), codes.as_mut_ptr()) })?;
+        let mut idx = Self::new(d, num_probes, device)?;
+        idx.set_trained_state(&cent, &cb, &off, &ids, &codes)?;
+        Ok(idx)
+    }
+    pub fn insert(&mut self, vector_id: u32, vector: &[f32]) -> Result<()> {
+        check(unsafe { ffi::shodh_index_ivfpq_insert(self.h, vector_id, vector.as_ptr()) })
+    }
+    pub fn search(&self, query: &[f32], k: usize) -> Result<Vec<(u32, f32)>> {
+        if query.len() != self.dim { return Err(anyhow!("Query dimension mismatch: expected {}, got {}", self.dim, query.len())); }
+        if k == 0 { return Ok(Vec::new()); }
+        let (mut ids, mut dist, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        check(unsafe { ffi::shodh_index_search(self.h, query.as_ptr(), 1, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), &mut n) })?;
+        Ok(ids.into_iter().zip(dist).take(n as usize).collect())
+    }
+}
+impl Drop for HipSpannIndex {
+    fn drop(&mut self) { unsafe { ffi::shodh_index_destroy(self.h) } }
+}
+
+/// What the embedder needs from a tokenizer (the reference uses the `tokenizers` crate with truncation 128 and pads to
+/// 256, minilm.rs:112-117, :153-154): token ids and attention mask of `text`, special tokens included.
+pub trait Tokenize: Send + Sync {
+    fn encode(&self, text: &str) -> Result<(Vec<u32>, Vec<u32>)>;
+    /// full sequence length without truncation (`count_tokens`, minilm.rs:1216-1229)
+    fn count(&self, text: &str) -> usize;
+}
+
+/// `impl Embedder` (src/embeddings/mod.rs:52-88). Tokenisation stays on the host; `session.run` + pooling
+/// (minilm.rs:939-981) run on the device. Add `impl crate::embeddings::Embedder for HipEmbedder<T>` in the reference
+/// tree forwarding to these inherent methods (the trait lives in that crate).
+pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize }
+unsafe impl<T: Tokenize> Send for HipEmbedder<T> {}
+unsafe impl<T: Tokenize> Sync for HipEmbedder<T> {}
+impl<T: Tokenize> HipEmbedder<T> {
+    /// `weights`: the f32 blob in HF `BertModel` parameter order (embedder.py::state_dict_to_blob documents every slice)
+    pub fn new(tok: T, weights: &[f32], device: i32, bf16: bool) -> Result<Self> {
+        let mut cfg = ffi::shodh_embed_cfg::default();
+        unsafe { ffi::shodh_embed_cfg_default(&mut cfg) };
+        cfg.device = device;
+        cfg.dtype = if bf16 { ffi::SHODH_DTYPE_BF16 as u32 } else { ffi::SHODH_DTYPE_FP32 as u32 };
+        let mut h = std::ptr::null_mut();
+        check(unsafe { ffi::shodh_embedder_create(&cfg, &mut h) })?;
+        let e = Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize };
+        check(unsafe { ffi::shodh_embedder_load_weights(e.h, weights.as_ptr(), weights.len() as u64) })?;
+        Ok(e)
+    }
+    pub fn dimension(&self) -> usize { self.dim }
+    pub fn encode(&self, text: &str) -> Result<Vec<f32>> {
+        if text.is_empty() { return Ok(vec![0.0; self.dim]); } // minilm.rs:1123-1125
+        Ok(self.encode_batch(&[text])?.pop().unwrap())
+    }
+    pub fn encode_query(&self, text: &str) -> Result<Vec<f32>> { self.encode(text) } // symmetric model
+    /// minilm.rs:1247-1376: one device call for the whole batch; empty texts give zero vectors
+    pub fn encode_batch(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> {
+        let b = texts.len();
+        let (mut ids, mut mask) = (vec![0i32; b * self.max_len], vec![0u8; b * self.max_len]);
+        for (r, text) in texts.iter().enumerate() {
+            if text.is_empty() { continue; }
+            let (t, m) = self.tok.encode(text)?;
+            for (i, (&tt, &mm)) in t.iter().zip(m.iter()).take(self.max_len).enumerate() {
+                ids[r * self.max_len + i] = tt as i32;
+                mask[r * self.max_len + i] = mm as u8;
+            }
+        }
+        let mut out = vec![0f32; b * self.dim];
+        check(unsafe { ffi::shodh_embedder_encode_ids(self.h, ids.as_ptr(), mask.as_ptr(), b as u32, out.as_mut_ptr()) })?;
+        Ok(out.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect())
+    }
+    pub fn count_tokens(&self, text: &str) -> usize { self.tok.count(text) }
+}
+impl<T: Tokenize> Drop for HipEmbedder<T> {
+    fn drop(&mut self) { unsafe { ffi::shodh_embedder_destroy(self.h) } }
+}
+
+/// `LearnedWeights::fuse_scores_full` (src/relevance.rs:529-594) with a `#[repr(C)]` copy of the seven weights
+pub fn fuse_scores_full(w: &ffi::shodh_weights, sem: f32, ent: f32, tag: f32, imp: f32, momentum_ema: f32, access_count: u32, graph_strength: f32) -> f32 {
+    unsafe { ffi::shodh_fuse_scores_full(w, sem, ent, tag, imp, momentum_ema, access_count, graph_strength) }
+}

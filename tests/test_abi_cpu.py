@@ -97,3 +97,15 @@ def test_host_fusion_matches_oracle(shodh, oracle):
     w2 = shodh.LearnedWeights(*([0.5] * 7))
     w2.normalize()
     assert all(abs(x - 1 / 7) < 1e-3 for x in w2.as_tuple())
+
+
+def test_rust_bindings_are_current_and_complete():
+    """rust/shodh-hip-sys/src/ffi.rs is generated from the header (tools/gen_rust_ffi.py): it must be up to date and
+    declare every symbol the header declares."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0
+    ffi = open(os.path.join(root, "rust", "shodh-hip-sys", "src", "ffi.rs")).read()
+    assert sorted(re.findall(r"pub fn (shodh_\w+)\(", ffi)) == declared_symbols()
