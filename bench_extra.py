@@ -2,7 +2,7 @@
 """Secondary measurements (NOT the driver's contract line; that is bench.py): the other
 BASELINE.json configurations and a few diagnostics, one JSON object per line.
 
-  python bench_extra.py flat10m | k120 | pcie | latency | encoder | pipeline [--texts N] | ivfpq [--rows N]
+  python bench_extra.py flat10m | k120 | pcie | latency | encoder | pipeline [--texts N] | kmeans [--rows N] | ivfpq [--rows N]
 """
 import json
 import os
@@ -138,6 +138,17 @@ def main():
                           "ingest_s": round(t_ingest, 3), "ingest_texts_per_s": round(n_texts / t_ingest, 1), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
                           "tokens": tokens, "index_rows": idx.len(), "recall_ms_per_batch_incl_query_encode": round(dt * 1e3, 4),
                           "recall_qps_incl_query_encode": round(256 / dt, 1), "search_only_ms_per_batch": round(dt_s * 1e3, 4), "scan_stats": idx.scan_stats()}), flush=True)
+    if what in ("kmeans",):
+        n = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 1_000_000
+        rows = bench.synth_rows(torch, n, 384, 1, dev).cpu().numpy()
+        idx = S.SpannIndex(384, num_probes=32)
+        P = idx.compute_partitions(n)
+        for ivf_it, pq_it in ((2, 1), (6, 3)):
+            t = time.perf_counter()
+            idx.train(rows, P, ivf_it, pq_it, seed=5)
+            dt = time.perf_counter() - t
+            print(json.dumps({"bench": "device k-means (SpannIndex::build training), %d rows x 384, P = %d, %d IVF + %d PQ iterations (incl. H2D of the rows)" % (n, P, ivf_it, pq_it),
+                              "seconds": round(dt, 3)}), flush=True)
     if what in ("ivfpq", "all"):
         n = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 10_000_000
         P, nprobe, nq, k = 4096, 32, 1024, 10

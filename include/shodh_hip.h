@@ -148,8 +148,10 @@ int shodh_index_ivfpq_insert(shodh_index *idx, uint32_t vector_id, const float *
 /* find_nearest_centroid + ProductQuantizer::encode for n rows on the device (spann.rs:545-558,
  * pq.rs:220-257): assign_out[n], codes_out[n][M] */
 int shodh_index_ivfpq_encode(shodh_index *idx, const float *rows, uint64_t n, uint32_t *assign_out, uint8_t *codes_out);
-/* seeded Lloyd k-means on the device following spann.rs:466-541 / pq.rs:152-217 given the
- * initial permutations (init_perm_ivf[n], init_perm_pq[M][n]); outputs the trained state */
+/* Lloyd k-means on the device following spann.rs:466-541 / pq.rs:152-217 operation for operation: GIVEN the initial
+ * shuffles (init_perm_ivf[n], init_perm_pq[M][n], M = dim/8; the reference draws them from thread_rng) centroids_out
+ * [P][dim] and codebook_out [M][256][8] are bit-identical to the reference's. rows: host [n][dim]. IVF stops early
+ * when no assignment changed; PQ runs all pq_iters iterations; empty clusters keep their centroid. */
 int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint32_t dim, uint32_t P, uint32_t ivf_iters,
                       uint32_t pq_iters, const uint32_t *init_perm_ivf, const uint32_t *init_perm_pq,
                       float *centroids_out, float *codebook_out);

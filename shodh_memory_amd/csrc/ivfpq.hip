@@ -20,6 +20,10 @@
 #include <shared_mutex>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
 #include "common.h"
 #include "topk.h"
 
@@ -509,13 +513,6 @@ int shodh_index_ivfpq_insert(shodh_index *idx, uint32_t vector_id, const float *
     return SHODH_OK;
 }
 
-int shodh_ivfpq_train(int, const float *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, float *, float *) {
-    // SURVEY.md 8(f) "next" row 4: device k-means is not built yet. Trained state is supplied through
-    // shodh_index_set_ivfpq (parity is defined given trained state; the reference's k-means is unseeded).
-    set_error("shodh_ivfpq_train: device k-means not implemented in this round; pass trained state to shodh_index_set_ivfpq");
-    return SHODH_ERR_UNSUPPORTED;
-}
-
 int shodh_cosine_similarity_batch(int device, const float *a, const float *b, uint64_t n, uint32_t dim, uint32_t order, float *out) {
     if (n && (!a || !b || !out)) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (n == 0) return SHODH_OK;
@@ -536,3 +533,177 @@ int shodh_cosine_similarity_batch(int device, const float *a, const float *b, ui
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// ---- Lloyd k-means of the IVF centroids and the PQ codebooks on the device.
+//
+// Follows SpannIndex::kmeans_cluster (src/vector_db/spann.rs:466-541) and ProductQuantizer::kmeans
+// (src/vector_db/pq.rs:152-217) operation for operation, so that GIVEN the initial shuffles (the reference draws them
+// from thread_rng) the trained state is bit-identical to the reference's -- checked against the oracle's restatement:
+//   assignment  : find_nearest_centroid (spann.rs:545-558: strictly sequential `1 - sum x*y`, strict '<' keeps the first
+//                 minimum) = the exact-order scan kernel over the centroids with k = 1;
+//                 PQ: squared L2 over 8 dims, sequential, strict '<' (pq.rs:180-191) = pq_encode_kernel;
+//   update      : the reference adds the members of a cluster INTO the new centroid in vector-index order, one f32 add
+//                 per member and coordinate, then divides by the count. A parallel tree sum would round differently, so
+//                 the members of every cluster are listed in index order (a STABLE radix sort of (cluster, index), rocPRIM)
+//                 and one thread per (cluster, coordinate) adds them in that order; the parallelism is across clusters and
+//                 coordinates (P x dim, or 48 x 256 x 8 for the codebooks), not inside a sum;
+//   empty cluster keeps its previous centroid (spann.rs:521-527, pq.rs:205-212);
+//   IVF stops early when no assignment changed (spann.rs:536-539, AFTER the update of that iteration); PQ always runs
+//   all its iterations.
+namespace shodh {
+namespace {
+
+__global__ void gather_rows_kernel(const float *rows, const uint32_t *perm, uint64_t n, uint32_t dim, uint32_t k, float *out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)k * dim) return;
+    const uint32_t c = (uint32_t)(t / dim), j = (uint32_t)(t % dim);
+    out[t] = rows[(uint64_t)perm[c % n] * dim + j];                 // centroids[c] = vectors[indices[c % n]] (spann.rs:476-488)
+}
+// codebook[m][c][:] = rows[perm[m][c % n]][8m : 8m+8]   (pq.rs:158-172)
+__global__ void gather_sub_kernel(const float *rows, const uint32_t *perm, uint64_t n, uint32_t dim, uint32_t M, uint32_t ncent, float *cb) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)M * ncent * 8) return;
+    const uint32_t j = (uint32_t)(t % 8), c = (uint32_t)((t / 8) % ncent), m = (uint32_t)(t / (8 * ncent));
+    cb[t] = rows[(uint64_t)perm[(uint64_t)m * n + c % n] * dim + m * 8 + j];
+}
+__global__ void iota_kernel(uint32_t *v, uint64_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) v[t] = (uint32_t)t;
+}
+__global__ void count_changed_kernel(const uint32_t *a, uint32_t *prev, uint64_t n, unsigned long long *changed) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned c = 0;
+    if (t < n) { c = a[t] != prev[t]; prev[t] = a[t]; }
+    const unsigned long long b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c != 0));
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(changed, b);
+}
+__global__ void histogram_kernel(const uint32_t *keys, uint64_t n, uint32_t *counts) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(counts + keys[t], 1u);
+}
+// codes [n][M] -> keys [M][n] as u32 (one contiguous key array per subspace for the stable sort)
+__global__ void split_codes_kernel(const uint8_t *codes, uint64_t n, uint32_t M, uint32_t *keys) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * M) return;
+    const uint64_t row = t / M;
+    const uint32_t m = (uint32_t)(t % M);
+    keys[(uint64_t)m * n + row] = codes[t];
+}
+// one thread per (cluster, coordinate): the members in index order, one add each, then / count (spann.rs:508-527)
+__global__ void mean_update_kernel(const float *rows, uint32_t dim, uint32_t col0, uint32_t width, const uint32_t *members,
+                                   const uint32_t *offsets /* [k+1] */, uint32_t k, float *cent /* [k][width] */) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)k * width) return;
+    const uint32_t c = (uint32_t)(t / width), j = (uint32_t)(t % width);
+    const uint32_t lo = offsets[c], hi = offsets[c + 1];
+    if (hi == lo) return;                                            // empty cluster keeps its centroid
+    float sum = 0.0f;
+    uint32_t i = lo;
+    for (; i + 8 <= hi; i += 8) {                                    // the loads are independent, only the adds are ordered
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rows[(uint64_t)members[i + u] * dim + col0 + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = sum + v[u];
+    }
+    for (; i < hi; ++i) sum = sum + rows[(uint64_t)members[i] * dim + col0 + j];
+    cent[t] = sum / (float)(hi - lo);
+}
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? SHODH_OK : SHODH_ERR_OOM; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// members of every cluster in index order: stable radix sort of (key, index) on the low `bits` bits of the key
+int sorted_members(const uint32_t *keys, uint64_t n, uint32_t k, uint32_t *idx_in, uint32_t *keys_out, uint32_t *members, uint32_t *offsets,
+                   Buf &tmp, size_t &tmp_bytes, std::vector<uint32_t> &host_counts, uint32_t *d_counts) {
+    int bits = 1;
+    while ((1u << bits) < k) ++bits;
+    size_t need = 0;
+    SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
+    if (need > tmp_bytes) { if (tmp.p) hipFree(tmp.p); tmp.p = nullptr; SHODH_TRY(tmp.alloc(need)); tmp_bytes = need; }
+    SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
+    SHODH_HIP_TRY(hipMemset(d_counts, 0, (size_t)k * 4));
+    hipLaunchKernelGGL(histogram_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, keys, n, d_counts);
+    host_counts.resize(k + 1);
+    SHODH_HIP_TRY(hipMemcpy(host_counts.data(), d_counts, (size_t)k * 4, hipMemcpyDeviceToHost));
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < k; ++c) { const uint32_t v = host_counts[c]; host_counts[c] = acc; acc += v; }
+    host_counts[k] = acc;
+    SHODH_HIP_TRY(hipMemcpy(offsets, host_counts.data(), (size_t)(k + 1) * 4, hipMemcpyHostToDevice));
+    return SHODH_OK;
+}
+
+}  // namespace
+}  // namespace shodh
+
+using namespace shodh;
+
+extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint32_t dim, uint32_t P, uint32_t ivf_iters, uint32_t pq_iters,
+                                 const uint32_t *init_perm_ivf, const uint32_t *init_perm_pq, float *centroids_out, float *codebook_out) {
+    if (!rows || !init_perm_ivf || !init_perm_pq || !centroids_out || !codebook_out) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (n == 0 || P == 0) { set_error("Cannot build index from empty vectors"); return SHODH_ERR_INVALID; }     // spann.rs:364-366
+    if (dim % 8 != 0) { set_error("Dimension %u not divisible by 8", dim); return SHODH_ERR_DIM; }               // pq.rs:43-48
+    if (n > 0x7FFFFFFFull) { set_error("k-means: more than 2^31 vectors"); return SHODH_ERR_UNSUPPORTED; }
+    SHODH_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SHODH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const uint32_t M = dim / 8, NC = 256;
+    const uint32_t kmax = P > NC ? P : NC;
+    Buf d_rows, d_cent, d_cb, d_assign, d_prev, d_idx, d_keys_out, d_members, d_off, d_counts, d_changed, d_perm, d_codes, d_keys, d_part, d_ad, d_ac, tmp;
+    size_t tmp_bytes = 0;
+    const uint64_t CH = n < 65536 ? n : 65536;                       // rows per assignment launch (each row is one "query")
+    const uint32_t gx = exact_grid_x(P, (uint32_t)CH, 1, cus);
+    SHODH_TRY(d_rows.alloc(n * dim * 4)); SHODH_TRY(d_cent.alloc((size_t)P * dim * 4)); SHODH_TRY(d_cb.alloc((size_t)M * NC * 8 * 4));
+    SHODH_TRY(d_assign.alloc(n * 4)); SHODH_TRY(d_prev.alloc(n * 4)); SHODH_TRY(d_idx.alloc(n * 4)); SHODH_TRY(d_keys_out.alloc(n * 4));
+    SHODH_TRY(d_members.alloc(n * 4)); SHODH_TRY(d_off.alloc((size_t)(kmax + 1) * 4)); SHODH_TRY(d_counts.alloc((size_t)kmax * 4));
+    SHODH_TRY(d_changed.alloc(8)); SHODH_TRY(d_perm.alloc((size_t)(M > 1 ? M : 1) * n * 4)); SHODH_TRY(d_codes.alloc(n * M));
+    SHODH_TRY(d_keys.alloc((size_t)M * n * 4)); SHODH_TRY(d_part.alloc(exact_partial_bytes((uint32_t)CH, dim, 1, gx) + 256));
+    SHODH_TRY(d_ad.alloc(CH * 4)); SHODH_TRY(d_ac.alloc(CH * 4));
+    SHODH_HIP_TRY(hipMemcpy(d_rows.p, rows, n * dim * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_idx.as<uint32_t>(), n);
+    std::vector<uint32_t> hc;
+
+    // ---- IVF centroids (spann.rs:466-541) ----
+    SHODH_HIP_TRY(hipMemcpy(d_perm.p, init_perm_ivf, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), d_perm.as<uint32_t>(), n, dim, P, d_cent.as<float>());
+    SHODH_HIP_TRY(hipMemset(d_prev.p, 0, n * 4));                   // `let mut assignments = vec![0usize; n]`
+    for (uint32_t it = 0; it < ivf_iters; ++it) {
+        for (uint64_t b = 0; b < n; b += CH) {
+            const uint64_t m = (n - b) < CH ? (n - b) : CH;
+            SHODH_TRY(launch_flat_exact(d_cent.as<float>(), P, dim, nullptr, d_rows.as<float>() + b * dim, (uint32_t)m, 1, EX_OP_SEQ_ONE_MINUS_DOT, 0,
+                                        d_part.as<uint64_t>(), gx, d_assign.as<uint32_t>() + b, d_ad.as<float>(), d_ac.as<uint32_t>(), nullptr, nullptr, nullptr));
+        }
+        SHODH_HIP_TRY(hipMemset(d_changed.p, 0, 8));
+        hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_assign.as<uint32_t>(), d_prev.as<uint32_t>(), n, d_changed.as<unsigned long long>());
+        SHODH_TRY(sorted_members(d_assign.as<uint32_t>(), n, P, d_idx.as<uint32_t>(), d_keys_out.as<uint32_t>(), d_members.as<uint32_t>(), d_off.as<uint32_t>(), tmp, tmp_bytes, hc, d_counts.as<uint32_t>()));
+        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), dim, 0u, dim, d_members.as<uint32_t>(), d_off.as<uint32_t>(), P, d_cent.as<float>());
+        SHODH_HIP_TRY(hipGetLastError());
+        unsigned long long changed = 0;
+        SHODH_HIP_TRY(hipMemcpy(&changed, d_changed.p, 8, hipMemcpyDeviceToHost));
+        if (changed == 0) break;                                     // "K-means converged" (spann.rs:536-539)
+    }
+    SHODH_HIP_TRY(hipMemcpy(centroids_out, d_cent.p, (size_t)P * dim * 4, hipMemcpyDeviceToHost));
+
+    // ---- PQ codebooks (pq.rs:131-217): the M subspaces advance in lock-step, they are independent ----
+    SHODH_HIP_TRY(hipMemcpy(d_perm.p, init_perm_pq, (size_t)M * n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gather_sub_kernel, dim3((uint32_t)ceil_div((uint64_t)M * NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), d_perm.as<uint32_t>(), n, dim, M, NC, d_cb.as<float>());
+    for (uint32_t it = 0; it < pq_iters; ++it) {
+        hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)ceil_div(n * M, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, d_cb.as<float>(), M, NC, d_codes.as<uint8_t>());
+        hipLaunchKernelGGL(split_codes_kernel, dim3((uint32_t)ceil_div(n * M, 256)), dim3(256), 0, nullptr, d_codes.as<uint8_t>(), n, M, d_keys.as<uint32_t>());
+        SHODH_HIP_TRY(hipGetLastError());
+        for (uint32_t m = 0; m < M; ++m) {
+            SHODH_TRY(sorted_members(d_keys.as<uint32_t>() + (uint64_t)m * n, n, NC, d_idx.as<uint32_t>(), d_keys_out.as<uint32_t>(), d_members.as<uint32_t>(), d_off.as<uint32_t>(), tmp, tmp_bytes, hc, d_counts.as<uint32_t>()));
+            hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), dim, m * 8, 8u, d_members.as<uint32_t>(), d_off.as<uint32_t>(), NC, d_cb.as<float>() + (size_t)m * NC * 8);
+        }
+        SHODH_HIP_TRY(hipGetLastError());
+    }
+    SHODH_HIP_TRY(hipMemcpy(codebook_out, d_cb.p, (size_t)M * NC * 8 * 4, hipMemcpyDeviceToHost));
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    return SHODH_OK;
+}

