@@ -539,7 +539,7 @@ int shodh_cosine_similarity_batch(int device, const float *a, const float *b, ui
 //
 // Follows SpannIndex::kmeans_cluster (src/vector_db/spann.rs:466-541) and ProductQuantizer::kmeans
 // (src/vector_db/pq.rs:152-217) operation for operation, so that GIVEN the initial shuffles (the reference draws them
-// from thread_rng) the trained state is bit-identical to the reference's -- checked against the oracle's restatement:
+// from thread_rng) the trained state is bit-identical to the reference's (tests/test_ivfpq_gpu.py checks it against a CPU restatement):
 //   assignment  : find_nearest_centroid (spann.rs:545-558: strictly sequential `1 - sum x*y`, strict '<' keeps the first
 //                 minimum) = the exact-order scan kernel over the centroids with k = 1;
 //                 PQ: squared L2 over 8 dims, sequential, strict '<' (pq.rs:180-191) = pq_encode_kernel;
