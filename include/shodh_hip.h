@@ -134,6 +134,10 @@ int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats4);
  * single-device search of the concatenated corpus. Padding entries have id 0xFFFFFFFF. */
 int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
                             uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
+/* the same with `list_stride` elements between the blocks of consecutive lists: lets every rank send ONE packed
+ * [ids | dist] buffer through ONE all-gather (in_dist = in_ids + nq*k reinterpreted, list_stride = 2*nq*k) */
+int shodh_topk_merge_strided_device(const uint32_t *d_in_ids, const float *d_in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                    uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
 
 /* ---- IVF-PQ trained state (SpannIndex given centroids/codebooks/postings) -------------------- */
 /* The reference's k-means is unseeded (spann.rs:472-474, pq.rs:155-157) so parity is defined

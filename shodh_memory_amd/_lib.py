@@ -93,6 +93,7 @@ SYMBOLS = {
     "shodh_index_kernel_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
+    "shodh_topk_merge_strided_device": (C.c_int, [_u32p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
     "shodh_index_ivfpq_insert": (C.c_int, [_vp, C.c_uint32, _fp]),
     "shodh_index_ivfpq_encode": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u8p]),

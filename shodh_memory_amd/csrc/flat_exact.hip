@@ -344,6 +344,7 @@ struct MergeListsArgs {
     const uint32_t *in_ids;
     const float *in_dist;
     uint32_t n_lists, nq, k, cap;
+    uint64_t list_stride;     // elements between the blocks of consecutive lists (nq*k when they are dense)
     uint32_t *ids;
     float *dist;
     uint32_t *counts;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(EX_NT) void merge_lists_kernel(MergeListsArgs a) {
     const uint64_t total = (uint64_t)a.n_lists * a.k;
     auto key_at = [&](uint64_t e) -> uint64_t {
         const uint64_t l = e / a.k, i = e % a.k;
-        const size_t off = ((size_t)l * a.nq + q) * a.k + i;
+        const size_t off = (size_t)l * a.list_stride + (size_t)q * a.k + i;
         const uint32_t id = a.in_ids[off];
         return id == 0xFFFFFFFFu ? KEY_NONE : make_key(a.in_dist[off], id);
     };
@@ -484,11 +485,11 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
     return SHODH_OK;
 }
 
-int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
+int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts, hipStream_t st) {
     if (nq == 0) return SHODH_OK;
     const uint32_t cap = topk_capacity(k);
-    MergeListsArgs a{in_ids, in_dist, n_lists, nq, k, cap, ids, dist, counts};
+    MergeListsArgs a{in_ids, in_dist, n_lists, nq, k, cap, list_stride, ids, dist, counts};
     const size_t lds = (size_t)cap * 8 + 2 * EX_NT * 8 + 8 + 4 + 16;
     SHODH_TRY(ensure_dynamic_lds((const void *)merge_lists_kernel, lds));
     hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(EX_NT), lds, st, a);

@@ -53,7 +53,7 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
                       uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
                       const uint32_t *qlist, const uint32_t *qcount, hipStream_t st);
 
-int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
+int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts, hipStream_t st);
 
 struct MfmaPlan {
@@ -618,8 +618,14 @@ uint32_t shodh_index_dim(const shodh_index *idx) { return idx ? idx->cfg.dim : 0
 int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
                             uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream) {
     if (nq && (!d_in_ids || !d_in_dist || !d_ids || !d_dist || !d_counts)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    return shodh_topk_merge_strided_device(d_in_ids, d_in_dist, (uint64_t)nq * k, n_lists, nq, k, d_ids, d_dist, d_counts, stream);
+}
+
+int shodh_topk_merge_strided_device(const uint32_t *d_in_ids, const float *d_in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                    uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream) {
+    if (nq && (!d_in_ids || !d_in_dist || !d_ids || !d_dist || !d_counts)) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (k > 8192) { set_error("k too large"); return SHODH_ERR_UNSUPPORTED; }
-    return launch_merge_lists(d_in_ids, d_in_dist, n_lists, nq, k, d_ids, d_dist, d_counts, (hipStream_t)stream);
+    return launch_merge_lists(d_in_ids, d_in_dist, list_stride, n_lists, nq, k, d_ids, d_dist, d_counts, (hipStream_t)stream);
 }
 
 int shodh_index_stage_timings(const shodh_index *idx, float *us4) {

@@ -78,22 +78,23 @@ class ShardedFlatIndex:
         key = (nq, k)
         if key not in self._bufs:
             dev = queries.device
+            # one packed [ids | dist] block per rank -> ONE all-gather per search (the payload is tiny, the collective is
+            # latency-bound: two collectives cost twice as much as one)
+            pack = torch.empty((2, nq, k), dtype=torch.int32, device=dev)
             self._bufs[key] = dict(
-                ids=torch.empty((nq, k), dtype=torch.int32, device=dev), dist=torch.empty((nq, k), dtype=torch.float32, device=dev),
-                counts=torch.empty((nq,), dtype=torch.int32, device=dev),
-                ids_all=torch.empty((self.world, nq, k), dtype=torch.int32, device=dev),
-                dist_all=torch.empty((self.world, nq, k), dtype=torch.float32, device=dev),
+                pack=pack, ids=pack[0], dist=pack[1].view(torch.float32), counts=torch.empty((nq,), dtype=torch.int32, device=dev),
+                pack_all=torch.empty((self.world, 2, nq, k), dtype=torch.int32, device=dev),
                 out_ids=torch.empty((nq, k), dtype=torch.int32, device=dev), out_dist=torch.empty((nq, k), dtype=torch.float32, device=dev),
                 out_counts=torch.empty((nq,), dtype=torch.int32, device=dev))
         b = self._bufs[key]
         self.index.search_batch_device(queries, k, out=(b["ids"], b["dist"], b["counts"]))
         if self.world == 1:
             return b["ids"], b["dist"], b["counts"]
-        # concatenation form [world*nq, k] (accepted by both RCCL and gloo); same memory as [world, nq, k]
-        self.dist.all_gather_into_tensor(b["ids_all"].view(self.world * nq, k), b["ids"], group=self.group)
-        self.dist.all_gather_into_tensor(b["dist_all"].view(self.world * nq, k), b["dist"], group=self.group)
+        # concatenation form [world*2*nq, k] (accepted by both RCCL and gloo); same memory as [world, 2, nq, k]
+        self.dist.all_gather_into_tensor(b["pack_all"].view(self.world * 2 * nq, k), b["pack"].view(2 * nq, k), group=self.group)
         st = torch.cuda.current_stream(queries.device).cuda_stream
-        L.check(L.lib().shodh_topk_merge_device(b["ids_all"].data_ptr(), b["dist_all"].data_ptr(), self.world, nq, k,
-                                                b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_counts"].data_ptr(),
-                                                C.c_void_p(st)))
+        base = b["pack_all"].data_ptr()
+        L.check(L.lib().shodh_topk_merge_strided_device(base, base + nq * k * 4, 2 * nq * k, self.world, nq, k,
+                                                        b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_counts"].data_ptr(),
+                                                        C.c_void_p(st)))
         return b["out_ids"], b["out_dist"], b["out_counts"]

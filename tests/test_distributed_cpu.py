@@ -27,11 +27,16 @@ def _worker(rank, world, port, tmpdir):
     lo, hi = shard_range(n, world, rank)
     ids, dd = O.brute_force_batch(rows[lo:hi], q, k)                     # this rank's shard, local ids
     ids = (ids + np.uint32(lo)).astype(np.uint32)                         # id_base
-    t_ids = torch.from_numpy(ids.view(np.int32).copy()); t_dd = torch.from_numpy(dd.copy())
-    all_ids = torch.empty((world, nq, k), dtype=torch.int32); all_dd = torch.empty((world, nq, k), dtype=torch.float32)
-    dist.all_gather_into_tensor(all_ids.view(world * nq, k), t_ids)      # same call shape as ShardedFlatIndex
-    dist.all_gather_into_tensor(all_dd.view(world * nq, k), t_dd)
-    m_ids, m_dd, counts = merge_gathered_numpy(all_ids.numpy().view(np.uint32), all_dd.numpy(), k)
+    # one packed [ids | dist] block per rank and ONE all-gather, the call shape of ShardedFlatIndex.search_batch_device
+    pack = torch.empty((2, nq, k), dtype=torch.int32)
+    pack[0] = torch.from_numpy(ids.view(np.int32).copy())
+    pack[1] = torch.from_numpy(dd.view(np.int32).copy())
+    pack_all = torch.empty((world, 2, nq, k), dtype=torch.int32)
+    dist.all_gather_into_tensor(pack_all.view(world * 2 * nq, k), pack.view(2 * nq, k))
+    g = pack_all.numpy()
+    all_ids = np.ascontiguousarray(g[:, 0]).view(np.uint32)
+    all_dd = np.ascontiguousarray(g[:, 1]).view(np.float32)
+    m_ids, m_dd, counts = merge_gathered_numpy(all_ids, all_dd, k)
     e_ids, e_dd = O.brute_force_batch(rows, q, k)
     ok = bool(np.array_equal(m_ids, e_ids) and m_dd.tobytes() == e_dd.tobytes() and (counts == k).all())
     open(os.path.join(tmpdir, "ok%d" % rank), "w").write("1" if ok else "0")
