@@ -852,8 +852,16 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     p.n_slots = p.passes * MF_BPAD;
     p.ksteps = dim / 16;
     p.n_tiles = ceil_div(n_rows, MF_TR);
-    // sample: every S-th tile (S = 16 unless SHODH_SAMPLE_STRIDE; measured: 32 -> 463, 16 -> 265, 8 -> 150 candidates/query at 1M), but at least 2k block maxima (4 per tile) and 64 tiles
-    static const uint32_t sample_stride = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 16u;
+    // sample: every S-th tile. The sample costs ~6 + 14*(16/S) us and leaves ~16*S/16*k survivors per query to emit and
+    // re-score, so S shrinks with k: 16 at k <= 10 (8/16/32 measured 277/271/272 us per step there), 16/sqrt(k/10) above
+    // (k = 120: S = 16 -> 2570 survivors per query, 0.70 ms per step; S = 4 -> ~650). SHODH_SAMPLE_STRIDE overrides.
+    static const uint32_t stride_env = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 0u;
+    uint32_t sample_stride = 16;
+    if (k > 10) {
+        sample_stride = (uint32_t)(16.0 / __builtin_sqrt((double)k / 10.0) + 0.5);
+        if (sample_stride < 2) sample_stride = 2;
+    }
+    if (stride_env) sample_stride = stride_env;
     uint64_t want = p.n_tiles / (sample_stride ? sample_stride : 16u);
     const uint64_t min_tiles = (uint64_t)k * 2 + 64;
     if (want < min_tiles) want = min_tiles;

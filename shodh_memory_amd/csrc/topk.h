@@ -162,8 +162,7 @@ __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, 
 }
 
 // k-th smallest (k >= 1) of n 32-bit keys key_at(0..n) -- the VALUE only, duplicates allowed. Returns
-// 0xFFFFFFFF if fewer than k keys exist, and sets *overflow if the bounded gather buffer (1024) was too small
-// (pathological inputs: thousands of equal keys) so that the caller can take another route.
+// 0xFFFFFFFF if fewer than k keys exist (*overflow is always false now).
 //   1. filter: the keys are dealt into k groups (by owning thread, tid % k); the k-th smallest key is <= the LARGEST
 //      of the k group minima (k distinct keys are <= it), and only ~k*H(k) keys pass that bound on random input;
 //   2. the survivors are gathered into LDS;
@@ -197,8 +196,8 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
     }
     __syncthreads();
     const uint32_t c = *cnt;
-    *overflow = c > (uint32_t)KTH_BUF;
-    if (c > (uint32_t)KTH_BUF || c < k) return 0xFFFFFFFFu;
+    *overflow = false;          // (kept in the signature: an overflowing gather now falls through to the direct radix select)
+    if (c < k) return 0xFFFFFFFFu;
     if (c <= 128u) {
         if (tid < c) {
             const uint32_t v = buf[tid];
@@ -216,14 +215,24 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
         __syncthreads();
         return *res;
     }
+    // many survivors: radix select over the gathered copy, or -- if even that overflowed (c > KTH_BUF: long runs of
+    // near-equal keys, or a large k) -- straight over the source keys that passed the filter
+    const bool gathered = c <= (uint32_t)KTH_BUF;
     uint32_t prefix = 0, mask = 0, kk = k;
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < c; i += NT) {
-            const uint32_t v = buf[i];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        if (gathered) {
+            for (uint32_t i = tid; i < c; i += NT) {
+                const uint32_t v = buf[i];
+                if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+            }
+        } else {
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint32_t v = key_at(i);
+                if (v <= T && v != 0xFFFFFFFFu && (v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {
