@@ -163,7 +163,7 @@ def test_id_base_sharding_offset(S, oracle):
 
 # ---- MFMA pre-scan + exact re-score vs oracle ----------------------------------------------------------
 @pytest.mark.parametrize("order", [0, 1])
-@pytest.mark.parametrize("n,nq,k", [(40000, 256, 10), (40000, 37, 120), (33000, 300, 10), (70000, 5, 1)])
+@pytest.mark.parametrize("n,nq,k", [(40000, 256, 10), (40000, 37, 120), (33000, 300, 10), (70000, 5, 1), (60000, 20, 300), (70000, 6, 1000)])
 def test_mfma_scan_matches_oracle(S, oracle, order, n, nq, k):
     q = synth.queries(nq)
     rows = synth.corpus(n, queries=q)
