@@ -74,7 +74,7 @@ struct MfmaArgs {
     float *blockmax;          // [passes][J][256], J = n_sel_tiles (one maximum per sampled 64-row tile and query)
     uint32_t tile_stride;     // tile index = sel * tile_stride
     uint32_t n_sel_tiles;
-    uint32_t ablate;          // diagnostics only (SHODH_ABLATE): 1 = skip the MFMA phase, 2 = skip the HBM loads
+    uint32_t ablate;          // diagnostics only (SHODH_ABLATE=8: thresholds forced to +inf, nothing is emitted; results invalid)
 };
 
 template <int KSTEPS>
@@ -246,8 +246,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): hipcc's own loads, so that it does not re-wait for them inside the loop
     __syncthreads();
 
-    if (a.ablate & 16u) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }
-    if (a.ablate & 32u) { if (wave & 1) __builtin_amdgcn_s_setprio(3); }
     floatx16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
