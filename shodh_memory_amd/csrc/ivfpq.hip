@@ -91,6 +91,9 @@ struct AdcArgs {
 
 constexpr int ADC_U = 2;        // postings per thread and iteration
 constexpr int ADC_MAXP = 256;   // probed lists per query (nprobe is capped at P and at this)
+// FULL256: 256 codewords per sub-quantiser (always the case for a reference-built index, pq.rs:27): an 8-bit code cannot
+// leave the table, so the range check disappears and the table row becomes an immediate offset of the LDS read.
+template <bool FULL256>
 __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *table = reinterpret_cast<float *>(smem);                              // [M][ncent]
@@ -187,8 +190,12 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             const uint32_t c = (word[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                            bad |= c > cmax;
-                            tv[j] = table[(w * 16 + j) * a.ncent + (c > cmax ? cmax : c)];
+                            if (FULL256) {
+                                tv[j] = table[(w * 16 + j) * 256 + c];
+                            } else {
+                                bad |= c > cmax;
+                                tv[j] = table[(w * 16 + j) * a.ncent + (c > cmax ? cmax : c)];
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 16; ++j) totald = totald + tv[j];
@@ -394,8 +401,13 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
     const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
     if (lds > 160 * 1024) { set_error("IVF-PQ: dim/k too large for LDS (%zu B)", lds); return SHODH_ERR_UNSUPPORTED; }
     if (nprobe > (uint32_t)ADC_MAXP) { set_error("IVF-PQ: nprobe %u > %d", nprobe, ADC_MAXP); return SHODH_ERR_UNSUPPORTED; }
-    SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel, lds));
-    hipLaunchKernelGGL(adc_scan_kernel, dim3(nq, split), dim3(256), lds, st, a);
+    if (s->ncent == 256) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<true>, lds));
+        hipLaunchKernelGGL(adc_scan_kernel<true>, dim3(nq, split), dim3(256), lds, st, a);
+    } else {
+        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<false>, lds));
+        hipLaunchKernelGGL(adc_scan_kernel<false>, dim3(nq, split), dim3(256), lds, st, a);
+    }
     SHODH_HIP_TRY(hipGetLastError());
     AdcMergeArgs m{partial, split, k, cap, d_ids, d_dist, d_counts};
     const size_t mlds = (size_t)cap * 8 + 512 * 8 + 8 + 4 + 16;
