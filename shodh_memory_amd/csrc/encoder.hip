@@ -183,7 +183,7 @@ constexpr int GS_TR = 64, GS_KSTEPS = 24, GS_DIM = 384, GS_PITCH = 768, GS_TILE 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ Wp /* fragment-major */,
                                                                    const float *__restrict__ bias, const __bf16 *__restrict__ resid,
-                                                                   __bf16 *__restrict__ out_b, float *__restrict__ out_f, int M, int N, int n_groups) {
+                                                                   __bf16 *__restrict__ out_b, float *__restrict__ out_f, int M, int N, int n_groups, int store_limit) {
     constexpr int NT = 512, CPR = 48, KSTEPS = GS_KSTEPS, NS = 2 * KSTEPS, D = 6, PF = GS_NBUF - 1;
     constexpr int NPC = 2 * (GS_TR * CPR / NT);      // DMA pieces per issuing thread (waves 0-3) and tile = 12
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -236,34 +236,75 @@ __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *
 #pragma unroll
     for (int j = 0; j < 8; ++j) aoff[j] = l31 * GS_PITCH + (((2 * j + hi) ^ sw) << 4);
 
-    auto epilogue = [&](const floatx16 &c, int m) {
-        if (m >= M) return;
-        f32x4e rv[4];
-        if (EPI == EPI_BIAS_RESID_F32) {
+    // Epilogue of one 32-token x 32-feature accumulator. In the C layout a lane owns a token and 4-feature groups, so direct
+    // stores would be 16-byte (bf16: 8 + 8) pieces scattered over 32 rows per instruction -- the write path handles such
+    // pieces at ~4 B/clk/CU and the epilogue doubled the kernel's time (QKV 314 us with, 187 us without it). So each wave
+    // turns its block through a private 2 KiB LDS scratch (16-B chunks XOR-swizzled by (token>>1)&3; same-wave LDS
+    // operations are ordered, no barrier) and stores rows: 64 contiguous bytes (bf16) / 128 (f32) per token.
+    unsigned char *scr = smem + GS_NBUF * GS_TILE + wave * 2048;
+    auto epilogue = [&](const floatx16 &c, int m_base /* token of lane l31 == 0 */) {
+        const int m = m_base + l31;
+        if (EPI == EPI_BIAS_GELU) {
+            // FFN up: the epilogue is VALU-bound (20 operations per element for the erf), the extra LDS round trip of the
+            // row-wise path only adds to it (518 vs 481 us measured): direct 8-byte stores here
+            if (m < store_limit) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4e ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob[e] = (__bf16)gelu_erf_fast(c[4 * g + e] + bv[4 * g + e]);
+                    *reinterpret_cast<bf16x4e *>(out_b + (size_t)m * N + nblk * 32 + 8 * g + 4 * hi) = ob;
+                }
+            }
+        } else if (EPI != EPI_BIAS_RESID_F32) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bf16x4e r4 = *reinterpret_cast<const bf16x4e *>(resid + (size_t)m * N + nblk * 32 + 8 * g + 4 * hi);
+                bf16x4e ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = c[4 * g + e] + bv[4 * g + e];
+                    if (EPI == EPI_BIAS_GELU) x = gelu_erf_fast(x);
+                    ob[e] = (__bf16)x;
+                }
+                // features 8g + 4hi .. +4 of token l31: chunk g (16 B), half hi
+                *reinterpret_cast<bf16x4e *>(scr + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = ob;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = h * 16 + (lane >> 2), ch = lane & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(scr + t * 64 + ((ch ^ ((t >> 1) & 3)) << 4));
+                if (m_base + t < store_limit) *reinterpret_cast<u32x4 *>(out_b + (size_t)(m_base + t) * N + nblk * 32 + ch * 8) = v;
+            }
+        } else {
+            // f32 output + bf16 residual: two halves of 16 tokens (16 x 128 B = the 2 KiB scratch)
+            f32x4e rv[4];
+            const int mc = m < M ? m : M - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4e r4 = *reinterpret_cast<const bf16x4e *>(resid + (size_t)mc * N + nblk * 32 + 8 * g + 4 * hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rv[g][e] = (float)r4[e];
             }
-        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4e v;
+            for (int half = 0; half < 2; ++half) {
+                if ((l31 >> 4) == half) {
+                    const int tl = l31 & 15;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = c[4 * g + e] + bv[4 * g + e];
-                if (EPI == EPI_BIAS_GELU) x = gelu_erf_fast(x);
-                v[e] = x;
-            }
-            const size_t o = (size_t)m * N + nblk * 32 + 8 * g + 4 * hi;
-            if (EPI == EPI_BIAS_RESID_F32) {
-                *reinterpret_cast<f32x4e *>(out_f + o) = v + rv[g];
-            } else {
-                bf16x4e ob;
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4e v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ob[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4e *>(out_b + o) = ob;
+                        for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] + bv[4 * g + e] + rv[g][e];
+                        // features 8g + 4hi .. +4 -> 16-B chunk 2g + hi of the token's 128-B row
+                        *reinterpret_cast<f32x4e *>(scr + tl * 128 + (((2 * g + hi) ^ (tl & 7)) << 4)) = v;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+                    const f32x4e v = *reinterpret_cast<const f32x4e *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                    const int mt = m_base + half * 16 + tl;
+                    if (mt < store_limit) *reinterpret_cast<f32x4e *>(out_f + (size_t)mt * N + nblk * 32 + ch * 4) = v;
+                }
             }
         }
     };
@@ -307,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *
         // in order with loads.
         if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
         if (active) {
-            epilogue(acc0, t * GS_TR + l31);
-            epilogue(acc1, t * GS_TR + 32 + l31);
+            epilogue(acc0, t * GS_TR);
+            epilogue(acc1, t * GS_TR + 32);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
@@ -706,9 +747,10 @@ static int gemm_k384_stream(const __bf16 *X, const __bf16 *Wp, const float *bias
     if (n_workers < 1) n_workers = 1;
     const int n_tiles = (M + GS_TR - 1) / GS_TR;
     if (n_workers > n_tiles) n_workers = n_tiles > 0 ? n_tiles : 1;
-    const size_t lds = (size_t)GS_NBUF * GS_TILE;
+    const size_t lds = (size_t)GS_NBUF * GS_TILE + 8 * 2048;      // + one 2 KiB epilogue scratch per wave = exactly 160 KiB
     SHODH_TRY(ensure_dynamic_lds((const void *)gemm_k384_stream_kernel<EPI>, lds));
-    hipLaunchKernelGGL((gemm_k384_stream_kernel<EPI>), dim3(n_groups * n_workers), dim3(512), lds, st, X, Wp, bias, resid, out_b, out_f, M, N, n_groups);
+    static const bool no_store = getenv("SHODH_ENC_NOSTORE") && atoi(getenv("SHODH_ENC_NOSTORE"));   // diagnostics: results invalid
+    hipLaunchKernelGGL((gemm_k384_stream_kernel<EPI>), dim3(n_groups * n_workers), dim3(512), lds, st, X, Wp, bias, resid, out_b, out_f, M, N, n_groups, no_store ? 0 : M);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
