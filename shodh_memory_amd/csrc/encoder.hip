@@ -608,15 +608,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const __bf16 *__res
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[ks], o, 0, 0, 0);
             }
         }
-        if (q < S) {
+        {
             const float invl = 1.0f / l;
-            // O^T layout: this lane = query q, value r = feature d = (r&3) + 8*(r>>2) + 4*hi
+            // O^T layout: this lane = query q, value r = feature d = (r&3) + 8*(r>>2) + 4*hi. Row-wise stores through a
+            // wave-private 2 KiB scratch (64 contiguous bytes per token instead of 8-byte pieces; see the GEMM epilogue)
+            unsigned char *scr = smem + (size_t)s_pad * 64 + 32 * (size_t)vt_pitch + wave * 2048;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4e ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = (__bf16)(o[4 * g + e] * invl);
-                *reinterpret_cast<bf16x4e *>(ctx + (size_t)(t0 + q) * H + head * 32 + 8 * g + 4 * hi) = ov;
+                *reinterpret_cast<bf16x4e *>(scr + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = ov;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = h * 16 + (lane >> 2), ch = lane & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(scr + t * 64 + ((ch ^ ((t >> 1) & 3)) << 4));
+                if (qb * 32 + t < S) *reinterpret_cast<u32x4 *>(ctx + (size_t)(t0 + qb * 32 + t) * H + head * 32 + ch * 8) = v;
             }
         }
     }
@@ -777,7 +785,7 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
     const size_t att_lds = (size_t)max_seq * 32 * 4 * 2;
     SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<T>, att_lds));
     const int s_pad = (max_seq + 31) & ~31;
-    const size_t att_mfma_lds = (size_t)s_pad * 64 + 32 * ((size_t)s_pad * 2 + 16);
+    const size_t att_mfma_lds = (size_t)s_pad * 64 + 32 * ((size_t)s_pad * 2 + 16) + 4 * 2048;   // K | V^T | per-wave output scratch
     if constexpr (!std::is_same<T, float>::value) SHODH_TRY(ensure_dynamic_lds((const void *)attention_mfma_kernel, att_mfma_lds));
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
