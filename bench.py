@@ -76,12 +76,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    backend = os.environ.get("SHODH_BENCH_BACKEND", "nccl")    # "gloo" + one GPU: a functional check of the N > 1 path (not a measurement)
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import shodh_memory_amd as S
     from shodh_memory_amd import _lib as L
@@ -208,8 +214,11 @@ def main():
                 "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "configs[1]: %d memories x %d-d f32, brute-force cosine (-dot) top-%d, batch=%d queries, %d x MI355X"
-                                       % (n_total, args.dim, args.k, args.nq, world),
+                "config": {"workload": ("configs[1]: %d memories x %d-d f32, brute-force cosine (-dot) top-%d, batch=%d queries, %d x MI355X"
+                                        % (n_total, args.dim, args.k, args.nq, world)) if world == 1 else
+                                       ("configs[4] shape (row-sharded corpus, RCCL top-k all-gather): %d memories = %d per GPU x %d MI355X, %d-d f32, "
+                                        "brute-force cosine (-dot) top-%d, batch=%d queries (weak scaling: the per-GPU shard is configs[1])"
+                                        % (n_total, hi - lo, world, args.dim, args.k, args.nq)),
                            "rows_total": n_total, "rows_per_gpu": rows_local, "batch": args.nq, "k": args.k, "scan": args.scan,
                            "layout": "row-sharded + RCCL all-gather of per-shard top-k" if world > 1 else "single device",
                            "prescan_dtype": "fp16 MFMA (f32 accumulate) + f32 reference-order re-score"},
