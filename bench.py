@@ -217,8 +217,8 @@ def main():
                 "config": {"workload": ("configs[1]: %d memories x %d-d f32, brute-force cosine (-dot) top-%d, batch=%d queries, %d x MI355X"
                                         % (n_total, args.dim, args.k, args.nq, world)) if world == 1 else
                                        ("configs[4] shape (row-sharded corpus, RCCL top-k all-gather): %d memories = %d per GPU x %d MI355X, %d-d f32, "
-                                        "brute-force cosine (-dot) top-%d, batch=%d queries (weak scaling: the per-GPU shard is configs[1])"
-                                        % (n_total, hi - lo, world, args.dim, args.k, args.nq)),
+                                        "brute-force cosine (-dot) top-%d, batch=%d queries (%s scaling)"
+                                        % (n_total, hi - lo, world, args.dim, args.k, args.nq, args.scaling)),
                            "rows_total": n_total, "rows_per_gpu": rows_local, "batch": args.nq, "k": args.k, "scan": args.scan,
                            "layout": "row-sharded + RCCL all-gather of per-shard top-k" if world > 1 else "single device",
                            "prescan_dtype": "fp16 MFMA (f32 accumulate) + f32 reference-order re-score"},
