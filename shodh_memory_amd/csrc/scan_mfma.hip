@@ -850,13 +850,14 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     p.n_slots = p.passes * MF_BPAD;
     p.ksteps = dim / 16;
     p.n_tiles = ceil_div(n_rows, MF_TR);
-    // sample: every S-th tile. The sample costs ~6 + 14*(16/S) us and leaves ~16*S/16*k survivors per query to emit and
-    // re-score, so S shrinks with k: 16 at k <= 10 (8/16/32 measured 277/271/272 us per step there), 16/sqrt(k/10) above
-    // (k = 120: S = 16 -> 2570 survivors per query, 0.70 ms per step; S = 4 -> ~650). SHODH_SAMPLE_STRIDE overrides.
+    // sample: every S-th tile. The sample costs ~6 + 13*(16/S) us and leaves ~16*S*k/16 survivors per query to emit and
+    // re-score, so S shrinks with k: 16 up to k = 40 (k = 10: S = 8/16/32 measured 277/271/272 us per step; k = 40: 8/12/16
+    // all 302), 16*sqrt(40/k) above (k = 120: S = 4/6/8/10/12/16 measured 375/364/354/350/356/400 us). SHODH_SAMPLE_STRIDE
+    // overrides.
     static const uint32_t stride_env = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 0u;
     uint32_t sample_stride = 16;
-    if (k > 10) {
-        sample_stride = (uint32_t)(16.0 / __builtin_sqrt((double)k / 10.0) + 0.5);
+    if (k > 40) {
+        sample_stride = (uint32_t)(16.0 * __builtin_sqrt(40.0 / (double)k) + 0.5);
         if (sample_stride < 2) sample_stride = 2;
     }
     if (stride_env) sample_stride = stride_env;
