@@ -27,6 +27,8 @@
 // k-th largest of the per-tile maxima is a valid lower bound of the k-th best score.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "topk.h"
 #include "glds.h"
@@ -904,7 +906,9 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[12]
 }
 
 template <int MODE>
-static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st) {
+// ev0 / ev1 (optional): start / stop timestamps of THIS dispatch (hipExtLaunchKernel attaches them to the kernel's own packet;
+// separate hipEventRecord calls are extra packets in the stream and cost 3-5 us each between two kernels)
+static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
     const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
@@ -912,7 +916,8 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
     case KS:                                                                                                       \
         SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_kernel<MODE, KS>, lds));                               \
-        hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS>), grid, dim3(512), lds, st, a);                              \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((mfma_scan_kernel<MODE, KS>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL((mfma_scan_kernel<MODE, KS>), grid, dim3(512), lds, st, a);                         \
         break;
     switch (p.ksteps) {
         SHODH_LAUNCH_KS(8)
@@ -961,9 +966,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     a.tile_stride = 1;
     a.n_sel_tiles = (uint32_t)p.n_tiles;
     a.ablate = ablate;
-    if (ev_emit0) SHODH_HIP_TRY(hipEventRecord(ev_emit0, st));
-    SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st));
-    if (ev_emit1) SHODH_HIP_TRY(hipEventRecord(ev_emit1, st));
+    SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st, ev_emit0, ev_emit1));
     if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
 
     const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
