@@ -50,7 +50,10 @@ enum { SHODH_METRIC_NDP = 0, SHODH_METRIC_EUCLIDEAN = 1, SHODH_METRIC_COSINE = 2
 /* which reference build's accumulation order the exact scores reproduce bit-for-bit:
  * SCALAR4 = dot_product_scalar_inline (distance_inline.rs:157-173; default Linux build),
  * AVX2    = dot_product_avx2_inline   (distance_inline.rs:67-111; -C target-cpu=native build) */
-enum { SHODH_ORDER_SCALAR4 = 0, SHODH_ORDER_AVX2 = 1 };
+enum { SHODH_ORDER_SCALAR4 = 0, SHODH_ORDER_AVX2 = 1,
+       /* distance = 1 - sum(x*y), the sum strictly sequential: SpannIndex::compute_distance (spann.rs:562-571). Used by the
+        * library itself for nearest-centroid searches (probe selection, k-means assignment); dist outputs are that distance */
+       SHODH_ORDER_SEQ_1M = 2 };
 /* index kinds: FLAT = VamanaIndex under SHODH_VECTOR_EXACT (vamana.rs:770-777, :1167-1188);
  * IVFPQ = SpannIndex (spann.rs:574-693) */
 enum { SHODH_INDEX_FLAT = 0, SHODH_INDEX_IVFPQ = 1 };

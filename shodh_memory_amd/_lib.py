@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(HERE, "libshodh_hip.so")
 OK = 0
 ERR_INVALID, ERR_DIM, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_IO, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
 METRIC_NDP, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
-ORDER_SCALAR4, ORDER_AVX2 = 0, 1
+ORDER_SCALAR4, ORDER_AVX2, ORDER_SEQ_1M = 0, 1, 2
 INDEX_FLAT, INDEX_IVFPQ = 0, 1
 SCAN_AUTO, SCAN_EXACT, SCAN_MFMA = 0, 1, 2
 DTYPE_FP32, DTYPE_BF16 = 0, 1

@@ -240,6 +240,7 @@ static bool use_mfma(const shodh_index *idx, uint32_t nq, uint32_t k) {
     if (idx->cfg.scan_mode == SHODH_SCAN_EXACT) return false;
     if (!idx->shadow || !idx->quantizable) return false;
     if (k == 0 || k > 2048) return false;
+    if (idx->cfg.order == SHODH_ORDER_SEQ_1M) return idx->n >= 512 && idx->n >= 8ull * k;   // centroid tables: thousands of rows, many queries
     if (idx->n < 16384 || idx->n < 64ull * k) return false;     // pre-scan sampling needs a real corpus
     (void)nq;
     // AUTO == MFMA whenever the shadow copy is usable: measured at 1M rows a single query takes 260 us on the
@@ -346,7 +347,7 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
     *out = nullptr;
     if (cfg->dim == 0 || cfg->dim > 4096) { set_error("dimension %u out of range", cfg->dim); return SHODH_ERR_DIM; }
     if (cfg->kind != SHODH_INDEX_FLAT && cfg->kind != SHODH_INDEX_IVFPQ) { set_error("unknown index kind %u", cfg->kind); return SHODH_ERR_INVALID; }
-    if (cfg->order > SHODH_ORDER_AVX2) { set_error("unknown accumulation order %u", cfg->order); return SHODH_ERR_INVALID; }
+    if (cfg->order > SHODH_ORDER_SEQ_1M) { set_error("unknown accumulation order %u", cfg->order); return SHODH_ERR_INVALID; }
     if (cfg->kind == SHODH_INDEX_FLAT && cfg->metric != SHODH_METRIC_NDP) {
         // RetrievalEngine refuses anything else (retrieval.rs:188-193)
         set_error("FLAT index requires NormalizedDotProduct (vectors are L2-normalised by the embedder)");

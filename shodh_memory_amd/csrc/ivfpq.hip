@@ -46,6 +46,8 @@ struct IvfpqState {
     int device = 0, cus = 256;
     uint32_t dim = 0, P = 0, M = 0, ncent = 0, metric = 0;
     float *centroids = nullptr;      // [P][dim]
+    shodh_index *cent_idx = nullptr; // flat index over the centroid table in SHODH_ORDER_SEQ_1M (NormalizedDotProduct only): nearest-centroid
+                                     // searches run as MFMA pre-scan + exact re-score instead of the exact-order scan when the table is big enough
     float *codebook = nullptr;       // [M][ncent][8]
     uint64_t *list_off = nullptr;    // [P+1]
     uint32_t *ids = nullptr;         // [total]
@@ -63,6 +65,7 @@ struct IvfpqState {
 void ivfpq_destroy(IvfpqState *s) {
     if (!s) return;
     hipSetDevice(s->device);
+    if (s->cent_idx) shodh_index_destroy(s->cent_idx);
     hipFree(s->centroids); hipFree(s->codebook); hipFree(s->list_off); hipFree(s->ids); hipFree(s->codes); hipFree(s->scratch);
     delete s;
 }
@@ -73,6 +76,26 @@ static int ensure_scratch(IvfpqState *s, size_t bytes) {
     s->scratch = nullptr; s->scratch_bytes = 0;
     SHODH_HIP_TRY(hipMalloc((void **)&s->scratch, bytes));
     s->scratch_bytes = bytes;
+    return SHODH_OK;
+}
+
+// ---- nearest centroids through a flat index (SpannIndex::find_nearest_centroid / probe selection, spann.rs:545-571, :595-607) ----
+// The k smallest (compute_distance, index) pairs are exactly what a flat search in SHODH_ORDER_SEQ_1M returns: strict '<' in
+// the reference keeps the first minimum, i.e. the smallest index among equal distances.
+static int make_centroid_index(int device, uint32_t dim, const float *d_centroids, uint32_t P, shodh_index **out) {
+    shodh_index_cfg c;
+    shodh_index_cfg_default(&c);
+    c.dim = dim; c.order = SHODH_ORDER_SEQ_1M; c.device = device; c.reserve_rows = P;
+    if (!*out) SHODH_TRY(shodh_index_create(&c, out));
+    return shodh_index_build_device(*out, d_centroids, P);
+}
+static int nearest_centroids(shodh_index *ci, const float *d_q, uint64_t nq, uint32_t dim, uint32_t k, uint32_t *d_ids, float *d_dist,
+                             uint32_t *d_cnt, hipStream_t st) {
+    const uint64_t CH = 4096;             // queries per call: bounds the pre-scan's candidate workspace
+    for (uint64_t b = 0; b < nq; b += CH) {
+        const uint32_t m = (uint32_t)((nq - b) < CH ? (nq - b) : CH);
+        SHODH_TRY(shodh_index_search_device(ci, d_q + b * dim, m, k, d_ids + b * k, d_dist + b * k, d_cnt + b, (void *)st));
+    }
     return SHODH_OK;
 }
 
@@ -394,8 +417,12 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
     uint64_t *partial = (uint64_t *)(s_scratch + o_partial);
     // 1. probe selection: the nprobe nearest centroids by (compute_distance, index)
     const uint32_t op = (s->metric == SHODH_METRIC_EUCLIDEAN) ? EX_OP_SEQ_L2 : EX_OP_SEQ_ONE_MINUS_DOT;
-    SHODH_TRY(launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_q, nq, nprobe, op, 0, (uint64_t *)(s_scratch + o_flat), gx,
-                                probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
+    if (s->cent_idx) {
+        SHODH_TRY(nearest_centroids(s->cent_idx, d_q, nq, s->dim, nprobe, probe_ids, probe_dist, probe_cnt, st));
+    } else {
+        SHODH_TRY(launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_q, nq, nprobe, op, 0, (uint64_t *)(s_scratch + o_flat), gx,
+                                    probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
+    }
     // 2. ADC table + list scan, 3. merge
     AdcArgs a{d_q, s->codebook, s->list_off, s->ids, s->codes, probe_ids, probe_cnt, nq, s->dim, s->M, s->ncent, nprobe, k, cap, split, partial};
     const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
@@ -445,7 +472,8 @@ static int encode_rows(IvfpqState *s, const float *rows, uint64_t n, uint32_t *a
         const uint64_t m = (n - b) < ch ? (n - b) : ch;
         if (hipMemcpy(d_rows, rows + b * s->dim, m * s->dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
         // find_nearest_centroid (spann.rs:545-558): strict '<' keeps the first minimum == smallest (dist, index)
-        rc = launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_rows, (uint32_t)m, 1, op, 0, d_part, gxc, d_assign, d_ad, d_ac, nullptr, nullptr, nullptr);
+        rc = s->cent_idx ? nearest_centroids(s->cent_idx, d_rows, m, s->dim, 1, d_assign, d_ad, d_ac, nullptr)
+                         : launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_rows, (uint32_t)m, 1, op, 0, d_part, gxc, d_assign, d_ad, d_ac, nullptr, nullptr, nullptr);
         if (rc != SHODH_OK) break;
         hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)ceil_div(m * s->M, 256)), dim3(256), 0, nullptr, d_rows, m, s->dim, s->codebook, s->M, s->ncent, d_codes);
         if (hipGetLastError() != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
@@ -486,6 +514,10 @@ int shodh_index_set_ivfpq(shodh_index *idx, const float *centroids, uint32_t P, 
     SHODH_HIP_TRY(hipMalloc((void **)&s->list_off, (size_t)(P + 1) * 8));
     SHODH_HIP_TRY(hipMemcpy(s->centroids, centroids, (size_t)P * cfg.dim * 4, hipMemcpyHostToDevice));
     SHODH_HIP_TRY(hipMemcpy(s->codebook, codebook, (size_t)M * ncent * 8 * 4, hipMemcpyHostToDevice));
+    if (cfg.metric != SHODH_METRIC_EUCLIDEAN) {
+        const int rc_ci = make_centroid_index(cfg.device, cfg.dim, s->centroids, P, &s->cent_idx);
+        if (rc_ci != SHODH_OK) { ivfpq_destroy(s); return rc_ci; }
+    }
     s->h_ids.resize(P); s->h_codes.resize(P);
     for (uint32_t p = 0; p < P; ++p) {
         if (list_off[p + 1] < list_off[p]) { ivfpq_destroy(s); set_error("list_off not monotone"); return SHODH_ERR_INVALID; }
@@ -667,29 +699,28 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const uint32_t M = dim / 8, NC = 256;
     const uint32_t kmax = P > NC ? P : NC;
-    Buf d_rows, d_cent, d_cb, d_assign, d_prev, d_idx, d_keys_out, d_members, d_off, d_counts, d_changed, d_perm, d_codes, d_keys, d_part, d_ad, d_ac, tmp;
+    Buf d_rows, d_cent, d_cb, d_assign, d_prev, d_idx, d_keys_out, d_members, d_off, d_counts, d_changed, d_perm, d_codes, d_keys, d_ad, d_ac, tmp;
     size_t tmp_bytes = 0;
-    const uint64_t CH = n < 65536 ? n : 65536;                       // rows per assignment launch (each row is one "query")
-    const uint32_t gx = exact_grid_x(P, (uint32_t)CH, 1, cus);
     SHODH_TRY(d_rows.alloc(n * dim * 4)); SHODH_TRY(d_cent.alloc((size_t)P * dim * 4)); SHODH_TRY(d_cb.alloc((size_t)M * NC * 8 * 4));
     SHODH_TRY(d_assign.alloc(n * 4)); SHODH_TRY(d_prev.alloc(n * 4)); SHODH_TRY(d_idx.alloc(n * 4)); SHODH_TRY(d_keys_out.alloc(n * 4));
     SHODH_TRY(d_members.alloc(n * 4)); SHODH_TRY(d_off.alloc((size_t)(kmax + 1) * 4)); SHODH_TRY(d_counts.alloc((size_t)kmax * 4));
     SHODH_TRY(d_changed.alloc(8)); SHODH_TRY(d_perm.alloc((size_t)(M > 1 ? M : 1) * n * 4)); SHODH_TRY(d_codes.alloc(n * M));
-    SHODH_TRY(d_keys.alloc((size_t)M * n * 4)); SHODH_TRY(d_part.alloc(exact_partial_bytes((uint32_t)CH, dim, 1, gx) + 256));
-    SHODH_TRY(d_ad.alloc(CH * 4)); SHODH_TRY(d_ac.alloc(CH * 4));
+    SHODH_TRY(d_keys.alloc((size_t)M * n * 4));
+    SHODH_TRY(d_ad.alloc(n * 4)); SHODH_TRY(d_ac.alloc(n * 4));
     SHODH_HIP_TRY(hipMemcpy(d_rows.p, rows, n * dim * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_idx.as<uint32_t>(), n);
     std::vector<uint32_t> hc;
+    struct CentIdx { shodh_index *p = nullptr; ~CentIdx() { if (p) shodh_index_destroy(p); } } ci;
 
     // ---- IVF centroids (spann.rs:466-541) ----
     SHODH_HIP_TRY(hipMemcpy(d_perm.p, init_perm_ivf, n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), d_perm.as<uint32_t>(), n, dim, P, d_cent.as<float>());
     SHODH_HIP_TRY(hipMemset(d_prev.p, 0, n * 4));                   // `let mut assignments = vec![0usize; n]`
     for (uint32_t it = 0; it < ivf_iters; ++it) {
-        for (uint64_t b = 0; b < n; b += CH) {
-            const uint64_t m = (n - b) < CH ? (n - b) : CH;
-            SHODH_TRY(launch_flat_exact(d_cent.as<float>(), P, dim, nullptr, d_rows.as<float>() + b * dim, (uint32_t)m, 1, EX_OP_SEQ_ONE_MINUS_DOT, 0,
-                                        d_part.as<uint64_t>(), gx, d_assign.as<uint32_t>() + b, d_ad.as<float>(), d_ac.as<uint32_t>(), nullptr, nullptr, nullptr));
+        {
+            const int rc_ci = make_centroid_index(device, dim, d_cent.as<float>(), P, &ci.p);
+            if (rc_ci != SHODH_OK) return rc_ci;
+            SHODH_TRY(nearest_centroids(ci.p, d_rows.as<float>(), n, dim, 1, d_assign.as<uint32_t>(), d_ad.as<float>(), d_ac.as<uint32_t>(), nullptr));
         }
         SHODH_HIP_TRY(hipMemset(d_changed.p, 0, 8));
         hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_assign.as<uint32_t>(), d_prev.as<uint32_t>(), n, d_changed.as<unsigned long long>());

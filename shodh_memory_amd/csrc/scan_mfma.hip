@@ -785,18 +785,35 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                         rowbuf4[c * (rp >> 2) + j] = *reinterpret_cast<const f32x4 *>(a.rows + (size_t)flist[c0 + c] * dim + j * 4);
                     }
                     __syncthreads();
-                    if (tid < nc * 8) {
-                        const uint32_t c = tid >> 3, l = tid & 7;
-                        float acc = 0.0f;
-                        for (uint32_t i = 0; i < dim; i += 8) acc = __builtin_fmaf(qs[i + l], rowbuf[c * rp + i + l], acc);
-                        tbuf[c * 8 + l] = acc;
-                    }
-                    __syncthreads();
-                    if (tid < nc) {
-                        const float *p8 = tbuf + tid * 8;
-                        float r = p8[0] + p8[1];
-                        r = r + p8[2]; r = r + p8[3]; r = r + p8[4]; r = r + p8[5]; r = r + p8[6]; r = r + p8[7];
-                        ekeys[c0 + tid] = make_key(-r, a.id_base + flist[c0 + tid]);
+                    if (ORDER == SHODH_ORDER_SEQ_1M) {
+                        // SpannIndex::compute_distance, NormalizedDotProduct arm (spann.rs:562-571): `1 - sum(x*y)`, the sum
+                        // strictly in index order from 0.0 (one product, one add per element; no FMA). One thread per row.
+                        if (tid < nc) {
+                            const float *rr = rowbuf + tid * rp;
+                            float dot = 0.0f;
+                            for (uint32_t i = 0; i < dim; i += 8) {
+                                float pr[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) pr[u] = qs[i + u] * rr[i + u];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) dot = dot + pr[u];
+                            }
+                            ekeys[c0 + tid] = make_key(1.0f - dot, a.id_base + flist[c0 + tid]);
+                        }
+                    } else {
+                        if (tid < nc * 8) {
+                            const uint32_t c = tid >> 3, l = tid & 7;
+                            float acc = 0.0f;
+                            for (uint32_t i = 0; i < dim; i += 8) acc = __builtin_fmaf(qs[i + l], rowbuf[c * rp + i + l], acc);
+                            tbuf[c * 8 + l] = acc;
+                        }
+                        __syncthreads();
+                        if (tid < nc) {
+                            const float *p8 = tbuf + tid * 8;
+                            float r = p8[0] + p8[1];
+                            r = r + p8[2]; r = r + p8[3]; r = r + p8[4]; r = r + p8[5]; r = r + p8[6]; r = r + p8[7];
+                            ekeys[c0 + tid] = make_key(-r, a.id_base + flist[c0 + tid]);
+                        }
                     }
                     __syncthreads();
                 }
@@ -956,7 +973,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
     // dim * 2^-23, reference rounding ~1e-5; absolute term for flushed/denormal fp16 after the 2^8 scale
     const float eps_rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
-    const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f;
+    const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f + (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);   // SEQ_1M: + the rounding of `1 - dot` (<= 2^-24 |1 - dot|, |dot| <= qn*maxnorm), charged generously
     ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps};
     const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
     (void)tlds;
@@ -975,7 +992,10 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32   (every part a multiple of 8 B; region at 16 B)
     const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 +
                         final_stage_region_bytes(dim) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)FS_STAGE * 8 + 16;
-    if (order == SHODH_ORDER_AVX2) {
+    if (order == SHODH_ORDER_SEQ_1M) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_SEQ_1M>, flds));
+        hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SEQ_1M>), dim3(nq), dim3(256), flds, st, f);
+    } else if (order == SHODH_ORDER_AVX2) {
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_AVX2>), dim3(nq), dim3(256), flds, st, f);
     } else {

@@ -11,6 +11,13 @@ import pytest
 from tests import synth
 
 pytestmark = pytest.mark.gpu
+
+
+def order_keys(d):
+    """f32::total_cmp as an unsigned key (sign-magnitude flip)"""
+    b = np.ascontiguousarray(d, np.float32).view(np.uint32)
+    return np.where(b & 0x80000000, ~b, b | 0x80000000).astype(np.uint32)
+
 f32 = np.float32
 
 
@@ -387,3 +394,24 @@ def test_strided_merge_equals_dense_merge(S, oracle):
     e_i, e_d, e_c = merge_gathered_numpy(ids, dist, k)
     for o_i, o_d, o_c in outs:
         assert np.array_equal(o_i.view(np.uint32), e_i) and o_d.tobytes() == e_d.tobytes() and np.array_equal(o_c.astype(np.uint32), e_c)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sequential_one_minus_dot_order(S, oracle, mode):
+    """SHODH_ORDER_SEQ_1M: distance = 1 - sum(x*y) strictly sequential (SpannIndex::compute_distance, spann.rs:562-571), the
+    order of the library's own nearest-centroid searches; exact scan and MFMA pre-scan + re-score against the oracle."""
+    from shodh_memory_amd import _lib as L
+    n, nq, k = 6000, 40, 32
+    q = synth.queries(nq)
+    rows = synth.corpus(n, queries=q)
+    idx = make_index(S, order=L.ORDER_SEQ_1M, scan_mode=mode)
+    idx.build(rows)
+    ids, dist, counts = idx.search_batch(q, k)
+    if mode == 2:
+        assert idx.scan_stats()["sampled_rows"] > 0, "MFMA path was not taken"
+    for i in range(nq):
+        d = np.array([oracle.spann_compute_distance(q[i], rows[j]) for j in range(n)], f32)
+        key = (order_keys(d).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        top = np.argsort(key, kind="stable")[:k]
+        assert ids[i].tolist() == top.tolist()
+        assert dist[i].tobytes() == d[top].tobytes()
