@@ -276,12 +276,16 @@ __global__ __launch_bounds__(256) void adc_merge_kernel(AdcMergeArgs a) {
 }
 
 // ---- PQ encode (pq.rs:220-257): nearest of ncent centroids per 8-d subvector, first minimum wins ------------
-__global__ __launch_bounds__(256) void pq_encode_kernel(const float *rows, uint64_t n, uint32_t dim, const float *codebook,
-                                                        uint32_t M, uint32_t ncent, uint8_t *codes) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n * M) return;
-    const uint64_t row = t / M;
-    const uint32_t m = (uint32_t)(t % M);
+// One workgroup = 256 rows of ONE subspace m (m is the fastest-varying part of blockIdx.x, so the workgroups that share a
+// row's 128-byte lines run next to each other): the centroid addresses are wave-uniform, so the centroids arrive through
+// scalar loads and sit in SGPRs; a lane holds its sub-vector in 8 VGPRs. KEYS: write u32 keys [M][n] (coalesced; what the
+// k-means member sort wants) instead of the byte codes [n][M].
+template <bool KEYS>
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim, const float *__restrict__ codebook,
+                                                        uint32_t M, uint32_t ncent, uint8_t *__restrict__ codes, uint32_t *__restrict__ keys) {
+    const uint32_t m = blockIdx.x % M;
+    const uint64_t row = (uint64_t)(blockIdx.x / M) * 256 + threadIdx.x;
+    if (row >= n) return;
     const float *v = rows + row * dim + m * 8;
     float x[8];
 #pragma unroll
@@ -289,14 +293,17 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *rows, uint6
     uint32_t best = 0;
     float best_dist = 3.4028234663852886e38f;      // f32::MAX
     const float *cb = codebook + (size_t)m * ncent * 8;
+#pragma unroll 4
     for (uint32_t c = 0; c < ncent; ++c) {
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = x[j] - cb[c * 8 + j]; sum = sum + d * d; }
         if (sum < best_dist) { best_dist = sum; best = c; }
     }
-    codes[row * M + m] = (uint8_t)best;
+    if (KEYS) keys[(uint64_t)m * n + row] = best;
+    else codes[row * M + m] = (uint8_t)best;
 }
+static inline uint32_t pq_encode_grid(uint64_t n, uint32_t M) { return (uint32_t)(ceil_div(n, 256) * M); }
 
 // ---- pairwise cosine (similarity.rs:10-24), one pair per thread ------------------------------------------------
 template <int ORDER>
@@ -475,7 +482,7 @@ static int encode_rows(IvfpqState *s, const float *rows, uint64_t n, uint32_t *a
         rc = s->cent_idx ? nearest_centroids(s->cent_idx, d_rows, m, s->dim, 1, d_assign, d_ad, d_ac, nullptr)
                          : launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_rows, (uint32_t)m, 1, op, 0, d_part, gxc, d_assign, d_ad, d_ac, nullptr, nullptr, nullptr);
         if (rc != SHODH_OK) break;
-        hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)ceil_div(m * s->M, 256)), dim3(256), 0, nullptr, d_rows, m, s->dim, s->codebook, s->M, s->ncent, d_codes);
+        hipLaunchKernelGGL(pq_encode_kernel<false>, dim3(pq_encode_grid(m, s->M)), dim3(256), 0, nullptr, d_rows, m, s->dim, s->codebook, s->M, s->ncent, d_codes, (uint32_t *)nullptr);
         if (hipGetLastError() != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
         if (hipMemcpy(assign_out + b, d_assign, m * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(codes_out + b * s->M, d_codes, m * s->M, hipMemcpyDeviceToHost) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
@@ -622,36 +629,37 @@ __global__ void count_changed_kernel(const uint32_t *a, uint32_t *prev, uint64_t
     const unsigned long long b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c != 0));
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(changed, b);
 }
-__global__ void histogram_kernel(const uint32_t *keys, uint64_t n, uint32_t *counts) {
+// offsets[c] = first position of the sorted keys that is >= c (c = 0..k): the member list boundaries, nsub key arrays at once
+__global__ void offsets_kernel(const uint32_t *sorted_keys, uint64_t n, uint32_t k, uint32_t nsub, uint32_t *offsets /* [nsub][k+1] */) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) atomicAdd(counts + keys[t], 1u);
+    if (t >= (uint64_t)nsub * (k + 1)) return;
+    const uint32_t sub = (uint32_t)(t / (k + 1)), c = (uint32_t)(t % (k + 1));
+    const uint32_t *keys = sorted_keys + (uint64_t)sub * n;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < c) lo = mid + 1; else hi = mid; }
+    offsets[t] = (uint32_t)lo;
 }
-// codes [n][M] -> keys [M][n] as u32 (one contiguous key array per subspace for the stable sort)
-__global__ void split_codes_kernel(const uint8_t *codes, uint64_t n, uint32_t M, uint32_t *keys) {
+// one thread per (sub-space, cluster, coordinate): the members in index order, one add each, then / count (spann.rs:508-527,
+// pq.rs:193-212). Sub-space `sub` owns columns [sub*width, sub*width+width) of the rows (IVF: one sub-space of width dim).
+__global__ void mean_update_kernel(const float *rows, uint64_t n, uint32_t dim, uint32_t width, uint32_t nsub, const uint32_t *members /* [nsub][n] */,
+                                   const uint32_t *offsets /* [nsub][k+1] */, uint32_t k, float *cent /* [nsub][k][width] */) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * M) return;
-    const uint64_t row = t / M;
-    const uint32_t m = (uint32_t)(t % M);
-    keys[(uint64_t)m * n + row] = codes[t];
-}
-// one thread per (cluster, coordinate): the members in index order, one add each, then / count (spann.rs:508-527)
-__global__ void mean_update_kernel(const float *rows, uint32_t dim, uint32_t col0, uint32_t width, const uint32_t *members,
-                                   const uint32_t *offsets /* [k+1] */, uint32_t k, float *cent /* [k][width] */) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)k * width) return;
-    const uint32_t c = (uint32_t)(t / width), j = (uint32_t)(t % width);
-    const uint32_t lo = offsets[c], hi = offsets[c + 1];
+    if (t >= (uint64_t)nsub * k * width) return;
+    const uint32_t j = (uint32_t)(t % width), c = (uint32_t)((t / width) % k), sub = (uint32_t)(t / ((uint64_t)width * k));
+    const uint32_t *mem = members + (uint64_t)sub * n;
+    const uint32_t lo = offsets[(uint64_t)sub * (k + 1) + c], hi = offsets[(uint64_t)sub * (k + 1) + c + 1];
     if (hi == lo) return;                                            // empty cluster keeps its centroid
+    const float *col = rows + (uint64_t)sub * width + j;
     float sum = 0.0f;
     uint32_t i = lo;
-    for (; i + 8 <= hi; i += 8) {                                    // the loads are independent, only the adds are ordered
-        float v[8];
+    for (; i + 16 <= hi; i += 16) {                                  // the loads are independent, only the adds are ordered
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = rows[(uint64_t)members[i + u] * dim + col0 + j];
+        for (int u = 0; u < 16; ++u) v[u] = col[(uint64_t)mem[i + u] * dim];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum = sum + v[u];
+        for (int u = 0; u < 16; ++u) sum = sum + v[u];
     }
-    for (; i < hi; ++i) sum = sum + rows[(uint64_t)members[i] * dim + col0 + j];
+    for (; i < hi; ++i) sum = sum + col[(uint64_t)mem[i] * dim];
     cent[t] = sum / (float)(hi - lo);
 }
 
@@ -663,22 +671,13 @@ struct Buf {
 };
 
 // members of every cluster in index order: stable radix sort of (key, index) on the low `bits` bits of the key
-int sorted_members(const uint32_t *keys, uint64_t n, uint32_t k, uint32_t *idx_in, uint32_t *keys_out, uint32_t *members, uint32_t *offsets,
-                   Buf &tmp, size_t &tmp_bytes, std::vector<uint32_t> &host_counts, uint32_t *d_counts) {
+int sorted_members(const uint32_t *keys, uint64_t n, uint32_t k, uint32_t *idx_in, uint32_t *keys_out, uint32_t *members, Buf &tmp, size_t &tmp_bytes) {
     int bits = 1;
     while ((1u << bits) < k) ++bits;
     size_t need = 0;
     SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
     if (need > tmp_bytes) { if (tmp.p) hipFree(tmp.p); tmp.p = nullptr; SHODH_TRY(tmp.alloc(need)); tmp_bytes = need; }
     SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
-    SHODH_HIP_TRY(hipMemset(d_counts, 0, (size_t)k * 4));
-    hipLaunchKernelGGL(histogram_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, keys, n, d_counts);
-    host_counts.resize(k + 1);
-    SHODH_HIP_TRY(hipMemcpy(host_counts.data(), d_counts, (size_t)k * 4, hipMemcpyDeviceToHost));
-    uint32_t acc = 0;
-    for (uint32_t c = 0; c < k; ++c) { const uint32_t v = host_counts[c]; host_counts[c] = acc; acc += v; }
-    host_counts[k] = acc;
-    SHODH_HIP_TRY(hipMemcpy(offsets, host_counts.data(), (size_t)(k + 1) * 4, hipMemcpyHostToDevice));
     return SHODH_OK;
 }
 
@@ -698,18 +697,16 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
     SHODH_HIP_TRY(hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const uint32_t M = dim / 8, NC = 256;
-    const uint32_t kmax = P > NC ? P : NC;
-    Buf d_rows, d_cent, d_cb, d_assign, d_prev, d_idx, d_keys_out, d_members, d_off, d_counts, d_changed, d_perm, d_codes, d_keys, d_ad, d_ac, tmp;
+    Buf d_rows, d_cent, d_cb, d_assign, d_prev, d_idx, d_members, d_off, d_changed, d_perm, d_keys, d_ad, d_ac, tmp;
     size_t tmp_bytes = 0;
     SHODH_TRY(d_rows.alloc(n * dim * 4)); SHODH_TRY(d_cent.alloc((size_t)P * dim * 4)); SHODH_TRY(d_cb.alloc((size_t)M * NC * 8 * 4));
-    SHODH_TRY(d_assign.alloc(n * 4)); SHODH_TRY(d_prev.alloc(n * 4)); SHODH_TRY(d_idx.alloc(n * 4)); SHODH_TRY(d_keys_out.alloc(n * 4));
-    SHODH_TRY(d_members.alloc(n * 4)); SHODH_TRY(d_off.alloc((size_t)(kmax + 1) * 4)); SHODH_TRY(d_counts.alloc((size_t)kmax * 4));
-    SHODH_TRY(d_changed.alloc(8)); SHODH_TRY(d_perm.alloc((size_t)(M > 1 ? M : 1) * n * 4)); SHODH_TRY(d_codes.alloc(n * M));
+    SHODH_TRY(d_assign.alloc(n * 4)); SHODH_TRY(d_prev.alloc(n * 4)); SHODH_TRY(d_idx.alloc(n * 4));
+    SHODH_TRY(d_members.alloc((size_t)M * n * 4)); SHODH_TRY(d_off.alloc(((size_t)(P + 1) + (size_t)M * (NC + 1)) * 4));
+    SHODH_TRY(d_changed.alloc(8)); SHODH_TRY(d_perm.alloc((size_t)M * n * 4));
     SHODH_TRY(d_keys.alloc((size_t)M * n * 4));
     SHODH_TRY(d_ad.alloc(n * 4)); SHODH_TRY(d_ac.alloc(n * 4));
     SHODH_HIP_TRY(hipMemcpy(d_rows.p, rows, n * dim * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_idx.as<uint32_t>(), n);
-    std::vector<uint32_t> hc;
     struct CentIdx { shodh_index *p = nullptr; ~CentIdx() { if (p) shodh_index_destroy(p); } } ci;
 
     // ---- IVF centroids (spann.rs:466-541) ----
@@ -724,8 +721,9 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
         }
         SHODH_HIP_TRY(hipMemset(d_changed.p, 0, 8));
         hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_assign.as<uint32_t>(), d_prev.as<uint32_t>(), n, d_changed.as<unsigned long long>());
-        SHODH_TRY(sorted_members(d_assign.as<uint32_t>(), n, P, d_idx.as<uint32_t>(), d_keys_out.as<uint32_t>(), d_members.as<uint32_t>(), d_off.as<uint32_t>(), tmp, tmp_bytes, hc, d_counts.as<uint32_t>()));
-        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), dim, 0u, dim, d_members.as<uint32_t>(), d_off.as<uint32_t>(), P, d_cent.as<float>());
+        SHODH_TRY(sorted_members(d_assign.as<uint32_t>(), n, P, d_idx.as<uint32_t>(), d_perm.as<uint32_t>(), d_members.as<uint32_t>(), tmp, tmp_bytes));
+        hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)ceil_div((uint64_t)P + 1, 256)), dim3(256), 0, nullptr, d_perm.as<uint32_t>(), n, P, 1u, d_off.as<uint32_t>());
+        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, dim, 1u, d_members.as<uint32_t>(), d_off.as<uint32_t>(), P, d_cent.as<float>());
         SHODH_HIP_TRY(hipGetLastError());
         unsigned long long changed = 0;
         SHODH_HIP_TRY(hipMemcpy(&changed, d_changed.p, 8, hipMemcpyDeviceToHost));
@@ -736,14 +734,13 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
     // ---- PQ codebooks (pq.rs:131-217): the M subspaces advance in lock-step, they are independent ----
     SHODH_HIP_TRY(hipMemcpy(d_perm.p, init_perm_pq, (size_t)M * n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gather_sub_kernel, dim3((uint32_t)ceil_div((uint64_t)M * NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), d_perm.as<uint32_t>(), n, dim, M, NC, d_cb.as<float>());
-    for (uint32_t it = 0; it < pq_iters; ++it) {
-        hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)ceil_div(n * M, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, d_cb.as<float>(), M, NC, d_codes.as<uint8_t>());
-        hipLaunchKernelGGL(split_codes_kernel, dim3((uint32_t)ceil_div(n * M, 256)), dim3(256), 0, nullptr, d_codes.as<uint8_t>(), n, M, d_keys.as<uint32_t>());
+    for (uint32_t it = 0; it < pq_iters; ++it) {                      // d_perm is free after the gather: it holds the sorted keys from here on
+        hipLaunchKernelGGL(pq_encode_kernel<true>, dim3(pq_encode_grid(n, M)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, d_cb.as<float>(), M, NC, (uint8_t *)nullptr, d_keys.as<uint32_t>());
         SHODH_HIP_TRY(hipGetLastError());
-        for (uint32_t m = 0; m < M; ++m) {
-            SHODH_TRY(sorted_members(d_keys.as<uint32_t>() + (uint64_t)m * n, n, NC, d_idx.as<uint32_t>(), d_keys_out.as<uint32_t>(), d_members.as<uint32_t>(), d_off.as<uint32_t>(), tmp, tmp_bytes, hc, d_counts.as<uint32_t>()));
-            hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), dim, m * 8, 8u, d_members.as<uint32_t>(), d_off.as<uint32_t>(), NC, d_cb.as<float>() + (size_t)m * NC * 8);
-        }
+        for (uint32_t m = 0; m < M; ++m)
+            SHODH_TRY(sorted_members(d_keys.as<uint32_t>() + (uint64_t)m * n, n, NC, d_idx.as<uint32_t>(), d_perm.as<uint32_t>() + (uint64_t)m * n, d_members.as<uint32_t>() + (uint64_t)m * n, tmp, tmp_bytes));
+        hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)ceil_div((uint64_t)M * (NC + 1), 256)), dim3(256), 0, nullptr, d_perm.as<uint32_t>(), n, NC, M, d_off.as<uint32_t>());
+        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)M * NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, 8u, M, d_members.as<uint32_t>(), d_off.as<uint32_t>(), NC, d_cb.as<float>());
         SHODH_HIP_TRY(hipGetLastError());
     }
     SHODH_HIP_TRY(hipMemcpy(codebook_out, d_cb.p, (size_t)M * NC * 8 * 4, hipMemcpyDeviceToHost));
