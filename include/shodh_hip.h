@@ -218,6 +218,44 @@ size_t shodh_search_ids_postprocess(const uint32_t *vec_ids, const float *dists,
 size_t shodh_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t *uuids, const size_t *list_len,
                       uint8_t *out_uuid, float *out_score, size_t out_cap);
 
+/* ---- recall Layer 4: fusion of the hybrid (vector + BM25) leg with the graph leg (memory/mod.rs:3878-4468) ------
+ * The step right after search_ids on the recall path. Pure arithmetic over at most a few hundred
+ * candidates per request: host code. The reference reads its switches from environment variables inside recall; here they
+ * are fields, and shodh_leg_fusion_cfg_default() gives the reference's behaviour with every variable unset. */
+typedef struct {
+    /* fusion mode switches: SHODH_FUSION_V2 / _FLAT / _SUM / _RRF (mod.rs:3951-3953, :3964-3966, :4020-4022, :4041-4044).
+     * flat = fusion_flat || !(fusion_rrf || fusion_v2 || fusion_sum); the legs test them in the reference's order */
+    uint8_t fusion_v2, fusion_flat, fusion_sum, fusion_rrf;
+    uint8_t isolate_leg;          /* SHODH_LEG (:3975-3988): 0 unset, 1 vector, 2 bm25, 3 graph */
+    uint8_t flat_adaptive;        /* SHODH_FLAT_ADAPTIVE, default on (:4063-4065) */
+    uint8_t adapt_feature;        /* SHODH_ADAPT_FEATURE: 0 fitted (default), 1 agreement, 2 peak (:4090-4092) */
+    uint8_t adapt_symmetric;      /* SHODH_ADAPT_SYMMETRIC, default on (:4237-4244) */
+    float   graph_w, hybrid_w;    /* density weights, see shodh_leg_fusion_weights (defaults 0.3 / 0.7, :3878-3880, :3921) */
+    float   rrf_k;                /* RRF_K_GRAPH_FUSION = 30 (constants.rs:1198) */
+    float   flat_consensus;       /* SHODH_FLAT_CONSENSUS 0.3, clamped to [0,1] (:3990-3994) */
+    float   adapt_trust_max;      /* SHODH_ADAPT_TRUST_MAX 2.0 (:4067) */
+    float   fw_graph, fw_vec, fw_bm25;          /* SHODH_FW_* 0.3 / 0.6 / 0.4 (:4029-4031) */
+    float   agree_k, agree_lo, agree_hi;        /* SHODH_ADAPT_AGREE_* 10 / 0.1 / 0.5 (:4170-4172) */
+    float   peak_lo, peak_hi;                   /* SHODH_ADAPT_PEAK_* 2 / 6 (:4207-4208) */
+} shodh_leg_fusion_cfg;
+void shodh_leg_fusion_cfg_default(shodh_leg_fusion_cfg *c);
+/* calculate_density_weights (memory/graph_retrieval.rs:81-101): out = {semantic_w, graph_w, linguistic_w} */
+void shodh_density_weights(float graph_density, float *out3 /*[3]*/);
+/* mod.rs:3878-3921: (semantic, graph, linguistic) = density weights, or (0.6, 0.3, 0.1) without a density (has_density = 0);
+ * graph_weight_override (SHODH_GRAPH_FUSION_WEIGHT) and graph_w_floor (SHODH_GRAPH_W_FLOOR) are NaN when unset;
+ * hybrid_w = semantic_w + linguistic_w */
+void shodh_leg_fusion_weights(int has_density, float graph_density, float graph_weight_override, float graph_w_floor,
+                              float *graph_w, float *hybrid_w);
+/* The fusion itself. hybrid leg: n_hybrid candidates in hybrid rank order, uuid [n][16] with their BM25 and vector component
+ * scores (HybridSearchResult.bm25_score / vector_score, 0 when absent; a repeated uuid keeps its LAST components, like the
+ * HashMap insert at :3832-3838). graph leg: n_graph candidates in activation rank order with their activation.
+ * query_len = query_text.len() in bytes (a feature of the fitted gate, :4162). Output: every fused candidate with its score,
+ * sorted (score total_cmp desc, uuid asc) -- the reference keeps them in a HashMap, the order is ours. vec_trust_out
+ * (may be NULL) receives effective_vec_trust. Returns the number of fused candidates (only the first out_cap are written). */
+size_t shodh_fuse_legs(const shodh_leg_fusion_cfg *c, const uint8_t *hybrid_uuid, const float *hybrid_bm25, const float *hybrid_vec,
+                       size_t n_hybrid, const uint8_t *graph_uuid, const float *graph_activation, size_t n_graph, size_t query_len,
+                       uint8_t *out_uuid /*[out_cap][16]*/, float *out_score /*[out_cap]*/, size_t out_cap, float *vec_trust_out);
+
 /* ---- on-disk index formats of the reference (host code; both little-endian, FNV-1a-64 over everything after the header) --- */
 /* VAMA v1: src/vector_db/vamana_persist.rs:6-34 layout, :98-112 header bytes, :175-284 save_to_file, :290-391 load_from_file */
 typedef struct {

@@ -100,6 +100,9 @@ def lib():
         "so_calculate_tag_score": (C.c_float, [C.c_char_p, C.POINTER(C.c_char_p), sz]),
         "so_apply_recency_boost": (C.c_float, [C.c_float, C.c_int64, C.c_uint64, C.c_float]),
         "so_rrf_fuse": (sz, [C.c_float, fp, sz, u8p, C.POINTER(sz), u8p, fp, sz]),
+        "so_density_weights": (None, [C.c_float, fp]),
+        "so_leg_fusion_weights": (None, [C.c_int, C.c_float, C.c_float, C.c_float, fp, fp]),
+        "so_fuse_legs": (sz, [C.POINTER(C.c_int), fp, u8p, fp, fp, sz, u8p, fp, sz, sz, u8p, fp, sz, fp]),
         "so_fnv1a64": (C.c_uint64, [u8p, sz]),
         "so_bench_brute_force": (C.c_double, [fp, sz, sz, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
     }
@@ -429,6 +432,47 @@ def rrf_fuse(k, weights, lists):
     os_ = np.zeros(cap, np.float32)
     m = lib().so_rrf_fuse(k, _p(w, C.c_float), len(lists), _p(flat, C.c_uint8), lens, _p(ou, C.c_uint8), _p(os_, C.c_float), cap)
     return [bytes(ou[i]) for i in range(m)], os_[:m].copy()
+
+
+def density_weights(density):
+    out = np.zeros(3, np.float32)
+    lib().so_density_weights(density, _p(out, C.c_float))
+    return out
+
+
+def leg_fusion_weights(density=None, graph_weight_override=None, graph_w_floor=None):
+    g, h = C.c_float(), C.c_float()
+    nan = float("nan")
+    lib().so_leg_fusion_weights(int(density is not None), 0.0 if density is None else density,
+                                nan if graph_weight_override is None else graph_weight_override,
+                                nan if graph_w_floor is None else graph_w_floor, C.byref(g), C.byref(h))
+    return np.float32(g.value), np.float32(h.value)
+
+
+LEG_SW_DEFAULT = dict(fusion_v2=0, fusion_flat=0, fusion_sum=0, fusion_rrf=0, isolate_leg=0, flat_adaptive=1, adapt_feature=0, adapt_symmetric=1)
+LEG_FP_DEFAULT = dict(graph_w=0.3, hybrid_w=float(np.float32(0.6) + np.float32(0.1)), rrf_k=30.0, flat_consensus=0.3, adapt_trust_max=2.0,
+                      fw_graph=0.3, fw_vec=0.6, fw_bm25=0.4, agree_k=10.0, agree_lo=0.1, agree_hi=0.5, peak_lo=2.0, peak_hi=6.0)
+
+
+def fuse_legs(hybrid, graph, query_len, **cfg):
+    """hybrid: [(uuid16, bm25, vec)] in hybrid rank order; graph: [(uuid16, activation)] in rank order.
+    cfg: any key of LEG_SW_DEFAULT / LEG_FP_DEFAULT. Returns (uuids, scores, effective_vec_trust)."""
+    sw = dict(LEG_SW_DEFAULT); fpv = dict(LEG_FP_DEFAULT)
+    for k_, v in cfg.items():
+        if k_ in sw: sw[k_] = int(v)
+        elif k_ in fpv: fpv[k_] = float(v)
+        else: raise KeyError(k_)
+    swa = (C.c_int * 8)(*[sw[k_] for k_ in LEG_SW_DEFAULT])
+    fpa = np.array([fpv[k_] for k_ in LEG_FP_DEFAULT], np.float32)
+    hu = np.frombuffer(b"".join(h[0] for h in hybrid), np.uint8).copy() if hybrid else np.zeros(16, np.uint8)
+    hb = np.array([h[1] for h in hybrid] or [0], np.float32); hv = np.array([h[2] for h in hybrid] or [0], np.float32)
+    gu = np.frombuffer(b"".join(g[0] for g in graph), np.uint8).copy() if graph else np.zeros(16, np.uint8)
+    ga = np.array([g[1] for g in graph] or [0], np.float32)
+    cap = len(hybrid) + len(graph) + 1
+    ou = np.zeros((cap, 16), np.uint8); os_ = np.zeros(cap, np.float32); tr = C.c_float()
+    m = lib().so_fuse_legs(swa, _p(fpa, C.c_float), _p(hu, C.c_uint8), _p(hb, C.c_float), _p(hv, C.c_float), len(hybrid),
+                           _p(gu, C.c_uint8), _p(ga, C.c_float), len(graph), int(query_len), _p(ou, C.c_uint8), _p(os_, C.c_float), cap, C.byref(tr))
+    return [bytes(ou[i]) for i in range(m)], os_[:m].copy(), np.float32(tr.value)
 
 
 def fnv1a64(b: bytes):

@@ -857,6 +857,226 @@ size_t so_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t 
     return out;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* memory/mod.rs recall Layer 4: hybrid + graph leg fusion                               */
+/* ------------------------------------------------------------------------------------ */
+
+static inline float f32_clamp(float x, float lo, float hi) { if (x < lo) return lo; if (x > hi) return hi; return x; }  /* NaN stays */
+
+/* memory/graph_retrieval.rs:81-101 with constants.rs:478-510 */
+void so_density_weights(float graph_density, float out3[3]) {
+    const float GW_MIN = 0.1f, GW_MAX = 0.5f, LING = 0.15f, TH_MIN = 0.5f, TH_MAX = 2.0f;
+    float graph_weight;
+    if (graph_density <= TH_MIN) graph_weight = GW_MAX;
+    else if (graph_density >= TH_MAX) graph_weight = GW_MIN;
+    else {
+        float ratio = (graph_density - TH_MIN) / (TH_MAX - TH_MIN);
+        graph_weight = GW_MAX - ratio * (GW_MAX - GW_MIN);
+    }
+    out3[2] = LING;
+    out3[0] = 1.0f - graph_weight - LING;
+    out3[1] = graph_weight;
+}
+
+/* memory/mod.rs:3878-3921 */
+void so_leg_fusion_weights(int has_density, float graph_density, float graph_weight_override, float graph_w_floor,
+                           float *graph_w_out, float *hybrid_w_out) {
+    float semantic_w = 0.6f, graph_w = 0.3f, linguistic_w = 0.1f;
+    if (has_density) { float w[3]; so_density_weights(graph_density, w); semantic_w = w[0]; graph_w = w[1]; linguistic_w = w[2]; }
+    if (!isnan(graph_weight_override)) graph_w = f32_clamp(graph_weight_override, 0.0f, 1.0f);
+    if (!isnan(graph_w_floor)) {
+        float f = graph_w_floor;
+        if (f > graph_w) {
+            float max_floor = f32_max(1.0f - linguistic_w - 0.05f, 0.0f);
+            float requested = f32_clamp(f, 0.0f, 0.95f);
+            graph_w = f32_min(requested, max_floor);
+            semantic_w = f32_max(1.0f - graph_w - linguistic_w, 0.0f);
+        }
+    }
+    *graph_w_out = graph_w;
+    *hybrid_w_out = semantic_w + linguistic_w;
+}
+
+typedef struct { int h; float s; } leg_item_t;                 /* (handle of the id, score) */
+static const uint8_t *g_leg_ids;                               /* id table the comparator looks handles up in */
+static int leg_item_cmp(const void *pa, const void *pb) {      /* b.1.total_cmp(&a.1).then_with(|| a.0.cmp(b.0)) */
+    const leg_item_t *a = (const leg_item_t *)pa, *b = (const leg_item_t *)pb;
+    int c = so_total_cmp(b->s, a->s);
+    if (c) return c;
+    return memcmp(g_leg_ids + (size_t)a->h * 16, g_leg_ids + (size_t)b->h * 16, 16);
+}
+static float leg_peak(const leg_item_t *xs, size_t n) {        /* mod.rs:4123-4134 */
+    if (n == 0) return 1.0f;
+    float max = xs[0].s, sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum = sum + xs[i].s;
+    float mean = sum / (float)n;
+    if (mean > 1e-6f) return max / mean;
+    return 1.0f;
+}
+static float leg_overlap(const leg_item_t *by_vec, size_t nv, const leg_item_t *by_bm, size_t nb, size_t k) {
+    if (nv < k) k = nv;
+    if (nb < k) k = nb;
+    if (k < 1) k = 1;
+    size_t count = 0;
+    for (size_t i = 0; i < k && i < nb; ++i) {
+        int in_top_v = 0;
+        for (size_t j = 0; j < k && j < nv; ++j) if (by_vec[j].h == by_bm[i].h) in_top_v = 1;
+        count += (size_t)in_top_v;
+    }
+    return (float)count / (float)k;
+}
+
+size_t so_fuse_legs(const int sw[8], const float fp[13], const uint8_t *hybrid_uuid, const float *hybrid_bm25,
+                    const float *hybrid_vec, size_t n_hybrid, const uint8_t *graph_uuid, const float *graph_activation,
+                    size_t n_graph, size_t query_len, uint8_t *out_uuid, float *out_score, size_t out_cap, float *vec_trust_out) {
+    const int v2_fusion = sw[0], explicit_flat = sw[1], sum_fusion = sw[2], rrf_escape = sw[3], leg = sw[4];
+    const int flat_adaptive = sw[5], adapt_feature = sw[6], symmetric = sw[7];
+    const float graph_w = fp[0], hybrid_w = fp[1], k = fp[2];
+    const float flat_consensus = f32_clamp(fp[3], 0.0f, 1.0f), adapt_trust_max = fp[4];
+    const float fw_graph = fp[5], fw_vec = fp[6], fw_bm25 = fp[7];
+    /* one table of distinct ids (hybrid first, then graph); everything below works on handles into it */
+    size_t cap = n_hybrid + n_graph + 1, nid = 0;
+    uint8_t *ids = (uint8_t *)malloc(cap * 16);
+    int *hh = (int *)malloc((n_hybrid + 1) * sizeof(int)), *gh = (int *)malloc((n_graph + 1) * sizeof(int));
+    float *c_bm = (float *)calloc(cap, sizeof(float)), *c_vec = (float *)calloc(cap, sizeof(float));
+    char *in_comp = (char *)calloc(cap, 1), *in_fused = (char *)calloc(cap, 1);
+    float *fused = (float *)calloc(cap, sizeof(float));
+    size_t *first_seen = (size_t *)calloc(cap, sizeof(size_t));
+    for (size_t i = 0; i < n_hybrid + n_graph; ++i) {
+        const uint8_t *u = i < n_hybrid ? hybrid_uuid + i * 16 : graph_uuid + (i - n_hybrid) * 16;
+        size_t j = 0;
+        while (j < nid && memcmp(ids + j * 16, u, 16) != 0) ++j;
+        if (j == nid) { memcpy(ids + nid * 16, u, 16); ++nid; }
+        if (i < n_hybrid) hh[i] = (int)j; else gh[i - n_hybrid] = (int)j;
+    }
+    /* hybrid_components: HashMap insert, the last (bm25, vector) of an id wins (:3832-3838) */
+    size_t order_n = 0;
+    for (size_t i = 0; i < n_hybrid; ++i) {
+        int h = hh[i];
+        if (!in_comp[h]) { in_comp[h] = 1; first_seen[order_n++] = (size_t)h; }
+        c_bm[h] = hybrid_bm25[i]; c_vec[h] = hybrid_vec[i];
+    }
+    float max_activation = 0.0f;
+    for (size_t i = 0; i < n_graph; ++i) max_activation = f32_max(max_activation, graph_activation[i]);
+    float graph_max_act = max_activation;
+    max_activation = f32_max(max_activation, 1e-6f);
+    float n_graph_f = (float)(n_graph > 0 ? n_graph : 1), n_hybrid_f = (float)(n_hybrid > 0 ? n_hybrid : 1);
+    /* SHODH_LEG (:3975-3988) */
+    for (size_t o = 0; o < order_n; ++o) {
+        size_t h = first_seen[o];
+        if (leg == 1) { if (!(c_vec[h] > 0.0f)) in_comp[h] = 0; c_bm[h] = 0.0f; }
+        else if (leg == 2) { if (!(c_bm[h] > 0.0f)) in_comp[h] = 0; c_vec[h] = 0.0f; }
+        else if (leg == 3) in_comp[h] = 0;
+    }
+    int graph_leg_on = !(leg == 1 || leg == 2);
+    float max_vec = 0.0f, max_bm = 0.0f;
+    size_t n_comp = 0;
+    for (size_t o = 0; o < order_n; ++o) {
+        size_t h = first_seen[o];
+        if (!in_comp[h]) continue;
+        ++n_comp;
+        max_vec = f32_max(max_vec, c_vec[h]); max_bm = f32_max(max_bm, c_bm[h]);
+    }
+    max_vec = f32_max(max_vec, 1e-6f); max_bm = f32_max(max_bm, 1e-6f);
+    int flat_fusion = explicit_flat || (!rrf_escape && !v2_fusion && !sum_fusion);
+
+    float effective_vec_trust = 1.0f;
+    if (flat_adaptive) {
+        leg_item_t *by_vec = (leg_item_t *)malloc((order_n + 1) * sizeof(leg_item_t));
+        leg_item_t *by_bm = (leg_item_t *)malloc((order_n + 1) * sizeof(leg_item_t));
+        size_t nv = 0, nb = 0;
+        for (size_t o = 0; o < order_n; ++o) {
+            size_t h = first_seen[o];
+            if (!in_comp[h]) continue;
+            if (c_vec[h] > 0.0f) { by_vec[nv].h = (int)h; by_vec[nv].s = c_vec[h]; ++nv; }
+            if (c_bm[h] > 0.0f) { by_bm[nb].h = (int)h; by_bm[nb].s = c_bm[h]; ++nb; }
+        }
+        g_leg_ids = ids;
+        qsort(by_vec, nv, sizeof(leg_item_t), leg_item_cmp);
+        qsort(by_bm, nb, sizeof(leg_item_t), leg_item_cmp);
+        float t;
+        if (adapt_feature == 0) {                              /* fitted gate (:4093-4168) */
+            static const float FIT[11][3] = {
+                {2.77242f, 1.87083f, -0.301375f}, {1.3841f, 0.180661f, -0.0212517f}, {0.307389f, 0.170755f, -0.243719f},
+                {93.4129f, 43.8602f, -0.556471f}, {0.597371f, 0.0823258f, 0.236463f}, {106.897f, 36.4931f, 0.597537f},
+                {31.4138f, 7.54534f, -0.881755f}, {116.222f, 38.3149f, 0.582615f}, {9.90148f, 0.987682f, 0.304049f},
+                {0.358194f, 0.0710801f, 0.0264384f}, {54.1034f, 16.0475f, -0.571797f}};
+            float agreement = (nv == 0 || nb == 0) ? 0.0f : leg_overlap(by_vec, nv, by_bm, nb, 10);
+            float feats[11];
+            feats[0] = leg_peak(by_bm, nb); feats[1] = leg_peak(by_vec, nv); feats[2] = agreement; feats[3] = max_bm;
+            feats[4] = max_vec; feats[5] = (float)nb; feats[6] = (float)nv; feats[7] = (float)n_comp; feats[8] = (float)n_graph;
+            feats[9] = graph_max_act; feats[10] = (float)query_len;
+            float s = -0.985886f;
+            for (int i = 0; i < 11; ++i) { float z = FIT[i][2] * (feats[i] - FIT[i][0]); s = s + z / FIT[i][1]; }
+            t = 1.0f / (1.0f + expf(-f32_clamp(s, -30.0f, 30.0f)));
+        } else if (adapt_feature == 1) {                       /* agreement (:4169-4205) */
+            float kf = f32_max(fp[8], 1.0f);
+            size_t agree_k = kf >= 1.8446744e19f ? (size_t)-1 : (size_t)kf;
+            if (nb == 0) t = 1.0f;
+            else if (nv == 0) t = 0.0f;
+            else {
+                float overlap = leg_overlap(by_vec, nv, by_bm, nb, agree_k);
+                float span = f32_max(fp[10] - fp[9], 1e-6f);
+                t = f32_clamp((fp[10] - overlap) / span, 0.0f, 1.0f);
+            }
+        } else {                                               /* BM25 peakedness (:4206-4228); positive scores summed in first-insertion order */
+            float sum = 0.0f; size_t cnt = 0;
+            for (size_t o = 0; o < order_n; ++o) { size_t h = first_seen[o]; if (in_comp[h] && c_bm[h] > 0.0f) { sum = sum + c_bm[h]; ++cnt; } }
+            float mean_bm = cnt == 0 ? 0.0f : sum / (float)cnt;
+            float bm_peak = mean_bm > 1e-6f ? max_bm / mean_bm : 1.0f;
+            float span = f32_max(fp[12] - fp[11], 1e-6f);
+            t = f32_clamp((fp[12] - bm_peak) / span, 0.0f, 1.0f);
+        }
+        if (symmetric) effective_vec_trust = f32_max(1.0f + (adapt_trust_max - 1.0f) * (2.0f * t - 1.0f), 0.2f);
+        else effective_vec_trust = 1.0f + (adapt_trust_max - 1.0f) * t;
+        free(by_vec); free(by_bm);
+    }
+    if (vec_trust_out) *vec_trust_out = effective_vec_trust;
+
+    /* graph leg (:4348-4413) */
+    for (size_t r = 0; r < n_graph; ++r) {
+        if (!graph_leg_on) break;
+        float activation = graph_activation[r], rrf_score;
+        if (sum_fusion) rrf_score = fw_graph * f32_clamp(activation / max_activation, 0.0f, 1.0f);
+        else if (v2_fusion) {
+            float borda = graph_w * ((n_graph_f - (float)r) / n_graph_f);
+            float rescue = graph_w * f32_clamp(activation / max_activation, 0.0f, 1.0f);
+            rrf_score = borda + rescue;
+        } else if (flat_fusion) rrf_score = graph_w * f32_clamp(activation / max_activation, 0.0f, 1.0f);
+        else rrf_score = graph_w / (k + (float)(r + 1));
+        int h = gh[r];
+        in_fused[h] = 1;
+        fused[h] = fused[h] + rrf_score;
+        float activation_factor = 1.0f;
+        if (!(v2_fusion || sum_fusion)) activation_factor = 1.0f + graph_w * 0.3f * f32_clamp(activation, 0.0f, 1.0f);
+        fused[h] = fused[h] * activation_factor;
+    }
+    /* hybrid leg (:4414-4468) */
+    for (size_t r = 0; r < n_hybrid; ++r) {
+        int h = hh[r];
+        float bm25 = in_comp[h] ? c_bm[h] : 0.0f, vec = in_comp[h] ? c_vec[h] : 0.0f;
+        float hybrid_rrf;
+        if (sum_fusion) hybrid_rrf = fw_vec * f32_clamp(vec / max_vec, 0.0f, 1.0f) + fw_bm25 * f32_clamp(bm25 / max_bm, 0.0f, 1.0f);
+        else if (flat_fusion) {
+            float vn = f32_clamp(vec / max_vec, 0.0f, 1.0f) * effective_vec_trust;
+            float bn = f32_clamp(bm25 / max_bm, 0.0f, 1.0f);
+            float hi, lo;
+            if (vn >= bn) { hi = vn; lo = bn; } else { hi = bn; lo = vn; }
+            hybrid_rrf = hybrid_w * (hi + flat_consensus * lo);
+        } else if (v2_fusion) hybrid_rrf = hybrid_w * ((n_hybrid_f - (float)r) / n_hybrid_f);
+        else hybrid_rrf = hybrid_w / (k + (float)(r + 1));
+        in_fused[h] = 1;
+        fused[h] = fused[h] + hybrid_rrf;
+    }
+    uuid_score_t *res = (uuid_score_t *)malloc((nid + 1) * sizeof(uuid_score_t));
+    size_t nres = 0;
+    for (size_t h = 0; h < nid; ++h) if (in_fused[h]) { memcpy(res[nres].u, ids + h * 16, 16); res[nres].s = fused[h]; ++nres; }
+    qsort(res, nres, sizeof(uuid_score_t), uuid_score_cmp_desc);
+    for (size_t i = 0; i < nres && i < out_cap; ++i) { memcpy(out_uuid + i * 16, res[i].u, 16); out_score[i] = res[i].s; }
+    free(res); free(first_seen); free(fused); free(in_fused); free(in_comp); free(c_vec); free(c_bm); free(gh); free(hh); free(ids);
+    return nres;
+}
+
 /* vector_db/vamana_persist.rs:155-163 */
 uint64_t so_fnv1a64(const uint8_t *data, size_t len) {
     uint64_t h = 0xcbf29ce484222325ULL;

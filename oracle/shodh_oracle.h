@@ -147,6 +147,23 @@ float so_apply_recency_boost(float base, int64_t age_hours, uint64_t boost_hours
 size_t so_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8_t *uuids,
                    const size_t *list_len, uint8_t *out_uuid, float *out_score, size_t out_cap);
 
+/* ---- memory/mod.rs recall Layer 4: hybrid leg + graph leg fusion (:3878-4468) ----------
+ * The reference has no unit test with literal values for this block (it lives inside MemorySystem::recall), so this
+ * restatement is cross-checked against an independent numpy float32 restatement in tests/test_legfusion_cpu.py and
+ * against the density-weight tests graph_retrieval.rs:2447-2472: "parity unpinned" beyond those.
+ * Switches (environment variables in the reference) arrive as an int/float parameter block:
+ *   sw[0] SHODH_FUSION_V2, sw[1] SHODH_FUSION_FLAT, sw[2] SHODH_FUSION_SUM, sw[3] SHODH_FUSION_RRF,
+ *   sw[4] SHODH_LEG (0 unset, 1 vector, 2 bm25, 3 graph), sw[5] SHODH_FLAT_ADAPTIVE, sw[6] SHODH_ADAPT_FEATURE
+ *   (0 fitted, 1 agreement, 2 peak), sw[7] SHODH_ADAPT_SYMMETRIC
+ *   fp[0] graph_w, fp[1] hybrid_w, fp[2] k, fp[3] flat_consensus, fp[4] adapt_trust_max, fp[5..7] fw graph/vec/bm25,
+ *   fp[8..10] agree k/lo/hi, fp[11..12] peak lo/hi */
+void so_density_weights(float graph_density, float out3[3]);                 /* graph_retrieval.rs:81-101 */
+void so_leg_fusion_weights(int has_density, float graph_density, float graph_weight_override, float graph_w_floor,
+                           float *graph_w, float *hybrid_w);                 /* mod.rs:3878-3921; NaN = variable unset */
+size_t so_fuse_legs(const int sw[8], const float fp[13], const uint8_t *hybrid_uuid, const float *hybrid_bm25,
+                    const float *hybrid_vec, size_t n_hybrid, const uint8_t *graph_uuid, const float *graph_activation,
+                    size_t n_graph, size_t query_len, uint8_t *out_uuid, float *out_score, size_t out_cap, float *vec_trust_out);
+
 /* ---- vamana_persist.rs / spann.rs checksums ---------------------------------------- */
 uint64_t so_fnv1a64(const uint8_t *data, size_t len);          /* vamana_persist.rs:155-163 */
 

@@ -296,3 +296,26 @@ impl<T: Tokenize> Drop for HipEmbedder<T> {
 pub fn fuse_scores_full(w: &ffi::shodh_weights, sem: f32, ent: f32, tag: f32, imp: f32, momentum_ema: f32, access_count: u32, graph_strength: f32) -> f32 {
     unsafe { ffi::shodh_fuse_scores_full(w, sem, ent, tag, imp, momentum_ema, access_count, graph_strength) }
 }
+
+/// Recall Layer 4 (src/memory/mod.rs:3878-4468): the hybrid (vector + BM25) leg and the graph leg fused into one score per
+/// memory. `hybrid`: `(id, bm25_score, vector_score)` in hybrid rank order; `graph`: `(id, activation)` in rank order (ids are
+/// the 16 uuid bytes of `MemoryId`). `cfg` comes from `shodh_leg_fusion_cfg_default` with the SHODH_* switches recall reads
+/// from the environment copied into its fields and `graph_w` / `hybrid_w` from `shodh_leg_fusion_weights`.
+/// Returns the fused map (sorted score desc, id asc) and `effective_vec_trust`.
+pub fn fuse_legs(cfg: &ffi::shodh_leg_fusion_cfg, hybrid: &[([u8; 16], f32, f32)], graph: &[([u8; 16], f32)], query_len: usize) -> (Vec<([u8; 16], f32)>, f32) {
+    let hu: Vec<u8> = hybrid.iter().flat_map(|h| h.0).collect();
+    let hb: Vec<f32> = hybrid.iter().map(|h| h.1).collect();
+    let hv: Vec<f32> = hybrid.iter().map(|h| h.2).collect();
+    let gu: Vec<u8> = graph.iter().flat_map(|g| g.0).collect();
+    let ga: Vec<f32> = graph.iter().map(|g| g.1).collect();
+    let cap = hybrid.len() + graph.len();
+    let mut ou = vec![0u8; cap.max(1) * 16];
+    let mut os = vec![0f32; cap.max(1)];
+    let mut trust = 1.0f32;
+    let n = unsafe {
+        ffi::shodh_fuse_legs(cfg, hu.as_ptr(), hb.as_ptr(), hv.as_ptr(), hybrid.len(), gu.as_ptr(), ga.as_ptr(), graph.len(), query_len,
+                             ou.as_mut_ptr(), os.as_mut_ptr(), cap, &mut trust)
+    };
+    let out = (0..n.min(cap)).map(|i| { let mut u = [0u8; 16]; u.copy_from_slice(&ou[i * 16..i * 16 + 16]); (u, os[i]) }).collect();
+    (out, trust)
+}

@@ -17,7 +17,7 @@ if not (_sys.argv and _sys.argv[0] == "-m"):
 
 from .index import (BackendConfig, BackendType, DistanceMetric, SpannIndex, VamanaConfig,   # noqa: E402
                     VamanaIndex, VectorIndexBackend)
-from .relevance import LearnedWeights, calibrate_score                                      # noqa: E402
+from .relevance import LearnedWeights, LegFusion, calculate_density_weights, calibrate_score                                      # noqa: E402
 from .embedder import Embedder, MiniLMEmbedder                                              # noqa: E402
 from .retrieval import IdMapping, RetrievalEngine                                           # noqa: E402
 

@@ -52,6 +52,14 @@ class Weights(C.Structure):
                 ("update_count", C.c_uint32)]
 
 
+class LegFusionCfg(C.Structure):
+    _fields_ = [("fusion_v2", C.c_uint8), ("fusion_flat", C.c_uint8), ("fusion_sum", C.c_uint8), ("fusion_rrf", C.c_uint8),
+                ("isolate_leg", C.c_uint8), ("flat_adaptive", C.c_uint8), ("adapt_feature", C.c_uint8), ("adapt_symmetric", C.c_uint8),
+                ("graph_w", C.c_float), ("hybrid_w", C.c_float), ("rrf_k", C.c_float), ("flat_consensus", C.c_float),
+                ("adapt_trust_max", C.c_float), ("fw_graph", C.c_float), ("fw_vec", C.c_float), ("fw_bm25", C.c_float),
+                ("agree_k", C.c_float), ("agree_lo", C.c_float), ("agree_hi", C.c_float), ("peak_lo", C.c_float), ("peak_hi", C.c_float)]
+
+
 # every symbol include/shodh_hip.h declares: name -> (restype, argtypes)
 _vp, _fp, _u8p, _u32p, _u64p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 class VamaInfo(C.Structure):
@@ -116,6 +124,11 @@ SYMBOLS = {
     "shodh_span_load": (C.c_int, [C.c_char_p, _fp, _fp, _u64p, _u32p, _u8p]),
     "shodh_span_save": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _fp, _fp, _u64p, _u32p, _u8p]),
     "shodh_rrf_fuse": (C.c_size_t, [C.c_float, _fp, C.c_size_t, _u8p, C.POINTER(C.c_size_t), _u8p, _fp, C.c_size_t]),
+    "shodh_leg_fusion_cfg_default": (None, [C.POINTER(LegFusionCfg)]),
+    "shodh_density_weights": (None, [C.c_float, _fp]),
+    "shodh_leg_fusion_weights": (None, [C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "shodh_fuse_legs": (C.c_size_t, [C.POINTER(LegFusionCfg), _u8p, _fp, _fp, C.c_size_t, _u8p, _fp, C.c_size_t, C.c_size_t, _u8p, _fp,
+                                     C.c_size_t, C.POINTER(C.c_float)]),
     "shodh_embedder_dimension": (C.c_uint32, [_vp]),
     "shodh_embedder_encode_ids": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp]),
     "shodh_embedder_encode_ids_device": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp, _vp]),

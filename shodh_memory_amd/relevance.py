@@ -60,3 +60,77 @@ class LearnedWeights:
 
 def calibrate_score(score):
     return float(L.lib().shodh_calibrate_score(score))
+
+
+# ---- recall Layer 4: hybrid (vector + BM25) leg + graph leg fusion (src/memory/mod.rs:3878-4468) ----
+def calculate_density_weights(graph_density):
+    """graph_retrieval.rs:81-101 -> (semantic_weight, graph_weight, linguistic_weight)"""
+    out = np.zeros(3, np.float32)
+    L.lib().shodh_density_weights(graph_density, out.ctypes.data)
+    return float(out[0]), float(out[1]), float(out[2])
+
+
+class LegFusion:
+    """The fusion step after `search_ids` on the recall path. The reference reads its switches from SHODH_* environment
+    variables inside `MemorySystem::recall`; `from_env()` does the same, the constructor takes them as keywords
+    (field names of `shodh_leg_fusion_cfg`)."""
+    _FEATURES = {"fitted": 0, "agreement": 1}          # anything else is the peakedness feature (mod.rs:4206)
+    _LEGS = {"vector": 1, "bm25": 2, "graph": 3}
+
+    def __init__(self, graph_density=None, graph_weight_override=None, graph_w_floor=None, **fields):
+        self.cfg = L.LegFusionCfg()
+        L.lib().shodh_leg_fusion_cfg_default(C.byref(self.cfg))
+        g, h = C.c_float(), C.c_float()
+        nan = float("nan")
+        L.lib().shodh_leg_fusion_weights(int(graph_density is not None), 0.0 if graph_density is None else graph_density,
+                                         nan if graph_weight_override is None else graph_weight_override,
+                                         nan if graph_w_floor is None else graph_w_floor, C.byref(g), C.byref(h))
+        self.cfg.graph_w, self.cfg.hybrid_w = g.value, h.value
+        names = {f[0] for f in L.LegFusionCfg._fields_}
+        for k, v in fields.items():
+            if k not in names:
+                raise TypeError(f"unknown fusion field {k!r}")
+            setattr(self.cfg, k, v)
+
+    @classmethod
+    def from_env(cls, env, graph_density=None):
+        """env: a mapping like os.environ. Parsing as the reference: flags are "1"/"true" (on-by-default ones: not "0"/"false")."""
+        def on(key):
+            v = env.get(key)
+            return v is not None and (v == "1" or v.lower() == "true")
+
+        def not_off(key):
+            v = env.get(key)
+            return not (v is not None and (v == "0" or v.lower() == "false"))
+
+        def num(key, default):
+            try:
+                return float(env[key])
+            except (KeyError, ValueError):
+                return default
+        fields = dict(fusion_v2=on("SHODH_FUSION_V2"), fusion_flat=on("SHODH_FUSION_FLAT"), fusion_sum=on("SHODH_FUSION_SUM"),
+                      fusion_rrf=on("SHODH_FUSION_RRF"), isolate_leg=cls._LEGS.get(env.get("SHODH_LEG", ""), 0),
+                      flat_adaptive=not_off("SHODH_FLAT_ADAPTIVE"), adapt_symmetric=not_off("SHODH_ADAPT_SYMMETRIC"),
+                      adapt_feature=cls._FEATURES.get(env.get("SHODH_ADAPT_FEATURE", "fitted").lower(), 2),
+                      flat_consensus=num("SHODH_FLAT_CONSENSUS", 0.3), adapt_trust_max=num("SHODH_ADAPT_TRUST_MAX", 2.0),
+                      fw_graph=num("SHODH_FW_GRAPH", 0.3), fw_vec=num("SHODH_FW_VEC", 0.6), fw_bm25=num("SHODH_FW_BM25", 0.4),
+                      agree_k=num("SHODH_ADAPT_AGREE_K", 10.0), agree_lo=num("SHODH_ADAPT_AGREE_LO", 0.1),
+                      agree_hi=num("SHODH_ADAPT_AGREE_HI", 0.5), peak_lo=num("SHODH_ADAPT_PEAK_LO", 2.0), peak_hi=num("SHODH_ADAPT_PEAK_HI", 6.0))
+        return cls(graph_density=graph_density,
+                   graph_weight_override=num("SHODH_GRAPH_FUSION_WEIGHT", None), graph_w_floor=num("SHODH_GRAPH_W_FLOOR", None), **fields)
+
+    def fuse(self, hybrid, graph, query_len):
+        """hybrid: [(uuid bytes16, bm25_score, vector_score)] in hybrid rank order; graph: [(uuid bytes16, activation)] in rank
+        order. Returns ([(uuid, fused score)] sorted score desc / uuid asc, effective_vec_trust)."""
+        hu = np.frombuffer(b"".join(h[0] for h in hybrid), np.uint8).copy() if hybrid else np.zeros(16, np.uint8)
+        hb = np.array([h[1] for h in hybrid] or [0], np.float32)
+        hv = np.array([h[2] for h in hybrid] or [0], np.float32)
+        gu = np.frombuffer(b"".join(g[0] for g in graph), np.uint8).copy() if graph else np.zeros(16, np.uint8)
+        ga = np.array([g[1] for g in graph] or [0], np.float32)
+        cap = len(hybrid) + len(graph) + 1
+        ou = np.zeros((cap, 16), np.uint8)
+        os_ = np.zeros(cap, np.float32)
+        trust = C.c_float()
+        m = L.lib().shodh_fuse_legs(C.byref(self.cfg), hu.ctypes.data, hb.ctypes.data, hv.ctypes.data, len(hybrid), gu.ctypes.data,
+                                    ga.ctypes.data, len(graph), int(query_len), ou.ctypes.data, os_.ctypes.data, cap, C.byref(trust))
+        return [(bytes(ou[i]), float(os_[i])) for i in range(m)], float(trust.value)
