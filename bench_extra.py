@@ -143,12 +143,17 @@ def main():
         rows = bench.synth_rows(torch, n, 384, 1, dev).cpu().numpy()
         idx = S.SpannIndex(384, num_probes=32)
         P = idx.compute_partitions(n)
-        for ivf_it, pq_it in ((2, 1), (6, 3)):
+        t = time.perf_counter()
+        rng = np.random.default_rng(5)                       # the initial shuffles (thread_rng in the reference): host work, timed apart
+        ip = rng.permutation(n).astype(np.uint32)
+        pp = [rng.permutation(n).astype(np.uint32) for _ in range(48)]
+        t_shuffle = time.perf_counter() - t
+        for ivf_it, pq_it in ((2, 1), (6, 3), (25, 20)):     # (25, 20) = the reference's default iteration counts (spann.rs:110, pq.rs:55)
             t = time.perf_counter()
-            idx.train(rows, P, ivf_it, pq_it, seed=5)
+            idx.train(rows, P, ivf_it, pq_it, ivf_perm=ip, pq_perms=pp)
             dt = time.perf_counter() - t
-            print(json.dumps({"bench": "device k-means (SpannIndex::build training), %d rows x 384, P = %d, %d IVF + %d PQ iterations (incl. H2D of the rows)" % (n, P, ivf_it, pq_it),
-                              "seconds": round(dt, 3)}), flush=True)
+            print(json.dumps({"bench": "device k-means (SpannIndex::build training), %d rows x 384, P = %d, %d IVF + %d PQ iterations (incl. H2D of the rows and shuffles)" % (n, P, ivf_it, pq_it),
+                              "seconds": round(dt, 3), "host_shuffles_seconds": round(t_shuffle, 3)}), flush=True)
     if what in ("ivfpq", "all"):
         n = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 10_000_000
         P, nprobe, nq, k = 4096, 32, 1024, 10

@@ -91,7 +91,7 @@ static int make_centroid_index(int device, uint32_t dim, const float *d_centroid
 }
 static int nearest_centroids(shodh_index *ci, const float *d_q, uint64_t nq, uint32_t dim, uint32_t k, uint32_t *d_ids, float *d_dist,
                              uint32_t *d_cnt, hipStream_t st) {
-    const uint64_t CH = 4096;             // queries per call: bounds the pre-scan's candidate workspace
+    const uint64_t CH = 8192;             // queries per call: bounds the pre-scan's candidate workspace (32 KiB per query)
     for (uint64_t b = 0; b < nq; b += CH) {
         const uint32_t m = (uint32_t)((nq - b) < CH ? (nq - b) : CH);
         SHODH_TRY(shodh_index_search_device(ci, d_q + b * dim, m, k, d_ids + b * k, d_dist + b * k, d_cnt + b, (void *)st));
@@ -639,28 +639,45 @@ __global__ void offsets_kernel(const uint32_t *sorted_keys, uint64_t n, uint32_t
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < c) lo = mid + 1; else hi = mid; }
     offsets[t] = (uint32_t)lo;
 }
-// one thread per (sub-space, cluster, coordinate): the members in index order, one add each, then / count (spann.rs:508-527,
-// pq.rs:193-212). Sub-space `sub` owns columns [sub*width, sub*width+width) of the rows (IVF: one sub-space of width dim).
-__global__ void mean_update_kernel(const float *rows, uint64_t n, uint32_t dim, uint32_t width, uint32_t nsub, const uint32_t *members /* [nsub][n] */,
-                                   const uint32_t *offsets /* [nsub][k+1] */, uint32_t k, float *cent /* [nsub][k][width] */) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)nsub * k * width) return;
-    const uint32_t j = (uint32_t)(t % width), c = (uint32_t)((t / width) % k), sub = (uint32_t)(t / ((uint64_t)width * k));
+// One WAVE per (sub-space, cluster, group of 8 coordinates): the members in index order, one add each, then / count
+// (spann.rs:508-527, pq.rs:193-212). The adds of one coordinate are a serial chain by definition, so the parallelism inside a
+// cluster is in the LOADS: lane = (member slot 0..7, coordinate 0..7); 16 x 8 members are fetched per step (and the next step's
+// are already in flight) and every lane then walks the 128 values of its coordinate in member order through ds_bpermute. Slots
+// past the end add +0.0, which leaves an f32 sum that started at +0.0 unchanged. Sub-space `sub` owns columns
+// [sub*width, sub*width+width) of the rows (IVF: one sub-space of width dim); width % 8 == 0.
+constexpr int MU_U = 16;
+__global__ __launch_bounds__(256) void mean_update_kernel(const float *rows, uint64_t n, uint32_t dim, uint32_t width, uint32_t nsub, const uint32_t *members /* [nsub][n] */,
+                                                          const uint32_t *offsets /* [nsub][k+1] */, uint32_t k, float *cent /* [nsub][k][width] */) {
+    const uint64_t w = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t groups = width >> 3;
+    if (w >= (uint64_t)nsub * k * groups) return;                                      // wave-uniform
+    const uint32_t lane = threadIdx.x & 63, slot = lane >> 3, j = lane & 7;
+    const uint32_t g = (uint32_t)(w % groups), c = (uint32_t)((w / groups) % k), sub = (uint32_t)(w / ((uint64_t)groups * k));
     const uint32_t *mem = members + (uint64_t)sub * n;
     const uint32_t lo = offsets[(uint64_t)sub * (k + 1) + c], hi = offsets[(uint64_t)sub * (k + 1) + c + 1];
-    if (hi == lo) return;                                            // empty cluster keeps its centroid
-    const float *col = rows + (uint64_t)sub * width + j;
+    if (hi == lo) return;                                                              // empty cluster keeps its centroid
+    const float *col = rows + (uint64_t)sub * width + g * 8 + j;
+    float cur[MU_U], nxt[MU_U] = {};
+    auto fetch = [&](uint32_t i0, float *v) {                                          // unconditional loads on clamped indices
+#pragma unroll
+        for (int u = 0; u < MU_U; ++u) {
+            const uint32_t i = i0 + u * 8 + slot;
+            const float x = col[(uint64_t)mem[i < hi ? i : hi - 1] * dim];
+            v[u] = i < hi ? x : 0.0f;
+        }
+    };
+    fetch(lo, cur);
     float sum = 0.0f;
-    uint32_t i = lo;
-    for (; i + 16 <= hi; i += 16) {                                  // the loads are independent, only the adds are ordered
-        float v[16];
+    for (uint32_t i0 = lo; i0 < hi; i0 += MU_U * 8) {
+        if (i0 + MU_U * 8 < hi) fetch(i0 + MU_U * 8, nxt);                             // wave-uniform condition
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = col[(uint64_t)mem[i + u] * dim];
+        for (int u = 0; u < MU_U; ++u)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sum = sum + v[u];
+            for (int s = 0; s < 8; ++s) sum = sum + __shfl(cur[u], s * 8 + (int)j);
+#pragma unroll
+        for (int u = 0; u < MU_U; ++u) cur[u] = nxt[u];
     }
-    for (; i < hi; ++i) sum = sum + col[(uint64_t)mem[i] * dim];
-    cent[t] = sum / (float)(hi - lo);
+    if (slot == 0) cent[((uint64_t)sub * k + c) * width + g * 8 + j] = sum / (float)(hi - lo);
 }
 
 struct Buf {
@@ -723,7 +740,7 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
         hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, nullptr, d_assign.as<uint32_t>(), d_prev.as<uint32_t>(), n, d_changed.as<unsigned long long>());
         SHODH_TRY(sorted_members(d_assign.as<uint32_t>(), n, P, d_idx.as<uint32_t>(), d_perm.as<uint32_t>(), d_members.as<uint32_t>(), tmp, tmp_bytes));
         hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)ceil_div((uint64_t)P + 1, 256)), dim3(256), 0, nullptr, d_perm.as<uint32_t>(), n, P, 1u, d_off.as<uint32_t>());
-        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)P * dim, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, dim, 1u, d_members.as<uint32_t>(), d_off.as<uint32_t>(), P, d_cent.as<float>());
+        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)P * (dim / 8) * 64, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, dim, 1u, d_members.as<uint32_t>(), d_off.as<uint32_t>(), P, d_cent.as<float>());
         SHODH_HIP_TRY(hipGetLastError());
         unsigned long long changed = 0;
         SHODH_HIP_TRY(hipMemcpy(&changed, d_changed.p, 8, hipMemcpyDeviceToHost));
@@ -740,7 +757,7 @@ extern "C" int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint
         for (uint32_t m = 0; m < M; ++m)
             SHODH_TRY(sorted_members(d_keys.as<uint32_t>() + (uint64_t)m * n, n, NC, d_idx.as<uint32_t>(), d_perm.as<uint32_t>() + (uint64_t)m * n, d_members.as<uint32_t>() + (uint64_t)m * n, tmp, tmp_bytes));
         hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)ceil_div((uint64_t)M * (NC + 1), 256)), dim3(256), 0, nullptr, d_perm.as<uint32_t>(), n, NC, M, d_off.as<uint32_t>());
-        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)M * NC * 8, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, 8u, M, d_members.as<uint32_t>(), d_off.as<uint32_t>(), NC, d_cb.as<float>());
+        hipLaunchKernelGGL(mean_update_kernel, dim3((uint32_t)ceil_div((uint64_t)M * NC * 64, 256)), dim3(256), 0, nullptr, d_rows.as<float>(), n, dim, 8u, M, d_members.as<uint32_t>(), d_off.as<uint32_t>(), NC, d_cb.as<float>());
         SHODH_HIP_TRY(hipGetLastError());
     }
     SHODH_HIP_TRY(hipMemcpy(codebook_out, d_cb.p, (size_t)M * NC * 8 * 4, hipMemcpyDeviceToHost));

@@ -548,6 +548,8 @@ struct FinalArgs {
     uint32_t cand_cap;
     const float *eps;         // [n_slots]
     uint32_t fcap;            // capacity of the re-score list
+    uint32_t stage_cap;       // candidate keys staged in LDS (<= FS_STAGE; the rest, if any, is re-read from global)
+    uint32_t ch_rows;         // AVX2 / sequential order: rows of the window staged at a time (<= FS_CH)
     uint32_t order;
     uint32_t id_base;
     uint32_t *fallback;       // [n_slots] in/out
@@ -599,10 +601,10 @@ constexpr int FS_RW = 16;      // scalar-4 order: rows in flight per wave (FS_TC
 constexpr int FS_STAGE = 2048; // candidate keys staged in LDS (the rest, if any, is re-read from global)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim) {
+__host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim, uint32_t order, uint32_t ch_rows) {
     const size_t a = (size_t)FS_TC * (dim / 4 + 1) * 4;
-    const size_t b = (size_t)FS_CH * (dim + 8) * 4 + (size_t)FS_CH * 8 * 4;
-    return ((a > b ? a : b) + 15) & ~(size_t)15;
+    const size_t b = (size_t)ch_rows * (dim + 8) * 4 + (size_t)ch_rows * 8 * 4;
+    return ((order == SHODH_ORDER_SCALAR4 ? a : b) + 15) & ~(size_t)15;
 }
 
 template <int ORDER>
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     uint32_t *cnt = flist + a.fcap;
     uint32_t *fcnt = cnt + 1;
     float *region = reinterpret_cast<float *>(fcnt + 1);                  // 16-B aligned: thr sits at a 16-B boundary
-    uint32_t *sel32 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(region) + final_stage_region_bytes(a.dim));   // [KTH_SCRATCH_U32]
+    uint32_t *sel32 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(region) + final_stage_region_bytes(a.dim, ORDER, a.ch_rows));   // [KTH_SCRATCH_U32]
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (q >= a.nq) return;
@@ -636,8 +638,8 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     bool bad = a.fallback[q] != 0 || n_ovf > a.cand_cap;
     const uint32_t n = n_main + (bad ? 0u : n_ovf);
     uint32_t *ecnt = sel32 + KTH_SCRATCH_U32 - 1;    // number of real candidates (statistics)
-    uint32_t *skey = sel32 + KTH_SCRATCH_U32;        // [FS_STAGE] score keys (high words) of the candidates, staged once
-    uint32_t *srow = skey + FS_STAGE;                // [FS_STAGE] their rows (low words)
+    uint32_t *skey = sel32 + KTH_SCRATCH_U32;        // [stage_cap] score keys (high words) of the candidates, staged once
+    uint32_t *srow = skey + a.stage_cap;             // [stage_cap] their rows (low words)
     PROF_DECL
     if (!bad) {
 #pragma unroll
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
         const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
         auto key_glb = [&](uint32_t i) -> uint64_t { return i < n_main ? slots_q[i] : list[i - n_main]; };
         // the candidate keys are read three times (filter, gather, window): stage them in LDS once
-        const uint32_t n_st = n < (uint32_t)FS_STAGE ? n : (uint32_t)FS_STAGE;
+        const uint32_t n_st = n < a.stage_cap ? n : a.stage_cap;
         const uint32_t st_main = n_main < n_st ? n_main : n_st;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; if (i < st_main) { skey[i] = (uint32_t)(kv[j] >> 32); srow[i] = (uint32_t)kv[j]; } }
@@ -777,9 +779,10 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                 const uint32_t rp = dim + 8;
                 float *rowbuf = region;
                 f32x4 *rowbuf4 = reinterpret_cast<f32x4 *>(rowbuf);
-                float *tbuf = rowbuf + (size_t)FS_CH * rp;
-                for (uint32_t c0 = 0; c0 < nf; c0 += FS_CH) {
-                    const uint32_t nc = (nf - c0) < (uint32_t)FS_CH ? (nf - c0) : (uint32_t)FS_CH;
+                const uint32_t ch = a.ch_rows;
+                float *tbuf = rowbuf + (size_t)ch * rp;
+                for (uint32_t c0 = 0; c0 < nf; c0 += ch) {
+                    const uint32_t nc = (nf - c0) < ch ? (nf - c0) : ch;
                     for (uint32_t e = tid; e < nc * d4; e += 256) {
                         const uint32_t c = e / d4, j = e % d4;
                         rowbuf4[c * (rp >> 2) + j] = *reinterpret_cast<const f32x4 *>(a.rows + (size_t)flist[c0 + c] * dim + j * 4);
@@ -987,11 +990,24 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
 
     const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
-    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, p.fcap, order, id_base,
+    // LDS of the final stage. One workgroup per query: with a few hundred queries every workgroup has a CU to itself and the
+    // generous sizes cost nothing; with thousands of queries (nearest-centroid searches of k-means / IVF encoding) the
+    // workgroups per CU are what counts, so the re-score list, the key staging and the row staging shrink to what such
+    // searches need (a query that outgrows them goes to the exact scan like any other overflow).
+    uint32_t fcap = p.fcap, stage_cap = (uint32_t)FS_STAGE, ch_rows = (uint32_t)FS_CH;
+    if (nq >= 1024) {
+        fcap = next_pow2(4u * (k ? k : 1) > 256u ? 4u * (k ? k : 1) : 256u);
+        if (fcap > p.fcap) fcap = p.fcap;
+        stage_cap = next_pow2(nb_emit * (uint32_t)MF_SLOTS + 256u);
+        if (stage_cap > (uint32_t)FS_STAGE) stage_cap = (uint32_t)FS_STAGE;
+        ch_rows = next_pow2(k ? k : 1);
+        ch_rows = ch_rows < 4u ? 4u : (ch_rows > (uint32_t)FS_CH ? (uint32_t)FS_CH : ch_rows);
+    }
+    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, fcap, stage_cap, ch_rows, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
-    // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32   (every part a multiple of 8 B; region at 16 B)
-    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)p.fcap * 8 + 8 + (size_t)p.fcap * 4 + 8 +
-                        final_stage_region_bytes(dim) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)FS_STAGE * 8 + 16;
+    // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
+    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
+                        final_stage_region_bytes(dim, order, ch_rows) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
     if (order == SHODH_ORDER_SEQ_1M) {
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_SEQ_1M>, flds));
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SEQ_1M>), dim3(nq), dim3(256), flds, st, f);

@@ -415,3 +415,22 @@ def test_sequential_one_minus_dot_order(S, oracle, mode):
         top = np.argsort(key, kind="stable")[:k]
         assert ids[i].tolist() == top.tolist()
         assert dist[i].tobytes() == d[top].tobytes()
+
+
+@pytest.mark.parametrize("order_name,k", [("ORDER_SEQ_1M", 1), ("ORDER_SEQ_1M", 32), ("ORDER_SCALAR4", 10), ("ORDER_AVX2", 3)])
+def test_many_query_batches_use_the_lean_final_stage(S, order_name, k):
+    """More than 1024 queries per call (the nearest-centroid searches of k-means and IVF encoding): the final stage runs with
+    its small LDS footprint. The MFMA path must return exactly what the exact-order scan returns."""
+    from shodh_memory_amd import _lib as L
+    n, nq = (3000 if order_name == "ORDER_SEQ_1M" else 20000), 2500      # the pre-scan needs >= 16384 rows outside the centroid order
+    q = synth.queries(nq)
+    rows = synth.corpus(n, queries=q[:50])
+    out = {}
+    for mode in (1, 2):
+        idx = make_index(S, order=getattr(L, order_name), scan_mode=mode)
+        idx.build(rows)
+        out[mode] = idx.search_batch(q, k)
+        if mode == 2:
+            st = idx.scan_stats()
+            assert st["sampled_rows"] > 0, "MFMA path was not taken"
+    assert np.array_equal(out[1][0], out[2][0]) and out[1][1].tobytes() == out[2][1].tobytes() and np.array_equal(out[1][2], out[2][2])
