@@ -112,12 +112,14 @@ struct AdcArgs {
     uint64_t *partial;         // [nq][split][k]
 };
 
-constexpr int ADC_U = 2;        // postings per thread and iteration
+constexpr int ADC_U = 1;        // postings per thread and iteration
+constexpr int ADC_NT = 1024;    // threads per workgroup: the 48 KiB table allows two workgroups per CU; 2 x 16 waves keep the LDS gathers busy
+                                // (measured at 10M rows, batch 1024: 256 threads x 2 postings 2.36 ms, 512 x 2 1.87 ms, 1024 x 1 1.73 ms)
 constexpr int ADC_MAXP = 256;   // probed lists per query (nprobe is capped at P and at this)
 // FULL256: 256 codewords per sub-quantiser (always the case for a reference-built index, pq.rs:27): an 8-bit code cannot
 // leave the table, so the range check disappears and the table row becomes an immediate offset of the LDS read.
-template <bool FULL256>
-__global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
+template <bool FULL256, int NT>
+__global__ __launch_bounds__(NT) void adc_scan_kernel(AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *table = reinterpret_cast<float *>(smem);                              // [M][ncent]
     uint64_t *keys = reinterpret_cast<uint64_t *>(table + (size_t)a.M * a.ncent);  // [cap]
@@ -128,11 +130,11 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     uint32_t *seg_start = reinterpret_cast<uint32_t *>(seg_base + ADC_MAXP);        // [ADC_MAXP + 1] start of each segment in the block's posting space
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x, part = blockIdx.y;
-    for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = a.q[(size_t)q * a.dim + i];
+    for (uint32_t i = tid; i < a.dim; i += NT) qs[i] = a.q[(size_t)q * a.dim + i];
     if (tid == 0) { *cnt = 0; *thr = a.k ? KEY_NONE : 0; }
     __syncthreads();
     // build_distance_table (pq.rs:329-351): one (m, c) entry per thread-iteration, 8 sequential terms
-    for (uint32_t e = tid; e < a.M * a.ncent; e += 256) {
+    for (uint32_t e = tid; e < a.M * a.ncent; e += NT) {
         const uint32_t m = e / a.ncent;
         const float *cb = a.codebook + (size_t)e * 8;
         const float *qq = qs + m * 8;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
     auto fetch = [&](uint32_t g0) {
 #pragma unroll
         for (int u = 0; u < ADC_U; ++u) {
-            const uint32_t g = g0 + u * 256 + tid;
+            const uint32_t g = g0 + u * NT + tid;
             const uint64_t e = locate(g < total ? g : (total ? total - 1 : 0));      // clamped: unconditional loads
             ev[u] = e;
             if (wide) {
@@ -188,16 +190,16 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
         }
     };
     if (total) fetch(0);
-    for (uint32_t g0 = 0; g0 < total; g0 += 256 * ADC_U) {
+    for (uint32_t g0 = 0; g0 < total; g0 += NT * ADC_U) {
         uint4 cc[ADC_U][3];
         uint32_t idc[ADC_U];
         uint64_t ec[ADC_U];
 #pragma unroll
         for (int u = 0; u < ADC_U; ++u) { cc[u][0] = cw[u][0]; cc[u][1] = cw[u][1]; cc[u][2] = cw[u][2]; idc[u] = idv[u]; ec[u] = ev[u]; }
-        if (g0 + 256 * ADC_U < total) fetch(g0 + 256 * ADC_U);
+        if (g0 + NT * ADC_U < total) fetch(g0 + NT * ADC_U);
 #pragma unroll
         for (int u = 0; u < ADC_U; ++u) {
-            const uint32_t g = g0 + u * 256 + tid;
+            const uint32_t g = g0 + u * NT + tid;
             if (g < total) {
                 float totald = 0.0f;
                 bool bad = false;
@@ -236,13 +238,13 @@ __global__ __launch_bounds__(256) void adc_scan_kernel(AdcArgs a) {
             }
         }
         __syncthreads();
-        if (*buf.cnt + 256 * ADC_U > a.cap) topk_compact<256>(buf);
+        if (*buf.cnt + NT * ADC_U > a.cap) topk_compact<NT>(buf);
     }
     __syncthreads();
-    topk_compact<256>(buf);
+    topk_compact<NT>(buf);
     uint64_t *out = a.partial + ((size_t)q * a.split + part) * a.k;
     const uint32_t m = *buf.cnt;
-    for (uint32_t i = tid; i < a.k; i += 256) out[i] = (i < m) ? buf.keys[i] : KEY_NONE;
+    for (uint32_t i = tid; i < a.k; i += NT) out[i] = (i < m) ? buf.keys[i] : KEY_NONE;
 }
 
 struct AdcMergeArgs {
@@ -386,7 +388,9 @@ static IvfpqLayout ivfpq_layout(const IvfpqState *s, const shodh_index_cfg &cfg,
     L.cap = topk_capacity(k);
     // split a query's probed lists over several blocks when the batch alone cannot fill the chip
     L.split = 1;
-    while ((uint64_t)nq * L.split < (uint64_t)s->cus * 4 && L.split < 32) L.split <<= 1;
+    while ((uint64_t)nq * L.split < (uint64_t)s->cus * 8 && L.split < 32) L.split <<= 1;    // two workgroups per CU are resident: at least four rounds of them
+    static const int env_split = getenv("SHODH_ADC_SPLIT") ? atoi(getenv("SHODH_ADC_SPLIT")) : 0;     // diagnostic
+    if (env_split > 0) L.split = (uint32_t)env_split;
     L.gx = exact_grid_x(s->P, nq, L.nprobe, s->cus);
     const size_t part_probe = exact_partial_bytes(nq, s->dim, L.nprobe, L.gx);
     size_t o = 0;
@@ -431,16 +435,18 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
                                     probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
     }
     // 2. ADC table + list scan, 3. merge
-    AdcArgs a{d_q, s->codebook, s->list_off, s->ids, s->codes, probe_ids, probe_cnt, nq, s->dim, s->M, s->ncent, nprobe, k, cap, split, partial};
-    const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
+    uint32_t scan_cap = next_pow2(k + (uint32_t)(ADC_NT * ADC_U));     // room for one iteration's pushes on top of the k kept keys
+    if (scan_cap < cap) scan_cap = cap;
+    AdcArgs a{d_q, s->codebook, s->list_off, s->ids, s->codes, probe_ids, probe_cnt, nq, s->dim, s->M, s->ncent, nprobe, k, scan_cap, split, partial};
+    const size_t lds = (size_t)s->M * s->ncent * 4 + (size_t)scan_cap * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
     if (lds > 160 * 1024) { set_error("IVF-PQ: dim/k too large for LDS (%zu B)", lds); return SHODH_ERR_UNSUPPORTED; }
     if (nprobe > (uint32_t)ADC_MAXP) { set_error("IVF-PQ: nprobe %u > %d", nprobe, ADC_MAXP); return SHODH_ERR_UNSUPPORTED; }
     if (s->ncent == 256) {
-        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<true>, lds));
-        hipLaunchKernelGGL(adc_scan_kernel<true>, dim3(nq, split), dim3(256), lds, st, a);
+        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<true, ADC_NT>, lds));
+        hipLaunchKernelGGL((adc_scan_kernel<true, ADC_NT>), dim3(nq, split), dim3(ADC_NT), lds, st, a);
     } else {
-        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<false>, lds));
-        hipLaunchKernelGGL(adc_scan_kernel<false>, dim3(nq, split), dim3(256), lds, st, a);
+        SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<false, ADC_NT>, lds));
+        hipLaunchKernelGGL((adc_scan_kernel<false, ADC_NT>), dim3(nq, split), dim3(ADC_NT), lds, st, a);
     }
     SHODH_HIP_TRY(hipGetLastError());
     AdcMergeArgs m{partial, split, k, cap, d_ids, d_dist, d_counts};
