@@ -757,7 +757,11 @@ static int gemm_k384_stream(const __bf16 *X, const __bf16 *Wp, const float *bias
     if (n_workers > n_tiles) n_workers = n_tiles > 0 ? n_tiles : 1;
     const size_t lds = (size_t)GS_NBUF * GS_TILE + 8 * 2048;      // + one 2 KiB epilogue scratch per wave = exactly 160 KiB
     SHODH_TRY(ensure_dynamic_lds((const void *)gemm_k384_stream_kernel<EPI>, lds));
-    static const bool no_store = getenv("SHODH_ENC_NOSTORE") && atoi(getenv("SHODH_ENC_NOSTORE"));   // diagnostics: results invalid
+#ifdef SHODH_DIAG      // diagnostic build only (-DSHODH_DIAG): drops the GEMM stores to time the rest, results invalid
+    static const bool no_store = getenv("SHODH_ENC_NOSTORE") && atoi(getenv("SHODH_ENC_NOSTORE"));
+#else
+    const bool no_store = false;
+#endif
     hipLaunchKernelGGL((gemm_k384_stream_kernel<EPI>), dim3(n_groups * n_workers), dim3(512), lds, st, X, Wp, bias, resid, out_b, out_f, M, N, n_groups, no_store ? 0 : M);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;

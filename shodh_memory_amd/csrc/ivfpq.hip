@@ -418,20 +418,16 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
     const IvfpqLayout L = ivfpq_layout(s, cfg, nq, k);
     const uint32_t nprobe = L.nprobe, cap = L.cap, split = L.split, gx = L.gx;
     const size_t o_probe_ids = L.o_probe_ids, o_probe_dist = L.o_probe_dist, o_probe_cnt = L.o_probe_cnt, o_partial = L.o_partial, o_flat = L.o_flat;
-    struct { unsigned char *scratch; } sref{scratch};
-    IvfpqState *const s_ = s;
-    (void)s_;
-#define s_scratch sref.scratch
-    uint32_t *probe_ids = (uint32_t *)(s_scratch + o_probe_ids);
-    float *probe_dist = (float *)(s_scratch + o_probe_dist);
-    uint32_t *probe_cnt = (uint32_t *)(s_scratch + o_probe_cnt);
-    uint64_t *partial = (uint64_t *)(s_scratch + o_partial);
+    uint32_t *probe_ids = (uint32_t *)(scratch + o_probe_ids);
+    float *probe_dist = (float *)(scratch + o_probe_dist);
+    uint32_t *probe_cnt = (uint32_t *)(scratch + o_probe_cnt);
+    uint64_t *partial = (uint64_t *)(scratch + o_partial);
     // 1. probe selection: the nprobe nearest centroids by (compute_distance, index)
     const uint32_t op = (s->metric == SHODH_METRIC_EUCLIDEAN) ? EX_OP_SEQ_L2 : EX_OP_SEQ_ONE_MINUS_DOT;
     if (s->cent_idx) {
         SHODH_TRY(nearest_centroids(s->cent_idx, d_q, nq, s->dim, nprobe, probe_ids, probe_dist, probe_cnt, st));
     } else {
-        SHODH_TRY(launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_q, nq, nprobe, op, 0, (uint64_t *)(s_scratch + o_flat), gx,
+        SHODH_TRY(launch_flat_exact(s->centroids, s->P, s->dim, nullptr, d_q, nq, nprobe, op, 0, (uint64_t *)(scratch + o_flat), gx,
                                     probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
     }
     // 2. ADC table + list scan, 3. merge
@@ -454,7 +450,6 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
     SHODH_TRY(ensure_dynamic_lds((const void *)adc_merge_kernel, mlds));
     hipLaunchKernelGGL(adc_merge_kernel, dim3(nq), dim3(256), mlds, st, m);
     SHODH_HIP_TRY(hipGetLastError());
-#undef s_scratch
     return SHODH_OK;
 }
 

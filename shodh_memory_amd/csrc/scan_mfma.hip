@@ -969,7 +969,11 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
     SHODH_HIP_TRY(hipGetLastError());
 
+#ifdef SHODH_DIAG      // diagnostic build only (-DSHODH_DIAG): switches parts of the emit scan off to time the rest, results invalid
     static const uint32_t ablate = getenv("SHODH_ABLATE") ? (uint32_t)atoi(getenv("SHODH_ABLATE")) : 0u;
+#else
+    const uint32_t ablate = 0u;
+#endif
     MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u};
     SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
 
