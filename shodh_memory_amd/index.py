@@ -10,6 +10,7 @@ numpy arrays go through the host entry points; torch CUDA tensors go through the
 entry points without leaving HBM.
 """
 import ctypes as C
+import math
 from dataclasses import dataclass
 from enum import Enum
 
@@ -300,6 +301,9 @@ class SpannIndex:
         self._hd = _Handle(cfg)
         self._n = 0
         self.num_probes = num_probes
+        self._metric = distance_metric.value
+        self._state = None
+        self._pending = []
 
     @property
     def handle(self):
@@ -325,11 +329,16 @@ class SpannIndex:
         L.check(L.lib().shodh_index_set_ivfpq(self.handle, c.ctypes.data, c.shape[0], cb.ctypes.data, M, ncent,
                                               lo.ctypes.data, i.ctypes.data, cd.ctypes.data))
         self._n = int(i.size)
+        self._state = dict(centroids=c, codebook=cb, list_off=lo, ids=i, codes=cd.reshape(-1, M))   # host copy, for save_to_file
+        self._pending = []
 
     @staticmethod
     def compute_partitions(num_vectors):
-        """SpannConfig::compute_partitions (spann.rs:136-139): sqrt(n) clamped to [16, 65536]"""
-        return max(16, min(65536, int(np.sqrt(float(num_vectors)))))
+        """SpannConfig::compute_partitions (spann.rs:135-139) with num_partitions unset: ceil(sqrt(n)) as f64, at least 1"""
+        return max(1, int(math.ceil(math.sqrt(float(num_vectors)))))
+
+    def num_partitions(self):
+        return 0 if self._state is None else int(self._state["centroids"].shape[0])
 
     def train(self, vectors, num_partitions=None, kmeans_iterations=25, pq_iterations=20, seed=None, ivf_perm=None, pq_perms=None):
         """The two k-means of SpannIndex::build on the device (spann.rs:466-541, pq.rs:152-217). The reference draws its
@@ -362,9 +371,52 @@ class SpannIndex:
         return dict(centroids=cent, codebook=cb, list_off=off, ids=order.astype(np.uint32), codes=codes[order], assign=assign)
 
     def insert(self, vector_id, vector):
+        """SpannIndex::insert (spann.rs:1006-1051): nearest centroid, PQ-encode, append to that posting list"""
         v = _as_rows(vector, self._hd.dim)
+        assign, codes = self.encode(v)                    # kept on the host side too, so that save_to_file sees the insert
         L.check(L.lib().shodh_index_ivfpq_insert(self.handle, int(vector_id), v.ctypes.data))
+        self._pending.append((int(assign[0]), int(vector_id), codes[0].copy()))
         self._n += 1
+
+    def _current_state(self):
+        """trained state + the inserts since, as CSR (an insert goes to the END of its posting list)"""
+        if self._state is None:
+            raise L.ShodhError(L.ERR_STATE, "Index not built")
+        st = self._state
+        if not self._pending:
+            return st
+        P = st["centroids"].shape[0]
+        part = np.concatenate([np.repeat(np.arange(P), np.diff(st["list_off"]).astype(np.int64)), np.array([p[0] for p in self._pending])])
+        order = np.argsort(part, kind="stable")
+        ids = np.concatenate([st["ids"], np.array([p[1] for p in self._pending], np.uint32)])[order]
+        codes = np.concatenate([st["codes"], np.stack([p[2] for p in self._pending])])[order]
+        off = np.zeros(P + 1, np.uint64)
+        off[1:] = np.cumsum(np.bincount(part, minlength=P))
+        self._state = dict(centroids=st["centroids"], codebook=st["codebook"], list_off=off, ids=np.ascontiguousarray(ids), codes=np.ascontiguousarray(codes))
+        self._pending = []
+        return self._state
+
+    def save_to_file(self, path):
+        """SpannIndex::save_to_file (spann.rs:750-876): SPAN v1"""
+        from . import persist
+        st = self._current_state()
+        persist.write_spann(path, self._n, st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"], metric=self._metric)
+
+    @classmethod
+    def load_from_file(cls, path, num_probes=10, device=0):
+        """SpannIndex::load_from_file (spann.rs:879-1003)"""
+        from . import persist
+        return persist.load_spann(path, num_probes=num_probes, device=device)
+
+    @staticmethod
+    def verify_index_file(path):
+        """SpannIndex::verify_index_file: magic, version and checksum"""
+        from . import persist
+        try:
+            persist.span_info(path)
+            return True
+        except L.ShodhError:
+            return False
 
     def encode(self, vectors):
         v = _as_rows(vectors, self._hd.dim)

@@ -71,3 +71,11 @@ def test_rrf_matches_oracle_and_reference_kats(L, oracle):
         a_ids, a_sc = fuse(60.0, w, lists)
         e_ids, e_sc = oracle.rrf_fuse(60.0, w, lists)
         assert a_ids == e_ids and a_sc.tobytes() == e_sc.tobytes()
+
+
+def test_reference_partition_count(oracle):
+    """spann.rs:1188-1195 test_partition_count: ceil(sqrt(n)), through the Python mirror (no device needed) and the oracle"""
+    from shodh_memory_amd.index import SpannIndex
+    for n, p in ((100, 10), (10000, 100), (1000000, 1000), (1, 1), (0, 1), (2000, 45), (101, 11)):
+        assert SpannIndex.compute_partitions(n) == p
+        assert oracle.spann_compute_partitions(n) == p

@@ -181,3 +181,56 @@ def test_device_kmeans_tiny_corpus_pads_centroids(S, oracle):
     assert cent.tobytes() == e_cent.tobytes()
     e_cb = oracle.pq_train(rows, pq_perms, ncent=256, iterations=3)
     assert cb.tobytes() == e_cb.tobytes()
+
+
+# ---- the reference's own SpannIndex unit tests (src/vector_db/spann.rs:1121-1237), run against the GPU index ----
+def _reference_random_vectors(n, dim, seed):
+    """generate_random_vectors (spann.rs:1105-1119): uniform [0,1) entries, divided by the L2 norm"""
+    rng = np.random.default_rng(seed)
+    v = rng.random((n, dim), dtype=np.float32)
+    return v / np.sqrt((v * v).sum(1, dtype=np.float32))[:, None]
+
+
+def test_reference_spann_build_and_search(S):
+    """spann.rs:1121-1150: build 1000 vectors (PQ, 20 probes, default 25 + 20 iterations), the query vector is in the top 3"""
+    vectors = _reference_random_vectors(1000, 384, 1)
+    index = S.SpannIndex(384, num_probes=20)
+    index.build(vectors, seed=7)
+    assert index.len() == 1000 and index.num_partitions() == 32
+    results = index.search(vectors[0], 10)
+    assert len(results) == 10, "Should return exactly k results"
+    pos = [i for i, (vid, _) in enumerate(results) if vid == 0]
+    assert pos and pos[0] < 3, ("Query vector should be in top 3 results", results[:5])
+    d = [r[1] for r in results]
+    assert d == sorted(d)
+
+
+def test_reference_spann_save_and_load(S, tmp_path):
+    """spann.rs:1152-1186 (+ an insert after the build, which must survive the round trip)"""
+    vectors = _reference_random_vectors(500, 384, 2)
+    index = S.SpannIndex(384)
+    index.build(vectors, seed=3)
+    index.insert(500, _reference_random_vectors(1, 384, 9)[0])
+    path = tmp_path / "test.spann"
+    index.save_to_file(path)
+    assert path.exists() and S.SpannIndex.verify_index_file(path)
+    loaded = S.SpannIndex.load_from_file(path)
+    assert loaded.len() == 501 and loaded.num_partitions() > 0
+    a, b = index.search(vectors[0], 10), loaded.search(vectors[0], 10)
+    assert a and a == b
+    bad = tmp_path / "bad.spann"
+    raw = bytearray(path.read_bytes()); raw[-1] ^= 0xFF
+    bad.write_bytes(bytes(raw))
+    assert not S.SpannIndex.verify_index_file(bad)
+
+
+def test_reference_spann_rejections(S):
+    """spann.rs:1197-1237: use_pq = false is refused up front; a query of the wrong dimension is an error, not a crash"""
+    with pytest.raises(S.ShodhError) as e:
+        S.VectorIndexBackend.new_spann(S.BackendConfig(dimension=384, use_pq=False))
+    assert "use_pq=true" in str(e.value)
+    index = S.SpannIndex(384)
+    index.build(_reference_random_vectors(100, 384, 4), seed=1)
+    with pytest.raises(S.ShodhError) as e:
+        index.search(np.full(128, 0.1, np.float32), 5)
+    assert "dimension" in str(e.value)
