@@ -83,14 +83,16 @@ impl HipIndex {
         if vector.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, vector.len())); }
         let mut id = 0u32;
         check(unsafe { ffi::shodh_index_add(self.h, vector.as_ptr(), 1, &mut id) })?;
-        self.incremental.fetch_add(1, std::sync::atomic::Ordering::AcqRel);
+        // the vector that seeds an empty index is not an incremental insert (vamana.rs:888-898)
+        if id > 0 { self.incremental.fetch_add(1, std::sync::atomic::Ordering::AcqRel); }
         Ok(id)
     }
     /// n sequential `add_vector` calls in one transfer; returns the first id
     pub fn add_vectors(&mut self, flat: &[f32]) -> Result<u32> {
         let mut id = 0u32;
         check(unsafe { ffi::shodh_index_add(self.h, flat.as_ptr(), (flat.len() / self.dim.max(1)) as u64, &mut id) })?;
-        self.incremental.fetch_add(flat.len() / self.dim.max(1), std::sync::atomic::Ordering::AcqRel);
+        let n = flat.len() / self.dim.max(1);
+        self.incremental.fetch_add(n - usize::from(n > 0 && id == 0), std::sync::atomic::Ordering::AcqRel);
         Ok(id)
     }
 

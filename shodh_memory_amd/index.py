@@ -157,7 +157,7 @@ class VamanaIndex:
             raise L.ShodhError(L.ERR_INVALID, "add_vector takes one vector; use add_vectors")
         first = C.c_uint32()
         L.check(L.lib().shodh_index_add(self.handle, a.ctypes.data, 1, C.byref(first)))
-        self._incremental += 1
+        self._incremental += 1 if first.value > self.config.id_base else 0     # the vector that seeds an empty index is not an incremental insert (vamana.rs:888-898)
         return int(first.value)
 
     def add_vectors(self, vectors):
@@ -166,11 +166,12 @@ class VamanaIndex:
         if _is_torch_cuda(vectors):
             assert vectors.is_contiguous() and vectors.shape[-1] == self._hd.dim
             L.check(L.lib().shodh_index_add_device(self.handle, vectors.data_ptr(), vectors.shape[0], C.byref(first)))
-            self._incremental += int(vectors.shape[0])
+            n = int(vectors.shape[0])
         else:
             a = _as_rows(vectors, self._hd.dim)
             L.check(L.lib().shodh_index_add(self.handle, a.ctypes.data, a.shape[0], C.byref(first)))
-            self._incremental += a.shape[0]
+            n = int(a.shape[0])
+        self._incremental += n - (1 if n and first.value == self.config.id_base else 0)      # see add_vector
         return int(first.value)
 
     # -- search (vamana.rs:764-808; exact path :1167-1188) ---------------------------------------------

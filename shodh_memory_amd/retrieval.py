@@ -14,17 +14,27 @@ VECTOR_SEARCH_CANDIDATE_MULTIPLIER = 2      # src/constants.rs:350
 
 
 class IdMapping:
-    """retrieval.rs:70-142: vector_id (u32) <-> MemoryId (uuid); several chunk vectors may map to one memory."""
+    """retrieval.rs:70-142: vector_id (u32) <-> MemoryId (uuid); several chunk vectors may map to one memory.
+    `insert` / `insert_chunks` REPLACE whatever the memory was mapped to before (re-indexing must not leave orphans)."""
 
     def __init__(self):
         self.vector_to_memory = {}
         self.memory_to_vectors = {}
 
+    def _drop(self, memory_id):
+        for old in self.memory_to_vectors.pop(memory_id, []):
+            self.vector_to_memory.pop(old, None)
+
     def insert(self, memory_id, vector_id):
-        if self.vector_to_memory.get(vector_id) == memory_id:
-            return                                      # idempotent (retrieval.rs:2160-2178)
+        self._drop(memory_id)                                     # retrieval.rs:89-99
         self.vector_to_memory[vector_id] = memory_id
-        self.memory_to_vectors.setdefault(memory_id, []).append(vector_id)
+        self.memory_to_vectors[memory_id] = [vector_id]
+
+    def insert_chunks(self, memory_id, vector_ids):
+        self._drop(memory_id)                                     # retrieval.rs:105-117
+        for v in vector_ids:
+            self.vector_to_memory[v] = memory_id
+        self.memory_to_vectors[memory_id] = list(vector_ids)
 
     def get_memory_id(self, vector_id):
         return self.vector_to_memory.get(vector_id)
@@ -33,11 +43,18 @@ class IdMapping:
         return list(self.memory_to_vectors.get(memory_id, []))
 
     def remove_all(self, memory_id):
-        for v in self.memory_to_vectors.pop(memory_id, []):
+        """-> ALL vector ids the memory had (retrieval.rs:124-133)"""
+        removed = self.memory_to_vectors.pop(memory_id, [])
+        for v in removed:
             self.vector_to_memory.pop(v, None)
+        return removed
 
     def len(self):
         return len(self.memory_to_vectors)
+
+    def clear(self):
+        self.memory_to_vectors.clear()
+        self.vector_to_memory.clear()
 
 
 class RetrievalEngine:
@@ -55,11 +72,11 @@ class RetrievalEngine:
             vecs = self.embedder.encode_batch(chunks)
         else:
             vecs = [np.asarray(embedding, np.float32) if embedding is not None else self.embedder.encode(content)]
-        ids = []
-        for v in vecs:
-            vid = self.vector_index.add_vector(v)
-            self.id_mapping.insert(memory_id, vid)
-            ids.append(vid)
+        ids = [self.vector_index.add_vector(v) for v in vecs]
+        if chunks:
+            self.id_mapping.insert_chunks(memory_id, ids)        # :690-693
+        else:
+            self.id_mapping.insert(memory_id, ids[0])             # :715
         return ids
 
     def _postprocess(self, results, limit, exclude=None):
@@ -91,3 +108,32 @@ class RetrievalEngine:
         """retrieval.rs:980-1031 (dedup / interference check of remember, memory/mod.rs:1252-1256)"""
         res = self.vector_index.search(embedding, limit * VECTOR_SEARCH_CANDIDATE_MULTIPLIER * 2)
         return self._postprocess(res, limit, exclude=exclude_id)
+
+    # -- index maintenance (retrieval.rs:1556-1627, :1658-1670) ---------------------------------------------
+    def index_health(self):
+        """IndexHealth (retrieval.rs:1658-1684)"""
+        from .index import DELETION_RATIO_THRESHOLD, REBUILD_THRESHOLD
+        ix = self.vector_index
+        return dict(total_vectors=ix.len(), incremental_inserts=ix.incremental_insert_count(), deleted_count=ix.deleted_count(),
+                    deletion_ratio=ix.deletion_ratio(), needs_rebuild=ix.needs_rebuild(), needs_compaction=ix.needs_compaction(),
+                    rebuild_threshold=REBUILD_THRESHOLD, deletion_ratio_threshold=DELETION_RATIO_THRESHOLD)
+
+    def force_quality_rebuild(self):
+        """retrieval.rs:1556-1627: rebuild the index from the MAPPED vectors in vector-id order (unmapped = soft-deleted
+        vectors drop out), new ids are positional, the mapping is regrouped per memory. For the exact index the rebuild
+        changes no result; what it does is compact and reset the incremental counter, like the reference's."""
+        ix = self.vector_index
+        if ix.is_empty() or ix.incremental_insert_count() == 0:
+            return
+        all_vectors = ix.extract_all_vectors()
+        pairs = sorted(self.id_mapping.vector_to_memory.items())
+        if any(vid >= len(all_vectors) for vid, _ in pairs):
+            raise L.ShodhError(L.ERR_STATE, "quality rebuild aborted: %d mapped vectors but %d extractable"
+                               % (len(pairs), sum(1 for vid, _ in pairs if vid < len(all_vectors))))
+        ix.rebuild_from_vectors(np.stack([all_vectors[vid] for vid, _ in pairs]) if pairs else np.zeros((0, ix.config.dimension), np.float32))
+        per_memory = {}
+        for new_id, (_, mid) in enumerate(pairs):
+            per_memory.setdefault(mid, []).append(new_id)
+        self.id_mapping.clear()
+        for mid, vids in per_memory.items():
+            self.id_mapping.insert_chunks(mid, vids)

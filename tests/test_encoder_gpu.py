@@ -138,3 +138,35 @@ def test_retrieval_engine_with_simplified_embedder(S):
     assert res[0][0] == big and abs(res[0][1] - 1.0) < 1e-5 and [r[0] for r in res].count(big) == 1
     assert eng.search_by_embedding(q, 5, exclude_id=big)[0][0] != big
     assert eng.search_ids() == []
+
+
+def test_reference_force_quality_rebuild(S):
+    """retrieval.rs:2446-2535 test_force_quality_rebuild_resets_counter_and_preserves_mapping, step for step"""
+    import uuid
+    from tests.test_oracle_kats import ref_test_vector
+    engine = S.RetrievalEngine(S.MiniLMEmbedder.new_simplified(), dimension=384)
+    ids = []
+    for i in range(25):
+        v = ref_test_vector(i, 384)
+        vid = engine.vector_index.add_vector(v)
+        mid = uuid.uuid4()
+        engine.id_mapping.insert(mid, vid)
+        ids.append((mid, v))
+    # 24, not 25: the first add_vector seeds an empty index and is not counted as an incremental insert
+    assert engine.index_health()["incremental_inserts"] == 24
+    for mid, v in ids[:5]:
+        assert engine.search_by_embedding(v, 3)[0][0] == mid, "top hit before rebuild must be the vector's own memory"
+    engine.force_quality_rebuild()
+    health = engine.index_health()
+    assert health["incremental_inserts"] == 0 and health["total_vectors"] == 25
+    post = engine.vector_index.extract_all_vectors()
+    assert len(post) == 25
+    for i, (_, v) in enumerate(ids):
+        assert np.abs(post[i] - v).max() < 1e-6, "vector %d content corrupted by rebuild" % i
+    for mid, v in ids[:5]:
+        assert engine.search_by_embedding(v, 3)[0][0] == mid, "top hit after rebuild must be the vector's own memory"
+    engine.force_quality_rebuild()                      # zero incremental inserts: a no-op, not an error
+    # a soft-deleted (unmapped) vector drops out of the rebuilt index
+    engine.vector_index.add_vector(ref_test_vector(30, 384))
+    engine.force_quality_rebuild()
+    assert engine.index_health()["total_vectors"] == 25

@@ -79,3 +79,38 @@ def test_reference_partition_count(oracle):
     for n, p in ((100, 10), (10000, 100), (1000000, 1000), (1, 1), (0, 1), (2000, 45), (101, 11)):
         assert SpannIndex.compute_partitions(n) == p
         assert oracle.spann_compute_partitions(n) == p
+
+
+def test_reference_id_mapping_tests():
+    """retrieval.rs:2152-2197, :2361-2428: the reference's IdMapping unit tests against the Python mirror"""
+    from shodh_memory_amd.retrieval import IdMapping
+    new_id = uuid.uuid4
+    m, mem = IdMapping(), new_id()                               # test_id_mapping_basic
+    m.insert(mem, 42)
+    assert m.len() == 1 and m.get_memory_id(42) == mem
+    m, mem = IdMapping(), new_id()                               # test_id_mapping_chunks
+    m.insert_chunks(mem, [1, 2, 3])
+    assert m.len() == 1 and [m.get_memory_id(i) for i in (1, 2, 3)] == [mem] * 3
+    removed = m.remove_all(mem)                                  # test_id_mapping_remove_all
+    assert len(removed) == 3 and m.len() == 0 and m.get_memory_id(1) is None and m.remove_all(mem) == []
+    m = IdMapping()                                              # test_id_mapping_clear
+    m.insert(new_id(), 1); m.insert(new_id(), 2)
+    m.clear()
+    assert m.len() == 0
+    m, mem = IdMapping(), new_id()                               # test_id_mapping_insert_is_idempotent
+    m.insert(mem, 10)
+    assert m.len() == 1 and m.get_memory_id(10) == mem
+    m.insert(mem, 20)
+    assert m.len() == 1 and m.get_memory_id(20) == mem and m.get_memory_id(10) is None, "old vector_id should be removed to prevent orphan"
+    assert m.memory_to_vectors[mem] == [20]
+    m, mem = IdMapping(), new_id()                               # test_id_mapping_insert_chunks_is_idempotent
+    m.insert_chunks(mem, [1, 2, 3])
+    assert m.len() == 1 and m.memory_to_vectors[mem] == [1, 2, 3]
+    m.insert_chunks(mem, [10, 11])
+    assert m.len() == 1 and m.memory_to_vectors[mem] == [10, 11]
+    assert all(m.get_memory_id(i) is None for i in (1, 2, 3)) and m.get_memory_id(10) == mem and m.get_memory_id(11) == mem
+    m, m1, m2 = IdMapping(), new_id(), new_id()                  # test_id_mapping_vector_count_stable_after_reinsert
+    m.insert(m1, 1); m.insert(m2, 2)
+    assert len(m.vector_to_memory) == 2
+    m.insert(m1, 3)
+    assert len(m.vector_to_memory) == 2, "vector_to_memory should not grow on re-insert"
