@@ -53,6 +53,9 @@ pub struct HipIndex {
 unsafe impl Send for HipIndex {}
 unsafe impl Sync for HipIndex {}
 
+pub const REBUILD_THRESHOLD: usize = 10_000;        // vamana.rs:103
+pub const REPAIR_THRESHOLD: usize = 1_000;          // vamana.rs:107
+
 impl HipIndex {
     pub fn new(config: VamanaConfig) -> Result<Self> {
         let mut cfg = ffi::shodh_index_cfg::default();
@@ -124,14 +127,34 @@ impl HipIndex {
     pub fn needs_compaction(&self) -> bool { unsafe { ffi::shodh_index_needs_compaction(self.h) == 1 } }
     pub fn clear_deleted(&self) { unsafe { ffi::shodh_index_clear_deleted(self.h) }; }
 
-    // the flat index never degrades with inserts: nothing to rebuild or repair (vamana.rs:985-1236)
-    pub fn needs_rebuild(&self) -> bool { false }
-    pub fn needs_repair(&self) -> bool { false }
-    pub fn incremental_repair(&self) -> Result<usize> { Ok(0) }
+    // Maintenance bookkeeping as the reference keeps it (vamana.rs:976-1232). The exact index has no graph that degrades, so
+    // a "repair" re-prunes nothing and recall is 1; the counters and thresholds still behave as callers (IndexHealth,
+    // auto_rebuild_index_if_needed) expect, and a rebuild is how tombstoned rows are compacted away.
+    pub fn needs_rebuild(&self) -> bool { self.incremental_insert_count() >= REBUILD_THRESHOLD || self.needs_compaction() }
+    pub fn needs_repair(&self) -> bool { (REPAIR_THRESHOLD..REBUILD_THRESHOLD).contains(&self.incremental_insert_count()) }
+    pub fn incremental_repair(&self) -> Result<usize> {
+        let inserts = self.incremental_insert_count();
+        if self.is_empty() || inserts < REPAIR_THRESHOLD { return Ok(0); }
+        self.incremental.store(inserts.saturating_sub(REPAIR_THRESHOLD), std::sync::atomic::Ordering::Release);   // vamana.rs:1108-1111
+        Ok(0)
+    }
     pub fn quality_degraded(&self) -> Result<bool> { Ok(false) }
-    pub fn estimate_recall(&self, _sample_size: usize, _k: usize) -> Result<f32> { Ok(1.0) }   // exact search
-    pub fn auto_maintain(&self) -> Result<String> { Ok("exact index: no maintenance needed".to_string()) }
-    pub fn auto_rebuild_if_needed(&self) -> Result<bool> { Ok(false) }
+    pub fn estimate_recall(&self, _sample_size: usize, _k: usize) -> Result<f32> { Ok(1.0) }   // search IS the brute-force search
+    pub fn auto_maintain(&mut self) -> Result<String> {
+        if self.needs_rebuild() {
+            return Ok(if self.auto_rebuild_if_needed()? { "full_rebuild" } else { "rebuild_skipped" }.to_string());
+        }
+        if self.needs_repair() { return Ok(format!("repaired_{}_nodes", self.incremental_repair()?)); }
+        Ok("no_action".to_string())
+    }
+    /// vamana.rs:1290-1340: rebuild from the live vectors (ids become positional; callers that keep an id mapping rebuild from
+    /// their own source of truth instead, retrieval.rs:1629-1656)
+    pub fn auto_rebuild_if_needed(&mut self) -> Result<bool> {
+        if !self.needs_rebuild() { return Ok(false); }
+        let live = self.extract_live_vectors();
+        self.build(live)?;
+        Ok(true)
+    }
     pub fn is_rebuilding(&self) -> bool { false }
     pub fn incremental_insert_count(&self) -> usize { self.incremental.load(std::sync::atomic::Ordering::Acquire) }
     pub fn reset_incremental_counter(&self) { self.incremental.store(0, std::sync::atomic::Ordering::Release) }

@@ -246,6 +246,32 @@ class VamanaIndex:
     def is_rebuilding(self):
         return False
 
+    def needs_repair(self):
+        return REPAIR_THRESHOLD <= self._incremental < REBUILD_THRESHOLD             # vamana.rs:1010-1016
+
+    def incremental_repair(self):
+        """vamana.rs:1033-1115. There is no graph to re-prune in the exact index: 0 nodes repaired, the counter moves as
+        the reference's does."""
+        if self.is_empty() or self._incremental < REPAIR_THRESHOLD:
+            return 0
+        self._incremental = max(0, self._incremental - REPAIR_THRESHOLD)
+        return 0
+
+    def estimate_recall(self, sample_size=100, k=10):
+        """vamana.rs:1128-1165 compares `search` with `brute_force_search`; here they are the same scan"""
+        return 1.0
+
+    def quality_degraded(self):
+        return False
+
+    def auto_maintain(self):
+        """vamana.rs:1217-1232"""
+        if self.needs_rebuild():
+            return "full_rebuild" if self.auto_rebuild_if_needed() else "rebuild_skipped"
+        if self.needs_repair():
+            return "repaired_%d_nodes" % self.incremental_repair()
+        return "no_action"
+
     def auto_rebuild_if_needed(self):
         """Compacts tombstoned rows away when the reference would rebuild. Returns True if it did."""
         if not self.needs_rebuild():

@@ -434,3 +434,27 @@ def test_many_query_batches_use_the_lean_final_stage(S, order_name, k):
             st = idx.scan_stats()
             assert st["sampled_rows"] > 0, "MFMA path was not taken"
     assert np.array_equal(out[1][0], out[2][0]) and out[1][1].tobytes() == out[2][1].tobytes() and np.array_equal(out[1][2], out[2][2])
+
+
+def test_reference_vamana_maintenance_tests(S):
+    """vamana.rs:1714-1805: test_incremental_repair, test_estimate_recall, test_auto_maintain against the exact index"""
+    index = S.VamanaIndex(S.VamanaConfig(dimension=4, max_degree=3, search_list_size=10))
+    index.build(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], f32))
+    assert not index.needs_repair() and index.incremental_insert_count() == 0
+    for i in range(5):
+        index.add_vector(np.array([0.1 * i, 0.1, 0.1, 0.1], f32))
+    assert index.incremental_insert_count() == 5 and not index.needs_repair()
+    assert index.incremental_repair() == 0                                   # nothing below the threshold
+
+    index = S.VamanaIndex(S.VamanaConfig(dimension=4, max_degree=4, search_list_size=20))
+    index.build(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [.5, .5, 0, 0], [.5, 0, .5, 0], [0, .5, .5, 0],
+                          [0, 0, .5, .5], [.25, .25, .25, .25], [.7, .3, 0, 0]], f32))
+    assert index.estimate_recall(5, 3) >= 0.6
+
+    index = S.VamanaIndex(S.VamanaConfig(dimension=4, max_degree=3, search_list_size=10))
+    index.build(np.array([[1, 0, 0, 0], [0, 1, 0, 0]], f32))
+    assert index.auto_maintain() == "no_action"
+    # tombstones above the 30 % ratio make the reference rebuild: the rows are compacted away
+    index.build(np.eye(4, dtype=f32))
+    index.mark_deleted(0); index.mark_deleted(1)
+    assert index.needs_rebuild() and index.auto_maintain() == "full_rebuild" and index.len() == 2 and index.deleted_count() == 0
