@@ -134,6 +134,7 @@ def main():
             idx.search_batch_device(qemb, 10, out=out)
         dt = timed(recall, 50, warmup=20)
         dt_s = timed(lambda: idx.search_batch_device(qemb, 10, out=out), 50, warmup=5)
+        idx.search_batch(qemb.cpu().numpy(), 10)      # one host-pointer call: it reads the pre-scan counters back (scan_stats)
         print(json.dumps({"bench": "pipeline (configs[2]): %d synthetic texts, MiniLM-L6 bf16 encode -> add_vectors -> recall top-10, batch 256 query texts" % n_texts,
                           "ingest_s": round(t_ingest, 3), "ingest_texts_per_s": round(n_texts / t_ingest, 1), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
                           "tokens": tokens, "index_rows": idx.len(), "recall_ms_per_batch_incl_query_encode": round(dt * 1e3, 4),

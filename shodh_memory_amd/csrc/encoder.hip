@@ -962,14 +962,19 @@ int shodh_embedder_synthetic_weights(const shodh_embed_cfg *cfg, uint64_t seed, 
     size_t o_word, o_pos, o_type, o_eg, o_eb; std::vector<LayerOff> lo; uint64_t n_params = 0;
     layout_cfg(*cfg, o_word, o_pos, o_type, o_eg, o_eb, lo, n_params);
     if (n_floats != n_params) { set_error("blob has %llu floats, expected %llu", (unsigned long long)n_floats, (unsigned long long)n_params); return SHODH_ERR_INVALID; }
-    // splitmix64 -> Box-Muller; weights and biases ~ N(0, 0.02), LayerNorm gamma 1 / beta 0
+    // splitmix64 -> Box-Muller; weights and biases ~ N(0, 0.02), word embeddings ~ N(0, 0.2), LayerNorm gamma 1 / beta 0.
+    // The wider word table makes a text's embedding depend on its tokens the way a trained model's does (pairwise cosine of
+    // random texts 0.2-0.8); with 0.02 everywhere the position/type terms dominate and every text lands within 0.1 of the
+    // same direction, a geometry no recall benchmark should be run on.
     uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
     auto next = [&]() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
     auto normal = [&]() { const double u1 = ((next() >> 11) + 1.0) / 9007199254740993.0, u2 = (next() >> 11) / 9007199254740992.0; return (float)(0.02 * std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2)); };
     auto fill_n = [&](size_t off, size_t n) { for (size_t i = 0; i < n; ++i) blob[off + i] = normal(); };
     auto fill_c = [&](size_t off, size_t n, float v) { for (size_t i = 0; i < n; ++i) blob[off + i] = v; };
     const size_t H = cfg->hidden, I = cfg->intermediate;
-    fill_n(o_word, (size_t)cfg->vocab * H); fill_n(o_pos, (size_t)cfg->max_pos * H); fill_n(o_type, (size_t)cfg->type_vocab * H);
+    fill_n(o_word, (size_t)cfg->vocab * H);
+    for (size_t i = 0; i < (size_t)cfg->vocab * H; ++i) blob[o_word + i] *= 10.0f;
+    fill_n(o_pos, (size_t)cfg->max_pos * H); fill_n(o_type, (size_t)cfg->type_vocab * H);
     fill_c(o_eg, H, 1.0f); fill_c(o_eb, H, 0.0f);
     for (auto &l : lo) {
         fill_n(l.qw, H * H); fill_n(l.qb, H); fill_n(l.kw, H * H); fill_n(l.kb, H); fill_n(l.vw, H * H); fill_n(l.vb, H);

@@ -25,7 +25,9 @@ def test_param_layout(blob):
     assert b.size == E.param_count() == 22_565_376           # BertModel(all-MiniLM-L6-v2) without the unused pooler
     sd = E.blob_to_state_dict(b)
     assert sd["encoder.layer.5.output.dense.weight"].shape == (384, 1536)
-    assert abs(float(b[:1000].std()) - 0.02) < 0.003 and (sd["embeddings.LayerNorm.weight"] == 1).all()
+    assert abs(float(sd["embeddings.word_embeddings.weight"][:4].std()) - 0.2) < 0.03          # word table N(0, 0.2) ...
+    assert abs(float(sd["encoder.layer.0.attention.self.query.weight"].std()) - 0.02) < 0.003   # ... everything else N(0, 0.02)
+    assert (sd["embeddings.LayerNorm.weight"] == 1).all()
     assert np.array_equal(E.state_dict_to_blob(sd), b)
     assert np.array_equal(E.synthetic_weights(1234), b) and not np.array_equal(E.synthetic_weights(1235)[:100], b[:100])
 
