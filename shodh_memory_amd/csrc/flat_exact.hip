@@ -45,12 +45,18 @@ struct ExactArgs {
 };
 
 // ---- fast kernel: dim % 32 == 0 -----------------------------------------------------------------
+// One lane = one row (the reference's sums are serial chains per (query, row), so the parallelism is across rows and queries):
+// a wave stages 64 rows x 32 floats through LDS (coalesced 128-B lines in, one row per lane out) and scores them against QB
+// queries. The query values are wave-uniform, so they come through SCALAR loads straight from global memory into SGPRs and
+// feed the VALU as scalar operands: no LDS traffic per query, which is what lets QB be 8 (an LDS-resident query block cost
+// one broadcast read per query and 4-float group and capped QB at 2: 128 passes over the corpus for a 256-query batch, HBM-bound).
+// Workgroups that share rows (same row range, different query group) are adjacent in dispatch order, so the re-reads of a
+// row by the other query groups hit L2 / Infinity Cache.
 template <int QB, int ORDER>
-__global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
+__global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a, const float *__restrict__ qglob) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim = a.dim;
-    float *qs = reinterpret_cast<float *>(smem);                          // [QB][dim]
-    float *stage = qs + QB * dim;                                         // [4 waves][64][EX_PITCH]
+    float *stage = reinterpret_cast<float *>(smem);                       // [4 waves][64][EX_PITCH]
     uint64_t *keys = reinterpret_cast<uint64_t *>(stage + 4 * 64 * EX_PITCH);   // [QB][cap]
     uint64_t *thr = keys + (size_t)QB * a.cap;                            // [QB]
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + QB);               // [QB]
@@ -59,21 +65,23 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint32_t nq_eff = a.qcount ? *a.qcount : a.nq;
+    // dispatch order is x-fastest: consecutive workgroups take consecutive query groups of the SAME rows
+    const uint32_t flat_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t bx = flat_id / gridDim.y, grp0 = flat_id % gridDim.y;
 
-  for (uint32_t grp = blockIdx.y; grp * QB < nq_eff; grp += gridDim.y) {
+  for (uint32_t grp = grp0; grp * QB < nq_eff; grp += gridDim.y) {
     const uint32_t q0 = grp * QB;
     __syncthreads();
-    for (uint32_t i = tid; i < QB * dim; i += EX_NT) {
-        const uint32_t s = q0 + i / dim;
-        float v = 0.0f;
-        if (s < nq_eff) {
-            const uint32_t q = a.qlist ? a.qlist[s] : s;
-            v = a.queries[(size_t)q * dim + (i % dim)];
-        }
-        qs[i] = v;
-    }
     if (tid < QB) { cnt[tid] = 0; thr[tid] = a.k ? KEY_NONE : 0; }
     __syncthreads();
+    // wave-uniform base of every query of the group (a slot past the end re-reads the group's first query; its results are dropped)
+    const float *qbase[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const uint32_t s_ = (q0 + q < nq_eff) ? q0 + q : q0;
+        const uint32_t qi = a.qlist ? a.qlist[s_] : s_;
+        qbase[q] = qglob + (size_t)qi * dim;
+    }
 
     TopKBuf buf[QB];
 #pragma unroll
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
 
     float *my = stage + wave * 64 * EX_PITCH;
     const uint64_t n_tiles = (a.n_rows + 63) / 64;
-    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t wave_gid = (uint64_t)bx * 4 + wave;
     const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
     const uint64_t n_iter = (n_tiles + wave_stride - 1) / wave_stride;
     const int nchunk = dim / EX_CHUNK;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
                 for (int g = 0; g < 8; ++g) v[g] = *reinterpret_cast<const f32x4 *>(my + lane * EX_PITCH + g * 4);
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
-                    const float *qp = qs + q * dim + c * EX_CHUNK;
+                    const float *qp = qbase[q] + c * EX_CHUNK;
                     if (ORDER == SHODH_ORDER_SCALAR4) {
                         // distance_inline.rs:165-168
 #pragma unroll
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a) {
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         topk_compact<EX_NT>(buf[q]);
-        uint64_t *out = a.partial + (((size_t)grp * gridDim.x + blockIdx.x) * QB + q) * a.k;
+        uint64_t *out = a.partial + (((size_t)grp * gridDim.x + bx) * QB + q) * a.k;
         const uint32_t m = *buf[q].cnt;
         for (uint32_t i = tid; i < a.k; i += EX_NT) out[i] = (i < m) ? buf[q].keys[i] : KEY_NONE;
     }
@@ -380,8 +388,10 @@ __global__ __launch_bounds__(EX_NT) void merge_lists_kernel(MergeListsArgs a) {
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-static size_t exact_lds_bytes(int qb, uint32_t dim, uint32_t cap) {
-    return (size_t)qb * dim * 4 + (size_t)4 * 64 * EX_PITCH * 4 + (size_t)qb * cap * 8 + (size_t)qb * 8 + (size_t)qb * 4 + 16;
+// per-query key buffer of the scan: the k kept keys plus one iteration's pushes (one per thread)
+static uint32_t exact_scan_cap(uint32_t k) { return next_pow2(k + (uint32_t)EX_NT); }
+static size_t exact_lds_bytes(int qb, uint32_t k) {
+    return (size_t)4 * 64 * EX_PITCH * 4 + (size_t)qb * exact_scan_cap(k) * 8 + (size_t)qb * 8 + (size_t)qb * 4 + 16;
 }
 
 uint32_t topk_capacity(uint32_t k) {
@@ -393,9 +403,9 @@ uint32_t topk_capacity(uint32_t k) {
 
 // choose queries-per-block so that LDS stays <= 64 KiB (>= 2 blocks per CU)
 int exact_pick_qb(uint32_t nq, uint32_t dim, uint32_t k) {
-    const uint32_t cap = topk_capacity(k);
-    int qb = 8;
-    while (qb > 1 && (exact_lds_bytes(qb, dim, cap) > 64 * 1024 || (uint32_t)qb > next_pow2(nq))) qb >>= 1;
+    (void)dim;
+    int qb = 8;      // two workgroups per CU: <= 80 KiB each
+    while (qb > 1 && (exact_lds_bytes(qb, k) > 80 * 1024 || (uint32_t)qb > next_pow2(nq))) qb >>= 1;
     return qb;
 }
 
@@ -418,7 +428,7 @@ uint32_t exact_grid_x(uint64_t n_rows, uint32_t nq, uint32_t k, int cus) {
 template <int QB, int OP>
 static int launch_fast_op(const ExactArgs &a, dim3 grid, size_t lds, hipStream_t st) {
     SHODH_TRY(ensure_dynamic_lds((const void *)flat_exact_kernel<QB, OP>, lds));
-    hipLaunchKernelGGL((flat_exact_kernel<QB, OP>), grid, dim3(EX_NT), lds, st, a);
+    hipLaunchKernelGGL((flat_exact_kernel<QB, OP>), grid, dim3(EX_NT), lds, st, a, a.queries);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
@@ -456,7 +466,8 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
         uint32_t gy = (uint32_t)ceil_div(nq, qb);
         if (qcount && gy > 4) gy = 4;          // fallback mode: few resident groups, they loop
         dim3 grid(grid_x, gy);
-        const size_t lds = exact_lds_bytes(qb, dim, cap);
+        a.cap = exact_scan_cap(k);
+        const size_t lds = exact_lds_bytes(qb, k);
         if (lds > 160 * 1024) { set_error("k=%u too large for the exact scan (LDS %zu B)", k, lds); return SHODH_ERR_UNSUPPORTED; }
         switch (qb) {
             case 8: SHODH_TRY(launch_fast<8>(a, order, grid, lds, st)); break;
