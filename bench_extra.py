@@ -62,6 +62,8 @@ def main():
     if what in ("latency", "all"):
         for mode, name in ((L.SCAN_EXACT, "exact-order f32 scan"), (L.SCAN_MFMA, "fp16 MFMA pre-scan + re-score")):
             idx, q = flat(1_000_000, 1, 10, steps=50, scan=mode, tag="flat 1M single query: " + name)
+        flat(1_000_000, 256, 10, steps=5, scan=L.SCAN_EXACT, tag="flat 1M, batch 256, top-10, exact-order f32 scan only (SHODH_SCAN_EXACT; also what an unquantisable corpus falls back to)")
+        flat(10_000, 1, 10, steps=200, tag="flat 10k x 384 single query (configs[0] size; below 16384 rows the exact-order scan is the path)")
     if what in ("pcie", "all"):
         rows = bench.synth_rows(torch, 1_000_000, 384, 1, dev)
         idx = S.VamanaIndex(S.VamanaConfig(dimension=384, reserve_rows=1_000_000))
