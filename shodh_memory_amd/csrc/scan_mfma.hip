@@ -77,6 +77,7 @@ struct MfmaArgs {
     uint32_t tile_stride;     // tile index = sel * tile_stride
     uint32_t n_sel_tiles;
     uint32_t ablate;          // diagnostics only (SHODH_ABLATE=8: thresholds forced to +inf, nothing is emitted; results invalid)
+    uint32_t nq;              // real queries of the call (the last pass may be partly padding)
 };
 
 template <int KSTEPS>
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const int l31 = lane & 31;
     const uint32_t pass = blockIdx.y;
     const uint32_t q_local = wave * 32 + l31;      // this lane's query within the pass
+    // a wave whose 32 queries are all padding (small batches: a single query leaves seven of the eight) multiplies nothing:
+    // it only keeps its share of the DMA and the barriers, so a small batch costs the bytes, not the MFMA work of a full one
+    const bool active = (uint32_t)(pass * MF_BPAD + wave * 32) < a.nq;      // wave-uniform
     if (MODE == MF_MODE_EMIT && tid < MF_BPAD) {
         qcount[tid] = 0;
         // this workgroup's private candidate slots of query tid start out empty (nobody else writes them)
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         const unsigned char *psrc = uniform_ptr(rows_b + (size_t)psel * tile_bytes_g);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * TILE_BYTES));
 
+      if (active) {
         half8 ring[RING];
         auto rd = [&](int st) {
             const int rb = st / KSTEPS, ks = st % KSTEPS;
@@ -344,6 +349,13 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             m = fmaxf(m, __shfl_xor(m, 32));        // the two half-waves hold different rows of the same query
             if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
         }
+      } else {
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * 4096);
+        }
+        if (MODE != MF_MODE_EMIT && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;   // padding queries: defined values
+      }
         // hand-over: the tile after this one must have landed (the DMA issued during this tile may stay in flight
         // when there are three buffers); all LDS traffic of this wave done; then the workgroup barrier
         PROF_T(4)
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the clamped tail DMA before the LDS is released
     if (MODE == MF_MODE_EMIT) {
-        if (have_prev) emit_block(acc1, (uint64_t)prev_sel * a.tile_stride * MF_TR + 32);   // (no maximum was folded for the last tile)
+        if (have_prev && active) emit_block(acc1, (uint64_t)prev_sel * a.tile_stride * MF_TR + 32);   // (no maximum was folded for the last tile)
         drain();
         // entries were dropped somewhere: poison every list of this pass so that the final stage sends
         // those queries to the exact scan (adversarial inputs only, e.g. thousands of identical rows)
@@ -974,7 +986,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 #else
     const uint32_t ablate = 0u;
 #endif
-    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u};
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u, nq};
     SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
 
     // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
