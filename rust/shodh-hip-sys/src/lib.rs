@@ -75,6 +75,11 @@ impl HipIndex {
             if v.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, v.len())); }
         }
         let flat: Vec<f32> = vectors.into_iter().flatten().collect();
+        self.build_flat(&flat)
+    }
+    // the library serialises build / add / delete on its own lock, so a shared reference is enough here; the reference's
+    // maintenance methods (`auto_rebuild_if_needed(&self)`, vamana.rs:1290) take `&self` for the same reason
+    fn build_flat(&self, flat: &[f32]) -> Result<()> {
         check(unsafe { ffi::shodh_index_build(self.h, flat.as_ptr(), (flat.len() / self.dim.max(1)) as u64) })?;
         self.incremental.store(0, std::sync::atomic::Ordering::Release);
         Ok(())
@@ -140,7 +145,7 @@ impl HipIndex {
     }
     pub fn quality_degraded(&self) -> Result<bool> { Ok(false) }
     pub fn estimate_recall(&self, _sample_size: usize, _k: usize) -> Result<f32> { Ok(1.0) }   // search IS the brute-force search
-    pub fn auto_maintain(&mut self) -> Result<String> {
+    pub fn auto_maintain(&self) -> Result<String> {
         if self.needs_rebuild() {
             return Ok(if self.auto_rebuild_if_needed()? { "full_rebuild" } else { "rebuild_skipped" }.to_string());
         }
@@ -149,10 +154,10 @@ impl HipIndex {
     }
     /// vamana.rs:1290-1340: rebuild from the live vectors (ids become positional; callers that keep an id mapping rebuild from
     /// their own source of truth instead, retrieval.rs:1629-1656)
-    pub fn auto_rebuild_if_needed(&mut self) -> Result<bool> {
+    pub fn auto_rebuild_if_needed(&self) -> Result<bool> {
         if !self.needs_rebuild() { return Ok(false); }
-        let live = self.extract_live_vectors();
-        self.build(live)?;
+        let live: Vec<f32> = self.extract_live_vectors().into_iter().flatten().collect();
+        self.build_flat(&live)?;
         Ok(true)
     }
     pub fn is_rebuilding(&self) -> bool { false }
