@@ -109,7 +109,7 @@ int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, u
                               uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */
 int shodh_index_is_deleted(const shodh_index *idx, uint32_t id);               /* :823-825 (1/0, <0 error) */
-uint64_t shodh_index_len(const shodh_index *idx);                              /* :184-186 */
+uint64_t shodh_index_len(const shodh_index *idx);                              /* :184-186; IVF-PQ: postings held (SpannIndex::len) */
 uint64_t shodh_index_deleted_count(const shodh_index *idx);                    /* :828-830 */
 float shodh_index_deletion_ratio(const shodh_index *idx);                      /* :834-840 */
 int shodh_index_needs_compaction(const shodh_index *idx);                      /* :843-845 (ratio >= 0.30) */

@@ -53,6 +53,7 @@ pub struct HipIndex {
 unsafe impl Send for HipIndex {}
 unsafe impl Sync for HipIndex {}
 
+pub const MODEL_TOKEN_WINDOW: usize = 128;          // embeddings/chunking.rs (the tokenizer truncation window, minilm.rs:112-117)
 pub const REBUILD_THRESHOLD: usize = 10_000;        // vamana.rs:103
 pub const REPAIR_THRESHOLD: usize = 1_000;          // vamana.rs:107
 
@@ -217,7 +218,7 @@ impl Drop for HipIndex {
 }
 
 /// `SpannIndex` search side (spann.rs:574-693) on a trained state (`load_from_file`, :879-1003, or `set_trained_state`).
-pub struct HipSpannIndex { h: *mut ffi::shodh_index, dim: usize }
+pub struct HipSpannIndex { h: *mut ffi::shodh_index, dim: usize, device: i32 }
 unsafe impl Send for HipSpannIndex {}
 unsafe impl Sync for HipSpannIndex {}
 impl HipSpannIndex {
@@ -230,7 +231,7 @@ impl HipSpannIndex {
         cfg.device = device;
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::shodh_index_create(&cfg, &mut h) })?;
-        Ok(Self { h, dim: dimension })
+        Ok(Self { h, dim: dimension, device })
     }
     #[allow(clippy::too_many_arguments)]
     pub fn set_trained_state(&mut self, centroids: &[f32], codebook: &[f32], list_off: &[u64], ids: &[u32], codes: &[u8]) -> Result<()> {
@@ -252,6 +253,40 @@ impl HipSpannIndex {
         idx.set_trained_state(&cent, &cb, &off, &ids, &codes)?;
         Ok(idx)
     }
+    /// `SpannIndex::build` (spann.rs:363-463): ceil(sqrt(n)) partitions, 25 IVF + 20 PQ Lloyd iterations on the device
+    /// (bit-identical to the reference's arithmetic given the shuffles), then every vector assigned and PQ-encoded into its
+    /// posting list. `shuffle(seed_stream, n)` supplies the initial permutations the reference draws from `thread_rng`
+    /// (one for the IVF centroids, then one per PQ sub-space), e.g. `|_, n| { let mut v: Vec<u32> = (0..n as u32).collect();
+    /// v.shuffle(&mut rand::thread_rng()); v }`.
+    pub fn build(&mut self, vectors: &[Vec<f32>], mut shuffle: impl FnMut(usize, usize) -> Vec<u32>) -> Result<()> {
+        let n = vectors.len();
+        if n == 0 { return Err(anyhow!("Cannot build index from empty vectors")); }       // spann.rs:364-366
+        let (d, m) = (self.dim, self.dim / 8);
+        let p = ((n as f64).sqrt().ceil() as usize).max(1);                                 // compute_partitions, spann.rs:135-139
+        let flat: Vec<f32> = vectors.iter().flatten().copied().collect();
+        let ivf_perm = shuffle(0, n);
+        let pq_perms: Vec<u32> = (0..m).flat_map(|s| shuffle(1 + s, n)).collect();
+        let (mut cent, mut cb) = (vec![0f32; p * d], vec![0f32; m * 256 * 8]);
+        check(unsafe { ffi::shodh_ivfpq_train(self.device, flat.as_ptr(), n as u64, d as u32, p as u32, 25, 20, ivf_perm.as_ptr(), pq_perms.as_ptr(), cent.as_mut_ptr(), cb.as_mut_ptr()) })?;
+        self.set_trained_state(&cent, &cb, &vec![0u64; p + 1], &[], &[])?;
+        let (mut assign, mut codes) = (vec![0u32; n], vec![0u8; n * m]);
+        check(unsafe { ffi::shodh_index_ivfpq_encode(self.h, flat.as_ptr(), n as u64, assign.as_mut_ptr(), codes.as_mut_ptr()) })?;
+        // posting lists in insertion order inside a partition (stable counting sort by partition)
+        let mut off = vec![0u64; p + 1];
+        for &a in &assign { off[a as usize + 1] += 1; }
+        for i in 0..p { off[i + 1] += off[i]; }
+        let mut cursor = off.clone();
+        let (mut ids, mut sorted) = (vec![0u32; n], vec![0u8; n * m]);
+        for (i, &a) in assign.iter().enumerate() {
+            let at = cursor[a as usize] as usize;
+            cursor[a as usize] += 1;
+            ids[at] = i as u32;
+            sorted[at * m..(at + 1) * m].copy_from_slice(&codes[i * m..(i + 1) * m]);
+        }
+        self.set_trained_state(&cent, &cb, &off, &ids, &sorted)
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::shodh_index_len(self.h) as usize } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
     pub fn insert(&mut self, vector_id: u32, vector: &[f32]) -> Result<()> {
         check(unsafe { ffi::shodh_index_ivfpq_insert(self.h, vector_id, vector.as_ptr()) })
     }
@@ -317,6 +352,8 @@ impl<T: Tokenize> HipEmbedder<T> {
         Ok(out.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect())
     }
     pub fn count_tokens(&self, text: &str) -> usize { self.tok.count(text) }
+    /// minilm.rs:1236-1245 for a model without a document prefix (MiniLM is symmetric): the whole window
+    pub fn chunk_budget_tokens(&self) -> usize { MODEL_TOKEN_WINDOW }
 }
 impl<T: Tokenize> Drop for HipEmbedder<T> {
     fn drop(&mut self) { unsafe { ffi::shodh_embedder_destroy(self.h) } }

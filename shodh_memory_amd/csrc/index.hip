@@ -77,6 +77,7 @@ int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uin
 
 struct IvfpqState;   // ivfpq.hip
 void ivfpq_destroy(IvfpqState *s);
+uint64_t ivfpq_len(IvfpqState *s);
 size_t ivfpq_scratch_bytes(const IvfpqState *s, const shodh_index_cfg &cfg, uint32_t nq, uint32_t k);
 int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, uint32_t nq, uint32_t k,
                  uint32_t *d_ids, float *d_dist, uint32_t *d_counts, unsigned char *scratch, hipStream_t st);
@@ -548,7 +549,7 @@ int shodh_index_is_deleted(const shodh_index *idx, uint32_t id) {
 uint64_t shodh_index_len(const shodh_index *idx) {
     if (!idx) return 0;
     std::shared_lock<std::shared_mutex> lk(idx->mu);
-    return idx->n;
+    return idx->cfg.kind == SHODH_INDEX_IVFPQ ? ivfpq_len(idx->ivfpq) : idx->n;
 }
 uint64_t shodh_index_deleted_count(const shodh_index *idx) {
     if (!idx) return 0;

@@ -62,6 +62,15 @@ struct IvfpqState {
     size_t scratch_bytes = 0;
 };
 
+// SpannIndex::len (spann.rs: num_vectors): the postings held, pending inserts included
+uint64_t ivfpq_len(IvfpqState *s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint64_t n = 0;
+    for (const auto &l : s->h_ids) n += l.size();
+    return n;
+}
+
 void ivfpq_destroy(IvfpqState *s) {
     if (!s) return;
     hipSetDevice(s->device);

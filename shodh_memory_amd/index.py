@@ -326,7 +326,6 @@ class SpannIndex:
         cfg.device = device
         cfg.nprobe = num_probes
         self._hd = _Handle(cfg)
-        self._n = 0
         self.num_probes = num_probes
         self._metric = distance_metric.value
         self._state = None
@@ -340,10 +339,10 @@ class SpannIndex:
         self._hd.close()
 
     def len(self):
-        return self._n
+        return int(L.lib().shodh_index_len(self.handle))       # postings held (SpannIndex::len)
 
     def is_empty(self):
-        return self._n == 0
+        return self.len() == 0
 
     def set_trained_state(self, centroids, codebook, list_off, ids, codes):
         c = np.ascontiguousarray(centroids, np.float32)
@@ -355,7 +354,6 @@ class SpannIndex:
         assert sub == 8
         L.check(L.lib().shodh_index_set_ivfpq(self.handle, c.ctypes.data, c.shape[0], cb.ctypes.data, M, ncent,
                                               lo.ctypes.data, i.ctypes.data, cd.ctypes.data))
-        self._n = int(i.size)
         self._state = dict(centroids=c, codebook=cb, list_off=lo, ids=i, codes=cd.reshape(-1, M))   # host copy, for save_to_file
         self._pending = []
 
@@ -403,7 +401,6 @@ class SpannIndex:
         assign, codes = self.encode(v)                    # kept on the host side too, so that save_to_file sees the insert
         L.check(L.lib().shodh_index_ivfpq_insert(self.handle, int(vector_id), v.ctypes.data))
         self._pending.append((int(assign[0]), int(vector_id), codes[0].copy()))
-        self._n += 1
 
     def _current_state(self):
         """trained state + the inserts since, as CSR (an insert goes to the END of its posting list)"""
@@ -427,7 +424,7 @@ class SpannIndex:
         """SpannIndex::save_to_file (spann.rs:750-876): SPAN v1"""
         from . import persist
         st = self._current_state()
-        persist.write_spann(path, self._n, st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"], metric=self._metric)
+        persist.write_spann(path, self.len(), st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"], metric=self._metric)
 
     @classmethod
     def load_from_file(cls, path, num_probes=10, device=0):
