@@ -296,6 +296,21 @@ class VamanaIndex:
             L.check(L.lib().shodh_index_extract_live_rows(self.handle, out.ctypes.data, None, n.value, C.byref(n)))
         return out
 
+    # -- persistence (vamana_persist.rs:175-424): VAMA v1 --------------------------------------------------------
+    def save_to_file(self, path):
+        from . import persist
+        persist.save_vamana(self, path)
+
+    @classmethod
+    def load_from_file(cls, path, device=0):
+        from . import persist
+        return persist.load_vamana(path, device=device)
+
+    @staticmethod
+    def verify_index_file(path):
+        from . import persist
+        return persist.verify_index_file(path)
+
     # -- diagnostics -------------------------------------------------------------------------------------------
     def stage_timings_us(self):
         a = (C.c_float * 4)()
@@ -507,6 +522,18 @@ class VectorIndexBackend:
 
     def is_empty(self):
         return self.len() == 0
+
+    def save_to_file(self, path):                                   # vector_db/mod.rs:188-193
+        return self.inner.save_to_file(path)
+
+    @classmethod
+    def load_from_file(cls, path, backend_type, device=0):          # :196-201
+        return cls(VamanaIndex.load_from_file(path, device=device) if backend_type == BackendType.Vamana
+                   else SpannIndex.load_from_file(path, device=device))
+
+    @staticmethod
+    def verify_index_file(path, backend_type):                      # :260-265
+        return VamanaIndex.verify_index_file(path) if backend_type == BackendType.Vamana else SpannIndex.verify_index_file(path)
 
     def build(self, vectors):
         return self.inner.build(vectors)

@@ -23,12 +23,28 @@ def test_vamana_file_save_load_search(S, oracle, tmp_path):
     idx = S.VamanaIndex(S.VamanaConfig(dimension=4, max_degree=8))
     idx.build(vectors)
     path = tmp_path / "test.vamana"
-    P.save_vamana(idx, path)
-    assert P.verify_index_file(path)
-    loaded = P.load_vamana(path)
+    idx.save_to_file(path)                                              # vamana_persist.rs:432-470 test_save_and_load, step for step
+    assert path.exists()
+    assert S.VamanaIndex.verify_index_file(path)
+    loaded = S.VamanaIndex.load_from_file(path)
     assert loaded.len() == 5
     res = loaded.search(np.array([1, 0, 0, 0], np.float32), 3)
     assert res and res[0][0] == 0                                       # "Should find vector 0 first" (:469)
+    # test_checksum_detects_corruption (:473-501): flip a byte behind the header
+    idx2 = S.VamanaIndex(S.VamanaConfig(dimension=4))
+    idx2.build(np.array([[1, 0, 0, 0], [0, 1, 0, 0]], np.float32))
+    cpath = tmp_path / "corrupt.vamana"
+    idx2.save_to_file(cpath)
+    raw = bytearray(cpath.read_bytes())
+    raw[64 + 10] ^= 0xFF                                                # HEADER_SIZE + 10
+    cpath.write_bytes(bytes(raw))
+    assert not S.VamanaIndex.verify_index_file(cpath)
+    # the facade (vector_db/mod.rs:188-201, :260-265)
+    be = S.VectorIndexBackend.load_from_file(path, S.BackendType.Vamana)
+    assert be.backend_type() == S.BackendType.Vamana and be.len() == 5 and be.search(np.array([0, 1, 0, 0], np.float32), 1)[0][0] == 1
+    assert S.VectorIndexBackend.verify_index_file(path, S.BackendType.Vamana) and not S.VectorIndexBackend.verify_index_file(cpath, S.BackendType.Vamana)
+    be.save_to_file(tmp_path / "again.vamana")
+    assert (tmp_path / "again.vamana").read_bytes() == path.read_bytes()
 
 
 def test_vamana_file_with_tombstones_matches_oracle(S, oracle, tmp_path):
