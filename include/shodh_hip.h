@@ -308,6 +308,32 @@ int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n,
                                  const float *tag, const float *imp, const float *momentum_ema,
                                  const uint32_t *access_count, const float *graph_strength, float *out);
 
+/* ---- the ranking tail of RelevanceEngine::surface_relevant_inner (src/relevance.rs:801-918), host code ------ */
+/* calculate_tag_score (:680-705): share of the tags that occur in the context (substring, or a context word that starts
+ * with the tag / is a prefix of it); both sides lower-cased. ASCII case folding only (the reference folds Unicode). */
+float shodh_calculate_tag_score(const char *context_utf8, const char *const *tags_utf8, size_t n_tags);
+/* apply_recency_boost (:1524-1547): age_hours = (now - created_at).num_hours(), cast to u64 like the reference does
+ * (a negative age becomes huge and gets no boost) */
+float shodh_apply_recency_boost(float base_score, int64_t age_hours, uint64_t boost_hours, float multiplier);
+typedef struct {
+    float    min_importance;              /* 0.3  (:167-169) */
+    uint64_t recency_boost_hours;         /* 24   (:171-173) */
+    float    recency_boost_multiplier;    /* 1.2  (:175-177) */
+    float    graph_boost_multiplier;      /* 1.15 (:147-149) */
+    uint32_t max_results;                 /* 5    (:159-161) */
+} shodh_relevance_cfg;
+void shodh_relevance_cfg_default(shodh_relevance_cfg *c);
+enum { SHODH_REASON_COMBINED = 0, SHODH_REASON_ENTITY_MATCH = 1, SHODH_REASON_SEMANTIC_SIMILARITY = 2, SHODH_REASON_RECENT_IMPORTANT = 3 };
+/* Phase 3 of surface_relevant_inner for n candidates: drop importance < min_importance (:809-812), fuse_scores_full
+ * (:847-855), recency boost (:869-874), graph boost for entity matches, capped at 1 (:877-881), sort (score total_cmp desc,
+ * created_at desc, id asc) (:904-909), keep score >= 0.25 (:913-914), truncate to max_results (:917). The memory_types filter
+ * (:815-825) is string matching on the caller's side. uuid: [n][16] (the id tie-break compares Uuid::to_string(), which
+ * orders like the bytes). Outputs (max_results entries each): index into the inputs, final score, reason. Returns the count. */
+size_t shodh_rank_surfaced(const shodh_weights *w, const shodh_relevance_cfg *cfg, size_t n, const float *semantic, const float *entity,
+                           const float *tag, const float *importance, const float *momentum_ema, const uint32_t *access_count,
+                           const float *graph_strength, const int64_t *age_hours, const int64_t *created_at_ns, const uint8_t *uuid,
+                           uint32_t *out_index, float *out_score, uint8_t *out_reason);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,8 @@ def lib():
         "so_fuse_scores_with_momentum": (C.c_float, [C.POINTER(Weights)] + [C.c_float] * 5),
         "so_calculate_tag_score": (C.c_float, [C.c_char_p, C.POINTER(C.c_char_p), sz]),
         "so_apply_recency_boost": (C.c_float, [C.c_float, C.c_int64, C.c_uint64, C.c_float]),
+        "so_rank_surfaced": (sz, [C.POINTER(Weights), C.c_float, C.c_uint64, C.c_float, C.c_float, sz, sz, fp, fp, fp, fp, fp, u32p, fp,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64), u8p, u32p, fp, u8p]),
         "so_rrf_fuse": (sz, [C.c_float, fp, sz, u8p, C.POINTER(sz), u8p, fp, sz]),
         "so_density_weights": (None, [C.c_float, fp]),
         "so_leg_fusion_weights": (None, [C.c_int, C.c_float, C.c_float, C.c_float, fp, fp]),
@@ -419,6 +421,24 @@ def calculate_tag_score(content: str, tags):
 
 def apply_recency_boost(base, age_hours, boost_hours, mult):
     return np.float32(lib().so_apply_recency_boost(base, int(age_hours), int(boost_hours), mult))
+
+
+def rank_surfaced(w, cands, min_importance=0.3, recency_boost_hours=24, recency_boost_multiplier=1.2, graph_boost_multiplier=1.15, max_results=5):
+    """cands: list of dicts(semantic, entity, tag, importance, momentum, access_count, graph_strength, age_hours, created_at_ns, uuid)
+    -> [(index, score, reason)]"""
+    n = len(cands)
+    f = lambda key: np.array([c[key] for c in cands] or [0], np.float32)
+    sem, ent, tag, imp, mom, gs = (f(k_) for k_ in ("semantic", "entity", "tag", "importance", "momentum", "graph_strength"))
+    acc = np.array([c["access_count"] for c in cands] or [0], np.uint32)
+    age = np.array([c["age_hours"] for c in cands] or [0], np.int64)
+    cre = np.array([c["created_at_ns"] for c in cands] or [0], np.int64)
+    uu = np.frombuffer(b"".join(c["uuid"] for c in cands), np.uint8).copy() if n else np.zeros(16, np.uint8)
+    oi = np.zeros(max(max_results, 1), np.uint32); os_ = np.zeros(max(max_results, 1), np.float32); orr = np.zeros(max(max_results, 1), np.uint8)
+    m = lib().so_rank_surfaced(C.byref(w), min_importance, recency_boost_hours, recency_boost_multiplier, graph_boost_multiplier, max_results, n,
+                               _p(sem, C.c_float), _p(ent, C.c_float), _p(tag, C.c_float), _p(imp, C.c_float), _p(mom, C.c_float), _p(acc, C.c_uint32),
+                               _p(gs, C.c_float), age.ctypes.data_as(C.POINTER(C.c_int64)), cre.ctypes.data_as(C.POINTER(C.c_int64)), _p(uu, C.c_uint8),
+                               _p(oi, C.c_uint32), _p(os_, C.c_float), _p(orr, C.c_uint8))
+    return [(int(oi[i]), np.float32(os_[i]), int(orr[i])) for i in range(m)]
 
 
 def rrf_fuse(k, weights, lists):

@@ -824,6 +824,48 @@ float so_apply_recency_boost(float base, int64_t age_hours_signed, uint64_t boos
     return base;
 }
 
+/* relevance.rs:801-918 */
+typedef struct { uint32_t index; float relevance_score; int64_t created_at; uint8_t id[16]; uint8_t reason; } surfaced_t;
+static int surfaced_cmp(const void *pa, const void *pb) {
+    const surfaced_t *a = (const surfaced_t *)pa, *b = (const surfaced_t *)pb;
+    int c = so_total_cmp(b->relevance_score, a->relevance_score);          /* b.relevance_score.total_cmp(&a.relevance_score) */
+    if (c) return c;
+    if (b->created_at != a->created_at) return b->created_at < a->created_at ? -1 : 1;   /* b.created_at.cmp(&a.created_at) */
+    return memcmp(a->id, b->id, 16);                                       /* a.id.cmp(&b.id): hyphenated lower-case hex orders like the bytes */
+}
+size_t so_rank_surfaced(const so_weights *w, float min_importance, uint64_t recency_boost_hours, float recency_boost_multiplier,
+                        float graph_boost_multiplier, size_t max_results, size_t n, const float *semantic, const float *entity,
+                        const float *tag, const float *importance, const float *momentum_ema, const uint32_t *access_count,
+                        const float *graph_strength, const int64_t *age_hours, const int64_t *created_at_ns, const uint8_t *uuid,
+                        uint32_t *out_index, float *out_score, uint8_t *out_reason) {
+    surfaced_t *results = (surfaced_t *)malloc((n ? n : 1) * sizeof(surfaced_t));
+    size_t nr = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float imp = importance[i];
+        if (imp < min_importance) continue;
+        float semantic_score = semantic[i], entity_score = entity[i];
+        float fused_score = so_fuse_scores_full(w, semantic_score, entity_score, tag[i], imp, momentum_ema[i], access_count[i], graph_strength[i]);
+        uint8_t reason;
+        if (semantic_score > 0.0f && entity_score > 0.0f) reason = 0;
+        else if (entity_score > 0.0f) reason = 1;
+        else if (semantic_score > 0.0f) reason = 2;
+        else reason = 3;
+        float recency_boosted = so_apply_recency_boost(fused_score, age_hours[i], recency_boost_hours, recency_boost_multiplier);
+        float final_score = recency_boosted;
+        if (entity_score > 0.0f) final_score = f32_min(recency_boosted * graph_boost_multiplier, 1.0f);
+        results[nr].index = (uint32_t)i; results[nr].relevance_score = final_score; results[nr].created_at = created_at_ns[i];
+        memcpy(results[nr].id, uuid + i * 16, 16); results[nr].reason = reason;
+        ++nr;
+    }
+    qsort(results, nr, sizeof(surfaced_t), surfaced_cmp);      /* keys are unique down to the id, so stability does not matter */
+    size_t kept = 0;
+    for (size_t i = 0; i < nr; ++i) if (results[i].relevance_score >= 0.25f) results[kept++] = results[i];
+    if (kept > max_results) kept = max_results;
+    for (size_t i = 0; i < kept; ++i) { out_index[i] = results[i].index; out_score[i] = results[i].relevance_score; out_reason[i] = results[i].reason; }
+    free(results);
+    return kept;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* hybrid_search.rs RRFusion                                                             */
 /* ------------------------------------------------------------------------------------ */

@@ -141,6 +141,15 @@ float so_fuse_scores_with_momentum(const so_weights *w, float sem, float ent, fl
 float so_calculate_tag_score(const char *content, const char *const *tags, size_t n_tags);  /* :680-705 */
 float so_apply_recency_boost(float base, int64_t age_hours, uint64_t boost_hours, float mult); /* :1524-1547 */
 
+/* ranking tail of RelevanceEngine::surface_relevant_inner (:801-918): min-importance filter, fuse_scores_full, recency boost,
+ * graph boost (entity matches), sort (score desc, created_at desc, id asc), score >= 0.25, truncate. Outputs hold max_results
+ * entries: index of the candidate, final score, reason (0 Combined, 1 EntityMatch, 2 SemanticSimilarity, 3 RecentImportant). */
+size_t so_rank_surfaced(const so_weights *w, float min_importance, uint64_t recency_boost_hours, float recency_boost_multiplier,
+                        float graph_boost_multiplier, size_t max_results, size_t n, const float *semantic, const float *entity,
+                        const float *tag, const float *importance, const float *momentum_ema, const uint32_t *access_count,
+                        const float *graph_strength, const int64_t *age_hours, const int64_t *created_at_ns, const uint8_t *uuid,
+                        uint32_t *out_index, float *out_score, uint8_t *out_reason);
+
 /* ---- hybrid_search.rs -------------------------------------------------------------- */
 /* RRFusion::new + fuse (:536-594). lists: n_lists ranked lists of uuids (16 B each),
  * list_len[l] entries each, concatenated in `uuids`. Output sorted (score desc, uuid asc). */

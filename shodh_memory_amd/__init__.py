@@ -17,7 +17,8 @@ if not (_sys.argv and _sys.argv[0] == "-m"):
 
 from .index import (BackendConfig, BackendType, DistanceMetric, SpannIndex, VamanaConfig,   # noqa: E402
                     VamanaIndex, VectorIndexBackend)
-from .relevance import LearnedWeights, LegFusion, calculate_density_weights, calibrate_score                                      # noqa: E402
+from .relevance import (LearnedWeights, LegFusion, apply_recency_boost, calculate_density_weights, calculate_tag_score,  # noqa: E402
+                        calibrate_score, rank_surfaced)                                      # noqa: E402
 from .embedder import Embedder, MiniLMEmbedder                                              # noqa: E402
 from .retrieval import IdMapping, RetrievalEngine                                           # noqa: E402
 

@@ -60,6 +60,11 @@ class LegFusionCfg(C.Structure):
                 ("agree_k", C.c_float), ("agree_lo", C.c_float), ("agree_hi", C.c_float), ("peak_lo", C.c_float), ("peak_hi", C.c_float)]
 
 
+class RelevanceCfg(C.Structure):
+    _fields_ = [("min_importance", C.c_float), ("recency_boost_hours", C.c_uint64), ("recency_boost_multiplier", C.c_float),
+                ("graph_boost_multiplier", C.c_float), ("max_results", C.c_uint32)]
+
+
 # every symbol include/shodh_hip.h declares: name -> (restype, argtypes)
 _vp, _fp, _u8p, _u32p, _u64p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 class VamaInfo(C.Structure):
@@ -124,6 +129,10 @@ SYMBOLS = {
     "shodh_span_load": (C.c_int, [C.c_char_p, _fp, _fp, _u64p, _u32p, _u8p]),
     "shodh_span_save": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _fp, _fp, _u64p, _u32p, _u8p]),
     "shodh_rrf_fuse": (C.c_size_t, [C.c_float, _fp, C.c_size_t, _u8p, C.POINTER(C.c_size_t), _u8p, _fp, C.c_size_t]),
+    "shodh_calculate_tag_score": (C.c_float, [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t]),
+    "shodh_apply_recency_boost": (C.c_float, [C.c_float, C.c_int64, C.c_uint64, C.c_float]),
+    "shodh_relevance_cfg_default": (None, [C.POINTER(RelevanceCfg)]),
+    "shodh_rank_surfaced": (C.c_size_t, [C.POINTER(Weights), C.POINTER(RelevanceCfg), C.c_size_t] + [_fp] * 5 + [_u32p, _fp, _vp, _vp, _u8p, _u32p, _fp, _u8p]),
     "shodh_leg_fusion_cfg_default": (None, [C.POINTER(LegFusionCfg)]),
     "shodh_density_weights": (None, [C.c_float, _fp]),
     "shodh_leg_fusion_weights": (None, [C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

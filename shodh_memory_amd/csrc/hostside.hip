@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -150,6 +152,91 @@ size_t shodh_rrf_fuse(float k, const float *weights, size_t n_lists, const uint8
     std::sort(acc.begin(), acc.end(), uuid_score_less);
     const size_t out = acc.size() < out_cap ? acc.size() : out_cap;
     for (size_t i = 0; i < out; ++i) { memcpy(out_uuid + i * 16, acc[i].u, 16); out_score[i] = acc[i].s; }
+    return out;
+}
+
+// ---- ranking tail of RelevanceEngine::surface_relevant_inner (relevance.rs:801-918) --------------------------------
+float shodh_calculate_tag_score(const char *context, const char *const *tags, size_t n_tags) {          // relevance.rs:680-705
+    if (n_tags == 0 || !context || !tags) return 0.0f;
+    auto lower = [](const char *z) { std::string o(z ? z : ""); for (char &c : o) if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a'); return o; };
+    const std::string ctx = lower(context);
+    // split_whitespace: Unicode White_Space
+    std::vector<std::pair<size_t, size_t>> words;
+    {
+        const uint8_t *t = (const uint8_t *)ctx.data();
+        const size_t len = ctx.size();
+        size_t pos = 0;
+        auto clen = [&](size_t p) { size_t l = u8len(t[p]); return p + l > len ? len - p : l; };
+        while (pos < len) {
+            while (pos < len) { const size_t l = clen(pos); if (!is_ws(u8dec(t + pos, l))) break; pos += l; }
+            if (pos >= len) break;
+            const size_t st = pos;
+            while (pos < len) { const size_t l = clen(pos); if (is_ws(u8dec(t + pos, l))) break; pos += l; }
+            words.emplace_back(st, pos - st);
+        }
+    }
+    size_t matches = 0;
+    for (size_t i = 0; i < n_tags; ++i) {
+        const std::string tag = lower(tags[i]);
+        if (ctx.find(tag) != std::string::npos) { ++matches; continue; }
+        for (const auto &wd : words) {
+            const bool word_starts_with_tag = wd.second >= tag.size() && ctx.compare(wd.first, tag.size(), tag) == 0;
+            const bool tag_starts_with_word = tag.size() >= wd.second && tag.compare(0, wd.second, ctx, wd.first, wd.second) == 0;
+            if (word_starts_with_tag || tag_starts_with_word) { ++matches; break; }
+        }
+    }
+    return (float)matches / (float)n_tags;
+}
+
+float shodh_apply_recency_boost(float base, int64_t age_hours_signed, uint64_t boost_hours, float multiplier) {   // relevance.rs:1524-1547
+    if (boost_hours == 0) return base;
+    const uint64_t age_hours = (uint64_t)age_hours_signed;
+    if (age_hours > boost_hours) return base;
+    const float decay = 1.0f - ((float)age_hours / (float)boost_hours);
+    const float boost = 1.0f + (multiplier - 1.0f) * decay;
+    const float v = base * boost;
+    return v != v ? 1.0f : (v < 1.0f ? v : 1.0f);          // f32::min(1.0): a NaN operand is ignored
+}
+
+void shodh_relevance_cfg_default(shodh_relevance_cfg *c) {
+    if (!c) return;
+    c->min_importance = 0.3f; c->recency_boost_hours = 24; c->recency_boost_multiplier = 1.2f; c->graph_boost_multiplier = 1.15f; c->max_results = 5;
+}
+
+size_t shodh_rank_surfaced(const shodh_weights *w, const shodh_relevance_cfg *cfg, size_t n, const float *semantic, const float *entity,
+                           const float *tag, const float *importance, const float *momentum_ema, const uint32_t *access_count,
+                           const float *graph_strength, const int64_t *age_hours, const int64_t *created_at_ns, const uint8_t *uuid,
+                           uint32_t *out_index, float *out_score, uint8_t *out_reason) {
+    if (!w || !cfg || (n && (!semantic || !entity || !tag || !importance || !momentum_ema || !access_count || !graph_strength || !age_hours ||
+                             !created_at_ns || !uuid))) { set_error("null argument"); return 0; }
+    struct Surfaced { uint32_t index; float score; uint8_t reason; };
+    std::vector<Surfaced> res;
+    res.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (importance[i] < cfg->min_importance) continue;                                                  // :809-812
+        const float fused = shodh_fuse_scores_full(w, semantic[i], entity[i], tag[i], importance[i], momentum_ema[i], access_count[i], graph_strength[i]);
+        const uint8_t reason = (semantic[i] > 0.0f && entity[i] > 0.0f) ? SHODH_REASON_COMBINED : entity[i] > 0.0f ? SHODH_REASON_ENTITY_MATCH
+                             : semantic[i] > 0.0f ? SHODH_REASON_SEMANTIC_SIMILARITY : SHODH_REASON_RECENT_IMPORTANT;   // :858-866
+        const float boosted = shodh_apply_recency_boost(fused, age_hours[i], cfg->recency_boost_hours, cfg->recency_boost_multiplier);
+        float final_score = boosted;
+        if (entity[i] > 0.0f) { const float g = boosted * cfg->graph_boost_multiplier; final_score = g != g ? 1.0f : (g < 1.0f ? g : 1.0f); }   // :877-881
+        res.push_back(Surfaced{(uint32_t)i, final_score, reason});
+    }
+    std::stable_sort(res.begin(), res.end(), [&](const Surfaced &a, const Surfaced &b) {                    // :904-909
+        const uint32_t ka = order_key(a.score), kb = order_key(b.score);
+        if (ka != kb) return ka > kb;
+        if (created_at_ns[a.index] != created_at_ns[b.index]) return created_at_ns[a.index] > created_at_ns[b.index];
+        return memcmp(uuid + (size_t)a.index * 16, uuid + (size_t)b.index * 16, 16) < 0;
+    });
+    size_t out = 0;
+    for (const Surfaced &r : res) {
+        if (!(r.score >= 0.25f)) continue;                                                                   // MIN_RELEVANCE_SCORE (:913-914)
+        if (out >= cfg->max_results) break;                                                                  // :917
+        if (out_index) out_index[out] = r.index;
+        if (out_score) out_score[out] = r.score;
+        if (out_reason) out_reason[out] = r.reason;
+        ++out;
+    }
     return out;
 }
 

@@ -134,3 +134,42 @@ class LegFusion:
         m = L.lib().shodh_fuse_legs(C.byref(self.cfg), hu.ctypes.data, hb.ctypes.data, hv.ctypes.data, len(hybrid), gu.ctypes.data,
                                     ga.ctypes.data, len(graph), int(query_len), ou.ctypes.data, os_.ctypes.data, cap, C.byref(trust))
         return [(bytes(ou[i]), float(os_[i])) for i in range(m)], float(trust.value)
+
+
+# ---- ranking tail of RelevanceEngine::surface_relevant_inner (src/relevance.rs:801-918) ----
+REASONS = ("Combined", "EntityMatch", "SemanticSimilarity", "RecentImportant")      # RelevanceReason
+
+
+def calculate_tag_score(context, tags):
+    """relevance.rs:680-705"""
+    arr = (C.c_char_p * max(len(tags), 1))(*[t.encode("utf-8") for t in tags])
+    return float(L.lib().shodh_calculate_tag_score(context.encode("utf-8"), arr, len(tags)))
+
+
+def apply_recency_boost(base_score, age_hours, boost_hours, multiplier):
+    """relevance.rs:1524-1547 with age_hours = (now - created_at).num_hours()"""
+    return float(L.lib().shodh_apply_recency_boost(base_score, int(age_hours), int(boost_hours), multiplier))
+
+
+def rank_surfaced(weights, candidates, **config):
+    """Phase 3 of surface_relevant_inner. candidates: dicts with semantic, entity, tag, importance, momentum, access_count,
+    graph_strength, age_hours, created_at_ns, uuid (bytes16). config: fields of RelevanceConfig (min_importance,
+    recency_boost_hours, recency_boost_multiplier, graph_boost_multiplier, max_results). -> [(index, score, reason name)]"""
+    cfg = L.RelevanceCfg()
+    L.lib().shodh_relevance_cfg_default(C.byref(cfg))
+    for k, v in config.items():
+        if k not in {f[0] for f in L.RelevanceCfg._fields_}:
+            raise TypeError(f"unknown RelevanceConfig field {k!r}")
+        setattr(cfg, k, v)
+    n = len(candidates)
+    col = lambda key, dt: np.array([c[key] for c in candidates] or [0], dt)
+    sem, ent, tag, imp, mom, gs = (col(k, np.float32) for k in ("semantic", "entity", "tag", "importance", "momentum", "graph_strength"))
+    acc, age, cre = col("access_count", np.uint32), col("age_hours", np.int64), col("created_at_ns", np.int64)
+    uu = np.frombuffer(b"".join(c["uuid"] for c in candidates), np.uint8).copy() if n else np.zeros(16, np.uint8)
+    cap = max(int(cfg.max_results), 1)
+    oi, os_, orr = np.zeros(cap, np.uint32), np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
+    w = weights._w if isinstance(weights, LearnedWeights) else weights
+    m = L.lib().shodh_rank_surfaced(C.byref(w), C.byref(cfg), n, sem.ctypes.data, ent.ctypes.data, tag.ctypes.data, imp.ctypes.data, mom.ctypes.data,
+                                    acc.ctypes.data, gs.ctypes.data, age.ctypes.data, cre.ctypes.data, uu.ctypes.data, oi.ctypes.data, os_.ctypes.data,
+                                    orr.ctypes.data)
+    return [(int(oi[i]), float(os_[i]), REASONS[int(orr[i])]) for i in range(m)]

@@ -114,3 +114,47 @@ def test_reference_id_mapping_tests():
     assert len(m.vector_to_memory) == 2
     m.insert(m1, 3)
     assert len(m.vector_to_memory) == 2, "vector_to_memory should not grow on re-insert"
+
+
+def test_ranking_tail_matches_oracle_and_reference_kats(L, oracle):
+    """relevance.rs:680-705, :1524-1547, :801-918 through the C ABI: the reference's own unit-test values, then random
+    candidate sets against the oracle's restatement (bit-for-bit: both go through the same libm expf / log2f)."""
+    import shodh_memory_amd as M
+    # relevance.rs tests (test_tag_score_*, recency): same literals as tests/test_oracle_kats.py::test_tag_score_and_recency
+    assert M.calculate_tag_score("I love Rust programming", ["rust"]) == 1.0
+    assert M.calculate_tag_score("Learning Rust", ["rust", "python"]) == 0.5
+    assert M.calculate_tag_score("Hello world", ["rust"]) == 0.0
+    assert M.calculate_tag_score("Test", []) == 0.0
+    assert M.calculate_tag_score("deploy kube clusters", ["kubernetes", "Deploy"]) == 1.0      # tag starts with a context word; case folded
+    assert M.apply_recency_boost(0.5, 0, 24, 1.2) > 0.5
+    assert abs(M.apply_recency_boost(0.5, 48, 24, 1.2) - 0.5) < 1e-3
+    assert M.apply_recency_boost(0.5, -3, 24, 1.2) == 0.5 and M.apply_recency_boost(0.95, 0, 24, 1.2) == 1.0
+    for ctx, tags in (("I love Rust programming", ["rust"]), ("a  b\tc", ["B", "zz", "c"]), ("naïve café", ["caf", "x"])):
+        assert np.float32(M.calculate_tag_score(ctx, tags)) == np.float32(oracle.calculate_tag_score(ctx, tags))
+    rng = np.random.default_rng(8)
+    w = M.LearnedWeights()
+    for trial in range(30):
+        n = int(rng.integers(0, 40))
+        cands = []
+        for i in range(n):
+            cands.append(dict(semantic=float(np.float32(rng.random())) if rng.random() < 0.8 else 0.0,
+                              entity=float(np.float32(rng.random())) if rng.random() < 0.5 else 0.0, tag=float(np.float32(rng.integers(0, 4) / 3)),
+                              importance=float(np.float32(rng.random())), momentum=float(np.float32(rng.uniform(-1, 1))), access_count=int(rng.integers(0, 40)),
+                              graph_strength=float(np.float32(rng.random())), age_hours=int(rng.integers(-5, 100)),
+                              created_at_ns=int(rng.integers(0, 4)) * 10 ** 9, uuid=uuid.UUID(int=int(rng.integers(1, 2 ** 62))).bytes))
+        if n > 4:                                                # exact score ties: created_at desc, then id asc decide
+            for j in (1, 2, 3):
+                cands[j] = dict(cands[0], created_at_ns=cands[0]["created_at_ns"] + (j % 2), uuid=uuid.UUID(int=j).bytes)
+        cfg = dict(max_results=int(rng.integers(1, 8)), min_importance=0.3, recency_boost_hours=int(rng.choice([0, 24, 72])))
+        got = M.rank_surfaced(w, cands, **cfg)
+        exp = oracle.rank_surfaced(oracle_weights(oracle), cands, **cfg)
+        assert [(g[0], np.float32(g[1]).tobytes(), g[2]) for g in got] == [(e[0], np.float32(e[1]).tobytes(), M.relevance.REASONS[e[2]]) for e in exp], trial
+        sc = [g[1] for g in got]
+        assert sc == sorted(sc, reverse=True) and all(s >= 0.25 for s in sc) and len(got) <= cfg["max_results"]
+        assert all(cands[g[0]]["importance"] >= np.float32(0.3) for g in got)
+
+
+def oracle_weights(oracle):
+    w = oracle.Weights()
+    oracle.lib().so_weights_default(C.byref(w))
+    return w
