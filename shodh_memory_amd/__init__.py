@@ -20,8 +20,9 @@ from .index import (BackendConfig, BackendType, DistanceMetric, SpannIndex, Vama
 from .relevance import (LearnedWeights, LegFusion, apply_recency_boost, calculate_density_weights, calculate_tag_score,  # noqa: E402
                         calibrate_score, rank_surfaced)                                      # noqa: E402
 from .embedder import Embedder, MiniLMEmbedder                                              # noqa: E402
-from .retrieval import IdMapping, RetrievalEngine                                           # noqa: E402
+from .retrieval import IdMapping, MemoryPathSlice, RetrievalEngine                                           # noqa: E402
 
 __all__ = ["ShodhError", "lib", "VamanaIndex", "VamanaConfig", "VectorIndexBackend", "BackendConfig", "BackendType",
            "DistanceMetric", "SpannIndex", "LearnedWeights", "calibrate_score", "Embedder", "MiniLMEmbedder",
-           "IdMapping", "RetrievalEngine"]
+           "IdMapping", "RetrievalEngine", "MemoryPathSlice", "LegFusion", "calculate_density_weights", "calculate_tag_score",
+           "apply_recency_boost", "rank_surfaced"]

@@ -3,7 +3,9 @@ search_by_embedding -- the glue between the embedder, the vector index and memor
 engine (RocksDB), chunker and event buffer of the reference are out of scope; an in-memory mapping
 stands in for `update_vector_mapping`.
 """
+import hashlib
 import uuid as _uuid
+from collections import OrderedDict
 
 import numpy as np
 
@@ -11,6 +13,8 @@ from . import _lib as L
 from .index import VamanaConfig, VamanaIndex
 
 VECTOR_SEARCH_CANDIDATE_MULTIPLIER = 2      # src/constants.rs:350
+POLAR_QUERY_VECTOR_POOL_MULTIPLIER = 2      # src/constants.rs:453
+EMBEDDING_CACHE_CAPACITY = 2_000            # memory/mod.rs:800-801 (moka caches; a plain LRU here)
 
 
 class IdMapping:
@@ -137,3 +141,75 @@ class RetrievalEngine:
         self.id_mapping.clear()
         for mid, vids in per_memory.items():
             self.id_mapping.insert_chunks(mid, vids)
+
+
+class _EmbeddingCache:
+    """SHA-256(text) -> embedding, bounded (memory/mod.rs:800-801, :5856-5860)."""
+
+    def __init__(self, capacity=EMBEDDING_CACHE_CAPACITY):
+        self.capacity, self.d, self.hits, self.misses = capacity, OrderedDict(), 0, 0
+
+    def get_or(self, text, encode):
+        key = hashlib.sha256(text.encode("utf-8")).digest()
+        if key in self.d:
+            self.hits += 1
+            self.d.move_to_end(key)
+            return self.d[key]
+        self.misses += 1
+        v = np.asarray(encode(text), np.float32)
+        self.d[key] = v
+        if len(self.d) > self.capacity:
+            self.d.popitem(last=False)
+        return v
+
+
+class MemoryPathSlice:
+    """The embed-and-index slice of `MemorySystem::remember` (memory/mod.rs:1025-1051, :1088-1094, :1252-1256) and the
+    query-embed + vector leg of `MemorySystem::recall` (:2873-2904, :3580-3617) over a `RetrievalEngine`. Everything else in
+    those two 1000-line functions (storage, graph, BM25, temporal facts, ...) is the reference's host code and out of scope."""
+
+    def __init__(self, retriever):
+        self.retriever = retriever
+        self.embedder = retriever.embedder
+        self.content_cache = _EmbeddingCache()
+        self.query_cache = _EmbeddingCache()
+
+    def remember(self, memory_id, content, embeddings=None):
+        """-> (embedding, indexed, similar): cache-or-encode the content, index it at once, then the k = 5 similarity search
+        that feeds the interference check, excluding the new memory itself."""
+        if embeddings is None:
+            embeddings = self.content_cache.get_or(content, self.embedder.encode)
+        indexed = True
+        try:
+            self.retriever.index_memory(memory_id, content=content, embedding=embeddings)
+        except L.ShodhError:
+            indexed = False                                         # the reference logs and carries on (:1088-1094)
+        similar = self.retriever.search_by_embedding(embeddings, 5, exclude_id=memory_id)
+        return embeddings, indexed, similar
+
+    def recall_vector_leg(self, query_text, max_results, query_embedding=None, polarity_sensitive=False, negated_embedding=None,
+                          episode_candidates=None):
+        """-> [(MemoryId, similarity)]: a pre-computed embedding wins, else the SHA-256-keyed query cache, else encode_query;
+        vector_top_k = max_results * 3 (* 2 for polarity-sensitive queries); with a negated-form embedding the two result lists
+        are united per memory (best score), ordered (score desc, id asc); an episode filter keeps its candidates only."""
+        if query_embedding is None or len(query_embedding) == 0:
+            query_embedding = self.query_cache.get_or(query_text, self.embedder.encode_query)
+        polar_mul = max(POLAR_QUERY_VECTOR_POOL_MULTIPLIER, 1) if polarity_sensitive else 1
+        vector_top_k = max_results * 3 * polar_mul
+        vr = self.retriever.search_ids(query_embedding=query_embedding, limit=vector_top_k)
+        if negated_embedding is not None:
+            best = {}
+            for mid, score in vr + self.retriever.search_ids(query_embedding=negated_embedding, limit=vector_top_k):
+                if mid not in best or score > best[mid]:
+                    best[mid] = score
+            key = lambda t: (-_total_order(t[1]), t[0].bytes)
+            vr = sorted(best.items(), key=key)
+        if episode_candidates is not None:
+            vr = [(mid, s) for mid, s in vr if mid in episode_candidates]
+        return vr
+
+
+def _total_order(x):
+    """f32::total_cmp as an integer key"""
+    b = int(np.array([x], np.float32).view(np.int32)[0])
+    return b ^ (((b >> 31) & 0xFFFFFFFF) >> 1)

@@ -170,3 +170,33 @@ def test_reference_force_quality_rebuild(S):
     engine.vector_index.add_vector(ref_test_vector(30, 384))
     engine.force_quality_rebuild()
     assert engine.index_health()["total_vectors"] == 25
+
+
+def test_remember_and_recall_slices(S):
+    """MemorySystem::remember embed+index slice and recall's query-embed + vector leg (memory/mod.rs:1025-1051, :1088-1094,
+    :1252-1256, :2873-2904, :3580-3617) over the simplified embedder."""
+    import uuid
+    eng = S.RetrievalEngine(S.MiniLMEmbedder.new_simplified(), dimension=384, scan_mode=1)
+    mp = S.MemoryPathSlice(eng)
+    texts = ["the cat sat on the mat", "a dog chased the cat", "quarterly revenue grew", "revenue grew last quarter", "gpu kernels are fun"]
+    ids = [uuid.UUID(int=100 + i) for i in range(len(texts))]
+    for mid, t in zip(ids, texts):
+        emb, indexed, similar = mp.remember(mid, t)
+        assert indexed and all(m != mid for m, _ in similar) and len(similar) <= 5         # the new memory is excluded from its own check
+    assert mp.content_cache.misses == 5 and mp.content_cache.hits == 0
+    emb2, _, similar = mp.remember(uuid.UUID(int=999), texts[0])                            # same content: cache hit, finds the original
+    assert mp.content_cache.hits == 1 and similar[0][0] == ids[0] and abs(similar[0][1] - 1.0) < 1e-5
+    res = mp.recall_vector_leg("revenue grew last quarter", max_results=2)
+    assert res[0][0] == ids[3] and len(res) <= 6 and mp.query_cache.misses == 1           # vector_top_k = max_results * 3
+    assert mp.recall_vector_leg("revenue grew last quarter", max_results=2) == res and mp.query_cache.hits == 1
+    pre = eng.embedder.encode("gpu kernels are fun")
+    assert mp.recall_vector_leg("ignored", 1, query_embedding=pre)[0][0] == ids[4] and mp.query_cache.misses == 1    # pre-computed embedding: no encode
+    # polarity-sensitive + negated form: union per memory, best score kept, (score desc, id asc)
+    neg = eng.embedder.encode("a dog chased the cat")
+    both = mp.recall_vector_leg("the cat sat on the mat", 1, polarity_sensitive=True, negated_embedding=neg)
+    top = {m for m, _ in both[:3]}
+    assert len(both) <= 6 * 2 and ids[1] in top and (ids[0] in top or uuid.UUID(int=999) in top)
+    assert [s for _, s in both] == sorted([s for _, s in both], reverse=True)
+    assert len({m for m, _ in both}) == len(both)
+    only = mp.recall_vector_leg("the cat sat on the mat", 3, episode_candidates={ids[1], ids[2]})
+    assert {m for m, _ in only} <= {ids[1], ids[2]}
