@@ -211,11 +211,16 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a, const fl
                 }
             }
         }
+        // at most 256 pushes per query per iteration: keep 256 free slots. The counters are read between two barriers so
+        // that every thread sees the same values (see topk_compact_if_short).
         __syncthreads();
-        // at most 256 pushes per query per iteration: keep 256 free slots
+        uint32_t filled[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) filled[q] = *buf[q].cnt;
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
-            if (*buf[q].cnt + EX_NT > a.cap) topk_compact<EX_NT>(buf[q]);   // block-uniform condition
+            if (filled[q] + EX_NT > a.cap) topk_compact<EX_NT>(buf[q]);   // block-uniform condition
         }
     }
     __syncthreads();
@@ -289,8 +294,7 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_generic_kernel(ExactArgs a) 
             }
             topk_push(buf, make_key(dist, a.id_base + (uint32_t)row));
         }
-        __syncthreads();
-        if (*buf.cnt + EX_NT > a.cap) topk_compact<EX_NT>(buf);
+        topk_compact_if_short<EX_NT>(buf, EX_NT);
     }
     __syncthreads();
     topk_compact<EX_NT>(buf);

@@ -246,8 +246,7 @@ __global__ __launch_bounds__(NT) void adc_scan_kernel(AdcArgs a) {
                 topk_push(buf, make_key(totald, idc[u]));
             }
         }
-        __syncthreads();
-        if (*buf.cnt + NT * ADC_U > a.cap) topk_compact<NT>(buf);
+        topk_compact_if_short<NT>(buf, NT * ADC_U);
     }
     __syncthreads();
     topk_compact<NT>(buf);

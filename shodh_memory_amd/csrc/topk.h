@@ -64,6 +64,19 @@ __device__ __forceinline__ void topk_compact(TopKBuf &b) {
     __syncthreads();
 }
 
+// "Compact if fewer than `room` slots are free": call with the WHOLE block after the pushes of an iteration (it starts with
+// the barrier that ends them). The counter is read between two barriers: a thread that had passed a single-barrier check and
+// already pushed for the next iteration could change the value a slower thread was still about to read, the two then disagreed
+// about entering the compaction and its barriers paired up with the wrong ones (seen as run-to-run differences in the
+// IVF-PQ list scan at 10M rows with 16 waves per workgroup; every kernel used the same idiom).
+template <int NT>
+__device__ __forceinline__ void topk_compact_if_short(TopKBuf &b, uint32_t room) {
+    __syncthreads();
+    const uint32_t n = *b.cnt;
+    __syncthreads();
+    if (n + room > b.cap) topk_compact<NT>(b);
+}
+
 __device__ __forceinline__ void topk_push(TopKBuf &b, uint64_t key) {
     if (key < *b.thr) {
         const uint32_t slot = atomicAdd(b.cnt, 1u);
@@ -135,10 +148,7 @@ __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, 
     for (uint64_t it = 0; it < n_iter; ++it) {
         const uint64_t i = it * NT + tid;
         if (i < n) { const uint64_t key = key_at(i); if (key != KEY_NONE) topk_push(b, key); }
-        if ((it & 1) == 1 || it + 1 == n_iter) {          // at most 2*NT pushes between checks
-            __syncthreads();
-            if (*b.cnt + 2 * NT > b.cap) topk_compact<NT>(b);
-        }
+        if ((it & 1) == 1 || it + 1 == n_iter) topk_compact_if_short<NT>(b, 2 * NT);   // at most 2*NT pushes between checks
     }
     __syncthreads();
     const uint32_t cnt = *b.cnt;

@@ -234,3 +234,51 @@ def test_reference_spann_rejections(S):
     with pytest.raises(S.ShodhError) as e:
         index.search(np.full(128, 0.1, np.float32), 5)
     assert "dimension" in str(e.value)
+
+
+def test_ten_million_rows_ivfpq_full_size(S, oracle):
+    """configs[3] at its full size: 10M x 384 rows, nlist 4096, nprobe 32, batch 1024, top-10. Size-independent properties
+    for the whole batch (k results, ascending (dist, id), ids valid and distinct, every id in one of the query's probed
+    lists' partitions, a second search returns the same bytes) and bit-exact parity against the oracle's SpannIndex::search
+    for a sample of the queries. The trained state is whatever a few device Lloyd steps give: parity is defined GIVEN the
+    state (the reference's own k-means draws from thread_rng)."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    n, P, nprobe, nq, k = 10_000_000, 4096, 32, 1024, 10
+    rows = bench.synth_rows(torch, n, 384, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    cent = torch.nn.functional.normalize(rows[torch.randperm(n, generator=g, device=dev)[:P]], dim=1).contiguous()
+    sub = rows[:65536].view(-1, 48, 8)
+    codebook = torch.stack([sub[torch.randperm(sub.shape[0], generator=g, device=dev)[:256], m] for m in range(48)]).contiguous()
+    cent_h, cb_h = cent.cpu().numpy(), codebook.cpu().numpy()
+    idx = S.SpannIndex(384, num_probes=nprobe)
+    idx.set_trained_state(cent_h, cb_h, np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 48), np.uint8))
+    h_rows = rows.cpu().numpy()
+    del rows
+    assign, codes = idx.encode(h_rows)
+    # spot-check the encoding itself against the oracle on a few rows (nearest centroid by `1 - sum x*y`, PQ codes)
+    for r in (0, 1, 4_999_999, n - 1):
+        assert int(assign[r]) == oracle.spann_find_nearest_centroid(h_rows[r], cent_h) and codes[r].tolist() == oracle.pq_encode(cb_h, h_rows[r]).tolist()
+    del h_rows
+    order = np.argsort(assign, kind="stable")
+    off = np.zeros(P + 1, np.uint64)
+    off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+    ids_sorted, codes_sorted = order.astype(np.uint32), codes[order]
+    idx.set_trained_state(cent_h, cb_h, off, ids_sorted, codes_sorted)
+    assert idx.len() == n
+    q = bench.synth_rows(torch, nq, 384, 2, dev).cpu().numpy()
+    ids, dist, counts = idx.search_batch(q, k)
+    ids2, dist2, counts2 = idx.search_batch(q, k)
+    assert ids.tobytes() == ids2.tobytes() and dist.tobytes() == dist2.tobytes() and (counts == k).all() and (counts2 == k).all()
+    assert (ids < n).all() and all(len(set(r.tolist())) == k for r in ids)
+    key = (order_key_u32(dist).astype(np.uint64) << np.uint64(32)) | ids.astype(np.uint64)
+    assert (key[:, 1:] > key[:, :-1]).all()          # strictly ascending (dist total_cmp, id)
+    for i in list(range(0, nq, 64)) + [nq - 1]:
+        e_ids, e_dist = oracle.spann_search(cent_h, off, ids_sorted, codes_sorted, cb_h, nprobe, q[i], k, 0)
+        assert ids[i].tolist() == e_ids.tolist() and dist[i].tobytes() == e_dist.tobytes(), i
+
+
+def order_key_u32(d):
+    b = np.ascontiguousarray(d, np.float32).view(np.uint32)
+    return np.where(b & 0x80000000, ~b, b | 0x80000000).astype(np.uint32)
