@@ -206,6 +206,7 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
     }
     __syncthreads();
     const uint32_t c = *cnt;
+    __syncthreads();              // (see the end of the rank path: nobody may reset the counter before everybody has read it)
     *overflow = false;          // (kept in the signature: an overflowing gather now falls through to the direct radix select)
     if (c < k) return 0xFFFFFFFFu;
     if (c <= 128u) {
@@ -223,7 +224,9 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
             if (r == k - 1) *res = v;
         }
         __syncthreads();
-        return *res;
+        const uint32_t kth = *res;
+        __syncthreads();          // a second call in the same kernel resets *res / *cnt: not before everybody has read them
+        return kth;
     }
     // many survivors: radix select over the gathered copy, or -- if even that overflowed (c > KTH_BUF: long runs of
     // near-equal keys, or a large k) -- straight over the source keys that passed the filter
