@@ -131,6 +131,10 @@ def test_ranking_tail_matches_oracle_and_reference_kats(L, oracle):
     assert M.apply_recency_boost(0.5, -3, 24, 1.2) == 0.5 and M.apply_recency_boost(0.95, 0, 24, 1.2) == 1.0
     for ctx, tags in (("I love Rust programming", ["rust"]), ("a  b\tc", ["B", "zz", "c"]), ("naïve café", ["caf", "x"])):
         assert np.float32(M.calculate_tag_score(ctx, tags)) == np.float32(oracle.calculate_tag_score(ctx, tags))
+    cfg0 = L.RelevanceCfg()
+    L.lib().shodh_relevance_cfg_default(C.byref(cfg0))                    # test_relevance_config_defaults (:1795-1802) + :147-177
+    assert (cfg0.max_results, cfg0.recency_boost_hours) == (5, 24)
+    assert (np.float32(cfg0.min_importance), np.float32(cfg0.recency_boost_multiplier), np.float32(cfg0.graph_boost_multiplier)) == (np.float32(0.3), np.float32(1.2), np.float32(1.15))
     rng = np.random.default_rng(8)
     w = M.LearnedWeights()
     for trial in range(30):
