@@ -60,7 +60,8 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--scan", choices=["auto", "exact", "mfma"], default="auto")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="N > 1: weak = --rows per GPU (the corpus grows with N, BASELINE configs[4] shape: ideal is constant queries/s), strong = --rows in total")
+                    help="N > 1: weak = --rows per GPU (the corpus grows with N, BASELINE configs[4] shape; value = queries x shards per second, the "
+                         "answered-query rate is config.end_to_end_queries_per_s, DESIGN.md section 5), strong = --rows in total (value = answered queries/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency section (keeps a rocprof kernel summary to the batch launches)")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
