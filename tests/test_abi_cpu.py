@@ -109,3 +109,37 @@ def test_rust_bindings_are_current_and_complete():
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0
     ffi = open(os.path.join(root, "rust", "shodh-hip-sys", "src", "ffi.rs")).read()
     assert sorted(re.findall(r"pub fn (shodh_\w+)\(", ffi)) == declared_symbols()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/shodh_hip.h must be consumable by a C compiler (the boundary is a C ABI: cgo / bindgen / ctypes users), and a
+    C program must link against the library and call entry points that need no device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "shodh_hip.h")
+    assert subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", hdr]).returncode == 0
+    assert subprocess.run(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", hdr]).returncode == 0
+    src = tmp_path / "t.c"
+    src.write_text('''
+#include <stdio.h>
+#include "shodh_hip.h"
+int main(void) {
+    shodh_weights w; shodh_weights_default(&w);
+    float s = shodh_fuse_scores_full(&w, 0.9f, 0.9f, 0.9f, 0.9f, 0.9f, 16, 0.9f);
+    float d[3]; shodh_density_weights(0.3f, d);
+    const char *tags[2] = {"rust", "python"};
+    float t = shodh_calculate_tag_score("Learning Rust", tags, 2);
+    shodh_leg_fusion_cfg c; shodh_leg_fusion_cfg_default(&c);
+    printf("%d %.6f %.3f %.2f %.1f\\n", shodh_abi_version(), s, d[1], t, c.rrf_k);
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    libdir = os.path.join(root, "shodh_memory_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lshodh_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ver, s, g, t, k = out.stdout.split()
+    assert abs(float(s) - 0.986757) < 1e-5 and float(g) == 0.5 and float(t) == 0.5 and float(k) == 30.0 and int(ver) >= 1
