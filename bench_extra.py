@@ -2,7 +2,7 @@
 """Secondary measurements (NOT the driver's contract line; that is bench.py): the other
 BASELINE.json configurations and a few diagnostics, one JSON object per line.
 
-  python bench_extra.py flat10m | k120 | pcie | latency | encoder | pipeline [--texts N] | kmeans [--rows N] | ivfpq [--rows N]
+  python bench_extra.py flat10m | k120 | pcie | latency | refshape | encoder | pipeline [--texts N] | kmeans [--rows N] | ivfpq [--rows N]
 """
 import json
 import os
@@ -64,6 +64,25 @@ def main():
             idx, q = flat(1_000_000, 1, 10, steps=50, scan=mode, tag="flat 1M single query: " + name)
         flat(1_000_000, 256, 10, steps=5, scan=L.SCAN_EXACT, tag="flat 1M, batch 256, top-10, exact-order f32 scan only (SHODH_SCAN_EXACT; also what an unquantisable corpus falls back to)")
         flat(10_000, 1, 10, steps=200, tag="flat 10k x 384 single query (configs[0] size; below 16384 rows the exact-order scan is the path)")
+    if what in ("refshape",):
+        # the reference's own criterion shapes (benches/memory_benchmarks.rs:156-181, :228-253): populate a small store, then time
+        # single recalls at k in {1, 5, 10, 25, 50}; here the vector leg only (one query vector, one synchronised call at a time)
+        for n_rows in (100, 1000, 10_000, 100_000):
+            rows = bench.synth_rows(torch, n_rows, 384, 1, dev)
+            idx = S.VamanaIndex(S.VamanaConfig(dimension=384, reserve_rows=n_rows))
+            idx.build(rows)
+            q1 = bench.synth_rows(torch, 1, 384, 2, dev)
+            res = {}
+            for k in (1, 5, 10, 25, 50):
+                o = (torch.empty((1, k), dtype=torch.int32, device=dev), torch.empty((1, k), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+                ts = []
+                for i in range(120):
+                    torch.cuda.synchronize(); a = time.perf_counter()
+                    idx.search_batch_device(q1, k, out=o)
+                    torch.cuda.synchronize(); ts.append(time.perf_counter() - a)
+                ts = sorted(ts[20:])
+                res["k=%d" % k] = round(ts[len(ts) // 2] * 1e3, 4)
+            print(json.dumps({"bench": "reference bench shape: %d memories, single recall (vector leg), p50 ms per call incl. launch + synchronise" % n_rows, "p50_ms": res}), flush=True)
     if what in ("pcie", "all"):
         rows = bench.synth_rows(torch, 1_000_000, 384, 1, dev)
         idx = S.VamanaIndex(S.VamanaConfig(dimension=384, reserve_rows=1_000_000))

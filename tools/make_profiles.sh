@@ -16,6 +16,6 @@ for W in encoder ivfpq; do
   python $ROOT/tools/stats_to_md.py /tmp/prof_$W "round ${R#r} -- rocprofv3 --kernel-trace --stats of \`python bench_extra.py $W $ARGS\`" > $OUT/${R}_${W}_kernel_stats.md
 done
 cd $ROOT
-for W in flat10m k120 latency pcie encoder pipeline kmeans; do timeout 400 python bench_extra.py $W; done > $OUT/${R}_extra_benchmarks.jsonl 2> $OUT/${R}_extra.err
+for W in flat10m k120 latency refshape pcie encoder pipeline kmeans; do timeout 400 python bench_extra.py $W; done > $OUT/${R}_extra_benchmarks.jsonl 2> $OUT/${R}_extra.err
 timeout 400 python bench_extra.py ivfpq --rows 10000000 2>> $OUT/${R}_extra.err | tail -1 >> $OUT/${R}_extra_benchmarks.jsonl
 tail -c 600 $OUT/${R}_bench_line.json; echo; cat $OUT/${R}_extra_benchmarks.jsonl | cut -c 1-400
