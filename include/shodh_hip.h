@@ -310,7 +310,8 @@ int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n,
 
 /* ---- the ranking tail of RelevanceEngine::surface_relevant_inner (src/relevance.rs:801-918), host code ------ */
 /* calculate_tag_score (:680-705): share of the tags that occur in the context (substring, or a context word that starts
- * with the tag / is a prefix of it); both sides lower-cased. ASCII case folding only (the reference folds Unicode). */
+ * with the tag / is a prefix of it); both sides lower-cased like str::to_lowercase (full Unicode mappings + Final_Sigma,
+ * from the Unicode 13 database), words split at Unicode White_Space. */
 float shodh_calculate_tag_score(const char *context_utf8, const char *const *tags_utf8, size_t n_tags);
 /* apply_recency_boost (:1524-1547): age_hours = (now - created_at).num_hours(), cast to u64 like the reference does
  * (a negative age becomes huge and gets no boost) */

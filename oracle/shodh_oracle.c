@@ -777,33 +777,82 @@ float so_fuse_scores_with_momentum(const so_weights *w, float sem, float ent, fl
     return so_fuse_scores_full(w, sem, ent, tag, imp, mom, 0, 0.5f);
 }
 
-static char *ascii_lower_dup(const char *s) {
-    /* str::to_lowercase is Unicode-aware; the reference's tests are ASCII. Non-ASCII bytes pass through. */
-    size_t n = strlen(s);
-    char *o = (char *)malloc(n + 1);
-    for (size_t i = 0; i <= n; ++i) o[i] = (s[i] >= 'A' && s[i] <= 'Z') ? (char)(s[i] + 32) : s[i];
-    return o;
+/* str::to_lowercase (library/alloc/src/str.rs): every char through its full Unicode lower-case mapping, U+03A3 through the
+ * Final_Sigma rule (map_uppercase_sigma / case_ignorable_then_cased). Data: oracle/unicode_lower.inc, generated from Python's
+ * Unicode 13 database by tools/gen_unicode_lower.py. Works on code points; returns a malloc'ed code-point array. */
+#include "unicode_lower.inc"
+static int cp_in(const unsigned int (*tab)[2], unsigned int n, uint32_t c) {
+    for (unsigned int lo = 0, hi = n; lo < hi;) {
+        unsigned int mid = lo + (hi - lo) / 2;
+        if (c < tab[mid][0]) hi = mid; else if (c > tab[mid][1]) lo = mid + 1; else return 1;
+    }
+    return 0;
+}
+static uint32_t *decode_cps(const char *s, size_t *n_out) {
+    size_t len = strlen(s), n = 0;
+    uint32_t *cps = (uint32_t *)malloc((len + 1) * sizeof(uint32_t));
+    for (size_t pos = 0; pos < len;) {
+        size_t l = utf8_len((uint8_t)s[pos]);
+        if (pos + l > len) l = len - pos;
+        cps[n++] = utf8_decode((const uint8_t *)s + pos, l);
+        pos += l;
+    }
+    *n_out = n;
+    return cps;
+}
+static uint32_t *lowercase_cps(const uint32_t *in, size_t n, size_t *n_out) {
+    uint32_t *out = (uint32_t *)malloc((3 * n + 1) * sizeof(uint32_t));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c = in[i];
+        if (c == 0x03A3) {
+            /* is_word_final = case_ignorable_then_cased(from[..i].chars().rev()) && !case_ignorable_then_cased(from[i+2..].chars()) */
+            int before = 0, after = 0;
+            for (size_t j = i; j-- > 0;) { if (cp_in(UCASE_IGNORABLE, UCASE_IGNORABLE_N, in[j])) continue; before = cp_in(UCASED, UCASED_N, in[j]); break; }
+            for (size_t j = i + 1; j < n; ++j) { if (cp_in(UCASE_IGNORABLE, UCASE_IGNORABLE_N, in[j])) continue; after = cp_in(UCASED, UCASED_N, in[j]); break; }
+            out[m++] = (before && !after) ? 0x03C2 : 0x03C3;
+            continue;
+        }
+        int mapped = 0;
+        for (unsigned int lo = 0, hi = ULOWER_N; lo < hi;) {
+            unsigned int mid = lo + (hi - lo) / 2;
+            if (ULOWER_FROM[mid] == c) { for (int j = 0; j < 3; ++j) if (ULOWER_TO[mid][j]) out[m++] = ULOWER_TO[mid][j]; mapped = 1; break; }
+            if (ULOWER_FROM[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        if (!mapped) out[m++] = c;
+    }
+    *n_out = m;
+    return out;
+}
+static size_t find_cps(const uint32_t *hay, size_t nh, const uint32_t *needle, size_t nn) {   /* str::contains on chars == on bytes */
+    if (nn == 0) return 0;
+    for (size_t i = 0; i + nn <= nh; ++i) if (memcmp(hay + i, needle, nn * sizeof(uint32_t)) == 0) return i;
+    return (size_t)-1;
 }
 
 /* relevance.rs:680-705 */
 float so_calculate_tag_score(const char *content, const char *const *tags, size_t n_tags) {
     if (n_tags == 0) return 0.0f;
-    char *ctx = ascii_lower_dup(content);
-    size_t clen = strlen(ctx);
+    size_t nc0, nc;
+    uint32_t *c0 = decode_cps(content, &nc0);
+    uint32_t *ctx = lowercase_cps(c0, nc0, &nc);
+    free(c0);
     int matches = 0;
     for (size_t t = 0; t < n_tags; ++t) {
-        char *tag = ascii_lower_dup(tags[t]);
-        size_t tl = strlen(tag);
-        if (strstr(ctx, tag) != NULL) { matches += 1; free(tag); continue; }
+        size_t nt0, nt;
+        uint32_t *t0 = decode_cps(tags[t], &nt0);
+        uint32_t *tag = lowercase_cps(t0, nt0, &nt);
+        free(t0);
+        if (find_cps(ctx, nc, tag, nt) != (size_t)-1) { matches += 1; free(tag); continue; }
         size_t pos = 0;
-        while (pos < clen) {
-            while (pos < clen && is_ws((uint8_t)ctx[pos])) ++pos;
-            if (pos >= clen) break;
+        while (pos < nc) {                                        /* split_whitespace */
+            while (pos < nc && is_ws(ctx[pos])) ++pos;
+            if (pos >= nc) break;
             size_t st = pos;
-            while (pos < clen && !is_ws((uint8_t)ctx[pos])) ++pos;
+            while (pos < nc && !is_ws(ctx[pos])) ++pos;
             size_t wl = pos - st;
-            int word_starts_with_tag = wl >= tl && memcmp(ctx + st, tag, tl) == 0;
-            int tag_starts_with_word = tl >= wl && memcmp(tag, ctx + st, wl) == 0;
+            int word_starts_with_tag = wl >= nt && memcmp(ctx + st, tag, nt * sizeof(uint32_t)) == 0;
+            int tag_starts_with_word = nt >= wl && memcmp(tag, ctx + st, wl * sizeof(uint32_t)) == 0;
             if (word_starts_with_tag || tag_starts_with_word) { matches += 1; break; }
         }
         free(tag);

@@ -1,6 +1,7 @@
 """Host-side glue exported by the C ABI (no device): hash embedder, search_ids post-processing and
 RRF must equal the oracle's restatement bit-for-bit."""
 import ctypes as C
+import os
 import uuid
 
 import numpy as np
@@ -162,3 +163,57 @@ def oracle_weights(oracle):
     w = oracle.Weights()
     oracle.lib().so_weights_default(C.byref(w))
     return w
+
+
+def test_tag_score_lowercases_like_str_to_lowercase(L, oracle):
+    """relevance.rs:685-689 lower-cases context and tags with str::to_lowercase (full Unicode mappings, Final_Sigma) and splits
+    at Unicode White_Space. Library and oracle against a restatement on top of Python's own str.lower() (same Unicode rules;
+    database 13.0 here), on text in several scripts, and the generated tables are current."""
+    import subprocess
+    import sys
+    import shodh_memory_amd as M
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_unicode_lower.py"), "--check"]).returncode == 0
+    WS = set([0x9, 0xA, 0xB, 0xC, 0xD, 0x20, 0x85, 0xA0, 0x1680, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000] + list(range(0x2000, 0x200B)))
+
+    def words(s):
+        out, cur = [], ""
+        for ch in s:
+            if ord(ch) in WS:
+                if cur:
+                    out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return out + ([cur] if cur else [])
+
+    def restated(context, tags):
+        if not tags:
+            return np.float32(0)
+        c, m = context.lower(), 0
+        for tag in tags:
+            t = tag.lower()
+            if t in c:
+                m += 1
+            elif any(w.startswith(t) or t.startswith(w) for w in words(c)):
+                m += 1
+        return np.float32(np.float32(m) / np.float32(len(tags)))
+
+    cases = [("Besuch in MÜNCHEN und Köln", ["münchen", "KÖLN", "berlin"]), ("ΟΔΟΣ ΑΘΗΝΑΣ", ["οδός", "οδος", "αθηνας", "αθηνασ"]),
+             ("ΣΑΣ ΣΟΦΟΣ. Σ", ["σας", "σοφος", "σοφοσ", "σ"]), ("İSTANBUL ve IĞDIR", ["i̇stanbul", "istanbul", "iğdir"]),
+             ("МОСКВА — столица", ["москва", "СТОЛИЦА"]), ("straße STRASSE", ["STRAẞE", "strasse"]), ("ᲐᲚᲐᲜᲘ ႠႡ", ["ალანი", "ⴀⴁ"]),
+             ("\U00010400\U00010401 deseret", ["\U00010428\U00010429"]), ("tab separated　words here", ["sep", "WORDS", "her", "nbsp"]),
+             ("à la carte", ["À", "car", "lac"]), ("ǅ ǈ ǋ titlecase", ["ǆ", "ǉ"]), ("Ω ohm K kelvin Å", ["ω", "k", "å"]), ("", ["x"]), ("x", [""])]
+    for ctx, tags in cases:
+        exp = restated(ctx, tags)
+        assert np.float32(M.calculate_tag_score(ctx, tags)) == exp, (ctx, tags, M.calculate_tag_score(ctx, tags), exp)
+        assert np.float32(oracle.calculate_tag_score(ctx, tags)) == exp, (ctx, tags)
+    rng = np.random.default_rng(3)
+    pool = [chr(c) for c in list(range(0x41, 0x5B)) + list(range(0xC0, 0x17F)) + list(range(0x386, 0x3D0)) + list(range(0x400, 0x460)) + [0x20, 0xA0, 0x2D, 0x27, 0x301, 0xB7]]
+    for _ in range(300):
+        ctx = "".join(rng.choice(pool, int(rng.integers(0, 30))))
+        tags = ["".join(rng.choice(pool, int(rng.integers(0, 4)))) for _ in range(int(rng.integers(1, 4)))]
+        if "\x00" in ctx or any("\x00" in t for t in tags):
+            continue
+        exp = restated(ctx, tags)
+        assert np.float32(M.calculate_tag_score(ctx, tags)) == exp and np.float32(oracle.calculate_tag_score(ctx, tags)) == exp, (ctx, tags)
