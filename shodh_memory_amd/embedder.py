@@ -79,6 +79,26 @@ def state_dict_to_blob(sd, cfg=None):
     return np.concatenate(parts)
 
 
+def estimate_tokens(text):
+    """token_estimation.rs:36-88: content-aware estimate used by `count_tokens` when no tokenizer is loaded. A 512-byte
+    sample decides the mode: CJK (more than 2.5 bytes per char) -> ceil(1.5 * chars); code (>= 8 % syntax punctuation in the
+    sample) -> bytes * 10 / 32; prose -> ceil(bytes / 4)."""
+    if text == "":
+        return 0
+    b = text.encode("utf-8")
+    byte_len = len(b)
+    sample = b[:min(byte_len, 512)]
+    syntax = sum(1 for x in sample if x in b'{}[]();=<>|&#@!~^\\"\'')
+    high = sum(1 for x in sample if x >= 0xC0)
+    if high > 0:
+        chars = len(text)
+        if chars > 0 and byte_len > chars * 2 + chars // 2:
+            return (chars * 3 + 1) // 2
+    if len(sample) > 0 and syntax * 100 >= len(sample) * 8:
+        return byte_len * 10 // 32
+    return (byte_len + 3) // 4
+
+
 class Embedder:
     """trait Embedder (embeddings/mod.rs:52-88)"""
 
@@ -95,7 +115,7 @@ class Embedder:
         return [self.encode(t) for t in texts]
 
     def count_tokens(self, text):
-        return max(1, len(text) // 4) + SPECIAL_TOKEN_OVERHEAD
+        return estimate_tokens(text) + SPECIAL_TOKEN_OVERHEAD
 
     def chunk_budget_tokens(self):
         return MODEL_TOKEN_WINDOW

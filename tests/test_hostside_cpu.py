@@ -217,3 +217,22 @@ def test_tag_score_lowercases_like_str_to_lowercase(L, oracle):
             continue
         exp = restated(ctx, tags)
         assert np.float32(M.calculate_tag_score(ctx, tags)) == exp and np.float32(oracle.calculate_tag_score(ctx, tags)) == exp, (ctx, tags)
+
+
+def test_reference_estimate_tokens_tests():
+    """token_estimation.rs:93-222, the fallback of Embedder::count_tokens (minilm.rs:1216-1229), against the Python mirror"""
+    from shodh_memory_amd.embedder import estimate_tokens
+    assert estimate_tokens("") == 0 and estimate_tokens("hello") == 2
+    text = "The quick brown fox jumps over the lazy dog. This is a typical English sentence with normal punctuation."
+    assert abs(estimate_tokens(text) - len(text) // 4) <= 2
+    code = '\nfn main() {\n    let mut v: Vec<String> = Vec::new();\n    for i in 0..100 {\n        v.push(format!("{}: {}", i, i * 2));\n    }\n    println!("{:?}", &v[0..5]);\n}\n'
+    assert estimate_tokens(code) != len(code) // 4 and estimate_tokens(code) == len(code) * 10 // 32
+    cjk = "你好世界这是一个测试用来验证中文内容的分词估算是否准确"
+    assert estimate_tokens(cjk) == (len(cjk) * 3 + 1) // 2
+    mixed = "This is an English sentence with a few Chinese characters 你好 in it."
+    assert abs(estimate_tokens(mixed) - len(mixed.encode()) // 4) <= 3
+    js = '{"users": [{"name": "Alice", "age": 30}, {"name": "Bob", "age": 25}], "total": 2}'
+    assert estimate_tokens(js) == len(js) * 10 // 32
+    big = "The quick brown fox jumps over the lazy dog. " * 200
+    assert abs(estimate_tokens(big) - len(big) // 4) <= 2
+    assert estimate_tokens("   \n\t  \n  ") > 0 and estimate_tokens("a") == 1
