@@ -249,7 +249,7 @@ class MiniLMEmbedder(Embedder):
                 return len(self.tokenizer.encode(text, add_special_tokens=True).ids)
             finally:
                 self.tokenizer.enable_truncation(max_length=MODEL_TOKEN_WINDOW)
-        return max(1, len(text) // 4) + SPECIAL_TOKEN_OVERHEAD
+        return estimate_tokens(text) + SPECIAL_TOKEN_OVERHEAD
 
     def chunk_budget_tokens(self):                                     # minilm.rs:1236-1245
         if not self.doc_prefix:
