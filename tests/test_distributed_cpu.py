@@ -11,6 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _worker(rank, world, port, tmpdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -60,6 +67,6 @@ def test_two_rank_gloo_sharded_search(tmp_path):
     build.build()
     from oracle import oracle as O
     O.build()
-    port = 29500 + (os.getpid() % 1000)
+    port = _free_port()
     mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"

@@ -326,6 +326,13 @@ def test_one_million_rows_properties(S):
     assert np.array_equal(ids2.cpu().numpy().view(np.uint32), ids) and dist2.cpu().numpy().tobytes() == dist.tobytes()
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _gloo_worker(rank, world, port, tmpdir):
     # two processes sharing cuda:0, gloo for the collective: everything of ShardedFlatIndex except RCCL itself
     import os
@@ -360,7 +367,7 @@ def _gloo_worker(rank, world, port, tmpdir):
 
 def test_two_process_sharded_search_on_one_gpu(S, oracle, tmp_path):
     import torch.multiprocessing as mp
-    port = 29700 + (os.getpid() % 200)
+    port = _free_port()
     mp.start_processes(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
     if errs and all("gloo" in e.lower() or "not supported" in e.lower() or "cuda" in e.lower() for e in errs):
