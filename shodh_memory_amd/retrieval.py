@@ -1,6 +1,6 @@
 """Hot subset of `RetrievalEngine` (src/memory/retrieval.rs): IdMapping, index_memory, search_ids,
-search_by_embedding -- the glue between the embedder, the vector index and memory ids. The storage
-engine (RocksDB), chunker and event buffer of the reference are out of scope; an in-memory mapping
+search_by_embedding -- the glue between the embedder, the vector index and memory ids (the structural chunker
+is mirrored in chunking.py). The storage engine (RocksDB) and event buffer of the reference are out of scope; an in-memory mapping
 stands in for `update_vector_mapping`.
 """
 import hashlib
@@ -69,11 +69,18 @@ class RetrievalEngine:
         self.id_mapping = IdMapping()
 
     def index_memory(self, memory_id, content=None, embedding=None, chunks=None):
-        """retrieval.rs:646-730. `chunks`: pre-chunked texts (the structural chunker is host text logic and out
-        of scope); short memories reuse `embedding` (:704-705)."""
+        """retrieval.rs:646-730: content longer than the embedder's token window is split by the structural chunker
+        (budget = `chunk_budget_tokens()`, counted with `count_tokens`) and every chunk gets its own vector, all mapped to the
+        memory; short content is one vector, a pre-computed `embedding` reused (:704-705). `chunks` passes pre-chunked texts
+        straight in (tests)."""
+        from .chunking import ChunkConfig, chunk_text
         assert isinstance(memory_id, _uuid.UUID)
+        if chunks is None and content is not None:
+            r = chunk_text(content, ChunkConfig.for_budget(self.embedder.chunk_budget_tokens()), self.embedder.count_tokens)
+            if r.was_chunked:
+                chunks = r.chunks
         if chunks:
-            vecs = self.embedder.encode_batch(chunks)
+            vecs = self.embedder.encode_batch(chunks)            # the reference encodes the chunks one by one (:671-679): same vectors
         else:
             vecs = [np.asarray(embedding, np.float32) if embedding is not None else self.embedder.encode(content)]
         ids = [self.vector_index.add_vector(v) for v in vecs]

@@ -200,3 +200,24 @@ def test_remember_and_recall_slices(S):
     assert len({m for m, _ in both}) == len(both)
     only = mp.recall_vector_leg("the cat sat on the mat", 3, episode_candidates={ids[1], ids[2]})
     assert {m for m, _ in only} <= {ids[1], ids[2]}
+
+
+def test_index_memory_chunks_long_content(S):
+    """retrieval.rs:646-700: content beyond the 128-token window is split by the structural chunker, one vector per chunk, all
+    mapped to the memory; a query for text from the END of the content still finds it (the reason the chunker exists)."""
+    import uuid
+    from shodh_memory_amd.chunking import ChunkConfig, chunk_text
+    eng = S.RetrievalEngine(S.MiniLMEmbedder.new_simplified(), dimension=384, scan_mode=1)
+    long_text = " ".join("Paragraph %d talks about topic number %d in some detail." % (i, i) for i in range(120)) + " The launch code is heliotrope-seven."
+    short = uuid.UUID(int=1)
+    eng.index_memory(short, content="a short note about cats")
+    big = uuid.UUID(int=2)
+    ids = eng.index_memory(big, content=long_text)
+    expect = chunk_text(long_text, ChunkConfig.for_budget(eng.embedder.chunk_budget_tokens()), eng.embedder.count_tokens)
+    assert expect.was_chunked and len(ids) == len(expect.chunks) > 3 and eng.id_mapping.get_vector_ids(big) == ids
+    assert all(eng.embedder.count_tokens(c) <= 128 for c in expect.chunks)
+    assert len(eng.id_mapping.get_vector_ids(short)) == 1
+    res = eng.search_ids(query_embedding=eng.embedder.encode(expect.chunks[-1]), limit=2)
+    assert res[0][0] == big and abs(res[0][1] - 1.0) < 1e-5 and [r[0] for r in res].count(big) == 1
+    eng.index_memory(big, content="now it is short")                         # re-index: the old chunk vectors lose their mapping
+    assert len(eng.id_mapping.get_vector_ids(big)) == 1 and all(eng.id_mapping.get_memory_id(v) is None for v in ids)
