@@ -67,6 +67,8 @@ impl HipIndex {
         check(unsafe { ffi::shodh_index_create(&cfg, &mut h) })?;
         Ok(Self { h, dim: config.dimension, max_degree: config.max_degree, incremental: Default::default() })
     }
+    /// vamana.rs:175-187: the storage path only tells the reference where to mmap its vectors; rows live in HBM here
+    pub fn with_storage_path(config: VamanaConfig, _storage_path: Option<std::path::PathBuf>) -> Result<Self> { Self::new(config) }
     pub fn len(&self) -> usize { unsafe { ffi::shodh_index_len(self.h) as usize } }
     pub fn is_empty(&self) -> bool { self.len() == 0 }
 

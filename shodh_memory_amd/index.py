@@ -122,6 +122,13 @@ class VamanaIndex:
     def new(cls, config: VamanaConfig):
         return cls(config)
 
+    @classmethod
+    def with_storage_path(cls, config: VamanaConfig, storage_path=None):
+        """vamana.rs:175-187: the path only tells the reference where to mmap its vectors; rows live in HBM here"""
+        idx = cls(config)
+        idx.storage_path = storage_path
+        return idx
+
     @property
     def handle(self):
         return self._hd._h
