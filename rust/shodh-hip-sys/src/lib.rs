@@ -43,6 +43,8 @@ impl Default for VamanaConfig {
 }
 
 /// Same method set as `VamanaIndex`. `search` returns ids and distances bit-identical to `brute_force_search`.
+/// Not carried over: the legacy serde/bincode `save` / `load` / `index_file_exists` trio (vamana.rs:1470-1660), which nothing in
+/// the reference calls any more; persistence is `save_to_file` / `load_from_file` (VAMA v1).
 pub struct HipIndex {
     h: *mut ffi::shodh_index,
     dim: usize,
