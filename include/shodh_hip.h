@@ -168,6 +168,12 @@ int shodh_ivfpq_train(int device, const float *rows, uint64_t n, uint32_t dim, u
  * 0 on zero norm) */
 int shodh_cosine_similarity_batch(int device, const float *a, const float *b, uint64_t n, uint32_t dim,
                                   uint32_t order, float *out);
+/* top_k_similar (similarity.rs:27-48): cosine_similarity(query, cands[i]) for i < n (0.0 for every candidate when
+ * query_dim != dim, :11-13), STABLE sort by OrderedFloat score descending (equal scores keep input order; NaN sorts first,
+ * -0.0 == +0.0), first min(k, n) kept. out_scores/out_index hold k entries; out_index[i] = position of the candidate in
+ * `cands` (the caller's items T are looked up with it); *count_out = entries written. */
+int shodh_top_k_similar(int device, const float *query, uint32_t query_dim, const float *cands /*[n][dim]*/, uint64_t n,
+                        uint32_t dim, uint64_t k, uint32_t order, float *out_scores, uint32_t *out_index, uint64_t *count_out);
 
 /* ---- embedder: trait Embedder / MiniLMEmbedder (src/embeddings/mod.rs:52-88, minilm.rs) ------- */
 enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1 };

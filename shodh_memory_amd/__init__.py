@@ -19,10 +19,11 @@ from .index import (BackendConfig, BackendType, DistanceMetric, SpannIndex, Vama
                     VamanaIndex, VectorIndexBackend)
 from .relevance import (LearnedWeights, LegFusion, apply_recency_boost, calculate_density_weights, calculate_tag_score,  # noqa: E402
                         calibrate_score, rank_surfaced)                                      # noqa: E402
+from .similarity import cosine_similarity, top_k_similar                                # noqa: E402
 from .embedder import Embedder, MiniLMEmbedder                                              # noqa: E402
 from .retrieval import IdMapping, MemoryPathSlice, RetrievalEngine                                           # noqa: E402
 
 __all__ = ["ShodhError", "lib", "VamanaIndex", "VamanaConfig", "VectorIndexBackend", "BackendConfig", "BackendType",
            "DistanceMetric", "SpannIndex", "LearnedWeights", "calibrate_score", "Embedder", "MiniLMEmbedder",
            "IdMapping", "RetrievalEngine", "MemoryPathSlice", "LegFusion", "calculate_density_weights", "calculate_tag_score",
-           "apply_recency_boost", "rank_surfaced"]
+           "apply_recency_boost", "rank_surfaced", "cosine_similarity", "top_k_similar"]

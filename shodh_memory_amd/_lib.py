@@ -112,6 +112,7 @@ SYMBOLS = {
     "shodh_index_ivfpq_encode": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u8p]),
     "shodh_ivfpq_train": (C.c_int, [C.c_int, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp]),
     "shodh_cosine_similarity_batch": (C.c_int, [C.c_int, _fp, _fp, C.c_uint64, C.c_uint32, C.c_uint32, _fp]),
+    "shodh_top_k_similar": (C.c_int, [C.c_int, _fp, C.c_uint32, _fp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _fp, _u32p, C.POINTER(C.c_uint64)]),
     "shodh_embed_cfg_default": (None, [C.POINTER(EmbedCfg)]),
     "shodh_embedder_create": (C.c_int, [C.POINTER(EmbedCfg), C.POINTER(C.c_void_p)]),
     "shodh_embedder_destroy": (None, [_vp]),

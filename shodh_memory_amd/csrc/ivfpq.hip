@@ -315,51 +315,6 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict_
 }
 static inline uint32_t pq_encode_grid(uint64_t n, uint32_t M) { return (uint32_t)(ceil_div(n, 256) * M); }
 
-// ---- pairwise cosine (similarity.rs:10-24), one pair per thread ------------------------------------------------
-template <int ORDER>
-__device__ __forceinline__ float ref_dot(const float *a, const float *b, uint32_t n) {
-    if (ORDER == SHODH_ORDER_SCALAR4) {
-        const uint32_t un = n & ~3u;
-        float sum = 0.0f;
-        for (uint32_t i = 0; i < un; i += 4) {
-            float t = a[i] * b[i];
-            t = t + a[i + 1] * b[i + 1];
-            t = t + a[i + 2] * b[i + 2];
-            t = t + a[i + 3] * b[i + 3];
-            sum = sum + t;
-        }
-        for (uint32_t j = un; j < n; ++j) sum = sum + a[j] * b[j];
-        return sum;
-    } else {
-        const uint32_t sn = n & ~7u;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = 0; i < sn; i += 8)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = __builtin_fmaf(a[i + l], b[i + l], acc[l]);
-        float r = acc[0] + acc[1];
-        r = r + acc[2]; r = r + acc[3]; r = r + acc[4]; r = r + acc[5]; r = r + acc[6]; r = r + acc[7];
-        for (uint32_t j = sn; j < n; ++j) r = r + a[j] * b[j];
-        return r;
-    }
-}
-template <int ORDER>
-__global__ void cosine_batch_kernel(const float *a, const float *b, uint64_t n, uint32_t dim, float *out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *x = a + i * dim, *y = b + i * dim;
-    const float dot = ref_dot<ORDER>(x, y, dim);
-    const float na = __builtin_sqrtf(ref_dot<ORDER>(x, x, dim));
-    const float nb = __builtin_sqrtf(ref_dot<ORDER>(y, y, dim));
-    float r;
-    if (na == 0.0f || nb == 0.0f) r = 0.0f;
-    else {
-        r = dot / (na * nb);
-        if (r < -1.0f) r = -1.0f;
-        if (r > 1.0f) r = 1.0f;
-    }
-    out[i] = r;
-}
-
 // ---- host --------------------------------------------------------------------------------------------------------
 static int upload_postings(IvfpqState *s) {
     // flatten the host lists into CSR and upload
@@ -570,25 +525,6 @@ int shodh_index_ivfpq_insert(shodh_index *idx, uint32_t vector_id, const float *
         s->h_codes[part].insert(s->h_codes[part].end(), code.begin(), code.end());
         s->dirty = true;
     }
-    return SHODH_OK;
-}
-
-int shodh_cosine_similarity_batch(int device, const float *a, const float *b, uint64_t n, uint32_t dim, uint32_t order, float *out) {
-    if (n && (!a || !b || !out)) { set_error("null argument"); return SHODH_ERR_INVALID; }
-    if (n == 0) return SHODH_OK;
-    SHODH_HIP_TRY(hipSetDevice(device));
-    float *d = nullptr;
-    SHODH_HIP_TRY(hipMalloc((void **)&d, (2 * n * dim + n) * 4));
-    hipError_t e = hipMemcpy(d, a, n * dim * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + n * dim, b, n * dim * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        if (order == SHODH_ORDER_AVX2) hipLaunchKernelGGL((cosine_batch_kernel<SHODH_ORDER_AVX2>), dim3((uint32_t)ceil_div(n, 64)), dim3(64), 0, nullptr, d, d + n * dim, n, dim, d + 2 * n * dim);
-        else hipLaunchKernelGGL((cosine_batch_kernel<SHODH_ORDER_SCALAR4>), dim3((uint32_t)ceil_div(n, 64)), dim3(64), 0, nullptr, d, d + n * dim, n, dim, d + 2 * n * dim);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n * dim, n * 4, hipMemcpyDeviceToHost);
-    hipFree(d);
-    if (e != hipSuccess) { set_error("cosine batch failed: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
     return SHODH_OK;
 }
 
