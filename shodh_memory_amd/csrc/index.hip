@@ -29,18 +29,23 @@ void set_error(const char *fmt, ...) {
 }
 
 int ensure_dynamic_lds(const void *fn, size_t bytes) {
+    // hipFuncSetAttribute acts on the CURRENT device's copy of the function: the cache is keyed by (device, function), so
+    // a second index on another GPU of the same process raises its own limit
+    struct Seen { int dev; const void *fn; size_t bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void *, size_t>> seen;
+    static std::vector<Seen> seen;
+    int dev = 0;
+    SHODH_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mu);
     for (auto &e : seen)
-        if (e.first == fn) {
-            if (e.second >= bytes) return SHODH_OK;
+        if (e.dev == dev && e.fn == fn) {
+            if (e.bytes >= bytes) return SHODH_OK;
             SHODH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            e.second = bytes;
+            e.bytes = bytes;
             return SHODH_OK;
         }
     SHODH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    seen.emplace_back(fn, bytes);
+    seen.push_back(Seen{dev, fn, bytes});
     return SHODH_OK;
 }
 
@@ -72,6 +77,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1);
 int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
+int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStream_t st);
 int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st);
 int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uint32_t *deleted, uint64_t n, uint32_t dim, hipStream_t st);
 
@@ -193,6 +199,10 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
 // after new rows [first, first+n) are in idx->rows: shadow copy + stats
 static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
     if (idx->shadow) {
+        // the running maxima are restored if the batch is rejected: an Inf row would otherwise leave maxnorm / maxabs at
+        // +Inf and silently disable the MFMA path for every later (valid) add
+        uint32_t before[4];
+        SHODH_HIP_TRY(hipMemcpy(before, idx->stats, sizeof(before), hipMemcpyDeviceToHost));
         SHODH_TRY(launch_convert_rows(idx->rows, first, n, idx->cfg.dim, idx->rows_h, idx->stats, nullptr));
         uint32_t st[4];
         SHODH_HIP_TRY(hipMemcpy(st, idx->stats, sizeof(st), hipMemcpyDeviceToHost));
@@ -200,14 +210,25 @@ static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
         memcpy(&nsq, &st[0], 4); memcpy(&ma, &st[1], 4);
         if (st[2] != 0) {
             // roll back: the rows are not published (n is not advanced by the caller)
-            uint32_t z = 0;
-            hipMemcpy(idx->stats + 2, &z, 4, hipMemcpyHostToDevice);
+            before[2] = 0;
+            hipMemcpy(idx->stats, before, sizeof(before), hipMemcpyHostToDevice);
             set_error("rows contain %u non-finite values (NaN/Inf are out of contract: MiniLM scrubs them, minilm.rs:847-851)", st[2]);
             return SHODH_ERR_NONFINITE;
         }
         idx->maxnorm = sqrtf(nsq) * 1.00001f;
         idx->maxabs = ma;
         idx->quantizable = (ma * 256.0f < 60000.0f);
+    } else {
+        // no shadow copy (dimension without an MFMA kernel): the same finite check, on the device, for host and device rows alike
+        uint32_t bad = 0;
+        SHODH_TRY(launch_count_nonfinite(idx->rows + first * idx->cfg.dim, n * idx->cfg.dim, idx->stats + 2, nullptr));
+        SHODH_HIP_TRY(hipMemcpy(&bad, idx->stats + 2, 4, hipMemcpyDeviceToHost));
+        if (bad) {
+            uint32_t z = 0;
+            hipMemcpy(idx->stats + 2, &z, 4, hipMemcpyHostToDevice);
+            set_error("rows contain %u non-finite values (NaN/Inf are out of contract: MiniLM scrubs them, minilm.rs:847-851)", bad);
+            return SHODH_ERR_NONFINITE;
+        }
     }
     return SHODH_OK;
 }
@@ -399,10 +420,6 @@ static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *f
     if (n == 0) return SHODH_OK;
     SHODH_TRY(grow(idx, idx->n + n));
     SHODH_HIP_TRY(hipMemcpy(idx->rows + idx->n * idx->cfg.dim, rows, n * idx->cfg.dim * 4, kind));
-    if (!idx->shadow && kind == hipMemcpyHostToDevice) {
-        for (uint64_t i = 0; i < n * idx->cfg.dim; ++i)
-            if (!(fabsf(rows[i]) <= 3.0e38f)) { set_error("rows contain non-finite values"); return SHODH_ERR_NONFINITE; }
-    }
     SHODH_TRY(finish_append(idx, idx->n, n));
     SHODH_HIP_TRY(hipDeviceSynchronize());
     idx->n += n;

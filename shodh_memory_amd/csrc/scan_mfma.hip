@@ -434,6 +434,15 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float *rows, ui
     }
 }
 
+// number of NaN / Inf values in x[0..n) added to *counter (indexes without a shadow copy: the check convert_rows_kernel does)
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float *x, uint64_t n, uint32_t *counter) {
+    uint32_t bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        if (!(__builtin_fabsf(x[i]) <= 3.0e38f)) bad++;
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(counter, bad);
+}
+
 // zero (tombstone) or restore one row of the shadow copy
 __global__ void shadow_set_row_kernel(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero) {
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
@@ -1044,6 +1053,14 @@ int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t 
     uint64_t blocks = ceil_div(n, 4);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, rows, first, n, dim, rows_h, stats);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStream_t st) {
+    if (n == 0) return SHODH_OK;
+    uint64_t blocks = ceil_div(n, 1024);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, x, n, counter);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }

@@ -71,6 +71,13 @@ def _is_torch_cuda(x):
     return hasattr(x, "is_cuda") and x.is_cuda
 
 
+def _check_device_rows(t, dim):
+    """device tensors are handed over as raw pointers: anything but contiguous float32 [n, dim] would be misread"""
+    import torch
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != dim or not t.is_contiguous():
+        raise L.ShodhError(L.ERR_INVALID, "device rows must be a contiguous float32 [n, %d] tensor (got %s %s)" % (dim, t.dtype, tuple(t.shape)))
+
+
 def _as_rows(vectors, dim):
     a = np.ascontiguousarray(vectors, dtype=np.float32)
     if a.ndim == 1:
@@ -116,6 +123,7 @@ class VamanaIndex:
         cfg.id_base = self.config.id_base
         self._hd = _Handle(cfg)
         self._incremental = 0
+        self._graph = None            # degree / neighbour arrays of a reference-built file (persist.load_vamana), while the rows are unchanged
 
     # -- VamanaIndex::new / with_storage_path ----------------------------------------------------
     @classmethod
@@ -148,12 +156,13 @@ class VamanaIndex:
     # -- build (vamana.rs:200-284) / rebuild_from_vectors (:1363-1462) -------------------------------
     def build(self, vectors):
         if _is_torch_cuda(vectors):
-            assert vectors.dtype.is_floating_point and vectors.is_contiguous() and vectors.shape[-1] == self._hd.dim
+            _check_device_rows(vectors, self._hd.dim)
             L.check(L.lib().shodh_index_build_device(self.handle, vectors.data_ptr(), vectors.shape[0]))
         else:
             a = _as_rows(vectors, self._hd.dim)
             L.check(L.lib().shodh_index_build(self.handle, a.ctypes.data, a.shape[0]))
         self._incremental = 0
+        self._graph = None
 
     rebuild_from_vectors = build
 
@@ -164,14 +173,16 @@ class VamanaIndex:
             raise L.ShodhError(L.ERR_INVALID, "add_vector takes one vector; use add_vectors")
         first = C.c_uint32()
         L.check(L.lib().shodh_index_add(self.handle, a.ctypes.data, 1, C.byref(first)))
+        self._graph = None
         self._incremental += 1 if first.value > self.config.id_base else 0     # the vector that seeds an empty index is not an incremental insert (vamana.rs:888-898)
         return int(first.value)
 
     def add_vectors(self, vectors):
         """n sequential add_vector calls in one transfer; returns the first id."""
         first = C.c_uint32()
+        self._graph = None
         if _is_torch_cuda(vectors):
-            assert vectors.is_contiguous() and vectors.shape[-1] == self._hd.dim
+            _check_device_rows(vectors, self._hd.dim)
             L.check(L.lib().shodh_index_add_device(self.handle, vectors.data_ptr(), vectors.shape[0], C.byref(first)))
             n = int(vectors.shape[0])
         else:
@@ -206,7 +217,7 @@ class VamanaIndex:
     def search_batch_device(self, queries, k, out=None, stream=None):
         """torch CUDA tensors in, torch CUDA tensors out, asynchronous on the current stream."""
         import torch
-        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        _check_device_rows(queries, self._hd.dim)
         nq = queries.shape[0]
         if out is None:
             ids = torch.empty((nq, k), dtype=torch.int32, device=queries.device)     # bit pattern of u32 ids

@@ -58,9 +58,10 @@ def write_vamana(path, vectors, max_degree=32, medoid=0, metric=0, deleted=(), i
 
 
 def load_vamana(path, device=0, scan_mode=L.SCAN_AUTO):
-    """A persisted Vamana index -> flat GPU index: same vectors, same ids, same tombstones (the graph is not needed:
-    this library answers with the exact scan, the reference's own `brute_force_search` semantics)."""
-    f = read_vamana(path)
+    """A persisted Vamana index -> flat GPU index: same vectors, same ids, same tombstones. The graph is not needed to
+    answer (this library runs the exact scan, the reference's own `brute_force_search` semantics) but it is KEPT on the
+    index object, so that `save_to_file` of an index whose rows did not change writes the reference-built graph back."""
+    f = read_vamana(path, with_graph=True)
     info = f["info"]
     if info["distance_metric"] != 0:
         raise L.ShodhError(L.ERR_UNSUPPORTED, "only NormalizedDotProduct indexes are served (retrieval.rs:188-193)")
@@ -71,15 +72,34 @@ def load_vamana(path, device=0, scan_mode=L.SCAN_AUTO):
     for i in f["deleted"]:
         idx.mark_deleted(int(i))
     idx._incremental = int(info["incremental_inserts"])
+    idx._graph = dict(n=int(info["num_vectors"]), medoid=int(info["medoid"]), degree=f["degree"], neighbors=f["neighbors"])
     return idx
 
 
 def save_vamana(index, path):
-    """VamanaIndex::save_to_file for an index of this library (empty adjacency lists)."""
+    """VamanaIndex::save_to_file (vamana_persist.rs:175-284) for an index of this library.
+
+    This library never builds a Vamana graph. Two cases:
+    * the index was loaded from a reference-written file and its rows are unchanged (`index._graph`): the loaded degree /
+      neighbour arrays and medoid are written back, so the file round-trips with its graph;
+    * otherwise every node gets an EMPTY adjacency list, and `incremental_inserts` is raised to REBUILD_THRESHOLD in the
+      header: the reference's default (non-exact) `search` would walk a graph without edges and return one hit per query
+      (vamana.rs:780-806), so the file says "needs_rebuild()" (vamana.rs:985-993) and the reference's maintenance path
+      (`auto_rebuild_if_needed`, retrieval.rs:1633-1656) rebuilds the graph from the vectors. Under SHODH_VECTOR_EXACT the
+      file is served as is.
+    Tombstones are collected by GLOBAL id (`id_base + row`): a shard of a row-sharded corpus keeps its own."""
+    from .index import REBUILD_THRESHOLD
     vec = index.extract_all_vectors()
     vec = np.ascontiguousarray(np.asarray(vec, np.float32)).reshape(-1, index.config.dimension)
-    deleted = [i for i in range(vec.shape[0]) if index.is_deleted(i)] if index.deleted_count() else []
-    write_vamana(path, vec, max_degree=index.config.max_degree, medoid=0, metric=0, deleted=deleted, incremental_inserts=index.incremental_insert_count())
+    base = int(index.config.id_base)
+    deleted = [i for i in range(vec.shape[0]) if index.is_deleted(base + i)] if index.deleted_count() else []
+    g = getattr(index, "_graph", None)
+    if g is not None and g["n"] == vec.shape[0]:
+        write_vamana(path, vec, max_degree=index.config.max_degree, medoid=g["medoid"], metric=0, deleted=deleted,
+                     incremental_inserts=index.incremental_insert_count(), degree=g["degree"], neighbors=g["neighbors"])
+    else:
+        write_vamana(path, vec, max_degree=index.config.max_degree, medoid=0, metric=0, deleted=deleted,
+                     incremental_inserts=max(index.incremental_insert_count(), REBUILD_THRESHOLD if vec.shape[0] > 1 else 0))
 
 
 def span_info(path):

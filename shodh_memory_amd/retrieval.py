@@ -91,18 +91,23 @@ class RetrievalEngine:
         return ids
 
     def _postprocess(self, results, limit, exclude=None):
+        """retrieval.rs:920-963. Only the returned vector ids are mapped (O(k) per query, like the reference's hash-map
+        lookups): the C entry point takes a vector_to_memory TABLE indexed by vector id, so the results are renumbered
+        0..m-1 in their rank order -- the per-memory max over chunks walks them in that order and the final sort is by
+        (similarity, MemoryId), neither depends on the vector id itself."""
         if not results:
             return []
-        n_vec = self.vector_index.len()
-        v2m = np.full((n_vec, 16), 0xFF, np.uint8)
-        for vid, mid in self.id_mapping.vector_to_memory.items():
-            if vid < n_vec and (exclude is None or mid != exclude):
-                v2m[vid] = np.frombuffer(mid.bytes, np.uint8)
-        vec_ids = np.array([r[0] for r in results], np.uint32)
+        m_in = len(results)
+        v2m = np.full((m_in, 16), 0xFF, np.uint8)
+        for i, (vid, _) in enumerate(results):
+            mid = self.id_mapping.get_memory_id(vid)
+            if mid is not None and (exclude is None or mid != exclude):
+                v2m[i] = np.frombuffer(mid.bytes, np.uint8)
+        vec_ids = np.arange(m_in, dtype=np.uint32)
         dists = np.array([r[1] for r in results], np.float32)
         out_u = np.zeros((max(limit, 1), 16), np.uint8)
         out_s = np.zeros(max(limit, 1), np.float32)
-        m = L.lib().shodh_search_ids_postprocess(vec_ids.ctypes.data, dists.ctypes.data, len(results), v2m.ctypes.data, n_vec, limit,
+        m = L.lib().shodh_search_ids_postprocess(vec_ids.ctypes.data, dists.ctypes.data, m_in, v2m.ctypes.data, m_in, limit,
                                                  out_u.ctypes.data, out_s.ctypes.data)
         return [(_uuid.UUID(bytes=bytes(out_u[i])), float(out_s[i])) for i in range(m)]
 

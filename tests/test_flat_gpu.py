@@ -465,3 +465,44 @@ def test_reference_vamana_maintenance_tests(S):
     index.build(np.eye(4, dtype=f32))
     index.mark_deleted(0); index.mark_deleted(1)
     assert index.needs_rebuild() and index.auto_maintain() == "full_rebuild" and index.len() == 2 and index.deleted_count() == 0
+
+
+def test_rejected_batch_leaves_the_running_maxima_alone(S, oracle):
+    """an Inf row used to leave max norm / max |x| at +Inf after the rollback, which silently switched the MFMA
+    pre-scan off for every later add. After a rejected batch the next valid one must still take the MFMA path."""
+    from shodh_memory_amd import _lib
+    rows = synth.corpus(20000)
+    idx = make_index(S, scan_mode=0)
+    idx.build(rows[:100])
+    bad = rows[100:104].copy(); bad[2, 5] = np.inf; bad[3, 9] = -np.inf
+    with pytest.raises(_lib.ShodhError) as e:
+        idx.add_vectors(bad)
+    assert e.value.code == _lib.ERR_NONFINITE and idx.len() == 100
+    idx.add_vectors(rows[100:])
+    q = synth.queries(4)
+    check_against_oracle(oracle, idx, rows, q, 10, 0)
+    assert idx.scan_stats()["sampled_rows"] > 0, "the MFMA pre-scan was switched off by the rejected batch"
+    # a dimension without a shadow copy: device rows are checked for NaN/Inf too
+    import torch
+    idx2 = make_index(S, dim=36)
+    t = torch.randn(50, 36, device="cuda")
+    t[7, 3] = float("nan")
+    with pytest.raises(_lib.ShodhError) as e:
+        idx2.add_vectors(t)
+    assert e.value.code == _lib.ERR_NONFINITE and idx2.len() == 0
+    with pytest.raises(_lib.ShodhError) as e:
+        idx2.add_vectors(torch.randn(50, 36, device="cuda", dtype=torch.float16))        # raw-pointer entry point: dtype is checked
+    assert e.value.code == _lib.ERR_INVALID
+
+
+def test_two_indexes_on_two_devices_in_one_process(S, oracle):
+    """the dynamic-LDS limit is raised per (device, kernel). Needs two GPUs; the 1-GPU boxes skip it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    rows = synth.corpus(30000)
+    q = synth.queries(3)
+    for dev in (0, 1):
+        idx = make_index(S, device=dev)
+        idx.build(rows)
+        check_against_oracle(oracle, idx, rows, q, 600, 0)         # large k: > 64 KiB of dynamic LDS in the exact scan

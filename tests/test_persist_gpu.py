@@ -79,3 +79,39 @@ def test_spann_file_load_search(S, oracle, tmp_path):
         e_ids, e_dist = oracle.spann_search(st["centroids"], st["list_off"], st["ids"], st["codes"], st["codebook"], 6, q[i], 10, 0)
         n = int(counts[i])
         assert n == len(e_ids) and ids[i, :n].tolist() == e_ids.tolist() and dist[i, :n].tobytes() == e_dist.tobytes()
+
+
+def test_reference_built_graph_survives_a_round_trip(S, tmp_path):
+    """ADVICE r1: load_vamana -> save_to_file must not discard the graph of a reference-built file while the rows are unchanged;
+    once rows are added the graph is dropped and the header asks the reference for a rebuild (vamana.rs:985-993)."""
+    from shodh_memory_amd import persist as P
+    from shodh_memory_amd.index import REBUILD_THRESHOLD
+    rng = np.random.default_rng(3)
+    rows = synth.corpus(300, adversarial=False)
+    degree = rng.integers(1, 9, 300).astype(np.uint16)
+    neighbors = rng.integers(0, 300, int(degree.sum())).astype(np.uint32)
+    src = tmp_path / "ref.vamana"
+    P.write_vamana(src, rows, max_degree=8, medoid=41, deleted=[7, 9], incremental_inserts=12, degree=degree, neighbors=neighbors)
+    idx = P.load_vamana(src)
+    idx.mark_deleted(100)                                   # tombstones do not touch the graph
+    out = tmp_path / "again.vamana"
+    idx.save_to_file(out)
+    f = P.read_vamana(out, with_graph=True)
+    assert f["info"]["medoid"] == 41 and f["info"]["incremental_inserts"] == 12 and f["info"]["graph_edges"] == int(degree.sum())
+    assert np.array_equal(f["degree"], degree) and np.array_equal(f["neighbors"], neighbors)
+    assert sorted(f["deleted"].tolist()) == [7, 9, 100] and f["vectors"].tobytes() == rows.tobytes()
+    idx.add_vector(rows[0])                                 # rows changed: no graph, and the file says so
+    idx.save_to_file(out)
+    f = P.read_vamana(out, with_graph=True)
+    assert f["info"]["graph_edges"] == 0 and f["info"]["incremental_inserts"] >= REBUILD_THRESHOLD and f["info"]["num_vectors"] == 301
+
+
+def test_shard_with_id_base_keeps_its_tombstones(S, tmp_path):
+    from shodh_memory_amd import persist as P
+    rows = synth.corpus(500, adversarial=False)
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=384, id_base=1_000_000))
+    idx.build(rows)
+    assert idx.mark_deleted(1_000_003) and idx.mark_deleted(1_000_499) and not idx.mark_deleted(3)
+    path = tmp_path / "shard.vamana"
+    idx.save_to_file(path)
+    assert sorted(P.read_vamana(path)["deleted"].tolist()) == [3, 499]           # file ids are local rows
