@@ -108,6 +108,9 @@ int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k,
                               uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */
+/* mark_deleted for n ids in one call (one bitmask upload, one kernel over the shadow rows): *n_marked_out = ids that were
+ * valid and not yet tombstoned. Same result as n mark_deleted calls. */
+int shodh_index_mark_deleted_batch(shodh_index *idx, const uint32_t *ids, uint64_t n, uint64_t *n_marked_out);
 int shodh_index_is_deleted(const shodh_index *idx, uint32_t id);               /* :823-825 (1/0, <0 error) */
 uint64_t shodh_index_len(const shodh_index *idx);                              /* :184-186; IVF-PQ: postings held (SpannIndex::len) */
 uint64_t shodh_index_deleted_count(const shodh_index *idx);                    /* :828-830 */
@@ -126,9 +129,10 @@ int shodh_index_stage_timings(const shodh_index *idx, float *us4);
  * scan) over the searches issued since the last reset, from HIP events recorded on the stream each
  * search ran on. The caller must have synchronised those streams. Used by bench.py's roofline. */
 int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float *min_us, uint32_t *count);
-/* diagnostics of the last MFMA-path search: [0]=rows pre-scanned, [1]=candidates emitted,
- * [2]=candidates re-scored exactly, [3]=queries that overflowed to the exact path */
-int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats4);
+/* diagnostics of the last host-pointer MFMA-path search, 8 values: [0]=rows sampled for the thresholds, [1]=candidates emitted
+ * by the pre-scan, [2]=candidates re-scored in reference order, [3]=queries that fell back to the exact scan of the corpus,
+ * [4]=queries whose fp16 window was narrowed by the level-2 f32 filter (dense corpora), [5..7] reserved (0) */
+int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats8);
 
 /* ---- multi-GPU: merge of per-shard results ------------------------------------------------------- */
 /* Row-sharded corpora: every rank searches its shard (ids carry id_base), the

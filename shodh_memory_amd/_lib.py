@@ -93,6 +93,7 @@ SYMBOLS = {
     "shodh_index_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "shodh_index_search_device": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
+    "shodh_index_mark_deleted_batch": (C.c_int, [_vp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "shodh_index_is_deleted": (C.c_int, [_vp, C.c_uint32]),
     "shodh_index_len": (C.c_uint64, [_vp]),
     "shodh_index_deleted_count": (C.c_uint64, [_vp]),
@@ -104,7 +105,7 @@ SYMBOLS = {
     "shodh_index_dim": (C.c_uint32, [_vp]),
     "shodh_index_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
     "shodh_index_kernel_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
-    "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
+    "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 8)]),
     "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_topk_merge_strided_device": (C.c_int, [_u32p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),

@@ -79,6 +79,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
 int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStream_t st);
 int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st);
+int launch_shadow_zero_rows(_Float16 *rows_h, const uint32_t *d_list, uint64_t n, uint32_t dim, hipStream_t st);
 int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uint32_t *deleted, uint64_t n, uint32_t dim, hipStream_t st);
 
 struct IvfpqState;   // ivfpq.hip
@@ -161,7 +162,7 @@ struct shodh_index {
     std::vector<Workspace *> ws_free;
     mutable std::mutex stat_mu;
     float last_us[4] = {0, 0, 0, 0};
-    uint64_t last_stats[4] = {0, 0, 0, 0};
+    uint64_t last_stats[5] = {0, 0, 0, 0, 0};
     IvfpqState *ivfpq = nullptr;
 };
 
@@ -287,7 +288,7 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
     if (*used_mfma) {
         MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-        size_t offs[12];
+        size_t offs[16];
         const size_t ws_bytes = mfma_workspace_bytes(p, dim, offs);
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
         const size_t part_bytes = exact_partial_bytes(nq, dim, k, gx);
@@ -512,14 +513,15 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (used_mfma) {
                 uint32_t st4[4] = {0, 0, 0, 0};
                 MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-                size_t offs[12];
+                size_t offs[16];
                 mfma_workspace_bytes(p, dim, offs);
                 hipMemcpy(st4, w->buf + offs[8], 16, hipMemcpyDeviceToHost);
                 std::lock_guard<std::mutex> g(idx->stat_mu);
                 idx->last_stats[0] = (uint64_t)p.n_sel_tiles * 64; idx->last_stats[1] = st4[0]; idx->last_stats[2] = st4[1]; idx->last_stats[3] = st4[2];
+                idx->last_stats[4] = st4[3];
             } else {
                 std::lock_guard<std::mutex> g(idx->stat_mu);
-                idx->last_stats[0] = idx->last_stats[1] = idx->last_stats[2] = idx->last_stats[3] = 0;
+                idx->last_stats[0] = idx->last_stats[1] = idx->last_stats[2] = idx->last_stats[3] = idx->last_stats[4] = 0;
             }
         }
     } while (0);
@@ -552,6 +554,37 @@ int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid) {
     SHODH_HIP_TRY(hipDeviceSynchronize());
     SHODH_HIP_TRY(hipMemcpy(idx->deleted + (local >> 5), &word, 4, hipMemcpyHostToDevice));
     if (idx->shadow) { SHODH_TRY(launch_shadow_set_row(idx->rows, idx->rows_h, local, idx->cfg.dim, 1, nullptr)); SHODH_HIP_TRY(hipDeviceSynchronize()); }
+    return SHODH_OK;
+}
+
+int shodh_index_mark_deleted_batch(shodh_index *idx, const uint32_t *ids, uint64_t n, uint64_t *n_marked_out) {
+    if (!idx || (!ids && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    std::vector<uint32_t> fresh;                 // local rows that become tombstones with this call
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t local = (uint64_t)ids[i] - idx->cfg.id_base;
+        if (ids[i] < idx->cfg.id_base || local >= idx->n) continue;          // not ours / not there: mark_deleted returns false (vamana.rs:814-819)
+        uint32_t &word = idx->deleted_host[local >> 5];
+        const uint32_t bit = 1u << (local & 31);
+        if (word & bit) continue;
+        word |= bit;
+        fresh.push_back((uint32_t)local);
+    }
+    if (n_marked_out) *n_marked_out = fresh.size();
+    if (fresh.empty()) return SHODH_OK;
+    idx->n_deleted += fresh.size();
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    SHODH_HIP_TRY(hipMemcpy(idx->deleted, idx->deleted_host.data(), (idx->cap_rows / 32 + 1) * 4, hipMemcpyHostToDevice));
+    if (idx->shadow) {
+        uint32_t *d_list = nullptr;
+        SHODH_HIP_TRY(hipMalloc((void **)&d_list, fresh.size() * 4));
+        hipError_t e = hipMemcpy(d_list, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice);
+        int rc = e == hipSuccess ? launch_shadow_zero_rows(idx->rows_h, d_list, fresh.size(), idx->cfg.dim, nullptr) : SHODH_ERR_DEVICE;
+        if (hipDeviceSynchronize() != hipSuccess) rc = SHODH_ERR_DEVICE;
+        hipFree(d_list);
+        if (rc != SHODH_OK) { set_error("tombstoning the shadow rows failed"); return rc; }
+    }
     return SHODH_OK;
 }
 
@@ -672,10 +705,11 @@ int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float
     return SHODH_OK;
 }
 
-int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats4) {
-    if (!idx || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats8) {
+    if (!idx || !stats8) { set_error("null argument"); return SHODH_ERR_INVALID; }
     std::lock_guard<std::mutex> g(idx->stat_mu);
-    memcpy(stats4, idx->last_stats, sizeof(idx->last_stats));
+    memset(stats8, 0, 8 * sizeof(uint64_t));
+    memcpy(stats8, idx->last_stats, sizeof(idx->last_stats));
     return SHODH_OK;
 }
 

@@ -448,6 +448,11 @@ __global__ void shadow_set_row_kernel(const float *rows, _Float16 *rows_h, uint6
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
         rows_h[row * dim + i] = zero ? (_Float16)0.0f : (_Float16)(rows[row * dim + i] * MF_SCALE);
 }
+// zero a list of rows of the shadow copy (mark_deleted for many ids at once); one workgroup per listed row
+__global__ void shadow_zero_rows_kernel(_Float16 *rows_h, const uint32_t *list, uint32_t dim) {
+    const uint64_t row = list[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) rows_h[row * dim + i] = (_Float16)0.0f;
+}
 // restore every row whose tombstone bit is set (clear_deleted)
 __global__ void shadow_restore_deleted_kernel(const float *rows, _Float16 *rows_h, const uint32_t *deleted, uint64_t n, uint32_t dim) {
     const uint64_t row = blockIdx.x;
@@ -515,6 +520,9 @@ struct ThrArgs {
     float maxnorm;
     float *thr;              // [n_slots] emit threshold
     float *eps;              // [n_slots]
+    float eps2_rel_maxnorm;  // level-2 (f32 FMA re-score) bound: eps2 = eps2_rel_maxnorm * |q| + eps2_abs_a * (|q| + maxnorm) + 1e-9
+    float eps2_abs_a;
+    float *eps2;             // [n_slots]
 };
 constexpr int THR_STAGE = 4096;
 __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     const uint32_t pass = slot / MF_BPAD, ql = slot % MF_BPAD;
     const float qn = a.qnorm[slot];
     const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;
+    if (tid == 0) a.eps2[slot] = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f;
     if (slot >= a.nq || a.fallback[slot]) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
         return;
@@ -562,12 +571,13 @@ struct FinalArgs {
     uint32_t dim;
     const float *q;           // [nq][dim] f32 queries
     uint32_t nq, k, cap;      // cap: TopKBuf capacity
-    const uint64_t *slots;    // [n_slots][nb][MF_SLOTS] private (query, workgroup) slots of the pre-scan, KEY_NONE = empty
+    uint64_t *slots;          // [n_slots][nb][MF_SLOTS] private (query, workgroup) slots of the pre-scan, KEY_NONE = empty (level 2 rewrites them in place)
     uint32_t nb;              // workgroups of the pre-scan launch
-    const uint64_t *cand;     // [n_slots][cand_cap] shared overflow list
+    uint64_t *cand;           // [n_slots][cand_cap] shared overflow list (level 2 rewrites it in place)
     const uint32_t *cand_cnt;
     uint32_t cand_cap;
     const float *eps;         // [n_slots]
+    const float *eps2;        // [n_slots] bound of the level-2 f32 score
     uint32_t fcap;            // capacity of the re-score list
     uint32_t stage_cap;       // candidate keys staged in LDS (<= FS_STAGE; the rest, if any, is re-read from global)
     uint32_t ch_rows;         // AVX2 / sequential order: rows of the window staged at a time (<= FS_CH)
@@ -579,7 +589,7 @@ struct FinalArgs {
     uint32_t *ids;            // [nq][k]
     float *dist;
     uint32_t *counts;
-    uint32_t *stats;          // [0] emitted, [1] rescored, [2] overflowed queries
+    uint32_t *stats;          // [0] emitted, [1] rescored, [2] overflowed queries, [3] queries that went through level 2
 };
 
 template <int ORDER>
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     // Everything the block needs first is requested in one go (unconditional loads on clamped indices: a load behind a
     // runtime condition makes hipcc wait for each one separately -- measured as 4 + 2 + 2 dependent round trips here).
     const uint32_t n_main = a.nb * MF_SLOTS;
-    const uint64_t *slots_q = a.slots + (size_t)q * n_main;
+    uint64_t *slots_q = a.slots + (size_t)q * n_main;
     uint64_t kv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; kv[j] = slots_q[i < n_main ? i : 0]; }
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
         for (int j = 0; j < 2; ++j) { const uint32_t i = j * 256 + tid; if (i < a.dim) qs[i] = qv[j]; }
         if (tid == 0) { *fcnt = 0; *ecnt = 0; }
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-        const uint64_t *list = a.cand + (size_t)q * a.cand_cap;
+        uint64_t *list = a.cand + (size_t)q * a.cand_cap;
         auto key_glb = [&](uint32_t i) -> uint64_t { return i < n_main ? slots_q[i] : list[i - n_main]; };
         // the candidate keys are read three times (filter, gather, window): stage them in LDS once
         const uint32_t n_st = n < a.stage_cap ? n : a.stage_cap;
@@ -686,45 +696,112 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
         auto key_at = [&](uint32_t i) -> uint64_t { return i < n_st ? (((uint64_t)skey[i] << 32) | srow[i]) : key_glb(i); };
         // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
         PROF_T(0)
-        float lo = -__builtin_inff();
-        if (a.k > 0 && a.k <= 128) {
-            auto key32 = [&](uint32_t i) -> uint32_t { return i < n_st ? skey[i] : (uint32_t)(key_glb(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
-            bool ovf = false;
-            const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
-            if (ovf) bad = true;        // block-uniform
-            else if (kk != 0xFFFFFFFFu) {
-                const float kth = -order_key_inv(kk);
-                lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
+        // lower end of the window around the k-th best of the current candidate scores: kth - 2 eps (-inf while fewer than k exist)
+        auto window_floor = [&](float eps_q) -> float {
+            float lo_ = -__builtin_inff();
+            if (a.k > 0 && a.k <= 128) {
+                auto key32 = [&](uint32_t i) -> uint32_t { return i < n_st ? skey[i] : (uint32_t)(key_glb(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
+                bool ovf = false;
+                const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
+                if (kk != 0xFFFFFFFFu) {
+                    const float kth = -order_key_inv(kk);
+                    lo_ = kth - (2.001f * eps_q + 1e-7f * __builtin_fabsf(kth));
+                }
+            } else if (a.k > 0) {
+                auto key_a = [&](uint64_t i) -> uint64_t { return key_at((uint32_t)i); };
+                const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
+                if (ma == a.k && buf.keys[a.k - 1] != KEY_NONE) {
+                    const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
+                    lo_ = kth - (2.001f * eps_q + 1e-7f * __builtin_fabsf(kth));
+                }
             }
-        } else if (a.k > 0) {
-            auto key_a = [&](uint64_t i) -> uint64_t { return key_at((uint32_t)i); };
-            const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
-            if (ma == a.k && buf.keys[a.k - 1] != KEY_NONE) {
-                const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
-                lo = kth - (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth));
-            }
-        }
-        PROF_T(1)
-        // window: every candidate with s~ >= kth - 2 eps (all of them if fewer than k exist)
-        __syncthreads();
-        if (!bad) {
+            return lo_;
+        };
+        // every candidate with score >= lo_ goes to the re-score list (all of them if fewer than k exist); returns the count
+        auto collect_window = [&](float lo_, bool count_real) -> uint32_t {
+            __syncthreads();
+            if (tid == 0) *fcnt = 0;
+            __syncthreads();
             uint32_t real = 0;
             for (uint32_t i = tid; i < n; i += 256) {
                 const uint64_t key = key_at(i);
                 if (key == KEY_NONE) continue;
                 ++real;
                 const float s = -order_key_inv((uint32_t)(key >> 32));
-                if (s >= lo) {
+                if (s >= lo_) {
                     const uint32_t slot = atomicAdd(fcnt, 1u);
                     if (slot < a.fcap) flist[slot] = (uint32_t)key;
                 }
             }
-            if (real) atomicAdd(ecnt, real);
-        }
-        __syncthreads();
-        const uint32_t nf = *fcnt;
+            if (count_real && real) atomicAdd(ecnt, real);
+            __syncthreads();
+            return *fcnt;
+        };
+        const float lo = window_floor(a.eps[q]);
+        PROF_T(1)
+        uint32_t nf = collect_window(lo, true);
         PROF_T(2)
-        if (nf > a.fcap) bad = true;       // block-uniform
+        if (nf > a.fcap) {
+            // ---- level 2 (block-uniform branch) -----------------------------------------------------------------------
+            // The fp16 window holds more rows than the reference-order re-score is sized for: a dense corpus (many rows within
+            // 2 eps ~ 2e-3 of the k-th best score). Every row of that window gets an f32 score s2 (FMA, any order) from the
+            // f32 master rows -- |s2 - dot_ref| <= eps2 ~ dim * 2^-23 |q| maxnorm, ~20x tighter than the fp16 bound -- which
+            // replaces its fp16 score IN PLACE; the window is then rebuilt around the k-th best s2 with 2 eps2. Cost is
+            // proportional to the survivors (one 4*dim-byte row read each), not to the corpus.
+            // One wave per group of 64 candidates; up to 8 member rows in flight per wave.
+            const uint32_t wv = tid >> 6, ln = tid & 63;
+            const uint32_t dim = a.dim, d4 = dim >> 2;
+            const f32x4 *qs4 = reinterpret_cast<const f32x4 *>(qs);
+            const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 qa = ln < d4 ? qs4[ln] : z4, qb = ln + 64 < d4 ? qs4[ln + 64] : z4;      // dim <= 512: two float4 groups per lane
+            const uint32_t ga = ln < d4 ? ln : 0u, gb = ln + 64 < d4 ? ln + 64 : 0u;
+            const uint32_t n_groups = (n + 63) >> 6;
+            for (uint32_t g = wv; g < n_groups; g += 4) {
+                const uint32_t i = g * 64 + ln;
+                const uint64_t key = i < n ? key_at(i) : KEY_NONE;
+                const bool in = key != KEY_NONE && -order_key_inv((uint32_t)(key >> 32)) >= lo;
+                const uint32_t myrow = (uint32_t)key;
+                uint64_t mask = __builtin_amdgcn_ballot_w64(in);
+                float s2 = 0.0f;
+                while (mask) {                                   // wave-uniform
+                    constexpr int R = 8;
+                    int src[R];
+                    uint32_t cnt_r = 0;
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        if (mask) { src[u] = __builtin_ctzll(mask); mask &= mask - 1; ++cnt_r; }
+                        else src[u] = src[u > 0 ? u - 1 : 0];     // clamp: a harmless repeat of the last member
+                    }
+                    f32x4 va[R], vb[R];
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const uint32_t r_u = (uint32_t)__builtin_amdgcn_readlane((int)myrow, src[u]);
+                        const f32x4 *rp = reinterpret_cast<const f32x4 *>(a.rows + (size_t)r_u * dim);
+                        va[u] = rp[ga]; vb[u] = rp[gb];
+                    }
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        float p = qa.x * va[u].x;
+                        p = __builtin_fmaf(qa.y, va[u].y, p); p = __builtin_fmaf(qa.z, va[u].z, p); p = __builtin_fmaf(qa.w, va[u].w, p);
+                        p = __builtin_fmaf(qb.x, vb[u].x, p); p = __builtin_fmaf(qb.y, vb[u].y, p);
+                        p = __builtin_fmaf(qb.z, vb[u].z, p); p = __builtin_fmaf(qb.w, vb[u].w, p);
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+                        if ((uint32_t)u < cnt_r && (int)ln == src[u]) s2 = p;
+                    }
+                }
+                if (i < n) {
+                    const uint64_t k2 = in ? make_key(-s2, myrow) : KEY_NONE;
+                    if (i < n_main) slots_q[i] = k2; else list[i - n_main] = k2;
+                    if (i < n_st) { skey[i] = (uint32_t)(k2 >> 32); srow[i] = (uint32_t)k2; }
+                }
+            }
+            __syncthreads();
+            const float lo2 = window_floor(a.eps2[q]);
+            nf = collect_window(lo2, false);
+            if (tid == 0) atomicAdd(a.stats + 3, 1u);
+        }
+        if (nf > a.fcap) bad = true;       // block-uniform: even the f32 window is too large (thousands of near-duplicates): exact scan
         if (!bad) {
             // pass B: exact reference-order scores of the window, then top-k by (dist, id).
             // The f32 rows of the window are cold in HBM, so every load of a chunk is put in flight at once
@@ -912,9 +989,17 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     if (p.tile_stride < 1) p.tile_stride = 1;
     p.n_sel_tiles = (uint32_t)ceil_div(p.n_tiles, p.tile_stride);
     p.J = p.n_sel_tiles;
+    // shared overflow list per query. It used to be 192 k (>= 4096) entries, and a query that outgrew it went to the exact
+    // scan of the whole corpus (a 24x cliff on dense corpora). Now it takes what 512 MiB of workspace allow, up to 65536
+    // entries per query (128 MiB at 256 queries): whatever lands in it is narrowed by the final stage's level-2 f32 filter at a
+    // cost proportional to the entries. Calls with thousands of queries (k-means assignment) keep the old size.
     uint32_t cc = 192u * (k ? k : 1);
     if (cc < 4096) cc = 4096;
-    p.cand_cap = next_pow2(cc);
+    cc = next_pow2(cc);
+    uint64_t room = (512ull << 20) / ((uint64_t)p.passes * MF_BPAD * 8);
+    uint32_t big = 65536;
+    while (big > cc && big > room) big >>= 1;
+    p.cand_cap = big > cc ? big : cc;
     uint32_t fc = 4u * (k ? k : 1);
     if (fc < 2048) fc = 2048;
     p.fcap = next_pow2(fc);
@@ -925,10 +1010,10 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
 
 struct MfmaWorkspace {
     _Float16 *q_h; float *qnorm; float *thr; float *eps; uint32_t *cand_cnt; uint32_t *fallback; uint32_t *fb_list;
-    uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand; uint64_t *slots;
+    uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand; uint64_t *slots; float *eps2;
 };
 
-size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[12]*/) {
+size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[MFMA_WS_PARTS = 16]*/) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     offs[0] = take((size_t)p.n_slots * dim * 2);         // q_h
@@ -943,6 +1028,7 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[12]
     offs[9] = take((size_t)p.passes * p.J * MF_BPAD * 4);  // blockmax
     offs[10] = take((size_t)p.n_slots * p.cand_cap * 8);   // cand (shared overflow lists)
     offs[11] = take((size_t)p.n_slots * p.grid_x * MF_SLOTS * 8);   // slots (private per query and workgroup)
+    offs[12] = take((size_t)p.n_slots * 4);              // eps2
     return o;
 }
 
@@ -985,6 +1071,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     w.eps = (float *)(ws_base + offs[3]); w.cand_cnt = (uint32_t *)(ws_base + offs[4]); w.fallback = (uint32_t *)(ws_base + offs[5]);
     w.fb_list = (uint32_t *)(ws_base + offs[6]); w.fb_count = (uint32_t *)(ws_base + offs[7]); w.stats = (uint32_t *)(ws_base + offs[8]);
     w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]); w.slots = (uint64_t *)(ws_base + offs[11]);
+    w.eps2 = (float *)(ws_base + offs[12]);
 
     QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
@@ -1002,7 +1089,12 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     // dim * 2^-23, reference rounding ~1e-5; absolute term for flushed/denormal fp16 after the 2^8 scale
     const float eps_rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
     const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f + (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);   // SEQ_1M: + the rounding of `1 - dot` (<= 2^-24 |1 - dot|, |dot| <= qn*maxnorm), charged generously
-    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps};
+    // level 2 (final stage, dense corpora only): s2 = f32 FMA dot in any order. Both s2 and the reference's sum are within
+    // gamma_dim * |q||c| of the exact dot (gamma_n = n 2^-24 / (1 - n 2^-24)), so |s2 - dot_ref| <= dim * 2^-23 * |q| * maxnorm
+    const float eps2_rel = (float)dim * 1.1921e-7f * 1.01f;
+    const float eps2_abs_a = (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);
+    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps,
+              eps2_rel * maxnorm, eps2_abs_a, w.eps2};
     const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
     (void)tlds;
     hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), 0, st, t);
@@ -1028,7 +1120,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
         ch_rows = next_pow2(k ? k : 1);
         ch_rows = ch_rows < 4u ? 4u : (ch_rows > (uint32_t)FS_CH ? (uint32_t)FS_CH : ch_rows);
     }
-    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, fcap, stage_cap, ch_rows, order, id_base,
+    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
     const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
@@ -1066,6 +1158,14 @@ int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStr
 }
 int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st) {
     hipLaunchKernelGGL(shadow_set_row_kernel, dim3(1), dim3(128), 0, st, rows, rows_h, row, dim, zero);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int launch_shadow_zero_rows(_Float16 *rows_h, const uint32_t *d_list, uint64_t n, uint32_t dim, hipStream_t st) {
+    for (uint64_t o = 0; o < n; o += 1u << 30) {
+        const uint64_t m = n - o < (1u << 30) ? n - o : (1u << 30);
+        hipLaunchKernelGGL(shadow_zero_rows_kernel, dim3((uint32_t)m), dim3(128), 0, st, rows_h, d_list + o, dim);
+    }
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }

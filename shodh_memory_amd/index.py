@@ -236,6 +236,13 @@ class VamanaIndex:
         L.check(L.lib().shodh_index_mark_deleted(self.handle, int(vector_id), C.byref(ok)))
         return bool(ok.value)
 
+    def mark_deleted_many(self, vector_ids):
+        """n mark_deleted calls in one (returns how many ids were valid and newly tombstoned)"""
+        ids = np.ascontiguousarray(vector_ids, np.uint32)
+        m = C.c_uint64()
+        L.check(L.lib().shodh_index_mark_deleted_batch(self.handle, ids.ctypes.data, ids.size, C.byref(m)))
+        return int(m.value)
+
     def is_deleted(self, vector_id):
         return bool(L.lib().shodh_index_is_deleted(self.handle, int(vector_id)))
 
@@ -342,9 +349,9 @@ class VamanaIndex:
         return m.value, mn.value, c.value
 
     def scan_stats(self):
-        a = (C.c_uint64 * 4)()
+        a = (C.c_uint64 * 8)()
         L.check(L.lib().shodh_index_scan_stats(self.handle, C.byref(a)))
-        return dict(sampled_rows=a[0], emitted=a[1], rescored=a[2], overflowed=a[3])
+        return dict(sampled_rows=a[0], emitted=a[1], rescored=a[2], overflowed=a[3], level2=a[4])
 
 
 class SpannIndex:

@@ -39,3 +39,20 @@ def tombstones(n, frac=0.05, seed=SEED + 2):
     d = np.zeros(n, np.uint8)
     d[rng.choice(n, int(n * frac), replace=False)] = 1
     return d
+
+
+def clustered_corpus(n, dim=384, n_clusters=64, within=0.8, between=0.3, seed=SEED + 7):
+    """Mixture of vMF-like clusters: rows of one cluster have pairwise cosine ~`within`, rows of different
+    clusters ~`within * between` .. `between` -- far denser than the half-i.i.d. corpus above, the regime of real sentence
+    embeddings. centre_c = normalize(sqrt(between) u + sqrt(1 - between) g_c); row = normalize(sqrt(within) centre + sqrt(1 - within) noise)."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal(dim).astype(np.float32); u /= np.linalg.norm(u)
+    g = rng.standard_normal((n_clusters, dim)).astype(np.float32); g /= np.linalg.norm(g, axis=1, keepdims=True)
+    cent = np.sqrt(np.float32(between)) * u[None, :] + np.sqrt(np.float32(1 - between)) * g
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    lab = rng.integers(0, n_clusters, n)
+    noise = rng.standard_normal((n, dim), dtype=np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    x = np.sqrt(np.float32(within)) * cent[lab] + np.sqrt(np.float32(1 - within)) * noise
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.ascontiguousarray(x.astype(np.float32)), lab

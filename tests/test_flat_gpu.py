@@ -506,3 +506,55 @@ def test_two_indexes_on_two_devices_in_one_process(S, oracle):
         idx = make_index(S, device=dev)
         idx.build(rows)
         check_against_oracle(oracle, idx, rows, q, 600, 0)         # large k: > 64 KiB of dynamic LDS in the exact scan
+
+
+# ---- dense corpora: the level-2 f32 filter of the final stage (round 2) ----------------------------------------------
+@pytest.mark.parametrize("order", [0, 1])
+def test_clustered_corpus_matches_oracle(S, oracle, order):
+    """vMF-like clusters, pairwise cosine 0.24 .. 0.8: queries are cluster members, so the top of every list is crowded"""
+    rows, lab = synth.clustered_corpus(60000, n_clusters=8)
+    rng = np.random.default_rng(1)
+    q = rows[rng.choice(60000, 48, replace=False)] + f32(0.05) * rng.standard_normal((48, 384)).astype(f32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.ascontiguousarray(q.astype(f32))
+    idx = make_index(S, order=order, scan_mode=2)
+    idx.build(rows)
+    for k in (10, 120):
+        ids, dist, counts = idx.search_batch(q, k)
+        st = idx.scan_stats()
+        e_ids, e_dist = oracle.brute_force_batch(rows, q, k, order=order)
+        assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes()
+        assert st["sampled_rows"] > 0 and st["overflowed"] == 0, st
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_very_dense_corpus_goes_through_level2_not_the_exact_scan(S, oracle, order):
+    """40k rows inside a cone of half-angle ~1.5 degrees: every row is within the fp16 bound (2 eps ~ 2e-3) of the k-th best score,
+    so the whole corpus lands in the fp16 window. Round 1 sent such queries to the exact scan of the corpus; now the level-2
+    f32 filter narrows the window (eps2 ~ 5e-5) and the reference-order re-score sees a few hundred rows."""
+    rng = np.random.default_rng(5)
+    base = synth.queries(1)[0]
+    rows = base[None, :] + f32(0.0015) * rng.standard_normal((40000, 384)).astype(f32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows = np.ascontiguousarray(rows.astype(f32))
+    far = base[None, :] + f32(0.03) * rng.standard_normal((2, 384)).astype(f32)       # ~30 degrees off the cone axis: positive scores, all rows still tie within 2e-3
+    far /= np.linalg.norm(far, axis=1, keepdims=True)
+    q = np.ascontiguousarray(np.concatenate([base[None, :], rows[[5, 777, 39999]], far]).astype(f32))
+    idx = make_index(S, order=order, scan_mode=2)
+    idx.build(rows)
+    if order == 2:                                   # SpannIndex::compute_distance order: distance = 1 - sum (spann.rs:562-571)
+        ids, dist, counts = idx.search_batch(q, 10)
+        for i in range(len(q)):
+            d = np.array([oracle.spann_compute_distance(q[i], rows[j]) for j in range(len(rows))], f32) if i < 2 else None
+            if d is not None:
+                o = np.lexsort((np.arange(len(rows)), order_keys(d)))[:10]
+                assert ids[i].tolist() == o.tolist() and dist[i].tobytes() == d[o].tobytes()
+    else:
+        check_against_oracle(oracle, idx, rows, q, 10, order)
+    st = idx.scan_stats()
+    assert st["level2"] >= 4 and st["overflowed"] == 0, st
+    assert st["rescored"] < 6 * 2048
+    # k = 300 (block_select_topk branch of the window floor) on the same corpus
+    if order != 2:
+        check_against_oracle(oracle, idx, rows, q[:3], 300, order)
+        assert idx.scan_stats()["overflowed"] == 0
