@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- recall throughput of the flat index on MI355X (BASELINE.json metric).
+"""bench.py -- recall throughput of the embed-and-recall hot path on MI355X (BASELINE.json metric).
 
-A step = one recall pass: one batch of `--nq` (256) query vectors against the whole corpus
-(`--rows`, 1M x 384 f32 = BASELINE.json configs[1]), top-`--k` (10), inputs resident in HBM.
-`value` = queries/s of the whole job.
+The contract line (`value`, `ms_per_step`, ...) is BASELINE.json configs[1]: one step = one recall pass of a batch of `--nq`
+(256) query vectors against the whole corpus (`--rows`, 1M x 384 f32), top-`--k` (10), inputs resident in HBM. The corpus is
+SURVEY.md 8(d)'s: half correlated / half i.i.d. unit rows + 1 % exact duplicates + 0.1 % rows equal to a query + 5 % tombstones;
+the steps cycle through a pool of distinct query batches.
 
   python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: the corpus is row-sharded over the ranks (shodh_memory_amd/distributed.py): every rank scans
-its shard for the same query batch, the per-shard top-k are all-gathered over RCCL and merged.
---scaling weak (default) holds --rows PER GPU, so the corpus grows with N (BASELINE.json configs[4] shape, 10M x 8:
-the ideal is a constant queries/s while the corpus grows N-fold); --scaling strong keeps the total corpus at --rows.
-
 Besides the driver's fields the JSON line carries
-  roofline     -- dominant kernel (MFMA emit scan): algorithmic bytes (live rows x dim x 4) / its mean
-                  duration from HIP events recorded by the library on the launch stream
-  cpu_baseline -- the CPU oracle's restatement of VamanaIndex::brute_force_search timed on this
-                  host's cores on a bounded sample (rank 0, N = 1 only)
-  latency_*    -- single-query (nq = 1) recall latency, p50 over 50 calls
+  roofline     -- dominant kernel (MFMA emit scan): ALGORITHMIC bytes (live rows x dim x 4) / its mean duration from HIP
+                  events recorded by the library on the launch stream; also the bytes the kernel really moves (fp16 shadow) and
+                  the MFMA fraction, and the same at step level (what a caller sees)
+  sustained    -- the same step repeated for >= 2 s (clocks settled; visible to an outside busy sampler)
+  cpu_baseline -- the CPU oracle's restatement of VamanaIndex::brute_force_search timed on this host's USABLE cores (affinity
+                  mask and cgroup quota, not os.cpu_count()), corpus pages spread over the NUMA nodes, bounded sample (rank 0, N = 1)
+  latency_single_query -- nq = 1 recall latency, p50
+  configs      -- (N = 1) the other north-star configurations timed in the same process: configs[0] (10k, B = 1, CPU reference
+                  path + GPU), 10M flat B = 256 (the ">= 10M at >= 70 % roofline" target), 1M k = 120, a dense clustered corpus,
+                  configs[3] IVF-PQ 10M/4096/32/B = 1024, the bf16 encoder and configs[2] (embed + insert + recall); each with
+                  ms_per_step, algorithmic AND actual-byte HBM fractions, MFMA fraction, survivors per query and fallback counts
+
+N > 1: the corpus is row-sharded over the ranks (shodh_memory_amd/distributed.py): every rank scans its shard for the same query
+batch, the per-shard top-k are all-gathered over RCCL and merged. Default is WEAK scaling at the configs[4] shape, 10M rows per
+GPU (80M at N = 8): `value` = ANSWERED queries/s over the whole N x 10M corpus -- the ideal is a flat value while the corpus
+grows N-fold; its one-GPU reference point is the `flat_10M_b256` entry of the N = 1 line's `configs`. `--scaling strong`
+keeps `--rows` in total.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -33,11 +42,14 @@ sys.path.insert(0, ROOT)
 SEED = 20260926
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 (2x bf16; MI355X_MICROARCH.md measured >= 3944)
 
 
-def synth_rows(torch, n, dim, seed, device):
-    """SURVEY 8d corpus, generated in HBM: half correlated rows (shared direction + one strong
-    component + noise), half i.i.d. unit rows, shuffled."""
+# ---- synthetic inputs, generated in HBM -------------------------------------------------------------------
+def synth_rows(torch, n, dim, seed, device, adversarial_queries=None):
+    """half correlated rows normalize(1 + 0.5 sqrt(D) e_{i mod D} + 0.3 N(0,I)) (the reference's own test_vector fixture,
+    retrieval.rs:2430-2438, plus noise), half i.i.d. unit rows, shuffled. With `adversarial_queries` ([nq, dim] tensor) also the
+    adversarial slice: 1 % exact duplicates of other rows and 0.1 % rows equal to a query (dot = 1)."""
     g = torch.Generator(device=device).manual_seed(seed)
     x = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
     half = n // 2
@@ -46,7 +58,330 @@ def synth_rows(torch, n, dim, seed, device):
     x[idx, idx % dim] += 0.5 * dim ** 0.5
     x = torch.nn.functional.normalize(x, dim=1)
     perm = torch.randperm(n, generator=g, device=device)
-    return x[perm].contiguous()
+    x = x[perm].contiguous()
+    if adversarial_queries is not None and n >= 200:
+        nd = max(n // 100, 1)
+        src = torch.randint(0, n, (nd,), generator=g, device=device)
+        dst = torch.randint(0, n, (nd,), generator=g, device=device)
+        x[dst] = x[src]
+        nqd = max(n // 1000, 1)
+        dst = torch.randint(0, n, (nqd,), generator=g, device=device)
+        x[dst] = adversarial_queries[torch.randint(0, adversarial_queries.shape[0], (nqd,), generator=g, device=device)]
+    return x
+
+
+def synth_clustered(torch, n, dim, seed, device, n_clusters=1000, within=0.8, between=0.3):
+    """mixture of vMF-like clusters: pairwise cosine ~`within` inside a cluster, ~within*between .. between across clusters
+    (tests/synth.py::clustered_corpus, generated on the device). -> rows, labels"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    u = torch.nn.functional.normalize(torch.randn((1, dim), generator=g, device=device), dim=1)
+    c = torch.nn.functional.normalize(torch.randn((n_clusters, dim), generator=g, device=device), dim=1)
+    cent = torch.nn.functional.normalize(between ** 0.5 * u + (1 - between) ** 0.5 * c, dim=1)
+    lab = torch.randint(0, n_clusters, (n,), generator=g, device=device)
+    noise = torch.nn.functional.normalize(torch.randn((n, dim), generator=g, device=device), dim=1)
+    x = torch.nn.functional.normalize(within ** 0.5 * cent[lab] + (1 - within) ** 0.5 * noise, dim=1)
+    return x.contiguous(), lab
+
+
+def synth_tokens(torch, n, max_len, gen, device):
+    """SURVEY 8d token inputs: lengths ~U[8,128], ids ~U[1000,30521], [CLS]=101 ... [SEP]=102, right-padded to max_len"""
+    lens = torch.randint(8, 129, (n,), generator=gen, device=device)
+    ids = torch.randint(1000, 30522, (n, max_len), generator=gen, device=device, dtype=torch.int32)
+    mask = torch.arange(max_len, device=device)[None, :] < lens[:, None]
+    ids = torch.where(mask, ids, torch.zeros_like(ids))
+    ids[:, 0] = 101
+    ids[torch.arange(n, device=device), lens - 1] = 102
+    return ids.contiguous(), mask.to(torch.uint8).contiguous(), lens
+
+
+def tombstone(torch, index, n, frac, seed, device, id_base=0):
+    """tombstones `frac` of the n local rows (mark_deleted takes GLOBAL ids = id_base + row); returns the LOCAL rows"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ids = torch.randperm(n, generator=g, device=device)[:int(n * frac)].cpu().numpy().astype("uint32")
+    assert index.mark_deleted_many(ids + np_u32(id_base)) == len(ids)
+    return ids
+
+
+def np_u32(x):
+    import numpy as np
+    return np.uint32(x)
+
+
+# ---- host facts --------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """what this process may really use: the affinity mask and the cgroup CPU quota, not os.cpu_count()"""
+    logical = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = logical
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except Exception:
+            continue
+    usable = aff if quota is None else max(1, min(aff, int(math.ceil(quota))))
+    model, nodes = "", None
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    try:
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except Exception:
+        pass
+    return {"logical": logical, "affinity": aff, "cgroup_quota_cpus": quota, "usable": usable, "cpu_model": model, "numa_nodes": nodes}
+
+
+# ---- timing helpers ----------------------------------------------------------------------------------------------------
+def timed_steps(torch, fn, steps, warmup):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / max(steps, 1)
+
+
+def flat_fractions(rows_total, rows_live, dim, nq, kern_us, step_ms):
+    """algorithmic / actual-byte HBM fractions and MFMA fraction of one flat recall step (SURVEY 8d definitions)"""
+    passes = (nq + 255) // 256
+    alg = rows_live * dim * 4                        # corpus at the reference's storage precision, read once per <= 256-query batch
+    moved = rows_total * dim * 2 * passes            # what the pre-scan streams: the fp16 shadow (tombstoned rows included), once per pass
+    flops = 2.0 * rows_total * dim * 256 * passes    # the pre-scan multiplies whole 256-query passes
+    d = {"algorithmic_bytes_per_step": alg, "bytes_moved_fp16_shadow_per_step": moved,
+         "step_hbm_frac_algorithmic": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "step_hbm_frac_actual_bytes": round(moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "step_mfma_frac": round(flops / (step_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+    if kern_us:
+        t = kern_us * 1e-6                           # one launch covers all passes (grid.y)
+        d.update({"scan_kernel_us": round(kern_us, 2),
+                  "kernel_hbm_frac_algorithmic": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+                  "kernel_hbm_frac_actual_bytes": round(moved / t / 1e9 / HBM_PEAK_GBS, 4),
+                  "kernel_mfma_tflops": round(flops / t / 1e12, 1), "kernel_mfma_frac": round(flops / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)})
+    return d
+
+
+def run_flat_config(torch, dev, index, qpool, k, steps, warmup, rows_total, rows_live, dim, want_stats=True):
+    nq = qpool[0].shape[0]
+    out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+           torch.empty((nq,), dtype=torch.int32, device=dev))
+    for i in range(warmup):
+        index.search_batch_device(qpool[i % len(qpool)], k, out=out)
+    torch.cuda.synchronize()
+    index.kernel_timing(reset=True)
+    dt = timed_steps(torch, lambda i: index.search_batch_device(qpool[i % len(qpool)], k, out=out), steps, 0)
+    km, kmin, kn = index.kernel_timing(reset=True)
+    r = {"ms_per_step": round(dt * 1e3, 4), "queries_per_s": round(nq / dt, 1), "steps": steps}
+    r.update(flat_fractions(rows_total, rows_live, dim, nq, km if kn else None, dt * 1e3))
+    if want_stats:
+        index.search_batch(qpool[0].cpu().numpy(), k)          # one host-pointer call reads the pre-scan counters back
+        st = index.scan_stats()
+        r.update({"survivors_emitted_per_query": round(st["emitted"] / nq, 1), "rescored_per_query": round(st["rescored"] / nq, 1),
+                  "level2_queries": int(st["level2"]), "exact_fallback_queries": int(st["overflowed"]),
+                  "path": "fp16 MFMA pre-scan + reference-order re-score" if st["sampled_rows"] else "exact-order f32 scan"})
+    return r
+
+
+# ---- the extra north-star configurations (N = 1) -------------------------------------------------------------------------
+def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_total, main_rows_live, cpu_info):
+    import numpy as np
+    cfgs = []
+
+    def done(entry, t0):
+        entry["wall_s"] = round(time.perf_counter() - t0, 2)
+        cfgs.append(entry)
+
+    # -- configs[0]: 10k memories, B = 1, top-10: the reference's CPU path, and the same shape on the GPU ------------------
+    t0 = time.perf_counter()
+    q1 = synth_rows(torch, 64, args.dim, SEED + 11, dev)
+    rows10k = synth_rows(torch, 10_000, args.dim, SEED + 10, dev, adversarial_queries=q1)
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=10_000))
+    idx.build(rows10k)
+    o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+    ts = []
+    for i in range(140):
+        qq = q1[i % 64:i % 64 + 1]
+        torch.cuda.synchronize(); a = time.perf_counter()
+        idx.search_batch_device(qq, 10, out=o1)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - a)
+    ts = sorted(ts[20:])
+    e = {"name": "cfg1_10k_b1", "workload": "configs[0]: 10k memories x %d-d, brute-force cosine top-10, one query at a time" % args.dim,
+         "gpu_p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "gpu_queries_per_s_synchronous": round(1.0 / ts[len(ts) // 2], 1)}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O      # CPU baseline leg: the oracle is the thing being timed here
+        h_rows, h_q = rows10k.cpu().numpy(), q1.cpu().numpy()
+        s_ref, c_ids, c_dist = O.bench_brute_force(h_rows, h_q, 10, 0, True, 1)         # the reference's shape: row clone + full sort, one thread
+        s_sel, _, _ = O.bench_brute_force(h_rows, h_q, 10, 0, False, 1)
+        g_ids, g_dist, _ = idx.search_batch(h_q, 10)
+        e.update({"cpu_reference_path_ms_per_query": round(s_ref / 64 * 1e3, 4), "cpu_reference_path_queries_per_s": round(64 / s_ref, 1),
+                  "cpu_bounded_select_queries_per_s": round(64 / s_sel, 1), "cpu_threads": 1,
+                  "gpu_matches_cpu_bit_exact": bool(np.array_equal(g_ids, c_ids) and g_dist.tobytes() == c_dist.tobytes())})
+    idx.close(); del idx, rows10k
+    done(e, t0)
+
+    # -- 1M, k = 120: the index-level k of a top-10 recall (retrieval.rs:913-918: limit * 4 * 3) ----------------------------
+    t0 = time.perf_counter()
+    e = {"name": "flat_1M_b256_k120", "workload": "the contract corpus, batch 256, k = 120 (what MemorySystem::recall asks the index for)"}
+    e.update(run_flat_config(torch, dev, main_index, main_qpool, 120, 30, 5, main_rows_total, main_rows_live, args.dim))
+    done(e, t0)
+
+    # -- 10M flat, B = 256: north_star's ">= 10M-memory recall at >= 70 % HBM roofline" (= one shard of configs[4]) ----------
+    if not args.skip_10m:
+        t0 = time.perf_counter()
+        n = 10_000_000
+        qp = [synth_rows(torch, 256, args.dim, SEED + 20 + i, dev) for i in range(4)]
+        rows = synth_rows(torch, n, args.dim, SEED + 19, dev, adversarial_queries=qp[0])
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+        idx.build(rows)
+        del rows
+        torch.cuda.empty_cache()
+        dead = tombstone(torch, idx, n, 0.05, SEED + 18, dev)
+        e = {"name": "flat_10M_b256", "workload": "10M memories x %d-d f32 (5 %% tombstoned), brute-force cosine top-10, batch 256" % args.dim,
+             "rows": n, "rows_live": n - len(dead)}
+        e.update(run_flat_config(torch, dev, idx, qp, 10, 20, 5, n, n - len(dead), args.dim))
+        q1 = qp[0][:1].contiguous()
+        o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+        e["single_query_ms"] = round(timed_steps(torch, lambda i: idx.search_batch_device(q1, 10, out=o1), 20, 3) * 1e3, 4)
+        idx.close(); del idx
+        torch.cuda.empty_cache()
+        done(e, t0)
+
+    # -- dense clustered corpus, 1M: the regime of real sentence embeddings (VERDICT r1 item 6) ------------------------------
+    t0 = time.perf_counter()
+    n = 1_000_000
+    rows, lab = synth_clustered(torch, n, args.dim, SEED + 30, dev, n_clusters=1000)
+    g = torch.Generator(device=dev).manual_seed(SEED + 31)
+    qp = []
+    for i in range(4):                                   # queries = noisy cluster members: the top of every list is crowded
+        pick = torch.randint(0, n, (256,), generator=g, device=dev)
+        qp.append(torch.nn.functional.normalize(rows[pick] + 0.02 * torch.randn((256, args.dim), generator=g, device=dev), dim=1).contiguous())
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+    idx.build(rows)
+    sample = rows[torch.randint(0, n, (2048,), generator=g, device=dev)]
+    cosm = sample @ sample.T
+    e = {"name": "flat_1M_clustered_b256", "workload": "1M memories in 1000 vMF-like clusters (pairwise cosine p05/p50/p95/p99.9 = %s), batch 256, top-10"
+         % "/".join("%.2f" % float(v) for v in torch.quantile(cosm.flatten()[::7].float(), torch.tensor([0.05, 0.5, 0.95, 0.999], device=dev)))}
+    del rows, cosm, sample
+    e.update(run_flat_config(torch, dev, idx, qp, 10, 30, 5, n, n, args.dim))
+    e120 = run_flat_config(torch, dev, idx, qp, 120, 20, 3, n, n, args.dim)
+    e["k120"] = {kk: e120[kk] for kk in ("ms_per_step", "survivors_emitted_per_query", "rescored_per_query", "level2_queries", "exact_fallback_queries")}
+    idx.close(); del idx
+    torch.cuda.empty_cache()
+    done(e, t0)
+
+    # -- configs[3]: 10M memories, IVF nlist = 4096, nprobe = 32, top-10, batch 1024 -------------------------------------------
+    if not args.skip_ivfpq:
+        t0 = time.perf_counter()
+        n, P, nprobe, nq, k = (10_000_000 if not args.skip_10m else 2_000_000), 4096, 32, 1024, 10
+        rows = synth_rows(torch, n, args.dim, SEED + 40, dev)
+        g = torch.Generator(device=dev).manual_seed(SEED + 41)
+        cent = rows[torch.randperm(n, generator=g, device=dev)[:P]].contiguous()
+        sample = rows[torch.randperm(n, generator=g, device=dev)[:min(n, 400_000)]]
+        for _ in range(4):          # a few Lloyd steps in torch: any trained state is valid input (parity is defined GIVEN the state)
+            a = (sample @ cent.T).argmax(1)
+            cent = torch.zeros_like(cent).index_add_(0, a, sample)
+            cent = torch.nn.functional.normalize(cent / torch.bincount(a, minlength=P).clamp(min=1)[:, None], dim=1)
+        sub = sample[:65536].view(-1, args.dim // 8, 8)
+        codebook = torch.stack([sub[torch.randperm(sub.shape[0], generator=g, device=dev)[:256], m] for m in range(args.dim // 8)]).contiguous()
+        idx = S.SpannIndex(args.dim, num_probes=nprobe)
+        M = args.dim // 8
+        idx.set_trained_state(cent.cpu().numpy(), codebook.cpu().numpy(), np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, M), np.uint8))
+        te = time.perf_counter()
+        assign, codes = idx.encode(rows.cpu().numpy())
+        t_enc = time.perf_counter() - te
+        del rows, sample
+        torch.cuda.empty_cache()
+        order = np.argsort(assign, kind="stable")
+        off = np.zeros(P + 1, np.uint64); off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+        idx.set_trained_state(cent.cpu().numpy(), codebook.cpu().numpy(), off, order.astype(np.uint32), codes[order])
+        del codes, order
+        qp = [synth_rows(torch, nq, args.dim, SEED + 42 + i, dev) for i in range(2)]
+        out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq,), dtype=torch.int32, device=dev))
+        dt = timed_steps(torch, lambda i: idx.search_batch_device(qp[i % 2], k, out=out), 20, 3)
+        lens = torch.from_numpy(np.diff(off.astype(np.int64))).to(dev)
+        probes = (1.0 - qp[0] @ cent.T).topk(nprobe, dim=1, largest=False).indices          # byte accounting only
+        alg = int(lens[probes].sum().item()) * (M + 4) + P * args.dim * 4                     # probed postings x 52 B + the centroid table once per batch
+        e = {"name": "cfg4_ivfpq_10M" if n == 10_000_000 else "cfg4_ivfpq_%dM" % (n // 1_000_000),
+             "workload": "configs[3]: %d memories, IVF-PQ nlist %d, nprobe %d, %d-d, top-%d, batch %d" % (n, P, nprobe, args.dim, k, nq),
+             "ms_per_step": round(dt * 1e3, 4), "queries_per_s": round(nq / dt, 1), "steps": 20,
+             "algorithmic_bytes_per_step": alg, "step_hbm_frac_algorithmic": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+             "postings_scanned_per_query": round(float(lens[probes].sum().item()) / nq, 1),
+             "list_len_mean": round(float(lens.float().mean()), 1), "list_len_max": int(lens.max()),
+             "encode_all_rows_s (nearest centroid + PQ encode, host rows in)": round(t_enc, 2)}
+        idx.close(); del idx
+        torch.cuda.empty_cache()
+        done(e, t0)
+
+    # -- MiniLM-L6 encoder (row a1), batch 4096 texts, real tokens only; then configs[2]: embed + insert + recall -------------
+    if not args.skip_encoder:
+        g = torch.Generator(device=dev).manual_seed(SEED + 50)
+        b, ML = 4096, 256
+        for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS),) + ((("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS),) if hasattr(L, "DTYPE_INT8") else ()):
+            t0 = time.perf_counter()
+            enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+            ids, mask, lens = synth_tokens(torch, b, ML, g, dev)
+            emb = torch.empty((b, args.dim), dtype=torch.float32, device=dev)
+            dt = timed_steps(torch, lambda i: enc.encode_ids_device(ids, mask, out=emb), 10, 3)
+            tokens = int(lens.sum())
+            H, F, LAYERS = 384, 1536, 6
+            flop = float(tokens * 2 * (4 * H * H + 2 * H * F) * LAYERS + float((lens.double() ** 2).sum()) * 4 * H * LAYERS)
+            e = {"name": "encoder_%s_b4096" % dname, "workload": "MiniLM-L6 (6 x 384, 12 heads, FFN 1536) forward + mean-pool, %d texts, lengths U[8,128], real tokens only" % b,
+                 "ms_per_step": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1), "tokens": tokens,
+                 "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / 1e12 / peak, 4), "mfma_peak_used": peak,
+                 "flop_per_step": flop}
+            done(e, t0)
+            if dname != "bf16":
+                enc.close()
+                continue
+            # configs[2]
+            t0 = time.perf_counter()
+            n_texts = args.pipeline_texts
+            idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n_texts))
+            t_enc = t_add = 0.0
+            tok = 0
+            done_n = 0
+            tt = time.perf_counter()
+            while done_n < n_texts:
+                bb = min(b, n_texts - done_n)
+                ids, mask, lens = synth_tokens(torch, bb, ML, g, dev)
+                torch.cuda.synchronize(); a = time.perf_counter()
+                enc.encode_ids_device(ids, mask, out=emb[:bb])
+                torch.cuda.synchronize(); c = time.perf_counter()
+                idx.add_vectors(emb[:bb])
+                torch.cuda.synchronize(); d = time.perf_counter()
+                t_enc += c - a; t_add += d - c; tok += int(lens.sum()); done_n += bb
+            t_ingest = time.perf_counter() - tt
+            qids, qmask, _ = synth_tokens(torch, 256, ML, g, dev)
+            qemb = torch.empty((256, args.dim), dtype=torch.float32, device=dev)
+            out = (torch.empty((256, 10), dtype=torch.int32, device=dev), torch.empty((256, 10), dtype=torch.float32, device=dev), torch.empty((256,), dtype=torch.int32, device=dev))
+
+            def recall(i):
+                enc.encode_ids_device(qids, qmask, out=qemb)
+                idx.search_batch_device(qemb, 10, out=out)
+            dt = timed_steps(torch, recall, 30, 5)
+            dts = timed_steps(torch, lambda i: idx.search_batch_device(qemb, 10, out=out), 30, 5)
+            idx.search_batch(qemb.cpu().numpy(), 10)
+            st = idx.scan_stats()
+            e = {"name": "cfg3_pipeline", "workload": "configs[2]: %d synthetic texts -> MiniLM-L6 bf16 -> add_vectors -> recall top-10 of 256 query TEXTS" % n_texts,
+                 "ingest_texts_per_s": round(n_texts / t_ingest, 1), "ingest_s": round(t_ingest, 3), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
+                 "tokens": tok, "recall_ms_per_step_incl_query_encode": round(dt * 1e3, 4), "recall_queries_per_s_incl_query_encode": round(256 / dt, 1),
+                 "search_only_ms_per_step": round(dts * 1e3, 4), "survivors_emitted_per_query": round(st["emitted"] / 256, 1),
+                 "rescored_per_query": round(st["rescored"] / 256, 1), "level2_queries": int(st["level2"]), "exact_fallback_queries": int(st["overflowed"])}
+            idx.close(); enc.close()
+            done(e, t0)
+    return cfgs
 
 
 def main():
@@ -54,16 +389,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--rows", type=int, default=0, help="memories per GPU (weak) / in total (strong); default 1M at N = 1, 10M per GPU at N > 1")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--nq", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--scan", choices=["auto", "exact", "mfma"], default="auto")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="N > 1: weak = --rows per GPU (the corpus grows with N, BASELINE configs[4] shape; value = queries x shards per second, the "
-                         "answered-query rate is config.end_to_end_queries_per_s, DESIGN.md section 5), strong = --rows in total (value = answered queries/s)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
+    ap.add_argument("--query-batches", type=int, default=8, help="distinct query batches the steps cycle through")
+    ap.add_argument("--tombstones", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency section (keeps a rocprof kernel summary to the batch launches)")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="only the contract line (no `configs` array)")
+    ap.add_argument("--skip-10m", action="store_true")
+    ap.add_argument("--skip-ivfpq", action="store_true")
+    ap.add_argument("--skip-encoder", action="store_true")
+    ap.add_argument("--pipeline-texts", type=int, default=262_144)
+    ap.add_argument("--sustained-s", type=float, default=2.0)
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed recall steps for this long BEFORE the contract's warm-up: the GPU idles at ~100 MHz while the corpus is "
                          "generated and needs a few hundred ms of load to reach its sustained clocks")
@@ -94,39 +435,46 @@ def main():
     from shodh_memory_amd import _lib as L
     from shodh_memory_amd.distributed import ShardedFlatIndex, shard_range
 
-    n_total = args.rows * (world if args.scaling == "weak" else 1)
+    rows_arg = args.rows or (1_000_000 if world == 1 else 10_000_000)
+    n_total = rows_arg * (world if args.scaling == "weak" else 1)
     scan_mode = {"auto": L.SCAN_AUTO, "exact": L.SCAN_EXACT, "mfma": L.SCAN_MFMA}[args.scan]
-    sh = ShardedFlatIndex(dim=args.dim, n_total=n_total, scan_mode=scan_mode, device=local_rank) if world > 1 else None
     lo, hi = shard_range(n_total, world, rank)
-    rows = synth_rows(torch, hi - lo, args.dim, SEED + 1000 * rank, dev)
-    queries = synth_rows(torch, args.nq, args.dim, SEED + 1, dev)      # identical on every rank
+    qpool = [synth_rows(torch, args.nq, args.dim, SEED + 1 + 100 * i, dev) for i in range(max(1, args.query_batches))]   # identical on every rank
+    rows = synth_rows(torch, hi - lo, args.dim, SEED + 1000 * rank, dev, adversarial_queries=qpool[0])
     if world > 1:
+        sh = ShardedFlatIndex(dim=args.dim, n_total=n_total, scan_mode=scan_mode, device=local_rank)
         sh.build_local(rows)
         index = sh.index
-        step = lambda: sh.search_batch_device(queries, args.k)        # noqa: E731
+        step = lambda i: sh.search_batch_device(qpool[i % len(qpool)], args.k)        # noqa: E731
     else:
         index = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, scan_mode=scan_mode, device=local_rank, reserve_rows=hi - lo))
         index.build(rows)
         out = (torch.empty((args.nq, args.k), dtype=torch.int32, device=dev), torch.empty((args.nq, args.k), dtype=torch.float32, device=dev),
                torch.empty((args.nq,), dtype=torch.int32, device=dev))
-        step = lambda: index.search_batch_device(queries, args.k, out=out)   # noqa: E731
+        step = lambda i: index.search_batch_device(qpool[i % len(qpool)], args.k, out=out)   # noqa: E731
+    h_rows = rows.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    del rows
+    torch.cuda.empty_cache()
+    dead = tombstone(torch, index, hi - lo, args.tombstones, SEED + 2 + 1000 * rank, dev, id_base=lo) if args.tombstones > 0 else np.zeros(0, np.uint32)
+    rows_local = hi - lo
+    rows_live = rows_local - index.deleted_count()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(int(args.prewarm_ms * 3)):      # ~0.3 ms per step; a fixed count, so that every rank issues the same collectives
-        step()
+    for i in range(int(args.prewarm_ms * 3)):      # ~0.3 ms per step; a fixed count, so that every rank issues the same collectives
+        step(i)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        res = step()
+    for i in range(args.warmup):
+        res = step(i)
     torch.cuda.synchronize()
     index.kernel_timing(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    for i in range(args.steps):
+        res = step(i)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -138,14 +486,33 @@ def main():
     kern_mean_us, kern_min_us, kern_n = index.kernel_timing(reset=True)
 
     # sanity: results are well-formed (full parity is the job of tests/)
+    last_q = qpool[(args.steps - 1) % len(qpool)]
     ids = res[0].cpu().numpy().view(np.uint32)
     dd = res[1].cpu().numpy()
     assert (np.diff(dd, axis=1) >= 0).all() and (ids != 0xFFFFFFFF).all()
 
     qps = args.nq * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    rows_local = hi - lo
-    alg_bytes = rows_local * args.dim * 4                 # corpus read once per batch at f32
+
+    # sustained run: the same step for >= --sustained-s seconds (same collectives on every rank: a fixed count)
+    sustained = None
+    if args.sustained_s > 0:
+        n_sus = max(args.steps, int(args.sustained_s / max(ms_per_step * 1e-3, 1e-6)) + 1)
+        if world > 1:
+            tn = torch.tensor([n_sus], device=dev, dtype=torch.int64)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            n_sus = int(tn.item())
+        barrier(); torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for i in range(n_sus):
+            step(i)
+        torch.cuda.synchronize(); barrier()
+        ts = time.perf_counter() - ts0
+        sk_mean, _, sk_n = index.kernel_timing(reset=True)
+        sustained = {"seconds": round(ts, 3), "steps": n_sus, "ms_per_step": round(ts / n_sus * 1e3, 4), "queries_per_s": round(args.nq * n_sus / ts, 1),
+                     "scan_kernel_us_mean_last_%d" % sk_n: round(sk_mean, 2)}
+
+    alg_bytes = rows_live * args.dim * 4                 # LIVE rows, read once per batch at f32
     # HBM traffic of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc in separate runs, not live)
     traffic = None
@@ -158,22 +525,26 @@ def main():
     roof = None
     if kern_n:
         ach = alg_bytes / (kern_mean_us * 1e-6) / 1e9
-        flops = 2.0 * rows_local * args.dim * 256         # the pre-scan always multiplies a 256-query pass
         roof = {"bound": "hbm", "kernel": "mfma_scan_kernel<EMIT>" if args.scan != "exact" else "flat_exact_kernel",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
-                "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_moved_fp16_shadow_per_launch": rows_local * args.dim * 2,
-                "mfma_tflops": round(flops / (kern_mean_us * 1e-6) / 1e12, 1), "mfma_frac": round(flops / (kern_mean_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+                "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes, "rows_live": rows_live, "rows_scanned": rows_local}
+        ff = flat_fractions(rows_local, rows_live, args.dim, args.nq, kern_mean_us, ms_per_step)
+        roof.update({"bytes_moved_fp16_shadow_per_launch": ff["bytes_moved_fp16_shadow_per_step"],
+                     "frac_actual_bytes": ff.get("kernel_hbm_frac_actual_bytes"), "mfma_tflops": ff.get("kernel_mfma_tflops"),
+                     "mfma_frac": ff.get("kernel_mfma_frac"), "step_frac_algorithmic": ff["step_hbm_frac_algorithmic"],
+                     "step_frac_actual_bytes": ff["step_hbm_frac_actual_bytes"],
+                     "note": "frac divides the ALGORITHMIC f32 bytes of the live rows (SURVEY 8d) by the kernel time; the kernel streams the fp16 shadow "
+                             "(half the bytes, tombstoned rows included): frac_actual_bytes is the hardware-level HBM fraction, mfma_frac the matrix-core one"})
 
     # single-query latency (recall(k) on one query: the reference's own bench shape, benches/memory_benchmarks.rs:228-253)
     lat = None
     if rank == 0 and world == 1 and not args.no_latency:
-        q1 = queries[:1].contiguous()
         o1 = (torch.empty((1, args.k), dtype=torch.int32, device=dev), torch.empty((1, args.k), dtype=torch.float32, device=dev),
               torch.empty((1,), dtype=torch.int32, device=dev))
         ts = []
-        for i in range(60):
+        for i in range(80):
+            q1 = qpool[i % len(qpool)][i % args.nq:i % args.nq + 1]
             torch.cuda.synchronize()
             a = time.perf_counter()
             index.search_batch_device(q1, args.k, out=o1)
@@ -183,42 +554,44 @@ def main():
         lat = {"nq": 1, "p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "p95_ms": round(ts[int(len(ts) * 0.95)] * 1e3, 4)}
 
     cpu = None
+    cpu_info = host_cpu_info() if rank == 0 else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O      # CPU baseline leg only: the oracle is the thing being timed here
-        cores = os.cpu_count() or 1
-        h_rows = rows.cpu().numpy()
-        h_q = queries.cpu().numpy()
+        cores = cpu_info["usable"]
+        h_q = last_q.cpu().numpy()
+        del_mask = np.zeros(rows_local, np.uint8)
+        del_mask[dead] = 1
+        ic = O.InterleavedCopy(h_rows, cores)            # pages first-touched by `cores` threads: spread over the NUMA nodes
+        h_rows = None
         # calibrate with one query on one thread, then size the sample to the budget
-        s1, _, _ = O.bench_brute_force(h_rows, h_q[:1], args.k, 0, True, 1)
-        nq_mt = int(max(cores, min(args.nq, args.cpu_seconds * 0.6 / max(s1, 1e-6) * cores)))
-        nq_mt = max(cores, min(nq_mt, args.nq))
-        s_mt, c_ids, c_dist = O.bench_brute_force(h_rows, h_q[:nq_mt], args.k, 0, True, cores)
-        nq_st = max(1, min(8, int(args.cpu_seconds * 0.2 / max(s1, 1e-6))))
-        s_st, _, _ = O.bench_brute_force(h_rows, h_q[:nq_st], args.k, 0, True, 1)
-        s_sel, _, _ = O.bench_brute_force(h_rows, h_q[:nq_mt], args.k, 0, False, cores)
-        s_avx, _, _ = O.bench_brute_force(h_rows, h_q[:nq_mt], args.k, 1, False, cores)
+        s1, _, _ = O.bench_brute_force(ic.array, h_q[:1], args.k, 0, True, 1, deleted=del_mask)
+        nq_mt = int(min(args.nq, max(cores, args.cpu_seconds * 0.5 / max(s1, 1e-6) * cores)))
+        s_mt, c_ids, c_dist = O.bench_brute_force(ic.array, h_q[:nq_mt], args.k, 0, True, cores, deleted=del_mask)
+        nq_st = max(1, min(8, int(args.cpu_seconds * 0.15 / max(s1, 1e-6))))
+        s_st, _, _ = O.bench_brute_force(ic.array, h_q[:nq_st], args.k, 0, True, 1, deleted=del_mask)
+        nq_x = min(nq_mt, max(cores, int(nq_mt / 3)))
+        s_sel, _, _ = O.bench_brute_force(ic.array, h_q[:nq_x], args.k, 0, False, cores, deleted=del_mask)
+        s_avx, _, _ = O.bench_brute_force(ic.array, h_q[:nq_x], args.k, 1, False, cores, deleted=del_mask)
+        ic.close()
         parity = bool(np.array_equal(c_ids, ids[:nq_mt]) and c_dist.tobytes() == dd[:nq_mt].tobytes())
-        model = ""
-        try:
-            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-        except Exception:
-            pass
+        st_qps = nq_st / s_st
         cpu = {"value": round(nq_mt / s_mt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-               "sample": "%d of the %d queries x all %d rows, top-%d; restated VamanaIndex::brute_force_search (row clone + full sort), "
-                         "scalar-4 order, one query per thread" % (nq_mt, args.nq, rows_local, args.k),
-               "single_thread_qps": round(nq_st / s_st, 3), "bounded_select_qps": round(nq_mt / s_sel, 3),
-               "avx2_order_bounded_select_qps": round(nq_mt / s_avx, 3), "cpu_model": model,
-               "gpu_matches_cpu_bit_exact": parity}
+               "sample": "%d of the %d queries x all %d rows (%d tombstoned), top-%d; restated VamanaIndex::brute_force_search (row clone + full sort), "
+                         "scalar-4 order, one query per thread on %d threads, corpus pages interleaved over the NUMA nodes"
+                         % (nq_mt, args.nq, rows_local, len(dead), args.k, cores),
+               "single_thread_qps": round(st_qps, 3), "effective_parallelism": round((nq_mt / s_mt) / st_qps, 2),
+               "bounded_select_qps": round(nq_x / s_sel, 3), "avx2_order_bounded_select_qps": round(nq_x / s_avx, 3),
+               "host": cpu_info, "gpu_matches_cpu_bit_exact": parity,
+               "note": "single_thread_qps is the reference's real behaviour (one recall = one thread); `cores` = min(affinity, cgroup quota)"}
+
+    cfgs = None
+    if rank == 0 and world == 1 and not args.no_extra_configs:
+        h_rows = None
+        cfgs = extra_configs(args, torch, dev, S, L, index, qpool, rows_local, rows_live, cpu_info)
 
     if rank == 0:
-        # N > 1, weak scaling (the corpus grows with the GPUs, north_star's "corpus shards across the GPUs"): every rank scans
-        # the SAME batch against its own shard, so the whole-job aggregate is queries x shards per second -- "recall queries/s at
-        # rows_per_gpu memories", summed over the shards. With that definition value_N / (N * value_1) is the usual weak-scaling
-        # efficiency t_1 / t_N. The end-to-end rate (answered queries/s over the N-times larger corpus) is config.end_to_end_queries_per_s.
-        weak_multi = world > 1 and args.scaling == "weak"
-        value = qps * world if weak_multi else qps
-        line = {"metric": ("recall queries/sec @ top-%d, %d-d, %d memories per GPU shard, summed over %d shards" % (args.k, args.dim, rows_local, world))
-                          if weak_multi else "recall queries/sec @ top-%d, %d-d, %d memories" % (args.k, args.dim, n_total),
+        value = qps                                           # ANSWERED queries per second, whatever N
+        line = {"metric": "recall queries/sec @ top-%d, %d-d, %d memories" % (args.k, args.dim, n_total),
                 "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -226,15 +599,19 @@ def main():
                                         % (n_total, args.dim, args.k, args.nq, world)) if world == 1 else
                                        ("configs[4] shape (row-sharded corpus, RCCL top-k all-gather): %d memories = %d per GPU x %d MI355X, %d-d f32, "
                                         "brute-force cosine (-dot) top-%d, batch=%d queries (%s scaling)"
-                                        % (n_total, hi - lo, world, args.dim, args.k, args.nq, args.scaling)),
-                           "rows_total": n_total, "rows_per_gpu": rows_local, "batch": args.nq, "k": args.k, "scan": args.scan,
+                                        % (n_total, rows_local, world, args.dim, args.k, args.nq, args.scaling)),
+                           "rows_total": n_total, "rows_per_gpu": rows_local, "rows_live_per_gpu": rows_live, "batch": args.nq, "k": args.k, "scan": args.scan,
+                           "corpus": "SURVEY 8d: 50%% correlated + 50%% i.i.d. unit rows, 1%% exact duplicates, 0.1%% rows equal to a query, %.0f%% tombstoned; "
+                                     "%d distinct query batches cycled" % (args.tombstones * 100, len(qpool)),
                            "layout": "row-sharded + RCCL all-gather of per-shard top-k" if world > 1 else "single device",
-                           "end_to_end_queries_per_s": round(qps, 1),
-                           "value_counts": ("queries x shards: each of the %d ranks scans the same %d-query batch against its own %d-memory shard, "
-                                            "then one all-gather + merge; end_to_end_queries_per_s is the answered-query rate over all %d memories"
-                                            % (world, args.nq, rows_local, n_total)) if weak_multi else "answered queries",
+                           "value_counts": "answered queries per second over the whole corpus",
+                           "weak_scaling_reference": ("per-GPU work is fixed at %d rows: the one-GPU point of this curve is the `flat_10M_b256` entry of the "
+                                                      "N = 1 line's `configs`; ideal = the same queries/s while the corpus grows %d-fold" % (rows_local, world))
+                                                     if world > 1 and args.scaling == "weak" else None,
                            "prescan_dtype": "fp16 MFMA (f32 accumulate) + f32 reference-order re-score"},
-                "roofline": roof, "cpu_baseline": cpu, "latency_single_query": lat}
+                "roofline": roof, "cpu_baseline": cpu, "latency_single_query": lat, "sustained": sustained}
+        if cfgs is not None:
+            line["configs"] = cfgs
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

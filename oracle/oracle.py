@@ -107,6 +107,9 @@ def lib():
         "so_fuse_legs": (sz, [C.POINTER(C.c_int), fp, u8p, fp, fp, sz, u8p, fp, sz, sz, u8p, fp, sz, fp]),
         "so_fnv1a64": (C.c_uint64, [u8p, sz]),
         "so_bench_brute_force": (C.c_double, [fp, sz, sz, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
+        "so_bench_brute_force_del": (C.c_double, [fp, sz, sz, u8p, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
+        "so_interleaved_copy": (C.c_void_p, [fp, sz, C.c_int]),
+        "so_free": (None, [C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -221,15 +224,41 @@ def brute_force_batch(rows, queries, k, deleted=None, order=ORDER_SCALAR4, threa
     return ids, dist
 
 
-def bench_brute_force(rows, queries, k, order, full_sort, threads):
+def bench_brute_force(rows, queries, k, order, full_sort, threads, deleted=None):
     rows = np.ascontiguousarray(rows, dtype=np.float32)
     queries = np.ascontiguousarray(queries, dtype=np.float32)
     nq = queries.shape[0]
     ids = np.zeros((nq, k), np.uint32)
     dist = np.zeros((nq, k), np.float32)
-    secs = lib().so_bench_brute_force(_p(rows, C.c_float), rows.shape[0], rows.shape[1], _p(queries, C.c_float),
-                                      nq, k, order, int(full_sort), threads, _p(ids, C.c_uint32), _p(dist, C.c_float))
+    dp = None
+    if deleted is not None:
+        deleted = np.ascontiguousarray(deleted, dtype=np.uint8)
+        dp = _p(deleted, C.c_uint8)
+    secs = lib().so_bench_brute_force_del(_p(rows, C.c_float), rows.shape[0], rows.shape[1], dp, _p(queries, C.c_float),
+                                          nq, k, order, int(full_sort), threads, _p(ids, C.c_uint32), _p(dist, C.c_float))
     return secs, ids, dist
+
+
+class InterleavedCopy:
+    """A copy of `rows` whose pages were first touched by `threads` threads in 2 MiB stripes (so_interleaved_copy): on a
+    multi-socket host it is spread over the NUMA nodes instead of sitting where the producing thread ran. `.array` is a
+    numpy view; the memory is released when the object goes away."""
+
+    def __init__(self, rows, threads):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self._ptr = lib().so_interleaved_copy(_p(rows, C.c_float), rows.size, int(threads))
+        if not self._ptr:
+            raise MemoryError("so_interleaved_copy")
+        self.array = np.ctypeslib.as_array((C.c_float * rows.size).from_address(self._ptr)).reshape(rows.shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            lib().so_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        self.close()
 
 
 def search_ids_postprocess(vec_ids, dists, vector_to_memory, limit):

@@ -1181,7 +1181,7 @@ uint64_t so_fnv1a64(const uint8_t *data, size_t len) {
 
 typedef struct {
     const float *rows; size_t n, dim; const float *queries; size_t nq, k; int order, full_sort;
-    uint32_t *out_ids; float *out_dist; size_t *next; pthread_mutex_t *mu;
+    uint32_t *out_ids; float *out_dist; size_t *next; pthread_mutex_t *mu; const uint8_t *deleted;
 } bf_job_t;
 
 static void *bf_worker(void *arg) {
@@ -1193,22 +1193,23 @@ static void *bf_worker(void *arg) {
         if (qi >= j->nq) break;
         const float *q = j->queries + qi * j->dim;
         if (j->full_sort)
-            so_brute_force_search(j->rows, j->n, j->dim, NULL, q, j->k, SO_METRIC_NDP, j->order,
+            so_brute_force_search(j->rows, j->n, j->dim, j->deleted, q, j->k, SO_METRIC_NDP, j->order,
                                   j->out_ids + qi * j->k, j->out_dist + qi * j->k);
         else
-            so_brute_force_search_select(j->rows, j->n, j->dim, NULL, q, j->k, SO_METRIC_NDP, j->order,
+            so_brute_force_search_select(j->rows, j->n, j->dim, j->deleted, q, j->k, SO_METRIC_NDP, j->order,
                                          j->out_ids + qi * j->k, j->out_dist + qi * j->k);
     }
     return NULL;
 }
 
-double so_bench_brute_force(const float *rows, size_t n, size_t dim, const float *queries,
-                            size_t nq, size_t k, int order, int full_sort, int threads,
-                            uint32_t *out_ids, float *out_dist) {
+/* `deleted` (may be NULL): one byte per row, non-zero = tombstoned (vamana.rs:1175-1177 skips them) */
+double so_bench_brute_force_del(const float *rows, size_t n, size_t dim, const uint8_t *deleted, const float *queries,
+                                size_t nq, size_t k, int order, int full_sort, int threads,
+                                uint32_t *out_ids, float *out_dist) {
     if (threads < 1) threads = 1;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     size_t next = 0;
-    bf_job_t job = {rows, n, dim, queries, nq, k, order, full_sort, out_ids, out_dist, &next, &mu};
+    bf_job_t job = {rows, n, dim, queries, nq, k, order, full_sort, out_ids, out_dist, &next, &mu, deleted};
     pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1218,3 +1219,38 @@ double so_bench_brute_force(const float *rows, size_t n, size_t dim, const float
     free(th);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+double so_bench_brute_force(const float *rows, size_t n, size_t dim, const float *queries,
+                            size_t nq, size_t k, int order, int full_sort, int threads,
+                            uint32_t *out_ids, float *out_dist) {
+    return so_bench_brute_force_del(rows, n, dim, NULL, queries, nq, k, order, full_sort, threads, out_ids, out_dist);
+}
+
+/* A copy of `src` whose pages are first touched by `threads` worker threads, page p by thread p % threads: on a multi-socket
+ * host the copy ends up spread over the NUMA nodes the workers run on instead of sitting on the node of the thread that
+ * produced `src` (bench.py's multi-threaded CPU baseline streams the corpus from every core). Free with so_free. */
+typedef struct { const char *src; char *dst; size_t bytes; int t, nt; } ic_job_t;
+static void *ic_worker(void *arg) {
+    ic_job_t *j = (ic_job_t *)arg;
+    const size_t page = 1u << 21;          /* 2 MiB: one THP / a few hundred 4K pages per stripe */
+    for (size_t off = (size_t)j->t * page; off < j->bytes; off += (size_t)j->nt * page) {
+        size_t len = j->bytes - off < page ? j->bytes - off : page;
+        memcpy(j->dst + off, j->src + off, len);
+    }
+    return NULL;
+}
+float *so_interleaved_copy(const float *src, size_t n_floats, int threads) {
+    if (threads < 1) threads = 1;
+    void *dst = NULL;
+    if (posix_memalign(&dst, 1u << 21, n_floats * 4 + 64) != 0) return NULL;
+    pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    ic_job_t *jobs = (ic_job_t *)malloc((size_t)threads * sizeof(ic_job_t));
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].src = (const char *)src; jobs[t].dst = (char *)dst; jobs[t].bytes = n_floats * 4; jobs[t].t = t; jobs[t].nt = threads;
+        pthread_create(&th[t], NULL, ic_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    return (float *)dst;
+}
+void so_free(void *p) { free(p); }

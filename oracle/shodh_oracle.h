@@ -183,6 +183,14 @@ uint64_t so_fnv1a64(const uint8_t *data, size_t len);          /* vamana_persist
 double so_bench_brute_force(const float *rows, size_t n, size_t dim, const float *queries,
                             size_t nq, size_t k, int order, int full_sort, int threads,
                             uint32_t *out_ids, float *out_dist);
+/* the same with tombstones (one byte per row, non-zero = deleted; NULL = none) */
+double so_bench_brute_force_del(const float *rows, size_t n, size_t dim, const uint8_t *deleted, const float *queries,
+                                size_t nq, size_t k, int order, int full_sort, int threads,
+                                uint32_t *out_ids, float *out_dist);
+/* copy of `src` first-touched by `threads` threads in 2 MiB stripes (NUMA-spread corpus for the multi-threaded baseline);
+ * release with so_free */
+float *so_interleaved_copy(const float *src, size_t n_floats, int threads);
+void so_free(void *p);
 
 #ifdef __cplusplus
 }

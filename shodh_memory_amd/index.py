@@ -506,6 +506,21 @@ class SpannIndex:
         return ids[:, :k], dist[:, :k], counts
 
 
+    # (SpannIndex) device-pointer search: torch CUDA tensors in and out, asynchronous on the current stream
+    def search_batch_device(self, queries, k, out=None, stream=None):
+        import torch
+        _check_device_rows(queries, self._hd.dim)
+        nq = queries.shape[0]
+        if out is None:
+            out = (torch.empty((nq, k), dtype=torch.int32, device=queries.device), torch.empty((nq, k), dtype=torch.float32, device=queries.device),
+                   torch.empty((nq,), dtype=torch.int32, device=queries.device))
+        ids, dist, counts = out
+        st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
+        L.check(L.lib().shodh_index_search_device(self.handle, queries.data_ptr(), nq, k, ids.data_ptr(), dist.data_ptr(),
+                                                  counts.data_ptr(), C.c_void_p(st)))
+        return ids, dist, counts
+
+
 class VectorIndexBackend:
     """vector_db/mod.rs:98-266 facade."""
 
