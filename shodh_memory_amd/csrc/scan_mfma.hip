@@ -204,7 +204,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     uint64_t *wq_key = eq_key + wave * MF_WQ_CAP;
     uint32_t *wq_q = eq_q + wave * MF_WQ_CAP;
     uint32_t wq_n = 0;                       // wave-uniform
-    bool wq_dropped = false;                 // wave-uniform: the queue overflowed at some point
     uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;   // + q * gridDim.x * MF_SLOTS
     auto drain = [&]() {
         const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
@@ -227,9 +226,23 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     // the survivors of one 32-row block (entered BY THE WHOLE WAVE when some lane's maximum reached its threshold: the
     // queue bookkeeping below is wave-uniform). C layout (32x32):
     // col = lane&31 (query), value r of a lane is row (r&3) + 8*(r>>2) + 4*(lane>>5) of the block.
+    // one survivor straight to its candidate slot (the body of drain() for the calling lane)
+    auto emit_direct = [&](uint64_t key) {
+        const uint32_t row = (uint32_t)key;
+        if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) return;
+        const uint32_t s_ = atomicAdd(qcount + q_local, 1u);
+        if (s_ < (uint32_t)MF_SLOTS) {
+            my_slots[(size_t)q_local * gridDim.x * MF_SLOTS + s_] = key;
+        } else {
+            const size_t qi = (size_t)pass * MF_BPAD + q_local;
+            const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
+            if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
+        }
+    };
     auto emit_block = [&](const floatx16 &c, uint64_t brow0 /* first row of the block */) {
         const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
         const uint32_t lim = left < 64 ? (uint32_t)left : 64u;      // this lane's values with row offset < lim exist
+        const uint32_t wq_n0 = wq_n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t roff = (r & 3) + 8 * (r >> 2);
@@ -244,7 +257,18 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
                 wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
             }
         }
-        if (wq_n > (uint32_t)MF_WQ_CAP) { wq_dropped = true; wq_n = MF_WQ_CAP; }
+        if (__builtin_expect(wq_n > (uint32_t)MF_WQ_CAP, 0)) {
+            // A dense block (a corpus inside a narrow cone: most lanes hit on most values) holds more survivors than the queue
+            // has room for. Its queue entries are discarded and every hit of the block goes straight to its candidate slot
+            // (round 1 dropped them and sent every query of the pass to the exact scan of the corpus).
+            wq_n = wq_n0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t roff = (r & 3) + 8 * (r >> 2);
+                if (c[r] >= thr_l && roff < lim) emit_direct(make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff)));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // these stores / atomics share the VM counter with the DMA (see the loop)
+        }
     };
 
     // the pipeline is primed: everything issued so far (DMA, query fragments, thresholds) lands before the stream starts
@@ -381,9 +405,6 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     if (MODE == MF_MODE_EMIT) {
         if (have_prev && active) emit_block(acc1, (uint64_t)prev_sel * a.tile_stride * MF_TR + 32);   // (no maximum was folded for the last tile)
         drain();
-        // entries were dropped somewhere: poison every list of this pass so that the final stage sends
-        // those queries to the exact scan (adversarial inputs only, e.g. thousands of identical rows)
-        if (wq_dropped && lane < 32) atomicAdd(a.cand_cnt + (size_t)pass * MF_BPAD + q_local, a.cand_cap + 1u);
     }
 #ifdef SHODH_PROF
     if (MODE == MF_MODE_EMIT && (blockIdx.x == 100 || blockIdx.x == 200) && blockIdx.y == 0 && tid == 0)
