@@ -146,6 +146,50 @@ int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, ui
 int shodh_topk_merge_strided_device(const uint32_t *d_in_ids, const float *d_in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
                                     uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
 
+/* ---- multi-GPU: ONE index over the GPUs of a node, one host process (SURVEY.md 8e / 8b `devices[], n_devices`) ---------------
+ * The VamanaIndex / SpannIndex method set again, over G shards, each an ordinary shodh_index on its own device. A search runs the
+ * query batch on every shard at once, exchanges the per-shard top-k ([ids | dist], 8*nq*k bytes per shard) with RCCL ncclAllGather
+ * (communicators from ncclCommInitAll; librccl is bound at run time) and merges with the comparator of vamana.rs:1185 on the
+ * first device: results are bit-identical to one index holding the whole corpus. Duplicate device ordinals are allowed (several
+ * shards on one GPU, e.g. for testing on a single-GPU host); the exchange then uses device-to-device copies.
+ * FLAT: ids stay dense and sequential (vamana.rs:854-855) and are dealt to the shards in blocks of 2^block_log2 rows, round robin,
+ * so appends stay balanced. IVFPQ: every posting list is cut into G pieces, shard g holds piece g of every list.
+ * One call at a time per handle (calls are serialised internally). */
+enum { SHODH_EXCHANGE_AUTO = 0,    /* RCCL when the devices are distinct and librccl loads, device copies otherwise */
+       SHODH_EXCHANGE_RCCL = 1,    /* RCCL or fail */
+       SHODH_EXCHANGE_COPY = 2 };  /* hipMemcpyAsync device-to-device into the first device */
+typedef struct shodh_sharded_index shodh_sharded_index;
+typedef struct {
+    uint32_t dim, metric, kind, order, scan_mode, nprobe;   /* as in shodh_index_cfg, applied to every shard */
+    uint32_t block_log2;             /* FLAT: rows per round-robin block = 2^block_log2 (default 16) */
+    uint32_t exchange;               /* SHODH_EXCHANGE_* */
+    uint64_t reserve_rows_per_shard;
+} shodh_sharded_cfg;
+void shodh_sharded_cfg_default(shodh_sharded_cfg *cfg);
+int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devices, uint32_t n_devices, shodh_sharded_index **out);
+void shodh_sharded_index_destroy(shodh_sharded_index *s);
+uint32_t shodh_sharded_index_shards(const shodh_sharded_index *s);
+int shodh_sharded_index_uses_rccl(const shodh_sharded_index *s);                 /* 1 = the exchange is an RCCL all-gather */
+uint64_t shodh_sharded_index_len(const shodh_sharded_index *s);                  /* vamana.rs:184-186 / SpannIndex::len */
+uint64_t shodh_sharded_index_shard_len(const shodh_sharded_index *s, uint32_t shard);
+int shodh_sharded_index_build(shodh_sharded_index *s, const float *rows, uint64_t n);                            /* vamana.rs:200-284 */
+int shodh_sharded_index_add(shodh_sharded_index *s, const float *rows, uint64_t n, uint32_t *first_id_out);      /* :853-974 */
+int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k,
+                               uint32_t *ids, float *dist, uint32_t *counts);                                    /* :764-808, :1167-1188; spann.rs:574-693 */
+int shodh_sharded_index_mark_deleted(shodh_sharded_index *s, uint32_t id, int *was_valid);                        /* :813-820 */
+int shodh_sharded_index_mark_deleted_batch(shodh_sharded_index *s, const uint32_t *ids, uint64_t n, uint64_t *n_marked_out);
+int shodh_sharded_index_is_deleted(shodh_sharded_index *s, uint32_t id);
+uint64_t shodh_sharded_index_deleted_count(shodh_sharded_index *s);
+int shodh_sharded_index_clear_deleted(shodh_sharded_index *s);
+int shodh_sharded_index_extract_rows(shodh_sharded_index *s, uint64_t first, uint64_t n, float *out_rows);        /* by global id, bit-for-bit */
+int shodh_sharded_index_set_ivfpq(shodh_sharded_index *s, const float *centroids, uint32_t P, const float *codebook, uint32_t M,
+                                  uint32_t ncent, const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes);
+int shodh_sharded_index_ivfpq_insert(shodh_sharded_index *s, uint32_t vector_id, const float *row);             /* spann.rs:1006-1051, shard = id % G */
+/* host wall clock of the last search, microseconds: enqueue of the shard searches, exchange enqueue, merge + wait, total */
+int shodh_sharded_index_host_timings(const shodh_sharded_index *s, float *us4);
+/* which librccl was bound and its version ("<path> version <n>"); SHODH_ERR_DEVICE if none could be loaded */
+int shodh_rccl_info(char *buf, size_t cap);
+
 /* ---- IVF-PQ trained state (SpannIndex given centroids/codebooks/postings) -------------------- */
 /* The reference's k-means is unseeded (spann.rs:472-474, pq.rs:155-157) so parity is defined
  * GIVEN trained state. centroids [P][dim]; codebook [M][ncent][8] (M = dim/8, ncent <= 256);

@@ -65,6 +65,13 @@ class RelevanceCfg(C.Structure):
                 ("graph_boost_multiplier", C.c_float), ("max_results", C.c_uint32)]
 
 
+class ShardedCfg(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("metric", C.c_uint32), ("kind", C.c_uint32), ("order", C.c_uint32), ("scan_mode", C.c_uint32),
+                ("nprobe", C.c_uint32), ("block_log2", C.c_uint32), ("exchange", C.c_uint32), ("reserve_rows_per_shard", C.c_uint64)]
+
+
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
+
 # every symbol include/shodh_hip.h declares: name -> (restype, argtypes)
 _vp, _fp, _u8p, _u32p, _u64p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 class VamaInfo(C.Structure):
@@ -108,6 +115,26 @@ SYMBOLS = {
     "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 8)]),
     "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_topk_merge_strided_device": (C.c_int, [_u32p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
+    "shodh_sharded_cfg_default": (None, [C.POINTER(ShardedCfg)]),
+    "shodh_sharded_index_create": (C.c_int, [C.POINTER(ShardedCfg), _i32p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "shodh_sharded_index_destroy": (None, [_vp]),
+    "shodh_sharded_index_shards": (C.c_uint32, [_vp]),
+    "shodh_sharded_index_uses_rccl": (C.c_int, [_vp]),
+    "shodh_sharded_index_len": (C.c_uint64, [_vp]),
+    "shodh_sharded_index_shard_len": (C.c_uint64, [_vp, C.c_uint32]),
+    "shodh_sharded_index_build": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "shodh_sharded_index_add": (C.c_int, [_vp, _fp, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "shodh_sharded_index_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "shodh_sharded_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
+    "shodh_sharded_index_mark_deleted_batch": (C.c_int, [_vp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "shodh_sharded_index_is_deleted": (C.c_int, [_vp, C.c_uint32]),
+    "shodh_sharded_index_deleted_count": (C.c_uint64, [_vp]),
+    "shodh_sharded_index_clear_deleted": (C.c_int, [_vp]),
+    "shodh_sharded_index_extract_rows": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _fp]),
+    "shodh_sharded_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
+    "shodh_sharded_index_ivfpq_insert": (C.c_int, [_vp, C.c_uint32, _fp]),
+    "shodh_sharded_index_host_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
+    "shodh_rccl_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "shodh_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
     "shodh_index_ivfpq_insert": (C.c_int, [_vp, C.c_uint32, _fp]),
     "shodh_index_ivfpq_encode": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u8p]),

@@ -1,0 +1,469 @@
+// sharded.hip -- ONE index over the GPUs of a node, behind the C ABI (BASELINE.json configs[4]).
+//
+// One host process, G devices. The corpus is row-sharded; every shard is an ordinary shodh_index on its own device:
+//   search = the same query batch on every shard (each on its own stream, all GPUs busy at once)
+//            -> per-shard top-k with GLOBAL ids, packed [ids | dist] (2*nq*k words)
+//            -> exchange: RCCL ncclAllGather inside one ncclGroup over communicators from ncclCommInitAll (no torch, no MPI);
+//               duplicate device ordinals (several shards on one GPU: the 1-GPU stand-in of the tests) use device copies
+//            -> merge by (dist total_cmp, id) (launch_merge_lists, the comparator of vamana.rs:1185) on the first device.
+// Every local distance was produced in the reference's accumulation order and the merge uses the reference's comparator, so
+// the result is bit-identical to one index over the whole corpus.
+//
+// FLAT: global ids stay dense and sequential, exactly as add_vector assigns them (vamana.rs:854-855), and are dealt to the
+// shards in blocks of B = 2^block_log2 rows, round robin:  block = id / B, shard = block % G, local row = (block / G) * B + id % B.
+// Appends therefore fill shard after shard and stay balanced to within one block whatever the insertion history (a contiguous
+// range per shard would put every append on the last shard). A shard's local ids are dense because global ids fill in order.
+// The local -> global map is monotone inside a shard, so a shard's list stays sorted by (dist, global id) after the remap.
+// IVFPQ: every posting list is cut into G contiguous pieces, shard g holds piece g of every list (balanced whatever the probe
+// set); postings carry their vector ids, so there is nothing to remap. Inserts go to shard id % G.
+//
+// RCCL is bound at run time (dlopen): a host that never creates a sharded index does not need librccl, and inside a
+// python process that has torch loaded the already-mapped RCCL is used instead of a second copy.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace shodh {
+
+int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
+                       uint32_t *ids, float *dist, uint32_t *counts, hipStream_t st);
+
+// ---- RCCL, bound by hand (the subset used here; declarations follow /opt/rocm/include/rccl/rccl.h) -----------------------
+typedef void *rcclComm_t;
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(rcclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int /*ncclDataType_t*/, rcclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    std::string path;
+};
+constexpr int RCCL_UINT32 = 3;   // ncclUint32 (rccl.h:462)
+
+static Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = getenv("SHODH_RCCL_LIB");
+        const char *names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        // first: a copy that is already mapped into the process (torch ships its own)
+        for (const char *n : names) {
+            if (!n || r.h) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (r.h) r.path = std::string(n) + " (already loaded)";
+        }
+        for (const char *n : names) {
+            if (!n || r.h) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) r.path = n;
+        }
+        if (!r.h) return;
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.h, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+        if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) { dlclose(r.h); r.h = nullptr; }
+    });
+    return r.h ? &r : nullptr;
+}
+
+#define SHODH_RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                       \
+        int e__ = (expr);                                                                                      \
+        if (e__ != 0) {                                                                                        \
+            ::shodh::set_error("%s: %s", #expr, R->GetErrorString ? R->GetErrorString(e__) : "RCCL error");     \
+            return SHODH_ERR_DEVICE;                                                                           \
+        }                                                                                                      \
+    } while (0)
+
+// local row -> global id of shard g (see the header comment); padding ids (0xFFFFFFFF) stay
+__global__ void remap_ids_kernel(uint32_t *ids, uint64_t n, uint32_t g, uint32_t G, uint32_t log2b) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = ids[i];
+    if (l == 0xFFFFFFFFu) return;
+    const uint32_t mask = (1u << log2b) - 1u;
+    ids[i] = ((((l >> log2b) * G) + g) << log2b) | (l & mask);
+}
+
+struct Shard {
+    int device = 0;
+    shodh_index *idx = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    rcclComm_t comm = nullptr;
+    float *d_q = nullptr; size_t q_floats = 0;
+    uint32_t *pack = nullptr; size_t pack_words = 0;        // [ids nq*k | dist nq*k]
+    uint32_t *all = nullptr; size_t all_words = 0;          // G packs (receive side of the all-gather; the COPY path fills shard 0's only)
+    uint32_t *d_counts = nullptr; size_t nq_cap = 0;
+    uint64_t rows = 0;                                      // FLAT: local rows held
+};
+
+}  // namespace shodh
+
+using namespace shodh;
+
+struct shodh_sharded_index {
+    shodh_sharded_cfg cfg{};
+    std::vector<int> devices;
+    std::vector<Shard> sh;
+    std::mutex mu;                 // one call at a time: the exchange buffers are per index
+    uint64_t n = 0;                // FLAT: global rows (= next id)
+    bool use_rccl = false;
+    // merged result on the first device
+    uint32_t *o_ids = nullptr; float *o_dist = nullptr; uint32_t *o_counts = nullptr; size_t o_elems = 0, o_nq = 0;
+    float last_us[4] = {0, 0, 0, 0};   // search, exchange, merge, total (host wall clock of the last search)
+};
+
+namespace shodh {
+
+static inline uint32_t shard_of(const shodh_sharded_index *s, uint64_t id) { return (uint32_t)((id >> s->cfg.block_log2) % s->sh.size()); }
+static inline uint64_t local_of(const shodh_sharded_index *s, uint64_t id) {
+    const uint64_t B = 1ull << s->cfg.block_log2;
+    return ((id >> s->cfg.block_log2) / s->sh.size()) * B + (id & (B - 1));
+}
+
+static int reserve_buffers(shodh_sharded_index *s, uint32_t nq, uint32_t k) {
+    const size_t G = s->sh.size();
+    const size_t words = 2ull * nq * k;
+    for (size_t g = 0; g < G; ++g) {
+        Shard &h = s->sh[g];
+        SHODH_HIP_TRY(hipSetDevice(h.device));
+        if ((size_t)nq * s->cfg.dim > h.q_floats) { if (h.d_q) hipFree(h.d_q); h.d_q = nullptr; h.q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.d_q, (size_t)nq * s->cfg.dim * 4)); h.q_floats = (size_t)nq * s->cfg.dim; }
+        if (words > h.pack_words) { if (h.pack) hipFree(h.pack); h.pack = nullptr; h.pack_words = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.pack, (words ? words : 1) * 4)); h.pack_words = words; }
+        const bool needs_all = s->use_rccl || g == 0;
+        if (needs_all && words * G > h.all_words) { if (h.all) hipFree(h.all); h.all = nullptr; h.all_words = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.all, (words * G ? words * G : 1) * 4)); h.all_words = words * G; }
+        if (nq > h.nq_cap) { if (h.d_counts) hipFree(h.d_counts); h.d_counts = nullptr; h.nq_cap = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.d_counts, (size_t)nq * 4)); h.nq_cap = nq; }
+    }
+    SHODH_HIP_TRY(hipSetDevice(s->sh[0].device));
+    if ((size_t)nq * k > s->o_elems) {
+        if (s->o_ids) hipFree(s->o_ids); if (s->o_dist) hipFree(s->o_dist); s->o_ids = nullptr; s->o_dist = nullptr; s->o_elems = 0;
+        SHODH_HIP_TRY(hipMalloc((void **)&s->o_ids, (size_t)nq * k * 4)); SHODH_HIP_TRY(hipMalloc((void **)&s->o_dist, (size_t)nq * k * 4)); s->o_elems = (size_t)nq * k;
+    }
+    if (nq > s->o_nq) { if (s->o_counts) hipFree(s->o_counts); s->o_counts = nullptr; s->o_nq = 0; SHODH_HIP_TRY(hipMalloc((void **)&s->o_counts, (size_t)nq * 4)); s->o_nq = nq; }
+    return SHODH_OK;
+}
+
+static double now_us() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e6 + (double)t.tv_nsec * 1e-3;
+}
+
+}  // namespace shodh
+
+extern "C" {
+
+void shodh_sharded_cfg_default(shodh_sharded_cfg *c) {
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->dim = 384;
+    c->metric = SHODH_METRIC_NDP;
+    c->kind = SHODH_INDEX_FLAT;
+    c->order = SHODH_ORDER_SCALAR4;
+    c->scan_mode = SHODH_SCAN_AUTO;
+    c->nprobe = 20;
+    c->block_log2 = 16;            // 65536 rows (96 MiB of f32 at 384-d) per block
+    c->exchange = SHODH_EXCHANGE_AUTO;
+}
+
+int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devices, uint32_t n_devices, shodh_sharded_index **out) {
+    if (!cfg || !out || !devices || n_devices == 0) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    *out = nullptr;
+    if (n_devices > 64) { set_error("at most 64 shards"); return SHODH_ERR_INVALID; }
+    if (cfg->block_log2 < 6 || cfg->block_log2 > 26) { set_error("block_log2 %u out of range [6, 26]", cfg->block_log2); return SHODH_ERR_INVALID; }
+    if (cfg->exchange > SHODH_EXCHANGE_COPY) { set_error("unknown exchange %u", cfg->exchange); return SHODH_ERR_INVALID; }
+    bool distinct = true;
+    for (uint32_t i = 0; i < n_devices; ++i)
+        for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+    bool want_rccl = cfg->exchange == SHODH_EXCHANGE_RCCL || (cfg->exchange == SHODH_EXCHANGE_AUTO && distinct);
+    if (cfg->exchange == SHODH_EXCHANGE_RCCL && !distinct) { set_error("RCCL needs distinct devices (one communicator rank per GPU)"); return SHODH_ERR_INVALID; }
+    Rccl *R = want_rccl ? rccl() : nullptr;
+    if (want_rccl && !R) {
+        if (cfg->exchange == SHODH_EXCHANGE_RCCL) { set_error("librccl could not be loaded (set SHODH_RCCL_LIB)"); return SHODH_ERR_DEVICE; }
+        want_rccl = false;         // AUTO: fall back to device copies
+    }
+    shodh_sharded_index *s = new shodh_sharded_index();
+    s->cfg = *cfg;
+    s->devices.assign(devices, devices + n_devices);
+    s->sh.resize(n_devices);
+    s->use_rccl = want_rccl;
+    int rc = SHODH_OK;
+    for (uint32_t g = 0; g < n_devices && rc == SHODH_OK; ++g) {
+        Shard &h = s->sh[g];
+        h.device = devices[g];
+        shodh_index_cfg ic;
+        shodh_index_cfg_default(&ic);
+        ic.dim = cfg->dim; ic.metric = cfg->metric; ic.kind = cfg->kind; ic.order = cfg->order; ic.device = devices[g];
+        ic.scan_mode = cfg->scan_mode; ic.reserve_rows = cfg->reserve_rows_per_shard; ic.id_base = 0; ic.nprobe = cfg->nprobe;
+        rc = shodh_index_create(&ic, &h.idx);
+        if (rc != SHODH_OK) break;
+        if (hipSetDevice(h.device) != hipSuccess || hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) { set_error("stream / event creation failed on device %d", h.device); rc = SHODH_ERR_DEVICE; }
+    }
+    if (rc == SHODH_OK && s->use_rccl) {
+        std::vector<rcclComm_t> comms(n_devices, nullptr);
+        const int e = R->CommInitAll(comms.data(), (int)n_devices, s->devices.data());
+        if (e != 0) {
+            if (cfg->exchange == SHODH_EXCHANGE_RCCL) { set_error("ncclCommInitAll: %s", R->GetErrorString ? R->GetErrorString(e) : "error"); rc = SHODH_ERR_DEVICE; }
+            else s->use_rccl = false;
+        } else {
+            for (uint32_t g = 0; g < n_devices; ++g) s->sh[g].comm = comms[g];
+        }
+    }
+    if (rc != SHODH_OK) { shodh_sharded_index_destroy(s); return rc; }
+    *out = s;
+    return SHODH_OK;
+}
+
+void shodh_sharded_index_destroy(shodh_sharded_index *s) {
+    if (!s) return;
+    Rccl *R = rccl();
+    for (Shard &h : s->sh) {
+        hipSetDevice(h.device);
+        if (h.st) hipStreamSynchronize(h.st);
+        if (h.comm && R) R->CommDestroy(h.comm);
+        if (h.idx) shodh_index_destroy(h.idx);
+        if (h.d_q) hipFree(h.d_q); if (h.pack) hipFree(h.pack); if (h.all) hipFree(h.all); if (h.d_counts) hipFree(h.d_counts);
+        if (h.ev) hipEventDestroy(h.ev);
+        if (h.st) hipStreamDestroy(h.st);
+    }
+    if (!s->sh.empty()) hipSetDevice(s->sh[0].device);
+    if (s->o_ids) hipFree(s->o_ids); if (s->o_dist) hipFree(s->o_dist); if (s->o_counts) hipFree(s->o_counts);
+    delete s;
+}
+
+uint32_t shodh_sharded_index_shards(const shodh_sharded_index *s) { return s ? (uint32_t)s->sh.size() : 0; }
+int shodh_sharded_index_uses_rccl(const shodh_sharded_index *s) { return s && s->use_rccl ? 1 : 0; }
+uint64_t shodh_sharded_index_len(const shodh_sharded_index *s) {
+    if (!s) return 0;
+    if (s->cfg.kind == SHODH_INDEX_FLAT) return s->n;
+    uint64_t t = 0;
+    for (const Shard &h : s->sh) t += shodh_index_len(h.idx);
+    return t;
+}
+uint64_t shodh_sharded_index_shard_len(const shodh_sharded_index *s, uint32_t shard) {
+    return (s && shard < s->sh.size()) ? shodh_index_len(s->sh[shard].idx) : 0;
+}
+
+// add_vector for n rows: ids n0 .. n0+n-1, dealt to the shards block by block
+int shodh_sharded_index_add(shodh_sharded_index *s, const float *rows, uint64_t n, uint32_t *first_id_out) {
+    if (!s || (!rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("add is for FLAT indexes; IVF-PQ uses shodh_sharded_index_ivfpq_insert"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->n + n > 0xFFFFFFFEull) { set_error("vector ids are u32: index full"); return SHODH_ERR_INVALID; }
+    if (first_id_out) *first_id_out = (uint32_t)s->n;
+    const uint64_t B = 1ull << s->cfg.block_log2;
+    uint64_t done = 0;
+    while (done < n) {
+        const uint64_t id = s->n;
+        const uint64_t take = std::min(n - done, B - (id & (B - 1)));
+        Shard &h = s->sh[shard_of(s, id)];
+        uint32_t first_local = 0;
+        SHODH_TRY(shodh_index_add(h.idx, rows + done * s->cfg.dim, take, &first_local));
+        if ((uint64_t)first_local != local_of(s, id)) { set_error("shard bookkeeping out of step (local %u, expected %llu)", first_local, (unsigned long long)local_of(s, id)); return SHODH_ERR_STATE; }
+        h.rows += take;
+        s->n += take;
+        done += take;
+    }
+    return SHODH_OK;
+}
+
+// build / rebuild_from_vectors: replaces the contents, ids 0..n-1
+int shodh_sharded_index_build(shodh_sharded_index *s, const float *rows, uint64_t n) {
+    if (!s || (!rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("build is for FLAT indexes; IVF-PQ uses shodh_sharded_index_set_ivfpq"); return SHODH_ERR_STATE; }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (Shard &h : s->sh) { SHODH_TRY(shodh_index_build(h.idx, nullptr, 0)); h.rows = 0; }
+        s->n = 0;
+    }
+    return shodh_sharded_index_add(s, rows, n, nullptr);
+}
+
+int shodh_sharded_index_mark_deleted(shodh_sharded_index *s, uint32_t id, int *was_valid) {
+    if (!s) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("tombstones are a FLAT index feature (SpannIndex has none)"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->n) { if (was_valid) *was_valid = 0; return SHODH_OK; }
+    return shodh_index_mark_deleted(s->sh[shard_of(s, id)].idx, (uint32_t)local_of(s, id), was_valid);
+}
+
+int shodh_sharded_index_mark_deleted_batch(shodh_sharded_index *s, const uint32_t *ids, uint64_t n, uint64_t *n_marked_out) {
+    if (!s || (!ids && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("tombstones are a FLAT index feature (SpannIndex has none)"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<std::vector<uint32_t>> per(s->sh.size());
+    for (uint64_t i = 0; i < n; ++i)
+        if (ids[i] < s->n) per[shard_of(s, ids[i])].push_back((uint32_t)local_of(s, ids[i]));
+    uint64_t total = 0;
+    for (size_t g = 0; g < s->sh.size(); ++g) {
+        uint64_t m = 0;
+        if (!per[g].empty()) SHODH_TRY(shodh_index_mark_deleted_batch(s->sh[g].idx, per[g].data(), per[g].size(), &m));
+        total += m;
+    }
+    if (n_marked_out) *n_marked_out = total;
+    return SHODH_OK;
+}
+
+int shodh_sharded_index_is_deleted(shodh_sharded_index *s, uint32_t id) {
+    if (!s) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->cfg.kind != SHODH_INDEX_FLAT || id >= s->n) return 0;
+    return shodh_index_is_deleted(s->sh[shard_of(s, id)].idx, (uint32_t)local_of(s, id));
+}
+
+uint64_t shodh_sharded_index_deleted_count(shodh_sharded_index *s) {
+    if (!s) return 0;
+    uint64_t t = 0;
+    for (const Shard &h : s->sh) t += shodh_index_deleted_count(h.idx);
+    return t;
+}
+
+int shodh_sharded_index_clear_deleted(shodh_sharded_index *s) {
+    if (!s) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (Shard &h : s->sh) SHODH_TRY(shodh_index_clear_deleted(h.idx));
+    return SHODH_OK;
+}
+
+// extract_all_vectors: rows [first, first+n) by GLOBAL id, bit-for-bit (retrieval.rs:2504-2516)
+int shodh_sharded_index_extract_rows(shodh_sharded_index *s, uint64_t first, uint64_t n, float *out_rows) {
+    if (!s || (!out_rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("IVF-PQ keeps codes, not rows"); return SHODH_ERR_STATE; }
+    if (first + n > s->n) { set_error("rows [%llu,%llu) out of range (len %llu)", (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)s->n); return SHODH_ERR_INVALID; }
+    const uint64_t B = 1ull << s->cfg.block_log2;
+    uint64_t done = 0;
+    while (done < n) {
+        const uint64_t id = first + done;
+        const uint64_t take = std::min(n - done, B - (id & (B - 1)));
+        SHODH_TRY(shodh_index_extract_rows(s->sh[shard_of(s, id)].idx, local_of(s, id), take, out_rows + done * s->cfg.dim));
+        done += take;
+    }
+    return SHODH_OK;
+}
+
+// SpannIndex trained state, postings cut into G pieces per list
+int shodh_sharded_index_set_ivfpq(shodh_sharded_index *s, const float *centroids, uint32_t P, const float *codebook, uint32_t M, uint32_t ncent,
+                                  const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes) {
+    if (!s || !centroids || !codebook || !list_off) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_IVFPQ) { set_error("not an IVF-PQ index"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t G = s->sh.size();
+    for (size_t g = 0; g < G; ++g) {
+        std::vector<uint64_t> off(P + 1, 0);
+        std::vector<uint32_t> sid;
+        std::vector<uint8_t> scd;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint64_t a = list_off[p], len = list_off[p + 1] - list_off[p];
+            const uint64_t lo = a + len * g / G, hi = a + len * (g + 1) / G;      // piece g of list p, in the list's own order
+            off[p + 1] = off[p] + (hi - lo);
+            if (hi > lo) {
+                sid.insert(sid.end(), ids + lo, ids + hi);
+                scd.insert(scd.end(), codes + lo * M, codes + hi * M);
+            }
+        }
+        SHODH_TRY(shodh_index_set_ivfpq(s->sh[g].idx, centroids, P, codebook, M, ncent, off.data(), sid.empty() ? nullptr : sid.data(), scd.empty() ? nullptr : scd.data()));
+    }
+    return SHODH_OK;
+}
+
+int shodh_sharded_index_ivfpq_insert(shodh_sharded_index *s, uint32_t vector_id, const float *row) {
+    if (!s || !row) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (s->cfg.kind != SHODH_INDEX_IVFPQ) { set_error("not an IVF-PQ index"); return SHODH_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    return shodh_index_ivfpq_insert(s->sh[vector_id % s->sh.size()].idx, vector_id, row);
+}
+
+int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+    if (!s || (nq && (!q || !counts)) || (nq && k && (!ids || !dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (nq == 0) return SHODH_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t G = s->sh.size();
+    if (k == 0) { for (uint32_t i = 0; i < nq; ++i) counts[i] = 0; return SHODH_OK; }
+    for (size_t i = 0; i < (size_t)nq * s->cfg.dim; ++i)
+        if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
+    SHODH_TRY(reserve_buffers(s, nq, k));
+    Rccl *R = s->use_rccl ? rccl() : nullptr;
+    const size_t words = 2ull * nq * k;
+    const double t0 = now_us();
+    // 1. every shard: queries in, local top-k out (global ids), asynchronously on its own stream
+    for (size_t g = 0; g < G; ++g) {
+        Shard &h = s->sh[g];
+        SHODH_HIP_TRY(hipSetDevice(h.device));
+        SHODH_HIP_TRY(hipMemcpyAsync(h.d_q, q, (size_t)nq * s->cfg.dim * 4, hipMemcpyHostToDevice, h.st));
+        SHODH_TRY(shodh_index_search_device(h.idx, h.d_q, nq, k, h.pack, reinterpret_cast<float *>(h.pack + (size_t)nq * k), h.d_counts, h.st));
+        if (s->cfg.kind == SHODH_INDEX_FLAT && G > 1) {
+            const uint64_t cnt = (uint64_t)nq * k;
+            hipLaunchKernelGGL(remap_ids_kernel, dim3((uint32_t)ceil_div(cnt, 256)), dim3(256), 0, h.st, h.pack, cnt, (uint32_t)g, (uint32_t)G, s->cfg.block_log2);
+            SHODH_HIP_TRY(hipGetLastError());
+        }
+    }
+    const double t1 = now_us();
+    // 2. exchange
+    Shard &h0 = s->sh[0];
+    if (s->use_rccl) {
+        SHODH_RCCL_TRY(R->GroupStart());
+        for (size_t g = 0; g < G; ++g) {
+            Shard &h = s->sh[g];
+            const int e = R->AllGather(h.pack, h.all, words, RCCL_UINT32, h.comm, h.st);
+            if (e != 0) { R->GroupEnd(); set_error("ncclAllGather: %s", R->GetErrorString ? R->GetErrorString(e) : "error"); return SHODH_ERR_DEVICE; }
+        }
+        SHODH_RCCL_TRY(R->GroupEnd());
+    } else {
+        for (size_t g = 0; g < G; ++g) {
+            Shard &h = s->sh[g];
+            SHODH_HIP_TRY(hipSetDevice(h.device));
+            SHODH_HIP_TRY(hipEventRecord(h.ev, h.st));
+        }
+        SHODH_HIP_TRY(hipSetDevice(h0.device));
+        for (size_t g = 0; g < G; ++g) {
+            if (g) SHODH_HIP_TRY(hipStreamWaitEvent(h0.st, s->sh[g].ev, 0));
+            SHODH_HIP_TRY(hipMemcpyAsync(h0.all + g * words, s->sh[g].pack, words * 4, hipMemcpyDeviceToDevice, h0.st));
+        }
+    }
+    const double t2 = now_us();
+    // 3. merge on the first device, results to the host
+    SHODH_HIP_TRY(hipSetDevice(h0.device));
+    SHODH_TRY(launch_merge_lists(h0.all, reinterpret_cast<const float *>(h0.all + (size_t)nq * k), words, (uint32_t)G, nq, k, s->o_ids, s->o_dist, s->o_counts, h0.st));
+    SHODH_HIP_TRY(hipMemcpyAsync(ids, s->o_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h0.st));
+    SHODH_HIP_TRY(hipMemcpyAsync(dist, s->o_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h0.st));
+    SHODH_HIP_TRY(hipMemcpyAsync(counts, s->o_counts, (size_t)nq * 4, hipMemcpyDeviceToHost, h0.st));
+    for (size_t g = G; g-- > 0;) {
+        SHODH_HIP_TRY(hipSetDevice(s->sh[g].device));
+        const hipError_t e = hipStreamSynchronize(s->sh[g].st);
+        if (e != hipSuccess) { set_error("sharded search failed on device %d: %s", s->sh[g].device, hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
+    }
+    const double t3 = now_us();
+    s->last_us[0] = (float)(t1 - t0); s->last_us[1] = (float)(t2 - t1); s->last_us[2] = (float)(t3 - t2); s->last_us[3] = (float)(t3 - t0);
+    return SHODH_OK;
+}
+
+int shodh_sharded_index_host_timings(const shodh_sharded_index *s, float *us4) {
+    if (!s || !us4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    memcpy(us4, s->last_us, sizeof(s->last_us));
+    return SHODH_OK;
+}
+
+int shodh_rccl_info(char *buf, size_t cap) {
+    Rccl *R = rccl();
+    if (!R) { if (buf && cap) snprintf(buf, cap, "librccl not loaded"); return SHODH_ERR_DEVICE; }
+    int v = 0;
+    if (R->GetVersion) R->GetVersion(&v);
+    if (buf && cap) snprintf(buf, cap, "%s version %d", R->path.c_str(), v);
+    return SHODH_OK;
+}
+
+}  // extern "C"

@@ -98,3 +98,130 @@ class ShardedFlatIndex:
                                                         b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_counts"].data_ptr(),
                                                         C.c_void_p(st)))
         return b["out_ids"], b["out_dist"], b["out_counts"]
+
+
+class MultiGpuIndex:
+    """ONE index over several GPUs of a node from ONE process, entirely behind the C ABI (`shodh_sharded_index_*`,
+    csrc/sharded.hip): per-device shards, RCCL all-gather of the per-shard top-k, device merge. The VamanaIndex / SpannIndex
+    method subset a caller needs (`build`, `add_vector(s)`, `search`, `mark_deleted`, `len`, `extract_all_vectors`,
+    `set_trained_state`, `insert`). `devices` may repeat an ordinal (several shards on one GPU: the exchange then uses device
+    copies instead of RCCL -- the single-GPU stand-in used by the tests)."""
+
+    def __init__(self, devices, dim=384, kind=L.INDEX_FLAT, order=L.ORDER_SCALAR4, scan_mode=L.SCAN_AUTO, nprobe=20, block_log2=16,
+                 exchange=L.EXCHANGE_AUTO, reserve_rows_per_shard=0):
+        cfg = L.ShardedCfg()
+        L.lib().shodh_sharded_cfg_default(C.byref(cfg))
+        cfg.dim, cfg.kind, cfg.order, cfg.scan_mode, cfg.nprobe = dim, kind, order, scan_mode, nprobe
+        cfg.block_log2, cfg.exchange, cfg.reserve_rows_per_shard = block_log2, exchange, reserve_rows_per_shard
+        dv = np.ascontiguousarray(devices, np.int32)
+        self._h = C.c_void_p()
+        L.check(L.lib().shodh_sharded_index_create(C.byref(cfg), dv.ctypes.data, dv.size, C.byref(self._h)))
+        self.dim, self.kind = dim, kind
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().shodh_sharded_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shards(self):
+        return int(L.lib().shodh_sharded_index_shards(self._h))
+
+    def uses_rccl(self):
+        return bool(L.lib().shodh_sharded_index_uses_rccl(self._h))
+
+    def len(self):
+        return int(L.lib().shodh_sharded_index_len(self._h))
+
+    def shard_len(self, g):
+        return int(L.lib().shodh_sharded_index_shard_len(self._h, g))
+
+    def _rows(self, vectors):
+        a = np.ascontiguousarray(vectors, np.float32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        if a.size and a.shape[1] != self.dim:
+            raise L.ShodhError(L.ERR_DIM, "Vector dimension %d doesn't match config %d" % (a.shape[1], self.dim))
+        return a.reshape(-1, self.dim)
+
+    def build(self, vectors):
+        a = self._rows(vectors)
+        L.check(L.lib().shodh_sharded_index_build(self._h, a.ctypes.data, a.shape[0]))
+
+    def add_vectors(self, vectors):
+        a = self._rows(vectors)
+        first = C.c_uint32()
+        L.check(L.lib().shodh_sharded_index_add(self._h, a.ctypes.data, a.shape[0], C.byref(first)))
+        return int(first.value)
+
+    def add_vector(self, vector):
+        return self.add_vectors(vector)
+
+    def search_batch(self, queries, k):
+        q = self._rows(queries)
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        L.check(L.lib().shodh_sharded_index_search(self._h, q.ctypes.data, nq, k, ids.ctypes.data, dist.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], dist[:, :k], counts
+
+    def search(self, query, k):
+        ids, dist, counts = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(counts[0]))]
+
+    def mark_deleted(self, vector_id):
+        ok = C.c_int()
+        L.check(L.lib().shodh_sharded_index_mark_deleted(self._h, int(vector_id), C.byref(ok)))
+        return bool(ok.value)
+
+    def mark_deleted_many(self, vector_ids):
+        ids = np.ascontiguousarray(vector_ids, np.uint32)
+        m = C.c_uint64()
+        L.check(L.lib().shodh_sharded_index_mark_deleted_batch(self._h, ids.ctypes.data, ids.size, C.byref(m)))
+        return int(m.value)
+
+    def is_deleted(self, vector_id):
+        return bool(L.lib().shodh_sharded_index_is_deleted(self._h, int(vector_id)))
+
+    def deleted_count(self):
+        return int(L.lib().shodh_sharded_index_deleted_count(self._h))
+
+    def clear_deleted(self):
+        L.check(L.lib().shodh_sharded_index_clear_deleted(self._h))
+
+    def extract_all_vectors(self):
+        n = self.len()
+        out = np.empty((n, self.dim), np.float32)
+        if n:
+            L.check(L.lib().shodh_sharded_index_extract_rows(self._h, 0, n, out.ctypes.data))
+        return out
+
+    def set_trained_state(self, centroids, codebook, list_off, ids, codes):
+        c = np.ascontiguousarray(centroids, np.float32)
+        cb = np.ascontiguousarray(codebook, np.float32)
+        lo = np.ascontiguousarray(list_off, np.uint64)
+        i = np.ascontiguousarray(ids, np.uint32)
+        cd = np.ascontiguousarray(codes, np.uint8)
+        L.check(L.lib().shodh_sharded_index_set_ivfpq(self._h, c.ctypes.data, c.shape[0], cb.ctypes.data, cb.shape[0], cb.shape[1],
+                                                      lo.ctypes.data, i.ctypes.data if i.size else None, cd.ctypes.data if cd.size else None))
+
+    def insert(self, vector_id, vector):
+        v = self._rows(vector)
+        L.check(L.lib().shodh_sharded_index_ivfpq_insert(self._h, int(vector_id), v.ctypes.data))
+
+    def host_timings_us(self):
+        a = (C.c_float * 4)()
+        L.check(L.lib().shodh_sharded_index_host_timings(self._h, C.byref(a)))
+        return dict(enqueue=a[0], exchange=a[1], merge_wait=a[2], total=a[3])
+
+
+def rccl_info():
+    buf = C.create_string_buffer(512)
+    rc = L.lib().shodh_rccl_info(buf, 512)
+    return rc == L.OK, buf.value.decode()

@@ -1,0 +1,129 @@
+"""The multi-GPU index behind the C ABI (`shodh_sharded_index_*`, csrc/sharded.hip; SURVEY.md 8e, BASELINE.json configs[4] shape).
+On a box with >= 2 GPUs the shards sit on distinct devices and the exchange is an RCCL all-gather; on the 1-GPU boxes of this
+pool (a) several shards share device 0 and the exchange is device copies -- everything but RCCL itself --, and (b) a one-shard
+index on device 0 runs the RCCL all-gather for real (communicator from ncclCommInitAll, world size 1). In every layout the result
+must be bit-identical to the oracle's brute force over the whole corpus."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def D():
+    from shodh_memory_amd import build
+    build.build()
+    from shodh_memory_amd import distributed
+    return distributed
+
+
+def layouts():
+    n = torch.cuda.device_count()
+    out = [("copy x3 on one GPU", [0, 0, 0], 2), ("copy x2 on one GPU", [0, 0], 2), ("rccl x1", [0], 1)]
+    if n >= 2:
+        out.append(("rccl x%d" % min(n, 8), list(range(min(n, 8))), 1))
+    return out
+
+
+def check(oracle, idx, rows, q, k, deleted=None):
+    ids, dist, counts = idx.search_batch(q, k)
+    for i in range(len(q)):
+        e_ids, e_dist = oracle.brute_force_search(rows, q[i], k, deleted, select=True)
+        n = int(counts[i])
+        assert n == len(e_ids) and ids[i, :n].tolist() == e_ids.tolist(), (i, ids[i, :8], e_ids[:8])
+        assert dist[i, :n].tobytes() == e_dist.tobytes()
+        assert (ids[i, n:] == 0xFFFFFFFF).all()
+
+
+def test_rccl_is_bound(D):
+    ok, info = D.rccl_info()
+    assert ok, info
+    print("RCCL:", info)
+
+
+@pytest.mark.parametrize("block_log2", [6, 10])
+def test_flat_sharded_matches_single_index(D, oracle, block_log2):
+    q = synth.queries(33)
+    rows = synth.corpus(30011, queries=q)                 # not a multiple of anything
+    for name, devs, exch in layouts():
+        from shodh_memory_amd import _lib as L
+        idx = D.MultiGpuIndex(devs, block_log2=block_log2, exchange=exch, scan_mode=0)
+        assert idx.uses_rccl() == (exch == L.EXCHANGE_RCCL), name
+        idx.build(rows[:20000])
+        assert idx.add_vectors(rows[20000:25000]) == 20000 and idx.add_vector(rows[25000]) == 25000     # ids dense, in insertion order
+        assert idx.add_vectors(rows[25001:]) == 25001 and idx.len() == len(rows)
+        per = [idx.shard_len(g) for g in range(idx.shards())]
+        assert sum(per) == len(rows) and max(per) - min(per) <= (1 << block_log2), (name, per)              # balanced to one block
+        assert idx.extract_all_vectors().tobytes() == rows.tobytes()                                        # bit-for-bit, by global id
+        check(oracle, idx, rows, q, 10)
+        check(oracle, idx, rows, q[:3], 120)
+        dead = np.unique(np.random.default_rng(4).integers(0, len(rows), 1500)).astype(np.uint32)
+        assert idx.mark_deleted_many(dead[:-1]) == len(dead) - 1 and idx.mark_deleted(int(dead[-1])) and not idx.mark_deleted(len(rows) + 5)
+        assert idx.deleted_count() == len(dead) and idx.is_deleted(int(dead[3])) and not idx.is_deleted(len(rows) + 5)
+        mask = np.zeros(len(rows), np.uint8); mask[dead] = 1
+        check(oracle, idx, rows, q, 10, mask)
+        idx.clear_deleted()
+        check(oracle, idx, rows, q[:4], 10)
+        idx.build(rows[:100])                                                                                # rebuild replaces the contents
+        assert idx.len() == 100
+        check(oracle, idx, rows[:100], q[:2], 10)
+        assert idx.search_batch(q[:2], 0)[2].tolist() == [0, 0]
+        t = idx.host_timings_us()
+        assert t["total"] > 0
+        idx.close()
+
+
+def test_empty_shards_and_tiny_corpora(D, oracle):
+    rows = synth.corpus(70)
+    q = synth.queries(3)
+    idx = D.MultiGpuIndex([0, 0, 0, 0], block_log2=6, exchange=2)
+    assert idx.search_batch(q, 5)[2].tolist() == [0, 0, 0]                 # empty index: Ok(vec![]) (vamana.rs:766-768)
+    idx.build(rows)                                                         # 64 + 6 rows: shards 2 and 3 stay empty
+    assert [idx.shard_len(g) for g in range(4)] == [64, 6, 0, 0]
+    check(oracle, idx, rows, q, 10)
+    check(oracle, idx, rows, q, 100)                                        # k > n
+    idx.close()
+
+
+def test_ivfpq_sharded_matches_oracle(D, oracle):
+    from shodh_memory_amd import _lib as L
+    rng = np.random.default_rng(5)
+    rows = synth.corpus(6000, adversarial=False)
+    Pn = 40
+    st = oracle.spann_build(rows, Pn, rng.permutation(6000).astype(np.uint32), [rng.permutation(6000).astype(np.uint32) for _ in range(48)], kmeans_iterations=3)
+    q = synth.queries(9)
+    for name, devs, exch in layouts():
+        idx = D.MultiGpuIndex(devs, kind=L.INDEX_IVFPQ, nprobe=7, exchange=exch)
+        idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+        assert idx.len() == 6000
+        ids, dist, counts = idx.search_batch(q, 10)
+        for i in range(len(q)):
+            e_ids, e_dist = oracle.spann_search(st["centroids"], st["list_off"], st["ids"], st["codes"], st["codebook"], 7, q[i], 10, 0)
+            n = int(counts[i])
+            assert n == len(e_ids) and ids[i, :n].tolist() == e_ids.tolist() and dist[i, :n].tobytes() == e_dist.tobytes(), name
+        idx.close()
+
+
+def test_sharded_one_million_rows_two_shards_on_one_gpu(D):
+    """size check: 2 x 500k rows on one GPU through the whole C path; properties instead of the oracle (self is the top hit,
+    lists sorted, equal to the single-index answer)"""
+    import shodh_memory_amd as S
+    import bench
+    dev = torch.device("cuda", 0)
+    q = bench.synth_rows(torch, 64, 384, 77, dev)
+    rows = bench.synth_rows(torch, 1_000_000, 384, 78, dev, adversarial_queries=q).cpu().numpy()
+    qh = q.cpu().numpy()
+    one = S.VamanaIndex(S.VamanaConfig(dimension=384))
+    one.build(rows)
+    e_ids, e_dist, _ = one.search_batch(qh, 10)
+    one.close()
+    idx = D.MultiGpuIndex([0, 0], exchange=2)
+    idx.build(rows)
+    ids, dist, counts = idx.search_batch(qh, 10)
+    assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes() and (counts == 10).all()
+    assert (np.diff(dist, axis=1) >= 0).all()
+    idx.close()
