@@ -281,6 +281,36 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
     torch.cuda.empty_cache()
     done(e, t0)
 
+    # -- the multi-GPU index behind the C ABI (shodh_sharded_index_*: RCCL all-gather + device merge inside the library), host-pointer API
+    t0 = time.perf_counter()
+    from shodh_memory_amd.distributed import MultiGpuIndex, rccl_info
+    ndev = torch.cuda.device_count()
+    n = 1_000_000
+    qh = [qq.cpu().numpy() for qq in main_qpool[:4]]
+    rows_h = synth_rows(torch, n, args.dim, SEED + 60, dev, adversarial_queries=main_qpool[0]).cpu().numpy()
+    e = {"name": "sharded_c_abi_1M_b256", "workload": "1M memories through shodh_sharded_index_* (one process, host pointers: H2D queries, per-shard search, "
+         "exchange, merge, D2H results), batch 256, top-10", "rccl": rccl_info()[1], "visible_gpus": ndev, "layouts": []}
+    one = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+    one.build(rows_h)
+    dt1 = timed_steps(torch, lambda i: one.search_batch(qh[i % 4], 10), 30, 5)
+    ref_ids, ref_dist, _ = one.search_batch(qh[0], 10)
+    one.close()
+    e["single_index_host_api_ms_per_step"] = round(dt1 * 1e3, 4)
+    lay = [("rccl_x%d" % ndev, list(range(ndev)), L.EXCHANGE_RCCL)]
+    if ndev == 1:
+        lay.append(("copy_2_shards_on_one_gpu", [0, 0], L.EXCHANGE_COPY))
+    for lname, devs, exch in lay:
+        mg = MultiGpuIndex(devs, dim=args.dim, exchange=exch, reserve_rows_per_shard=n // len(devs) + 65536)
+        mg.build(rows_h)
+        dtm = timed_steps(torch, lambda i: mg.search_batch(qh[i % 4], 10), 30, 5)
+        ids_m, dist_m, _ = mg.search_batch(qh[0], 10)
+        e["layouts"].append({"layout": lname, "shards": len(devs), "uses_rccl": mg.uses_rccl(), "ms_per_step": round(dtm * 1e3, 4),
+                             "queries_per_s": round(256 / dtm, 1), "host_timings_us_last": {kk: round(v, 1) for kk, v in mg.host_timings_us().items()},
+                             "identical_to_single_index": bool(np.array_equal(ids_m, ref_ids) and dist_m.tobytes() == ref_dist.tobytes())})
+        mg.close()
+    del rows_h
+    done(e, t0)
+
     # -- configs[3]: 10M memories, IVF nlist = 4096, nprobe = 32, top-10, batch 1024 -------------------------------------------
     if not args.skip_ivfpq:
         t0 = time.perf_counter()

@@ -390,3 +390,73 @@ pub fn fuse_legs(cfg: &ffi::shodh_leg_fusion_cfg, hybrid: &[([u8; 16], f32, f32)
     let out = (0..n.min(cap)).map(|i| { let mut u = [0u8; 16]; u.copy_from_slice(&ou[i * 16..i * 16 + 16]); (u, os[i]) }).collect();
     (out, trust)
 }
+
+/// ONE `VamanaIndex`-shaped index over several GPUs of a node (BASELINE.json configs[4]): per-device shards,
+/// RCCL all-gather of the per-shard top-k, merge with the comparator of vamana.rs:1185 -- all inside the library
+/// (`shodh_sharded_index_*`, csrc/sharded.hip). Same ids, same results as a `HipIndex` holding the whole corpus.
+pub struct HipShardedIndex {
+    h: *mut ffi::shodh_sharded_index,
+    dim: usize,
+}
+unsafe impl Send for HipShardedIndex {}
+unsafe impl Sync for HipShardedIndex {}
+
+impl HipShardedIndex {
+    /// `devices`: HIP ordinals, one shard each (e.g. `&[0, 1, 2, 3, 4, 5, 6, 7]`)
+    pub fn new(config: VamanaConfig, devices: &[i32]) -> Result<Self> {
+        let mut cfg = ffi::shodh_sharded_cfg::default();
+        unsafe { ffi::shodh_sharded_cfg_default(&mut cfg) };
+        cfg.dim = config.dimension as u32;
+        let mut h = std::ptr::null_mut();
+        check(unsafe { ffi::shodh_sharded_index_create(&cfg, devices.as_ptr(), devices.len() as u32, &mut h) })?;
+        Ok(Self { h, dim: config.dimension })
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::shodh_sharded_index_len(self.h) as usize } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+    pub fn shards(&self) -> usize { unsafe { ffi::shodh_sharded_index_shards(self.h) as usize } }
+    pub fn uses_rccl(&self) -> bool { unsafe { ffi::shodh_sharded_index_uses_rccl(self.h) == 1 } }
+    pub fn build(&mut self, vectors: Vec<Vec<f32>>) -> Result<()> {
+        for v in &vectors {
+            if v.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, v.len())); }
+        }
+        let flat: Vec<f32> = vectors.into_iter().flatten().collect();
+        check(unsafe { ffi::shodh_sharded_index_build(self.h, flat.as_ptr(), (flat.len() / self.dim.max(1)) as u64) })
+    }
+    pub fn add_vector(&mut self, vector: Vec<f32>) -> Result<u32> {
+        if vector.len() != self.dim { return Err(anyhow!("Vector dimension mismatch: expected {}, got {}", self.dim, vector.len())); }
+        let mut id = 0u32;
+        check(unsafe { ffi::shodh_sharded_index_add(self.h, vector.as_ptr(), 1, &mut id) })?;
+        Ok(id)
+    }
+    pub fn search(&self, query: &[f32], k: usize) -> Result<Vec<(u32, f32)>> {
+        if query.len() != self.dim { return Err(anyhow!("Query dimension mismatch: expected {}, got {}", self.dim, query.len())); }
+        if k == 0 || self.is_empty() { return Ok(Vec::new()); }
+        let (mut ids, mut dist, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        check(unsafe { ffi::shodh_sharded_index_search(self.h, query.as_ptr(), 1, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), &mut n) })?;
+        Ok(ids.into_iter().zip(dist).take(n as usize).collect())
+    }
+    pub fn search_batch(&self, queries: &[f32], k: usize) -> Result<Vec<Vec<(u32, f32)>>> {
+        let nq = queries.len() / self.dim.max(1);
+        if nq == 0 || k == 0 { return Ok(vec![Vec::new(); nq]); }
+        let (mut ids, mut dist, mut n) = (vec![0u32; nq * k], vec![0f32; nq * k], vec![0u32; nq]);
+        check(unsafe { ffi::shodh_sharded_index_search(self.h, queries.as_ptr(), nq as u32, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), n.as_mut_ptr()) })?;
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], dist[q * k + i])).collect()).collect())
+    }
+    pub fn mark_deleted(&self, id: u32) -> bool {
+        let mut ok = 0;
+        unsafe { ffi::shodh_sharded_index_mark_deleted(self.h, id, &mut ok) };
+        ok != 0
+    }
+    pub fn is_deleted(&self, id: u32) -> bool { unsafe { ffi::shodh_sharded_index_is_deleted(self.h, id) == 1 } }
+    pub fn deleted_count(&self) -> usize { unsafe { ffi::shodh_sharded_index_deleted_count(self.h) as usize } }
+    pub fn clear_deleted(&self) { unsafe { ffi::shodh_sharded_index_clear_deleted(self.h) }; }
+    pub fn extract_all_vectors(&self) -> Result<Vec<Vec<f32>>> {
+        let n = self.len();
+        let mut flat = vec![0f32; n * self.dim];
+        check(unsafe { ffi::shodh_sharded_index_extract_rows(self.h, 0, n as u64, flat.as_mut_ptr()) })?;
+        Ok(flat.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect())
+    }
+}
+impl Drop for HipShardedIndex {
+    fn drop(&mut self) { unsafe { ffi::shodh_sharded_index_destroy(self.h) } }
+}
