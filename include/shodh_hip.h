@@ -224,14 +224,21 @@ int shodh_top_k_similar(int device, const float *query, uint32_t query_dim, cons
                         uint32_t dim, uint64_t k, uint32_t order, float *out_scores, uint32_t *out_index, uint64_t *count_out);
 
 /* ---- embedder: trait Embedder / MiniLMEmbedder (src/embeddings/mod.rs:52-88, minilm.rs) ------- */
-enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1 };
+enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1,
+       /* the reference's DEFAULT model is the ONNX Runtime dynamic-quantisation export model_quint8_avx2.onnx (downloader.rs:31,
+        * minilm.rs:212-220): 8-bit per-tensor weights (and word table), DynamicQuantizeLinear uint8 activations per dense layer,
+        * MatMulInteger int32 accumulation on v_mfma_i32_32x32x32_i8, fp32 softmax / GELU / LayerNorm. Parity with that file is
+        * unpinned (no ONNX Runtime / checkpoint offline); the operator semantics restated are in oracle/int8_ref.py */
+       SHODH_DTYPE_INT8 = 2 };
 typedef struct {
     int32_t  device;
     uint32_t dtype;          /* GEMM operand type (accumulation is always fp32) */
     uint32_t max_len;        /* EmbeddingConfig.max_length = 256 (minilm.rs:225) */
     uint32_t vocab, hidden, layers, heads, intermediate, max_pos, type_vocab;  /* 30522,384,6,12,1536,512,2 */
     float    ln_eps;         /* 1e-12 */
-    uint32_t compute_padded; /* 0: skip padded positions (exact in fp32/bf16, minilm.rs:153-154); 1: compute all max_len */
+    uint32_t compute_padded; /* 0: only real tokens (exact in fp32/bf16, minilm.rs:153-154); 1 (INT8 only): all max_len positions of every
+                              * non-empty text, as the reference's tensor has them -- DynamicQuantizeLinear takes its range over
+                              * the padded tensor, so the padding is part of the INT8 embedding function (minilm.rs:588-593) */
 } shodh_embed_cfg;
 void shodh_embed_cfg_default(shodh_embed_cfg *cfg);
 int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out);   /* MiniLMEmbedder::new minilm.rs:652-690 */
@@ -255,6 +262,12 @@ int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8
 int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b,
                                      float *d_out, void *stream);
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /* StageTiming.embedding_us */
+/* One dynamically quantised dense layer, y = dequant(MatMulInteger(DynamicQuantizeLinear(x), quantise(w))) + bias, on host data:
+ * x [M][K], w [N][K] (quantised per tensor, symmetric 8 bit), bias [N] or NULL, y [M][N]; N % 128 == 0, K % 128 == 0.
+ * Optional outputs: acc_out [M][N] the exact int32 accumulators sum_k (a - a_zp)(w_q), a_scale / a_zp the activation
+ * quantisation parameters, w_scale the weight scale. The building block of SHODH_DTYPE_INT8. */
+int shodh_int8_dense(int device, const float *x, const float *w, const float *bias, uint32_t M, uint32_t N, uint32_t K,
+                     float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale);
 
 /* ---- host-side glue of the same path (string / uuid work: stays on the host by design) ------------------ */
 /* MiniLMEmbedder::new_simplified / generate_embedding_simplified (minilm.rs:777-831): SipHash-1-3

@@ -25,7 +25,7 @@ METRIC_NDP, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
 ORDER_SCALAR4, ORDER_AVX2, ORDER_SEQ_1M = 0, 1, 2
 INDEX_FLAT, INDEX_IVFPQ = 0, 1
 SCAN_AUTO, SCAN_EXACT, SCAN_MFMA = 0, 1, 2
-DTYPE_FP32, DTYPE_BF16 = 0, 1
+DTYPE_FP32, DTYPE_BF16, DTYPE_INT8 = 0, 1, 2
 
 
 class ShodhError(RuntimeError):
@@ -170,6 +170,7 @@ SYMBOLS = {
     "shodh_embedder_dimension": (C.c_uint32, [_vp]),
     "shodh_embedder_encode_ids": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp]),
     "shodh_embedder_encode_ids_device": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp, _vp]),
+    "shodh_int8_dense": (C.c_int, [C.c_int, _fp, _fp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _fp, _i32p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "shodh_embedder_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 2)]),
     "shodh_weights_default": (None, [C.POINTER(Weights)]),
     "shodh_weights_normalize": (None, [C.POINTER(Weights)]),

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "glds.h"
+#include "encoder_int8.h"
 
 namespace shodh {
 
@@ -455,7 +456,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
                                                        const int32_t *__restrict__ tok_pos, const float *__restrict__ word,
                                                        const float *__restrict__ pos, const float *__restrict__ type0,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                       T *__restrict__ out, int ntok, int H, int max_len, int vocab, float eps) {
+                                                       T *__restrict__ out, int ntok, int H, int max_len, int vocab, float eps,
+                                                       const int8_t *__restrict__ word_q /* INT8 mode: the 8-bit word table, else null */, const float *__restrict__ word_scale) {
     const int lane = threadIdx.x & 63;
     const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (tok >= ntok) return;
@@ -466,7 +468,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     float x[16];
     int cnt = 0;
     float s = 0.0f;
-    for (int i = lane; i < H; i += 64) { const float v = word[(size_t)id * H + i] + pos[(size_t)p * H + i] + type0[i]; x[cnt++] = v; s += v; }
+    const float wsc = word_q ? *word_scale : 0.0f;
+    for (int i = lane; i < H; i += 64) {
+        const float wv = word_q ? (float)word_q[(size_t)id * H + i] * wsc : word[(size_t)id * H + i];      // Gather + DequantizeLinear
+        const float v = wv + pos[(size_t)p * H + i] + type0[i]; x[cnt++] = v; s += v;
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)H;
     float v = 0.0f;
@@ -478,12 +484,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 }
 
 // ---- attention: one workgroup per (sequence, head); d_head = 32; online softmax per query row ---------------
+// klen (may be null): keys attended per sequence (the padded INT8 tensor computes every position as a QUERY but only real tokens
+// are KEYS: HF BERT adds finfo.min to masked keys, which is the restriction to the real ones)
 template <class T>
 __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qkv, const int32_t *__restrict__ cu, T *__restrict__ ctx,
-                                                        int H, int heads) {
+                                                        int H, int heads, const int32_t *__restrict__ klen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
-    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int t0 = cu[seq], Sq = cu[seq + 1] - t0;
+    const int S = klen ? klen[seq] : Sq;
     float *Ks = reinterpret_cast<float *>(smem);          // [S][32]
     float *Vs = Ks + (size_t)S * 32;                       // [S][32]
     const int H3 = 3 * H;
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qk
     }
     __syncthreads();
     const float scale = 0.17677669529663688110f;          // 1/sqrt(32)
-    for (int i = threadIdx.x; i < S; i += 128) {
+    for (int i = threadIdx.x; i < Sq; i += 128) {
         float q[32], o[32];
 #pragma unroll
         for (int d = 0; d < 32; ++d) { q[d] = to_f32(qkv[(size_t)(t0 + i) * H3 + head * 32 + d]) * scale; o[d] = 0.0f; }
@@ -632,10 +641,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const __bf16 *__res
 
 // ---- masked mean-pool + finalize_pooled (minilm.rs:959-981, :846-878) -------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, const int32_t *__restrict__ cu, float *__restrict__ out, int H) {
+__global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, const int32_t *__restrict__ cu, float *__restrict__ out, int H,
+                                                   const int32_t *__restrict__ klen /* real tokens per sequence, or null = all */, const int32_t *__restrict__ out_row /* or null */) {
     __shared__ float red[256];
     const int seq = blockIdx.x;
-    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int t0 = cu[seq], S = klen ? klen[seq] : cu[seq + 1] - t0;
+    const int orow = out_row ? out_row[seq] : seq;
     float part = 0.0f;
     float vals[4];
     int nv = 0;
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, cons
     const float norm = sqrtf(red[0]);
     const bool ok = norm > 1.1920929e-07f;                                         // f32::EPSILON, !is_nan
     nv = 0;
-    for (int d = threadIdx.x; d < H; d += 256) { const float p = vals[nv++]; out[(size_t)seq * H + d] = ok ? p / norm : p; }
+    for (int d = threadIdx.x; d < H; d += 256) { const float p = vals[nv++]; out[(size_t)orow * H + d] = ok ? p / norm : p; }
 }
 
 template <class T>
@@ -680,6 +691,15 @@ struct shodh_embedder {
     float *wqkv32 = nullptr;             // [layers][3H][H] fused q,k,v weight (the blob interleaves weights and biases)
     __bf16 *wqkv16 = nullptr;
     __bf16 *wp16 = nullptr;              // [layers][3H + H + I][H] fragment-major copies of the K = H weights (streaming GEMM), H == 384 only
+    // INT8 mode (dynamic quantisation, encoder_int8.h): per layer the fused q|k|v matrix [3H][H], attention output [H][H], FFN up
+    // [I][H], FFN down [H][I] as signed 8-bit values with one scale per output feature (per-tensor scales, repeated) and row sums;
+    // the word table 8-bit as well
+    std::vector<QWeight> q_qkv, q_o, q_up, q_dn;
+    int8_t *word_q = nullptr; float *word_scale = nullptr;
+    int8_t *XQ = nullptr;                // quantised activations of the current dense layer [tok_cap][max(H, I)]
+    float *act_params = nullptr;         // {scale, zp} of the current activation tensor
+    uint32_t *qscratch = nullptr;        // min/max keys, absmax
+    int32_t *d_klen = nullptr, *d_orow = nullptr;   // padded mode: real tokens per computed sequence, output row of each computed sequence
     bool loaded = false;
     int cus = 256;
     // workspace
@@ -712,11 +732,12 @@ static void layout(shodh_embedder *e) {
 
 static int reserve(shodh_embedder *e, size_t ntok, size_t nseq) {
     const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
-    const size_t es = e->cfg.dtype == SHODH_DTYPE_FP32 ? 4 : 2;
+    const size_t es = e->cfg.dtype == SHODH_DTYPE_BF16 ? 2 : 4;
     if (ntok > e->tok_cap) {
-        hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos);
-        e->X = e->QKV = e->CTX = e->FF = nullptr; e->PRE = nullptr; e->d_tok_seq = e->d_tok_pos = nullptr; e->tok_cap = 0;
+        hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->XQ);
+        e->X = e->QKV = e->CTX = e->FF = nullptr; e->PRE = nullptr; e->d_tok_seq = e->d_tok_pos = nullptr; e->XQ = nullptr; e->tok_cap = 0;
         size_t cap = ntok + ntok / 4 + 256;
+        if (e->cfg.dtype == SHODH_DTYPE_INT8) SHODH_HIP_TRY(hipMalloc((void **)&e->XQ, cap * std::max(H, I)));
         SHODH_HIP_TRY(hipMalloc(&e->X, cap * H * es));
         SHODH_HIP_TRY(hipMalloc(&e->QKV, cap * 3 * H * es));
         SHODH_HIP_TRY(hipMalloc(&e->CTX, cap * H * es));
@@ -727,9 +748,11 @@ static int reserve(shodh_embedder *e, size_t ntok, size_t nseq) {
         e->tok_cap = cap;
     }
     if (nseq > e->seq_cap) {
-        hipFree(e->d_ids); hipFree(e->d_cu); hipFree(e->d_out);
-        e->d_ids = nullptr; e->d_cu = nullptr; e->d_out = nullptr; e->seq_cap = 0;
+        hipFree(e->d_ids); hipFree(e->d_cu); hipFree(e->d_out); hipFree(e->d_klen); hipFree(e->d_orow);
+        e->d_ids = nullptr; e->d_cu = nullptr; e->d_out = nullptr; e->d_klen = nullptr; e->d_orow = nullptr; e->seq_cap = 0;
         size_t cap = nseq + nseq / 4 + 16;
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_klen, (cap + 1) * 4));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->d_orow, (cap + 1) * 4));
         SHODH_HIP_TRY(hipMalloc((void **)&e->d_ids, cap * e->cfg.max_len * 4));
         SHODH_HIP_TRY(hipMalloc((void **)&e->d_cu, (cap + 1) * 4));
         SHODH_HIP_TRY(hipMalloc((void **)&e->d_out, cap * H * 4));
@@ -784,7 +807,7 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
     const int tok_blocks = (ntok * 64 + 255) / 256;
     const int ln_blocks = (ntok * 32 + 255) / 256;
     hipLaunchKernelGGL((embed_ln_kernel<T>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
-                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps);
+                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)nullptr, (const float *)nullptr);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_seq * 32 * 4 * 2;
     SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<T>, att_lds));
@@ -804,7 +827,7 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
             else SHODH_TRY(gemm_bf16<EPI_BIAS>(X, e->wqkv16 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, nullptr, ntok, 3 * H, H, st));
         }
         if constexpr (std::is_same<T, float>::value) {
-            hipLaunchKernelGGL((attention_kernel<T>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads);
+            hipLaunchKernelGGL((attention_kernel<T>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, (const int32_t *)nullptr);
         } else {
             if (H / heads != 32) { set_error("the MFMA attention kernel needs head size 32"); return SHODH_ERR_UNSUPPORTED; }
             hipLaunchKernelGGL(attention_mfma_kernel, dim3(nseq * heads), dim3(256), att_mfma_lds, st, QKV, e->d_cu, CTX, H, heads, s_pad);
@@ -829,8 +852,96 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
         SHODH_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL((pool_kernel<T>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H);
+    hipLaunchKernelGGL((pool_kernel<T>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H, (const int32_t *)nullptr, (const int32_t *)nullptr);
     SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+// INT8 mode: the fp32 graph with every constant-weight MatMul replaced by DynamicQuantizeLinear -> MatMulInteger -> dequantise
+// (encoder_int8.h). `klen` / `orow` (device, may be null): real tokens per computed sequence and the output row of each -- the padded
+// tensor computes all max_len positions of every non-empty text (compute_padded = 1, the reference's tensor), keys and pooling stay
+// restricted to the real tokens.
+static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, const int32_t *klen, const int32_t *orow, float *d_out, hipStream_t st) {
+    const int H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
+    const float eps = e->cfg.ln_eps;
+    float *X = (float *)e->X, *QKV = (float *)e->QKV, *CTX = (float *)e->CTX, *FF = (float *)e->FF;
+    const float *w = e->w32;
+    const int tok_blocks = (ntok * 64 + 255) / 256;
+    const int ln_blocks = (ntok * 32 + 255) / 256;
+    hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
+                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale);
+    SHODH_HIP_TRY(hipGetLastError());
+    const size_t att_lds = (size_t)max_keys * 32 * 4 * 2;
+    SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
+    uint32_t *mm = e->qscratch;
+    for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+        const LayerOff &l = e->lo[li];
+        const float *bqkv = e->bqkv + (size_t)li * 3 * H;
+        SHODH_TRY(dynamic_quantize(X, (size_t)ntok * H, e->XQ, e->act_params, mm, st));                 // one quantisation feeds q, k and v (same tensor)
+        SHODH_TRY(gemm_i8<EPI8_BIAS>(e->XQ, e->q_qkv[li], 0, 3 * H, e->act_params, bqkv, nullptr, QKV, nullptr, ntok, st));
+        hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen);
+        SHODH_HIP_TRY(hipGetLastError());
+        SHODH_TRY(dynamic_quantize(CTX, (size_t)ntok * H, e->XQ, e->act_params, mm, st));
+        SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_o[li], 0, H, e->act_params, w + l.ob, X, e->PRE, nullptr, ntok, st));
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
+        SHODH_HIP_TRY(hipGetLastError());
+        SHODH_TRY(dynamic_quantize(X, (size_t)ntok * H, e->XQ, e->act_params, mm, st));
+        SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, e->q_up[li], 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st));
+        SHODH_TRY(dynamic_quantize(FF, (size_t)ntok * I, e->XQ, e->act_params, mm, st));
+        SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_dn[li], 0, H, e->act_params, w + l.db, X, e->PRE, nullptr, ntok, st));
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
+        SHODH_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL((pool_kernel<float>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H, klen, orow);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+static int alloc_qweight(QWeight &q, int N, int K) {
+    q.N = N; q.K = K;
+    SHODH_HIP_TRY(hipMalloc((void **)&q.q, (size_t)N * K));
+    SHODH_HIP_TRY(hipMalloc((void **)&q.scale, (size_t)N * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&q.rowsum, (size_t)N * 4));
+    return SHODH_OK;
+}
+static void free_qweight(QWeight &q) { hipFree(q.q); hipFree(q.scale); hipFree(q.rowsum); q = QWeight(); }
+
+static int finish_weights_int8(shodh_embedder *e) {
+    const int H = e->cfg.hidden, I = e->cfg.intermediate;
+    for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) { for (auto &q : *v) free_qweight(q); v->assign(e->cfg.layers, QWeight()); }
+    if (!e->word_q) {
+        SHODH_HIP_TRY(hipMalloc((void **)&e->word_q, (size_t)e->cfg.vocab * H));
+        SHODH_HIP_TRY(hipMalloc((void **)&e->word_scale, 256 * 4));
+    }
+    {   // word table: its row sums are not needed; borrow a scratch row-sum buffer
+        int32_t *tmp = nullptr;
+        SHODH_HIP_TRY(hipMalloc((void **)&tmp, (size_t)e->cfg.vocab * 4));
+        float *sc = nullptr;
+        SHODH_HIP_TRY(hipMalloc((void **)&sc, (size_t)e->cfg.vocab * 4));
+        int rc = quantize_weight_into(e->w32 + e->o_word, (int)e->cfg.vocab, H, e->word_q, sc, tmp, e->qscratch + 2, nullptr);
+        if (rc == SHODH_OK && hipMemcpy(e->word_scale, sc, 4, hipMemcpyDeviceToDevice) != hipSuccess) rc = SHODH_ERR_DEVICE;
+        hipFree(tmp); hipFree(sc);
+        if (rc != SHODH_OK) return rc;
+    }
+    for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+        const LayerOff &l = e->lo[li];
+        SHODH_TRY(alloc_qweight(e->q_qkv[li], 3 * H, H));
+        SHODH_TRY(alloc_qweight(e->q_o[li], H, H));
+        SHODH_TRY(alloc_qweight(e->q_up[li], I, H));
+        SHODH_TRY(alloc_qweight(e->q_dn[li], H, I));
+        const size_t qkv_off[3] = {l.qw, l.kw, l.vw};
+        for (int j = 0; j < 3; ++j) {      // q, k and v are separate tensors in the graph: one scale each
+            QWeight &q = e->q_qkv[li];
+            SHODH_TRY(quantize_weight_into(e->w32 + qkv_off[j], H, H, q.q + (size_t)j * H * H, q.scale + j * H, q.rowsum + j * H, e->qscratch + 2, nullptr));
+            SHODH_HIP_TRY(hipDeviceSynchronize());
+        }
+        SHODH_TRY(quantize_weight_into(e->w32 + l.ow, H, H, e->q_o[li].q, e->q_o[li].scale, e->q_o[li].rowsum, e->qscratch + 2, nullptr));
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+        SHODH_TRY(quantize_weight_into(e->w32 + l.iw, I, H, e->q_up[li].q, e->q_up[li].scale, e->q_up[li].rowsum, e->qscratch + 2, nullptr));
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+        SHODH_TRY(quantize_weight_into(e->w32 + l.dw, H, I, e->q_dn[li].q, e->q_dn[li].scale, e->q_dn[li].rowsum, e->qscratch + 2, nullptr));
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+    }
     return SHODH_OK;
 }
 
@@ -866,6 +977,7 @@ static int finish_weights(shodh_embedder *e) {
         SHODH_HIP_TRY(hipGetLastError());
         SHODH_HIP_TRY(hipDeviceSynchronize());
     }
+    if (e->cfg.dtype == SHODH_DTYPE_INT8) SHODH_TRY(finish_weights_int8(e));
     e->loaded = true;
     return SHODH_OK;
 }
@@ -894,7 +1006,8 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         return SHODH_ERR_UNSUPPORTED;
     }
     if (cfg->max_len == 0 || cfg->max_len > cfg->max_pos || cfg->max_len > 512) { set_error("max_len %u out of range", cfg->max_len); return SHODH_ERR_INVALID; }
-    if (cfg->compute_padded) { set_error("compute_padded=1 only matters for the INT8 graph, which is not built; fp32/bf16 results are identical without padding"); return SHODH_ERR_UNSUPPORTED; }
+    if (cfg->dtype > SHODH_DTYPE_INT8) { set_error("unknown dtype %u", cfg->dtype); return SHODH_ERR_INVALID; }
+    if (cfg->compute_padded && cfg->dtype != SHODH_DTYPE_INT8) { set_error("compute_padded=1 only matters for the INT8 graph (its activation ranges span the padded tensor, minilm.rs:588-593); fp32/bf16 results are identical without padding"); return SHODH_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libshodh_hip has no CPU fallback"); return SHODH_ERR_DEVICE; }
     if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d not present", cfg->device); return SHODH_ERR_DEVICE; }
@@ -910,6 +1023,9 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         hipMalloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
+    if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess)) {
+        shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
+    }
     SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     SHODH_HIP_TRY(hipEventCreate(&e->ev0));
     SHODH_HIP_TRY(hipEventCreate(&e->ev1));
@@ -923,6 +1039,8 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     hipDeviceSynchronize();
     hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->wp16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
     hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
+    for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) for (auto &q : *v) free_qweight(q);
+    hipFree(e->word_q); hipFree(e->word_scale); hipFree(e->XQ); hipFree(e->act_params); hipFree(e->qscratch); hipFree(e->d_klen); hipFree(e->d_orow);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -1012,8 +1130,10 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
         SHODH_HIP_TRY(hipMemcpy(hmask.data(), mask, (size_t)b * ML, hipMemcpyDeviceToHost));
         m = hmask.data();
     }
-    std::vector<int32_t> cu(b + 1, 0), tok_seq, tok_pos;
+    std::vector<int32_t> cu(b + 1, 0), tok_seq, tok_pos, klen, orow;
     int max_seq = 1;
+    const bool int8 = e->cfg.dtype == SHODH_DTYPE_INT8;
+    if (int8) cu.assign(1, 0);
     for (uint32_t s = 0; s < b; ++s) {
         int len = 0;
         for (uint32_t p = 0; p < ML; ++p) {
@@ -1022,24 +1142,43 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
                 ++len;
             }
         }
-        cu[s + 1] = cu[s] + len;
         if (len > max_seq) max_seq = len;
-        for (int p = 0; p < len; ++p) { tok_seq.push_back((int32_t)s); tok_pos.push_back(p); }
+        if (!int8) {
+            cu[s + 1] = cu[s] + len;
+            for (int p = 0; p < len; ++p) { tok_seq.push_back((int32_t)s); tok_pos.push_back(p); }
+        } else if (len > 0) {
+            // INT8: the computed tensor holds the non-empty texts only (the reference never runs empty ones, minilm.rs:1123-1125,
+            // :1319-1350), each with all max_len positions when compute_padded = 1 -- the activation ranges of
+            // DynamicQuantizeLinear span the padded tensor (minilm.rs:588-593)
+            const int positions = e->cfg.compute_padded ? (int)ML : len;
+            for (int p = 0; p < positions; ++p) { tok_seq.push_back((int32_t)s); tok_pos.push_back(p); }
+            cu.push_back(cu.back() + positions);
+            klen.push_back(len); orow.push_back((int32_t)s);
+        }
     }
-    const int ntok = cu[b];
+    const int nseq_c = int8 ? (int)klen.size() : (int)b;
+    const int ntok = cu.back();
     SHODH_TRY(reserve(e, (size_t)(ntok ? ntok : 1), b));
     if (device_io) SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyDeviceToDevice, st));
     else SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyHostToDevice, st));
-    SHODH_HIP_TRY(hipMemcpyAsync(e->d_cu, cu.data(), (size_t)(b + 1) * 4, hipMemcpyHostToDevice, st));
+    SHODH_HIP_TRY(hipMemcpyAsync(e->d_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice, st));
     if (ntok) {
         SHODH_HIP_TRY(hipMemcpyAsync(e->d_tok_seq, tok_seq.data(), (size_t)ntok * 4, hipMemcpyHostToDevice, st));
         SHODH_HIP_TRY(hipMemcpyAsync(e->d_tok_pos, tok_pos.data(), (size_t)ntok * 4, hipMemcpyHostToDevice, st));
+    }
+    if (int8 && nseq_c) {
+        SHODH_HIP_TRY(hipMemcpyAsync(e->d_klen, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(e->d_orow, orow.data(), orow.size() * 4, hipMemcpyHostToDevice, st));
     }
     // the host vectors must outlive the async copies: synchronise before leaving (pageable memory copies are staged, but be explicit)
     SHODH_HIP_TRY(hipEventRecord(e->ev0, st));
     float *d_out = device_io ? out : e->d_out;
     int rc;
     if (ntok == 0) { rc = (hipMemsetAsync(d_out, 0, (size_t)b * H * 4, st) == hipSuccess) ? SHODH_OK : SHODH_ERR_DEVICE; }
+    else if (int8) {
+        rc = (nseq_c == (int)b || hipMemsetAsync(d_out, 0, (size_t)b * H * 4, st) == hipSuccess) ? SHODH_OK : SHODH_ERR_DEVICE;    // empty texts -> zero vectors
+        if (rc == SHODH_OK) rc = forward_int8(e, ntok, nseq_c, max_seq, e->d_klen, e->d_orow, d_out, st);
+    }
     else if (e->cfg.dtype == SHODH_DTYPE_FP32) rc = forward<float>(e, ntok, (int)b, max_seq, d_out, st);
     else rc = forward<__bf16>(e, ntok, (int)b, max_seq, d_out, st);
     if (rc != SHODH_OK) return rc;
@@ -1058,6 +1197,43 @@ int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8
 int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b, float *d_out, void *stream) {
     return encode_impl(e, d_ids, d_mask, b, d_out, true, (hipStream_t)stream);
 }
+// One dynamically quantised dense layer on host data: the building block of the INT8 mode, exposed so that its integer
+// arithmetic can be checked bit for bit (tests/test_encoder_int8_gpu.py) and reused by callers that quantise their own layers.
+int shodh_int8_dense(int device, const float *x, const float *w, const float *bias, uint32_t M, uint32_t N, uint32_t K,
+                     float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale) {
+    if (!x || !w || !y || M == 0) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (N % 128 != 0 || K % 128 != 0) { set_error("shodh_int8_dense needs N %% 128 == 0 and K %% 128 == 0 (got N %u, K %u)", N, K); return SHODH_ERR_UNSUPPORTED; }
+    SHODH_HIP_TRY(hipSetDevice(device));
+    float *d_x = nullptr, *d_w = nullptr, *d_b = nullptr, *d_y = nullptr, *d_par = nullptr;
+    int32_t *d_acc = nullptr; int8_t *d_xq = nullptr; uint32_t *d_scr = nullptr;
+    QWeight qw;
+    int rc = SHODH_OK;
+    auto fail = [&](const char *what) { set_error("shodh_int8_dense: %s", what); rc = SHODH_ERR_DEVICE; };
+    do {
+        if (hipMalloc((void **)&d_x, (size_t)M * K * 4) != hipSuccess || hipMalloc((void **)&d_w, (size_t)N * K * 4) != hipSuccess ||
+            hipMalloc((void **)&d_y, (size_t)M * N * 4) != hipSuccess || hipMalloc((void **)&d_par, 64) != hipSuccess ||
+            hipMalloc((void **)&d_xq, (size_t)M * K) != hipSuccess || hipMalloc((void **)&d_scr, 64) != hipSuccess ||
+            (bias && hipMalloc((void **)&d_b, (size_t)N * 4) != hipSuccess) || (acc_out && hipMalloc((void **)&d_acc, (size_t)M * N * 4) != hipSuccess)) { fail("out of HBM"); rc = SHODH_ERR_OOM; break; }
+        if ((rc = alloc_qweight(qw, (int)N, (int)K)) != SHODH_OK) break;
+        if (hipMemcpy(d_x, x, (size_t)M * K * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_w, w, (size_t)N * K * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (bias && hipMemcpy(d_b, bias, (size_t)N * 4, hipMemcpyHostToDevice) != hipSuccess)) { fail("H2D copy"); break; }
+        if ((rc = quantize_weight_into(d_w, (int)N, (int)K, qw.q, qw.scale, qw.rowsum, d_scr + 2, nullptr)) != SHODH_OK) break;
+        if ((rc = dynamic_quantize(d_x, (size_t)M * K, d_xq, d_par, d_scr, nullptr)) != SHODH_OK) break;
+        if ((rc = gemm_i8<EPI8_BIAS>(d_xq, qw, 0, (int)N, d_par, d_b, nullptr, d_y, d_acc, (int)M, nullptr)) != SHODH_OK) break;
+        if (hipDeviceSynchronize() != hipSuccess) { fail("kernel execution"); break; }
+        float par[2] = {0, 0}, ws = 0;
+        if (hipMemcpy(y, d_y, (size_t)M * N * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(par, d_par, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&ws, qw.scale, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            (acc_out && hipMemcpy(acc_out, d_acc, (size_t)M * N * 4, hipMemcpyDeviceToHost) != hipSuccess)) { fail("D2H copy"); break; }
+        if (a_scale) *a_scale = par[0];
+        if (a_zp) *a_zp = (int32_t)par[1];
+        if (w_scale) *w_scale = ws;
+    } while (0);
+    hipFree(d_x); hipFree(d_w); hipFree(d_b); hipFree(d_y); hipFree(d_par); hipFree(d_acc); hipFree(d_xq); hipFree(d_scr);
+    free_qweight(qw);
+    return rc;
+}
+
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2) {
     if (!e || !us2) { set_error("null argument"); return SHODH_ERR_INVALID; }
     us2[0] = e->last_us[0]; us2[1] = e->last_us[1];

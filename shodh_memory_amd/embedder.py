@@ -123,7 +123,7 @@ class Embedder:
 
 class MiniLMEmbedder(Embedder):
     def __init__(self, tokenizer=None, weights=None, synthetic_seed=None, dtype=L.DTYPE_BF16, device=0,
-                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384):
+                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384, compute_padded=None):
         self._dim = dim
         self.simplified_mode = simplified
         self.query_prefix, self.doc_prefix = query_prefix, doc_prefix
@@ -136,7 +136,9 @@ class MiniLMEmbedder(Embedder):
             # minilm.rs:112-117: truncation pinned to the model window; padding is done by the embedder
             tokenizer.enable_truncation(max_length=MODEL_TOKEN_WINDOW)
             tokenizer.no_padding()
-        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim)
+        if compute_padded is None:
+            compute_padded = dtype == L.DTYPE_INT8      # the reference's INT8 tensor is padded to max_length (minilm.rs:588-593)
+        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim, compute_padded=int(bool(compute_padded)))
         L.check(L.lib().shodh_embedder_create(C.byref(cfg), C.byref(self._h)))
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).reshape(-1)
