@@ -228,7 +228,7 @@ enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1,
        /* the reference's DEFAULT model is the ONNX Runtime dynamic-quantisation export model_quint8_avx2.onnx (downloader.rs:31,
         * minilm.rs:212-220): 8-bit per-tensor weights (and word table), DynamicQuantizeLinear uint8 activations per dense layer,
         * MatMulInteger int32 accumulation on v_mfma_i32_32x32x32_i8, fp32 softmax / GELU / LayerNorm. Parity with that file is
-        * unpinned (no ONNX Runtime / checkpoint offline); the operator semantics restated are in oracle/int8_ref.py */
+        * unpinned (no ONNX Runtime / checkpoint offline): what is implemented is the published semantics of those ONNX operators */
        SHODH_DTYPE_INT8 = 2 };
 typedef struct {
     int32_t  device;

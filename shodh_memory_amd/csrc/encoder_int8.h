@@ -10,8 +10,8 @@
 //                      stored as the SIGNED value q - 128 (v_mfma_i32_32x32x32_i8 multiplies signed bytes)
 //   gemm_i8_kernel     128 x 128 x 128 tiles, 4 waves x (2 x 2) MFMA blocks, int32 accumulators (exact), epilogue
 //                      acc + (128 - zp) * rowsum(W_q)  ==  sum_k (a - zp) * w   ->  float * (a_scale * w_scale[n]) + bias [+ GELU | + residual]
-// Parity with the real checkpoint is unpinned (no ONNX Runtime, no weights offline); the restatement of these operator
-// semantics is oracle/int8_ref.py, and tests/test_encoder_int8_gpu.py checks the int32 accumulators bit for bit.
+// Parity with the real checkpoint is unpinned (no ONNX Runtime, no weights offline); tests/test_encoder_int8_gpu.py checks the
+// int32 accumulators bit for bit against a numpy restatement of these operator semantics.
 #pragma once
 #include "common.h"
 
