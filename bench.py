@@ -366,9 +366,13 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             dt = timed_steps(torch, lambda i: enc.encode_ids_device(ids, mask, out=emb), 10, 3)
             tokens = int(lens.sum())
             H, F, LAYERS = 384, 1536, 6
-            flop = float(tokens * 2 * (4 * H * H + 2 * H * F) * LAYERS + float((lens.double() ** 2).sum()) * 4 * H * LAYERS)
-            e = {"name": "encoder_%s_b4096" % dname, "workload": "MiniLM-L6 (6 x 384, 12 heads, FFN 1536) forward + mean-pool, %d texts, lengths U[8,128], real tokens only" % b,
-                 "ms_per_step": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1), "tokens": tokens,
+            # INT8 computes the reference's PADDED tensor (every position of every text is a query; keys are the real tokens)
+            tok_c = b * ML if dname == "int8" else tokens
+            att = float((lens.double() * ML).sum()) if dname == "int8" else float((lens.double() ** 2).sum())
+            flop = float(tok_c * 2 * (4 * H * H + 2 * H * F) * LAYERS + att * 4 * H * LAYERS)
+            e = {"name": "encoder_%s_b4096" % dname, "workload": "MiniLM-L6 (6 x 384, 12 heads, FFN 1536) forward + mean-pool, %d texts, lengths U[8,128], %s"
+                 % (b, "the padded [B, 256] tensor of the reference's quantised export (dynamic uint8 activations x 8-bit weights, int32 MFMA)" if dname == "int8" else "real tokens only"),
+                 "ms_per_step": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1), "tokens": tokens, "positions_computed": tok_c,
                  "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / 1e12 / peak, 4), "mfma_peak_used": peak,
                  "flop_per_step": flop}
             done(e, t0)

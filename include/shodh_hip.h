@@ -274,6 +274,11 @@ int shodh_int8_dense(int device, const float *x, const float *w, const float *bi
  * (DefaultHasher, zero keys) over whitespace words and char bigrams -> dim-d unit vector; zeros if
  * normalisation fails. The reference's unit tests index with this embedder (retrieval.rs:2451-2455). */
 int shodh_hash_embed(const char *utf8, size_t len, uint32_t dim, float *out);
+/* MiniLMEmbedder::finalize_pooled (minilm.rs:846-878) on a pooled vector, both branches: NaN/Inf scrub; apply_prenorm != 0 (the
+ * nomic recipe, SHODH_EMBEDDER=nomic) adds the parameter-free LayerNorm over the full width n; truncation to out_dim (Matryoshka);
+ * L2 over the kept prefix. out holds min(n, out_dim) floats; returns that length. (The device encoder applies the MiniLM branch
+ * itself; a host running another ONNX tower can finish its pooled vectors here.) */
+size_t shodh_finalize_pooled(const float *pooled, size_t n, int apply_prenorm, size_t out_dim, float *out);
 /* RetrievalEngine::search_ids post-processing (retrieval.rs:920-963): vector ids -> memory ids
  * (vector_to_memory: [n_vectors][16] uuid bytes, all-0xFF = unmapped), similarity = -distance, per-memory
  * max over chunks (strict '>'), sort (similarity total_cmp desc, uuid asc), truncate. Returns the count. */

@@ -106,6 +106,7 @@ def lib():
         "so_leg_fusion_weights": (None, [C.c_int, C.c_float, C.c_float, C.c_float, fp, fp]),
         "so_fuse_legs": (sz, [C.POINTER(C.c_int), fp, u8p, fp, fp, sz, u8p, fp, sz, sz, u8p, fp, sz, fp]),
         "so_fnv1a64": (C.c_uint64, [u8p, sz]),
+        "so_finalize_pooled": (sz, [fp, sz, C.c_int, sz, fp]),
         "so_bench_brute_force": (C.c_double, [fp, sz, sz, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
         "so_bench_brute_force_del": (C.c_double, [fp, sz, sz, u8p, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
         "so_interleaved_copy": (C.c_void_p, [fp, sz, C.c_int]),
@@ -396,6 +397,13 @@ def mean_pool_finalize(hidden, mask):
     out = np.zeros(h.shape[1], np.float32)
     lib().so_mean_pool_finalize(_p(h, C.c_float), _p(m, C.c_int64), h.shape[0], h.shape[1], _p(out, C.c_float))
     return out
+
+
+def finalize_pooled(pooled, apply_prenorm=False, out_dim=None):
+    p, pp = _f(pooled)
+    out = np.zeros(max(p.size, 1), np.float32)
+    m = lib().so_finalize_pooled(pp, p.size, int(apply_prenorm), p.size if out_dim is None else int(out_dim), _p(out, C.c_float))
+    return out[:m].copy()
 
 
 def siphash13_str(b: bytes):

@@ -595,6 +595,33 @@ void so_mean_pool_finalize(const float *hidden, const int64_t *mask, size_t S, s
     if (norm > FLT_EPSILON && !isnan(norm)) for (size_t d = 0; d < H; ++d) out[d] = out[d] / norm;
 }
 
+/* MiniLMEmbedder::finalize_pooled (minilm.rs:846-878) with the nomic branch: NaN/Inf scrub; if apply_prenorm: parameter-free
+ * LayerNorm over the FULL width (mean = sum/n, var = sum((x-mean)^2)/n, denom = sqrt(var + 1e-5), applied when denom > EPSILON);
+ * truncate to out_dim (Matryoshka); L2-normalise the kept prefix when norm > EPSILON. Returns the output length. */
+size_t so_finalize_pooled(const float *pooled, size_t n, int apply_prenorm, size_t out_dim, float *out) {
+    float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    for (size_t i = 0; i < n; ++i) tmp[i] = (isnan(pooled[i]) || isinf(pooled[i])) ? 0.0f : pooled[i];
+    if (apply_prenorm) {
+        const float nf = (float)n;
+        float sum = 0.0f;
+        for (size_t i = 0; i < n; ++i) sum = sum + tmp[i];
+        const float mean = sum / nf;
+        float vs = 0.0f;
+        for (size_t i = 0; i < n; ++i) vs = vs + (tmp[i] - mean) * (tmp[i] - mean);
+        const float var = vs / nf;
+        const float denom = sqrtf(var + 1e-5f);
+        if (denom > FLT_EPSILON) for (size_t i = 0; i < n; ++i) tmp[i] = (tmp[i] - mean) / denom;
+    }
+    size_t m = n > out_dim ? out_dim : n;
+    float nsq = 0.0f;
+    for (size_t i = 0; i < m; ++i) nsq = nsq + tmp[i] * tmp[i];
+    const float norm = sqrtf(nsq);
+    const int ok = norm > FLT_EPSILON && !isnan(norm);
+    for (size_t i = 0; i < m; ++i) out[i] = ok ? tmp[i] / norm : tmp[i];
+    free(tmp);
+    return m;
+}
+
 /* SipHash-1-3, keys (0,0): std::collections::hash_map::DefaultHasher::new() */
 #define ROTL64(x, b) (((x) << (b)) | ((x) >> (64 - (b))))
 #define SIPROUND do { v0 += v1; v1 = ROTL64(v1, 13); v1 ^= v0; v0 = ROTL64(v0, 32); \

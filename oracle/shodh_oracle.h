@@ -176,6 +176,9 @@ size_t so_fuse_legs(const int sw[8], const float fp[13], const uint8_t *hybrid_u
 /* ---- vamana_persist.rs / spann.rs checksums ---------------------------------------- */
 uint64_t so_fnv1a64(const uint8_t *data, size_t len);          /* vamana_persist.rs:155-163 */
 
+/* finalize_pooled with the nomic branch (minilm.rs:846-878) */
+size_t so_finalize_pooled(const float *pooled, size_t n, int apply_prenorm, size_t out_dim, float *out);
+
 /* ---- multi-threaded CPU baseline driver (bench.py cpu_baseline leg only) ------------ */
 /* Runs so_brute_force_search[_select] for nq queries on `threads` pthreads (one query per
  * thread at a time, the reference's "concurrent readers under RwLock" shape). Returns

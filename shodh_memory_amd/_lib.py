@@ -150,6 +150,7 @@ SYMBOLS = {
     "shodh_embed_param_count": (C.c_uint64, [C.POINTER(EmbedCfg)]),
     "shodh_embedder_synthetic_weights": (C.c_int, [C.POINTER(EmbedCfg), C.c_uint64, _fp, C.c_uint64]),
     "shodh_hash_embed": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, _fp]),
+    "shodh_finalize_pooled": (C.c_size_t, [_fp, C.c_size_t, C.c_int, C.c_size_t, _fp]),
     "shodh_search_ids_postprocess": (C.c_size_t, [_u32p, _fp, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, _u8p, _fp]),
     "shodh_vama_info_read": (C.c_int, [C.c_char_p, C.POINTER(VamaInfo)]),
     "shodh_vama_load": (C.c_int, [C.c_char_p, _fp, _u32p, C.c_void_p, _u32p]),

@@ -79,6 +79,14 @@ def state_dict_to_blob(sd, cfg=None):
     return np.concatenate(parts)
 
 
+def finalize_pooled(pooled, apply_prenorm=False, dimension=None):
+    """MiniLMEmbedder::finalize_pooled (minilm.rs:846-878): scrub, optional parameter-free LayerNorm (nomic), truncate, L2."""
+    p = np.ascontiguousarray(pooled, np.float32).reshape(-1)
+    out = np.zeros(max(p.size, 1), np.float32)
+    m = L.lib().shodh_finalize_pooled(p.ctypes.data, p.size, int(bool(apply_prenorm)), p.size if dimension is None else int(dimension), out.ctypes.data)
+    return out[:m].copy()
+
+
 def estimate_tokens(text):
     """token_estimation.rs:36-88: content-aware estimate used by `count_tokens` when no tokenizer is loaded. A 512-byte
     sample decides the mode: CJK (more than 2.5 bytes per char) -> ceil(1.5 * chars); code (>= 8 % syntax punctuation in the

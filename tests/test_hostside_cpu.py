@@ -236,3 +236,25 @@ def test_reference_estimate_tokens_tests():
     big = "The quick brown fox jumps over the lazy dog. " * 200
     assert abs(estimate_tokens(big) - len(big) // 4) <= 2
     assert estimate_tokens("   \n\t  \n  ") > 0 and estimate_tokens("a") == 1
+
+
+def test_finalize_pooled_both_branches(oracle):
+    """minilm.rs:846-878: MiniLM branch (scrub + L2) and the nomic branch (parameter-free LayerNorm over the full width, Matryoshka
+    truncation, L2 over the kept prefix); product vs the C restatement bit for bit, and vs an independent numpy float32 form"""
+    from shodh_memory_amd import embedder as E
+    rng = np.random.default_rng(9)
+    for n, out_dim, pre in ((384, None, False), (768, 768, True), (768, 256, True), (768, 128, False), (16, 64, True)):
+        v = (rng.standard_normal(n) * 3 + 0.7).astype(np.float32)
+        v[3] = np.nan; v[5] = np.inf; v[6] = -np.inf
+        got = E.finalize_pooled(v, apply_prenorm=pre, dimension=out_dim)
+        exp = oracle.finalize_pooled(v, apply_prenorm=pre, out_dim=out_dim)
+        assert got.tobytes() == exp.tobytes()
+        x = np.where(np.isfinite(v), v, np.float32(0)).astype(np.float32)
+        if pre:
+            mean = np.float32(x.astype(np.float64).sum() / n)
+            x = ((x - mean) / np.sqrt(np.float32(((x - mean) ** 2).astype(np.float64).sum() / n) + np.float32(1e-5))).astype(np.float32)
+        x = x[:min(n, out_dim or n)]
+        x = x / np.linalg.norm(x)
+        assert np.abs(got - x).max() < 2e-6 and abs(np.linalg.norm(got) - 1) < 1e-6 and len(got) == min(n, out_dim or n)
+    z = E.finalize_pooled(np.zeros(8, np.float32), apply_prenorm=True)          # constant input: var 0, denom = sqrt(1e-5) > EPSILON -> zeros stay zeros; norm 0 -> unchanged
+    assert not z.any()
