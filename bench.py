@@ -445,6 +445,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else that native libraries print there (RCCL's version banner
+    # at communicator creation, for one) is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -646,7 +652,8 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu, "latency_single_query": lat, "sustained": sustained}
         if cfgs is not None:
             line["configs"] = cfgs
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

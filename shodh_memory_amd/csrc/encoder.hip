@@ -26,6 +26,7 @@
 #include "common.h"
 #include "glds.h"
 #include "encoder_int8.h"
+#include "encoder_ffn.h"
 
 namespace shodh {
 
@@ -700,6 +701,7 @@ struct shodh_embedder {
     float *act_params = nullptr;         // {scale, zp} of the current activation tensor
     uint32_t *qscratch = nullptr;        // min/max keys, absmax
     int32_t *d_klen = nullptr, *d_orow = nullptr;   // padded mode: real tokens per computed sequence, output row of each computed sequence
+    __bf16 *w2p16 = nullptr;             // [layers][48 chunks][12][2][64][8] FFN-down weights packed for the fused FFN kernel (encoder_ffn.h)
     bool loaded = false;
     int cus = 256;
     // workspace
@@ -845,6 +847,16 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
             SHODH_TRY(gemm_f32<EPI_BIAS_GELU>(X, w + l.iw, w + l.ib, nullptr, FF, ntok, I, H, st));
             SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(FF, w + l.dw, w + l.db, X, e->PRE, ntok, H, I, st));
         } else {
+            static const bool unfused = getenv("SHODH_ENC_UNFUSED") && atoi(getenv("SHODH_ENC_UNFUSED"));     // speed only: the round-1 three-kernel form
+            if (stream_gemm && I == FF_I && !unfused) {
+                // FFN up + GELU + FFN down + residual + LayerNorm in one kernel, in place (a workgroup reads and writes only its own rows)
+                SHODH_TRY(ensure_dynamic_lds((const void *)ffn_fused_kernel, FF_LDS));
+                const int n_tiles = (ntok + FF_TOK - 1) / FF_TOK;
+                hipLaunchKernelGGL(ffn_fused_kernel, dim3(n_tiles < e->cus ? n_tiles : e->cus), dim3(512), FF_LDS, st, (const __bf16 *)X, wp + (size_t)4 * H * H,
+                                   e->w2p16 + (size_t)li * I * H, w + l.ib, w + l.db, w + l.ln2g, w + l.ln2b, (__bf16 *)X, ntok, eps);
+                SHODH_HIP_TRY(hipGetLastError());
+                continue;
+            }
             if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_GELU>(X, wp + (size_t)4 * H * H, w + l.ib, nullptr, FF, nullptr, ntok, I, e->cus, st));
             else SHODH_TRY(gemm_bf16<EPI_BIAS_GELU>(X, e->w16 + l.iw, w + l.ib, nullptr, FF, nullptr, ntok, I, H, st));
             SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(FF, e->w16 + l.dw, w + l.db, X, nullptr, e->PRE, ntok, H, I, st));
@@ -973,6 +985,8 @@ static int finish_weights(shodh_embedder *e) {
             hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(3 * H * H, 256)), dim3(256), 0, nullptr, e->wqkv16 + (size_t)li * 3 * H * H, dst, (int)(3 * H), (int)H);
             hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(H * H, 256)), dim3(256), 0, nullptr, e->w16 + l.ow, dst + 3 * H * H, (int)H, (int)H);
             hipLaunchKernelGGL(pack_frag_kernel, dim3((uint32_t)ceil_div(I * H, 256)), dim3(256), 0, nullptr, e->w16 + l.iw, dst + 4 * H * H, (int)I, (int)H);
+            if (H == (size_t)FF_H && I == (size_t)FF_I)
+                hipLaunchKernelGGL(pack_w2_kernel, dim3((uint32_t)ceil_div(I * H, 256)), dim3(256), 0, nullptr, e->w16 + l.dw, e->w2p16 + (size_t)li * I * H);
         }
         SHODH_HIP_TRY(hipGetLastError());
         SHODH_HIP_TRY(hipDeviceSynchronize());
@@ -1020,7 +1034,8 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         hipMalloc((void **)&e->bqkv, (size_t)cfg->layers * 3 * cfg->hidden * 4) != hipSuccess ||
         hipMalloc((void **)&e->wqkv32, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 4) != hipSuccess ||
         hipMalloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess ||
-        hipMalloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess) {
+        hipMalloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess ||
+        hipMalloc((void **)&e->w2p16, (size_t)cfg->layers * cfg->intermediate * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
     if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess)) {
@@ -1037,7 +1052,7 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     hipDeviceSynchronize();
-    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->wp16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
+    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->wp16); hipFree(e->w2p16); hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE);
     hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
     for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) for (auto &q : *v) free_qweight(q);
     hipFree(e->word_q); hipFree(e->word_scale); hipFree(e->XQ); hipFree(e->act_params); hipFree(e->qscratch); hipFree(e->d_klen); hipFree(e->d_orow);
