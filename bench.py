@@ -198,47 +198,53 @@ def run_flat_config(torch, dev, index, qpool, k, steps, warmup, rows_total, rows
 def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_total, main_rows_live, cpu_info):
     import numpy as np
     cfgs = []
+    only = [x for x in args.only_configs.split(",") if x]
+
+    def want(*names):
+        return not only or any(any(o in n for o in only) for n in names)
 
     def done(entry, t0):
         entry["wall_s"] = round(time.perf_counter() - t0, 2)
         cfgs.append(entry)
 
     # -- configs[0]: 10k memories, B = 1, top-10: the reference's CPU path, and the same shape on the GPU ------------------
-    t0 = time.perf_counter()
-    q1 = synth_rows(torch, 64, args.dim, SEED + 11, dev)
-    rows10k = synth_rows(torch, 10_000, args.dim, SEED + 10, dev, adversarial_queries=q1)
-    idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=10_000))
-    idx.build(rows10k)
-    o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
-    ts = []
-    for i in range(140):
-        qq = q1[i % 64:i % 64 + 1]
-        torch.cuda.synchronize(); a = time.perf_counter()
-        idx.search_batch_device(qq, 10, out=o1)
-        torch.cuda.synchronize(); ts.append(time.perf_counter() - a)
-    ts = sorted(ts[20:])
-    e = {"name": "cfg1_10k_b1", "workload": "configs[0]: 10k memories x %d-d, brute-force cosine top-10, one query at a time" % args.dim,
-         "gpu_p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "gpu_queries_per_s_synchronous": round(1.0 / ts[len(ts) // 2], 1)}
-    if not args.no_cpu_baseline:
-        from oracle import oracle as O      # CPU baseline leg: the oracle is the thing being timed here
-        h_rows, h_q = rows10k.cpu().numpy(), q1.cpu().numpy()
-        s_ref, c_ids, c_dist = O.bench_brute_force(h_rows, h_q, 10, 0, True, 1)         # the reference's shape: row clone + full sort, one thread
-        s_sel, _, _ = O.bench_brute_force(h_rows, h_q, 10, 0, False, 1)
-        g_ids, g_dist, _ = idx.search_batch(h_q, 10)
-        e.update({"cpu_reference_path_ms_per_query": round(s_ref / 64 * 1e3, 4), "cpu_reference_path_queries_per_s": round(64 / s_ref, 1),
-                  "cpu_bounded_select_queries_per_s": round(64 / s_sel, 1), "cpu_threads": 1,
-                  "gpu_matches_cpu_bit_exact": bool(np.array_equal(g_ids, c_ids) and g_dist.tobytes() == c_dist.tobytes())})
-    idx.close(); del idx, rows10k
-    done(e, t0)
+    if want("cfg1_10k_b1"):
+        t0 = time.perf_counter()
+        q1 = synth_rows(torch, 64, args.dim, SEED + 11, dev)
+        rows10k = synth_rows(torch, 10_000, args.dim, SEED + 10, dev, adversarial_queries=q1)
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=10_000))
+        idx.build(rows10k)
+        o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+        ts = []
+        for i in range(140):
+            qq = q1[i % 64:i % 64 + 1]
+            torch.cuda.synchronize(); a = time.perf_counter()
+            idx.search_batch_device(qq, 10, out=o1)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - a)
+        ts = sorted(ts[20:])
+        e = {"name": "cfg1_10k_b1", "workload": "configs[0]: 10k memories x %d-d, brute-force cosine top-10, one query at a time" % args.dim,
+             "gpu_p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "gpu_queries_per_s_synchronous": round(1.0 / ts[len(ts) // 2], 1)}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O      # CPU baseline leg: the oracle is the thing being timed here
+            h_rows, h_q = rows10k.cpu().numpy(), q1.cpu().numpy()
+            s_ref, c_ids, c_dist = O.bench_brute_force(h_rows, h_q, 10, 0, True, 1)         # the reference's shape: row clone + full sort, one thread
+            s_sel, _, _ = O.bench_brute_force(h_rows, h_q, 10, 0, False, 1)
+            g_ids, g_dist, _ = idx.search_batch(h_q, 10)
+            e.update({"cpu_reference_path_ms_per_query": round(s_ref / 64 * 1e3, 4), "cpu_reference_path_queries_per_s": round(64 / s_ref, 1),
+                      "cpu_bounded_select_queries_per_s": round(64 / s_sel, 1), "cpu_threads": 1,
+                      "gpu_matches_cpu_bit_exact": bool(np.array_equal(g_ids, c_ids) and g_dist.tobytes() == c_dist.tobytes())})
+        idx.close(); del idx, rows10k
+        done(e, t0)
 
     # -- 1M, k = 120: the index-level k of a top-10 recall (retrieval.rs:913-918: limit * 4 * 3) ----------------------------
-    t0 = time.perf_counter()
-    e = {"name": "flat_1M_b256_k120", "workload": "the contract corpus, batch 256, k = 120 (what MemorySystem::recall asks the index for)"}
-    e.update(run_flat_config(torch, dev, main_index, main_qpool, 120, 30, 5, main_rows_total, main_rows_live, args.dim))
-    done(e, t0)
+    if want("flat_1M_b256_k120"):
+        t0 = time.perf_counter()
+        e = {"name": "flat_1M_b256_k120", "workload": "the contract corpus, batch 256, k = 120 (what MemorySystem::recall asks the index for)"}
+        e.update(run_flat_config(torch, dev, main_index, main_qpool, 120, 30, 5, main_rows_total, main_rows_live, args.dim))
+        done(e, t0)
 
     # -- 10M flat, B = 256: north_star's ">= 10M-memory recall at >= 70 % HBM roofline" (= one shard of configs[4]) ----------
-    if not args.skip_10m:
+    if want("flat_10M_b256") and not args.skip_10m:
         t0 = time.perf_counter()
         n = 10_000_000
         qp = [synth_rows(torch, 256, args.dim, SEED + 20 + i, dev) for i in range(4)]
@@ -259,60 +265,62 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         done(e, t0)
 
     # -- dense clustered corpus, 1M: the regime of real sentence embeddings ------------------------------
-    t0 = time.perf_counter()
-    n = 1_000_000
-    rows, lab = synth_clustered(torch, n, args.dim, SEED + 30, dev, n_clusters=1000)
-    g = torch.Generator(device=dev).manual_seed(SEED + 31)
-    qp = []
-    for i in range(4):                                   # queries = noisy cluster members: the top of every list is crowded
-        pick = torch.randint(0, n, (256,), generator=g, device=dev)
-        qp.append(torch.nn.functional.normalize(rows[pick] + 0.02 * torch.randn((256, args.dim), generator=g, device=dev), dim=1).contiguous())
-    idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
-    idx.build(rows)
-    sample = rows[torch.randint(0, n, (2048,), generator=g, device=dev)]
-    cosm = sample @ sample.T
-    e = {"name": "flat_1M_clustered_b256", "workload": "1M memories in 1000 vMF-like clusters (pairwise cosine p05/p50/p95/p99.9 = %s), batch 256, top-10"
-         % "/".join("%.2f" % float(v) for v in torch.quantile(cosm.flatten()[::7].float(), torch.tensor([0.05, 0.5, 0.95, 0.999], device=dev)))}
-    del rows, cosm, sample
-    e.update(run_flat_config(torch, dev, idx, qp, 10, 30, 5, n, n, args.dim))
-    e120 = run_flat_config(torch, dev, idx, qp, 120, 20, 3, n, n, args.dim)
-    e["k120"] = {kk: e120[kk] for kk in ("ms_per_step", "survivors_emitted_per_query", "rescored_per_query", "level2_queries", "exact_fallback_queries")}
-    idx.close(); del idx
-    torch.cuda.empty_cache()
-    done(e, t0)
+    if want("flat_1M_clustered_b256"):
+        t0 = time.perf_counter()
+        n = 1_000_000
+        rows, lab = synth_clustered(torch, n, args.dim, SEED + 30, dev, n_clusters=1000)
+        g = torch.Generator(device=dev).manual_seed(SEED + 31)
+        qp = []
+        for i in range(4):                                   # queries = noisy cluster members: the top of every list is crowded
+            pick = torch.randint(0, n, (256,), generator=g, device=dev)
+            qp.append(torch.nn.functional.normalize(rows[pick] + 0.02 * torch.randn((256, args.dim), generator=g, device=dev), dim=1).contiguous())
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+        idx.build(rows)
+        sample = rows[torch.randint(0, n, (2048,), generator=g, device=dev)]
+        cosm = sample @ sample.T
+        e = {"name": "flat_1M_clustered_b256", "workload": "1M memories in 1000 vMF-like clusters (pairwise cosine p05/p50/p95/p99.9 = %s), batch 256, top-10"
+             % "/".join("%.2f" % float(v) for v in torch.quantile(cosm.flatten()[::7].float(), torch.tensor([0.05, 0.5, 0.95, 0.999], device=dev)))}
+        del rows, cosm, sample
+        e.update(run_flat_config(torch, dev, idx, qp, 10, 30, 5, n, n, args.dim))
+        e120 = run_flat_config(torch, dev, idx, qp, 120, 20, 3, n, n, args.dim)
+        e["k120"] = {kk: e120[kk] for kk in ("ms_per_step", "survivors_emitted_per_query", "rescored_per_query", "level2_queries", "exact_fallback_queries")}
+        idx.close(); del idx
+        torch.cuda.empty_cache()
+        done(e, t0)
 
     # -- the multi-GPU index behind the C ABI (shodh_sharded_index_*: RCCL all-gather + device merge inside the library), host-pointer API
-    t0 = time.perf_counter()
-    from shodh_memory_amd.distributed import MultiGpuIndex, rccl_info
-    ndev = torch.cuda.device_count()
-    n = 1_000_000
-    qh = [qq.cpu().numpy() for qq in main_qpool[:4]]
-    rows_h = synth_rows(torch, n, args.dim, SEED + 60, dev, adversarial_queries=main_qpool[0]).cpu().numpy()
-    e = {"name": "sharded_c_abi_1M_b256", "workload": "1M memories through shodh_sharded_index_* (one process, host pointers: H2D queries, per-shard search, "
-         "exchange, merge, D2H results), batch 256, top-10", "rccl": rccl_info()[1], "visible_gpus": ndev, "layouts": []}
-    one = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
-    one.build(rows_h)
-    dt1 = timed_steps(torch, lambda i: one.search_batch(qh[i % 4], 10), 30, 5)
-    ref_ids, ref_dist, _ = one.search_batch(qh[0], 10)
-    one.close()
-    e["single_index_host_api_ms_per_step"] = round(dt1 * 1e3, 4)
-    lay = [("rccl_x%d" % ndev, list(range(ndev)), L.EXCHANGE_RCCL)]
-    if ndev == 1:
-        lay.append(("copy_2_shards_on_one_gpu", [0, 0], L.EXCHANGE_COPY))
-    for lname, devs, exch in lay:
-        mg = MultiGpuIndex(devs, dim=args.dim, exchange=exch, reserve_rows_per_shard=n // len(devs) + 65536)
-        mg.build(rows_h)
-        dtm = timed_steps(torch, lambda i: mg.search_batch(qh[i % 4], 10), 30, 5)
-        ids_m, dist_m, _ = mg.search_batch(qh[0], 10)
-        e["layouts"].append({"layout": lname, "shards": len(devs), "uses_rccl": mg.uses_rccl(), "ms_per_step": round(dtm * 1e3, 4),
-                             "queries_per_s": round(256 / dtm, 1), "host_timings_us_last": {kk: round(v, 1) for kk, v in mg.host_timings_us().items()},
-                             "identical_to_single_index": bool(np.array_equal(ids_m, ref_ids) and dist_m.tobytes() == ref_dist.tobytes())})
-        mg.close()
-    del rows_h
-    done(e, t0)
+    if want("sharded_c_abi_1M_b256"):
+        t0 = time.perf_counter()
+        from shodh_memory_amd.distributed import MultiGpuIndex, rccl_info
+        ndev = torch.cuda.device_count()
+        n = 1_000_000
+        qh = [qq.cpu().numpy() for qq in main_qpool[:4]]
+        rows_h = synth_rows(torch, n, args.dim, SEED + 60, dev, adversarial_queries=main_qpool[0]).cpu().numpy()
+        e = {"name": "sharded_c_abi_1M_b256", "workload": "1M memories through shodh_sharded_index_* (one process, host pointers: H2D queries, per-shard search, "
+             "exchange, merge, D2H results), batch 256, top-10", "rccl": rccl_info()[1], "visible_gpus": ndev, "layouts": []}
+        one = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+        one.build(rows_h)
+        dt1 = timed_steps(torch, lambda i: one.search_batch(qh[i % 4], 10), 30, 5)
+        ref_ids, ref_dist, _ = one.search_batch(qh[0], 10)
+        one.close()
+        e["single_index_host_api_ms_per_step"] = round(dt1 * 1e3, 4)
+        lay = [("rccl_x%d" % ndev, list(range(ndev)), L.EXCHANGE_RCCL)]
+        if ndev == 1:
+            lay.append(("copy_2_shards_on_one_gpu", [0, 0], L.EXCHANGE_COPY))
+        for lname, devs, exch in lay:
+            mg = MultiGpuIndex(devs, dim=args.dim, exchange=exch, reserve_rows_per_shard=n // len(devs) + 65536)
+            mg.build(rows_h)
+            dtm = timed_steps(torch, lambda i: mg.search_batch(qh[i % 4], 10), 30, 5)
+            ids_m, dist_m, _ = mg.search_batch(qh[0], 10)
+            e["layouts"].append({"layout": lname, "shards": len(devs), "uses_rccl": mg.uses_rccl(), "ms_per_step": round(dtm * 1e3, 4),
+                                 "queries_per_s": round(256 / dtm, 1), "host_timings_us_last": {kk: round(v, 1) for kk, v in mg.host_timings_us().items()},
+                                 "identical_to_single_index": bool(np.array_equal(ids_m, ref_ids) and dist_m.tobytes() == ref_dist.tobytes())})
+            mg.close()
+        del rows_h
+        done(e, t0)
 
     # -- configs[3]: 10M memories, IVF nlist = 4096, nprobe = 32, top-10, batch 1024 -------------------------------------------
-    if not args.skip_ivfpq:
+    if want("cfg4_ivfpq") and not args.skip_ivfpq:
         t0 = time.perf_counter()
         n, P, nprobe, nq, k = (10_000_000 if not args.skip_10m else 2_000_000), 4096, 32, 1024, 10
         rows = synth_rows(torch, n, args.dim, SEED + 40, dev)
@@ -355,7 +363,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         done(e, t0)
 
     # -- MiniLM-L6 encoder (row a1), batch 4096 texts, real tokens only; then configs[2]: embed + insert + recall -------------
-    if not args.skip_encoder:
+    if want("encoder", "cfg3_pipeline") and not args.skip_encoder:
         g = torch.Generator(device=dev).manual_seed(SEED + 50)
         b, ML = 4096, 256
         for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS),) + ((("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS),) if hasattr(L, "DTYPE_INT8") else ()):
@@ -415,6 +423,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
                  "rescored_per_query": round(st["rescored"] / 256, 1), "level2_queries": int(st["level2"]), "exact_fallback_queries": int(st["overflowed"])}
             idx.close(); enc.close()
             done(e, t0)
+
     return cfgs
 
 
@@ -434,6 +443,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="only the contract line (no `configs` array)")
+    ap.add_argument("--only-configs", default="", help="comma-separated names of `configs` entries to run (e.g. cfg4_ivfpq_10M,encoder); empty = all")
     ap.add_argument("--skip-10m", action="store_true")
     ap.add_argument("--skip-ivfpq", action="store_true")
     ap.add_argument("--skip-encoder", action="store_true")
