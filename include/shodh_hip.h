@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SHODH_HIP_ABI_VERSION 1
+#define SHODH_HIP_ABI_VERSION 2
 
 typedef enum {
     SHODH_OK = 0,
@@ -61,7 +61,12 @@ enum { SHODH_INDEX_FLAT = 0, SHODH_INDEX_IVFPQ = 1 };
  * EXACT = every score computed in reference order on the f32 rows (HBM-bound for nq <= ~16);
  * MFMA  = fp16 matrix-core pre-scan with a proven error bound + reference-order re-score of the
  *         surviving candidates; AUTO picks per call. */
-enum { SHODH_SCAN_AUTO = 0, SHODH_SCAN_EXACT = 1, SHODH_SCAN_MFMA = 2 };
+enum { SHODH_SCAN_AUTO = 0, SHODH_SCAN_EXACT = 1, SHODH_SCAN_MFMA = 2,
+       /* GRAPH = the reference's DEFAULT search path (no SHODH_VECTOR_EXACT): the Vamana graph is maintained on the device exactly as
+        * add_vector (vamana.rs:853-974) / build (:200-284) maintain it, and search walks it like greedy_search (:576-657, :764-808).
+        * Results are those of the reference's graph walk -- approximate by nature, bit-identical to the reference for an index
+        * grown through add (a deterministic path) or carrying a reference-built graph (shodh_index_set_graph / a VAMA v1 file). */
+       SHODH_SCAN_GRAPH = 3 };
 
 typedef struct shodh_index shodh_index;
 typedef struct shodh_embedder shodh_embedder;
@@ -77,6 +82,11 @@ typedef struct {
     uint64_t id_base;       /* global id of local row 0 (row-sharded multi-GPU corpora); ids returned = id_base + local */
     uint32_t nprobe;        /* IVFPQ: SpannConfig.num_probes (default 10; BackendConfig 20) */
     uint32_t reserved;
+    /* SHODH_SCAN_GRAPH only (VamanaConfig, vamana.rs:120-166): */
+    uint32_t max_degree;        /* 32 */
+    uint32_t search_list_size;  /* 75 (VamanaConfig::default); the beam of build() */
+    float    alpha;             /* 1.2 */
+    uint32_t reserved2;
 } shodh_index_cfg;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -133,6 +143,20 @@ int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float
  * by the pre-scan, [2]=candidates re-scored in reference order, [3]=queries that fell back to the exact scan of the corpus,
  * [4]=queries whose fp16 window was narrowed by the level-2 f32 filter (dense corpora), [5..7] reserved (0) */
 int shodh_index_scan_stats(const shodh_index *idx, uint64_t *stats8);
+
+/* ---- SHODH_SCAN_GRAPH: the Vamana graph itself ------------------------------------------------------------------------------- */
+/* attach a graph to the rows the index holds (e.g. the degree / neighbour arrays of a VAMA v1 file, vamana_persist.rs:290-391):
+ * deg [len], nbr [len][stride] (entries beyond deg[i] ignored), medoid = entry point */
+int shodh_index_set_graph(shodh_index *idx, const uint32_t *deg, const uint32_t *nbr, uint32_t stride, uint32_t medoid);
+/* replace the contents by `rows` WITH their graph, nothing constructed (VamanaIndex::load_from_file, vamana_persist.rs:290-424) */
+int shodh_index_build_with_graph(shodh_index *idx, const float *rows, uint64_t n, const uint32_t *deg, const uint32_t *nbr, uint32_t stride, uint32_t medoid);
+/* read it back: deg [len], nbr [len][stride] with stride >= max_degree + 1; any output may be NULL */
+int shodh_index_get_graph(const shodh_index *idx, uint32_t *deg, uint32_t *nbr, uint32_t stride, uint32_t *medoid);
+/* VamanaIndex::build's graph construction over the rows the index holds (vamana.rs:200-284): find_medoid, then up to two passes of
+ * greedy_search(search_list_size) + robust_prune(alpha) + back edges, node after node. The reference starts from a random graph
+ * drawn from thread_rng (:287-312): pass it as init_deg / init_nbr [len][init_stride] (each list <= max_degree) to reproduce a
+ * given run bit for bit, or NULL to draw one here from `seed`. */
+int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *init_deg, const uint32_t *init_nbr, uint32_t init_stride);
 
 /* ---- multi-GPU: merge of per-shard results ------------------------------------------------------- */
 /* Row-sharded corpora: every rank searches its shard (ids carry id_base), the

@@ -21,6 +21,7 @@ def build(force=False):
     src = os.path.join(_HERE, "shodh_oracle.c")
     if (not force and os.path.exists(_SO)
             and os.path.getmtime(_SO) >= os.path.getmtime(src)
+            and os.path.getmtime(_SO) >= os.path.getmtime(os.path.join(_HERE, "vamana_oracle.c"))
             and os.path.getmtime(_SO) >= os.path.getmtime(os.path.join(_HERE, "shodh_oracle.h"))):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libshodh_oracle.so"],
@@ -107,6 +108,12 @@ def lib():
         "so_fuse_legs": (sz, [C.POINTER(C.c_int), fp, u8p, fp, fp, sz, u8p, fp, sz, sz, u8p, fp, sz, fp]),
         "so_fnv1a64": (C.c_uint64, [u8p, sz]),
         "so_finalize_pooled": (sz, [fp, sz, C.c_int, sz, fp]),
+        "so_vamana_greedy_search": (sz, [fp, sz, sz, u32p, u32p, sz, fp, sz, C.c_uint32, C.c_int, u32p, fp]),
+        "so_vamana_search": (sz, [fp, sz, sz, u32p, u32p, sz, C.c_uint32, u8p, fp, sz, C.c_int, u32p, fp]),
+        "so_vamana_add_vector": (None, [fp, sz, sz, u32p, u32p, sz, sz, C.c_uint32, C.c_int]),
+        "so_vamana_robust_prune": (sz, [fp, sz, C.c_uint32, u32p, fp, sz, sz, C.c_float, C.c_int, u32p]),
+        "so_vamana_find_medoid": (C.c_uint32, [fp, sz, sz, C.c_int]),
+        "so_vamana_build": (C.c_uint32, [fp, sz, sz, u32p, u32p, sz, sz, sz, C.c_float, C.c_int]),
         "so_bench_brute_force": (C.c_double, [fp, sz, sz, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
         "so_bench_brute_force_del": (C.c_double, [fp, sz, sz, u8p, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
         "so_interleaved_copy": (C.c_void_p, [fp, sz, C.c_int]),
@@ -404,6 +411,72 @@ def finalize_pooled(pooled, apply_prenorm=False, out_dim=None):
     out = np.zeros(max(p.size, 1), np.float32)
     m = lib().so_finalize_pooled(pp, p.size, int(apply_prenorm), p.size if out_dim is None else int(out_dim), _p(out, C.c_float))
     return out[:m].copy()
+
+
+# ---- Vamana graph (vamana_oracle.c) -------------------------------------------------------------------------------------
+class VamanaGraph:
+    """deg [n] + nbr [n, cap] (cap = R + 1) + medoid over rows [n, dim]: the graph side of VamanaIndex, restated."""
+
+    def __init__(self, dim, R=32, L=100, alpha=1.2, order=ORDER_SCALAR4, capacity=1024):
+        self.dim, self.R, self.L, self.alpha, self.order = dim, R, L, np.float32(alpha), order
+        self.cap = R + 1
+        self.rows = np.zeros((capacity, dim), np.float32)
+        self.deg = np.zeros(capacity, np.uint32)
+        self.nbr = np.zeros((capacity, self.cap), np.uint32)
+        self.n = 0
+        self.medoid = 0
+
+    def _grow(self, need):
+        if need <= self.rows.shape[0]:
+            return
+        c = max(need, self.rows.shape[0] * 2)
+        for name in ("rows", "deg", "nbr"):
+            a = getattr(self, name)
+            b = np.zeros((c,) + a.shape[1:], a.dtype)
+            b[:a.shape[0]] = a
+            setattr(self, name, b)
+
+    def add_vector(self, v):
+        """VamanaIndex::add_vector (vamana.rs:853-974)"""
+        self._grow(self.n + 1)
+        self.rows[self.n] = np.asarray(v, np.float32)
+        lib().so_vamana_add_vector(_p(self.rows, C.c_float), self.n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32),
+                                   self.cap, self.R, self.medoid, self.order)
+        self.n += 1
+        return self.n - 1
+
+    def build(self, rows, init_deg, init_nbr):
+        """VamanaIndex::build (vamana.rs:200-284) GIVEN the initial graph (init_nbr [n, <= R])"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n = rows.shape[0]
+        self._grow(n)
+        self.rows[:n] = rows
+        self.n = n
+        self.deg[:n] = init_deg
+        self.nbr[:n] = 0
+        self.nbr[:n, :init_nbr.shape[1]] = init_nbr
+        self.medoid = int(lib().so_vamana_build(_p(self.rows, C.c_float), n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32),
+                                                self.cap, self.R, self.L, self.alpha, self.order))
+        return self.medoid
+
+    def greedy_search(self, q, k, entry=None):
+        q, pq = _f(q)
+        ids = np.zeros(max(k, 1), np.uint32); dist = np.zeros(max(k, 1), np.float32)
+        m = lib().so_vamana_greedy_search(_p(self.rows, C.c_float), self.n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32), self.cap,
+                                          pq, k, self.medoid if entry is None else entry, self.order, _p(ids, C.c_uint32), _p(dist, C.c_float))
+        return ids[:m].copy(), dist[:m].copy()
+
+    def search(self, q, k, deleted=None):
+        """VamanaIndex::search without SHODH_VECTOR_EXACT (vamana.rs:764-808)"""
+        q, pq = _f(q)
+        ids = np.zeros(max(k, 1), np.uint32); dist = np.zeros(max(k, 1), np.float32)
+        dp = None
+        if deleted is not None:
+            deleted = np.ascontiguousarray(deleted, np.uint8)
+            dp = _p(deleted, C.c_uint8)
+        m = lib().so_vamana_search(_p(self.rows, C.c_float), self.n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32), self.cap,
+                                   self.medoid, dp, pq, k, self.order, _p(ids, C.c_uint32), _p(dist, C.c_float))
+        return ids[:m].copy(), dist[:m].copy()
 
 
 def siphash13_str(b: bytes):

@@ -176,6 +176,20 @@ size_t so_fuse_legs(const int sw[8], const float fp[13], const uint8_t *hybrid_u
 /* ---- vamana_persist.rs / spann.rs checksums ---------------------------------------- */
 uint64_t so_fnv1a64(const uint8_t *data, size_t len);          /* vamana_persist.rs:155-163 */
 
+/* ---- the Vamana GRAPH (vamana_oracle.c): greedy_search :576-657, search (ANN) :764-808, add_vector :853-974, robust_prune :665-746,
+ * find_medoid :407-441, build :200-284 given the initial graph. Graph = deg[n] + nbr[n][cap] (cap >= R + 1). -------------------- */
+size_t so_vamana_greedy_search(const float *vecs, size_t n, size_t dim, const uint32_t *deg, const uint32_t *nbr, size_t cap,
+                               const float *q, size_t k, uint32_t entry, int order, uint32_t *out_ids, float *out_dist);
+size_t so_vamana_search(const float *vecs, size_t n, size_t dim, const uint32_t *deg, const uint32_t *nbr, size_t cap, uint32_t medoid,
+                        const uint8_t *deleted, const float *q, size_t k, int order, uint32_t *out_ids, float *out_dist);
+void so_vamana_add_vector(const float *vecs, size_t n_before, size_t dim, uint32_t *deg, uint32_t *nbr, size_t cap, size_t R,
+                          uint32_t medoid, int order);
+size_t so_vamana_robust_prune(const float *vecs, size_t dim, uint32_t node, const uint32_t *c_ids, const float *c_dist, size_t n_c,
+                              size_t R, float alpha, int order, uint32_t *out);
+uint32_t so_vamana_find_medoid(const float *vecs, size_t n, size_t dim, int order);
+uint32_t so_vamana_build(const float *vecs, size_t n, size_t dim, uint32_t *deg, uint32_t *nbr, size_t cap, size_t R, size_t L, float alpha,
+                         int order);
+
 /* finalize_pooled with the nomic branch (minilm.rs:846-878) */
 size_t so_finalize_pooled(const float *pooled, size_t n, int apply_prenorm, size_t out_dim, float *out);
 

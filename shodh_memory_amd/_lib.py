@@ -24,7 +24,7 @@ ERR_INVALID, ERR_DIM, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_IO, ERR_NONFINITE, ERR
 METRIC_NDP, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
 ORDER_SCALAR4, ORDER_AVX2, ORDER_SEQ_1M = 0, 1, 2
 INDEX_FLAT, INDEX_IVFPQ = 0, 1
-SCAN_AUTO, SCAN_EXACT, SCAN_MFMA = 0, 1, 2
+SCAN_AUTO, SCAN_EXACT, SCAN_MFMA, SCAN_GRAPH = 0, 1, 2, 3
 DTYPE_FP32, DTYPE_BF16, DTYPE_INT8 = 0, 1, 2
 
 
@@ -37,7 +37,8 @@ class ShodhError(RuntimeError):
 class IndexCfg(C.Structure):
     _fields_ = [("dim", C.c_uint32), ("metric", C.c_uint32), ("kind", C.c_uint32), ("order", C.c_uint32),
                 ("device", C.c_int32), ("scan_mode", C.c_uint32), ("reserve_rows", C.c_uint64),
-                ("id_base", C.c_uint64), ("nprobe", C.c_uint32), ("reserved", C.c_uint32)]
+                ("id_base", C.c_uint64), ("nprobe", C.c_uint32), ("reserved", C.c_uint32),
+                ("max_degree", C.c_uint32), ("search_list_size", C.c_uint32), ("alpha", C.c_float), ("reserved2", C.c_uint32)]
 
 
 class EmbedCfg(C.Structure):
@@ -113,6 +114,10 @@ SYMBOLS = {
     "shodh_index_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
     "shodh_index_kernel_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "shodh_index_scan_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 8)]),
+    "shodh_index_set_graph": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, C.c_uint32]),
+    "shodh_index_get_graph": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "shodh_index_build_with_graph": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32]),
+    "shodh_index_vamana_build": (C.c_int, [_vp, C.c_uint64, _u32p, _u32p, C.c_uint32]),
     "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_topk_merge_strided_device": (C.c_int, [_u32p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_sharded_cfg_default": (None, [C.POINTER(ShardedCfg)]),

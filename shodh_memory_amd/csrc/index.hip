@@ -82,6 +82,17 @@ int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uin
 int launch_shadow_zero_rows(_Float16 *rows_h, const uint32_t *d_list, uint64_t n, uint32_t dim, hipStream_t st);
 int launch_shadow_restore_deleted(const float *rows, _Float16 *rows_h, const uint32_t *deleted, uint64_t n, uint32_t dim, hipStream_t st);
 
+// vamana_graph.hip
+struct VgGraph { const float *rows; uint32_t dim; uint32_t *deg; uint32_t *nbr; uint32_t stride; uint32_t order; };
+struct VgSearchArgs { VgGraph g; uint32_t n, medoid; const float *q; uint32_t nq, k, search_k; const uint32_t *deleted; uint32_t id_base;
+                      uint32_t *visited; uint32_t vis_words; uint32_t *ids; float *dist; uint32_t *counts; uint32_t *overflow; };
+struct VgInsertArgs { VgGraph g; uint32_t first, count, R, medoid; uint32_t *visited; uint32_t *overflow; };
+struct VgBuildArgs { VgGraph g; uint32_t n, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; };
+int vg_launch_search(const VgSearchArgs &a, hipStream_t st);
+int vg_launch_insert(const VgInsertArgs &a, hipStream_t st);
+int vg_launch_build(const VgBuildArgs &a, hipStream_t st);
+int vg_launch_centroid(const float *rows, uint32_t n, uint32_t dim, float *centroid, hipStream_t st);
+
 struct IvfpqState;   // ivfpq.hip
 void ivfpq_destroy(IvfpqState *s);
 uint64_t ivfpq_len(IvfpqState *s);
@@ -164,6 +175,12 @@ struct shodh_index {
     float last_us[4] = {0, 0, 0, 0};
     uint64_t last_stats[5] = {0, 0, 0, 0, 0};
     IvfpqState *ivfpq = nullptr;
+    // SHODH_SCAN_GRAPH: the Vamana graph (vamana_graph.hip)
+    uint32_t *g_deg = nullptr, *g_nbr = nullptr;   // [cap_rows], [cap_rows][g_stride]
+    uint32_t *g_visited = nullptr;                 // [cap_rows / 32 + 1] visited bits of the insert / build walk
+    uint32_t *g_overflow = nullptr;                // device flag: a frontier array overflowed (never in practice)
+    uint32_t g_stride = 0, g_medoid = 0;
+    uint64_t g_nodes = 0;                          // rows that have a node in the graph (== n when the graph is usable)
 };
 
 namespace shodh {
@@ -188,6 +205,20 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
         SHODH_HIP_TRY(hipMemcpy(nr, idx->rows, idx->n * dim * 4, hipMemcpyDeviceToDevice));
         if (nh) SHODH_HIP_TRY(hipMemcpy(nh, idx->rows_h, idx->n * dim * 2, hipMemcpyDeviceToDevice));
         SHODH_HIP_TRY(hipMemcpy(nd, idx->deleted, (idx->cap_rows / 32 + 1) * 4, hipMemcpyDeviceToDevice));
+    }
+    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
+        uint32_t *gd = nullptr, *gn = nullptr, *gv = nullptr;
+        if (hipMalloc((void **)&gd, nc * 4) != hipSuccess || hipMalloc((void **)&gn, nc * (size_t)idx->g_stride * 4) != hipSuccess ||
+            hipMalloc((void **)&gv, (nc / 32 + 1) * 4) != hipSuccess) { set_error("out of HBM (graph)"); return SHODH_ERR_OOM; }
+        SHODH_HIP_TRY(hipMemset(gd, 0, nc * 4));
+        if (idx->g_nodes) {
+            SHODH_HIP_TRY(hipMemcpy(gd, idx->g_deg, idx->g_nodes * 4, hipMemcpyDeviceToDevice));
+            SHODH_HIP_TRY(hipMemcpy(gn, idx->g_nbr, idx->g_nodes * (size_t)idx->g_stride * 4, hipMemcpyDeviceToDevice));
+        }
+        if (idx->g_deg) hipFree(idx->g_deg);
+        if (idx->g_nbr) hipFree(idx->g_nbr);
+        if (idx->g_visited) hipFree(idx->g_visited);
+        idx->g_deg = gd; idx->g_nbr = gn; idx->g_visited = gv;
     }
     if (idx->rows) hipFree(idx->rows);
     if (idx->rows_h) hipFree(idx->rows_h);
@@ -363,6 +394,9 @@ void shodh_index_cfg_default(shodh_index_cfg *cfg) {
     cfg->reserve_rows = 0;
     cfg->id_base = 0;
     cfg->nprobe = 20;                     // BackendConfig.spann_probes
+    cfg->max_degree = 32;                 // VamanaConfig::default (vamana.rs:79-90)
+    cfg->search_list_size = 75;
+    cfg->alpha = 1.2f;
 }
 
 int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
@@ -387,7 +421,19 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
     shodh_index *idx = new shodh_index();
     idx->cfg = *cfg;
     idx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    idx->shadow = (cfg->kind == SHODH_INDEX_FLAT) && mfma_supported(cfg->dim);
+    if (cfg->scan_mode > SHODH_SCAN_GRAPH) { delete idx; set_error("unknown scan mode %u", cfg->scan_mode); return SHODH_ERR_INVALID; }
+    if (cfg->scan_mode == SHODH_SCAN_GRAPH) {
+        if (cfg->kind != SHODH_INDEX_FLAT || cfg->order > SHODH_ORDER_AVX2 || cfg->dim % 8 != 0 || cfg->max_degree == 0 || cfg->max_degree > 126 ||
+            cfg->search_list_size == 0 || cfg->search_list_size > 1000 || cfg->id_base != 0) {
+            delete idx;
+            set_error("SHODH_SCAN_GRAPH needs a FLAT index, scalar-4 or AVX2 order, dim %% 8 == 0, 1 <= max_degree <= 126, search_list_size <= 1000, id_base 0");
+            return SHODH_ERR_UNSUPPORTED;
+        }
+        idx->g_stride = cfg->max_degree + 1;
+        if (hipMalloc((void **)&idx->g_overflow, 64) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
+        hipMemset(idx->g_overflow, 0, 64);
+    }
+    idx->shadow = (cfg->kind == SHODH_INDEX_FLAT) && cfg->scan_mode != SHODH_SCAN_GRAPH && mfma_supported(cfg->dim);
     if (hipMalloc((void **)&idx->stats, 16) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
     hipMemset(idx->stats, 0, 16);
     if (cfg->kind == SHODH_INDEX_FLAT && cfg->reserve_rows) {
@@ -408,10 +454,28 @@ void shodh_index_destroy(shodh_index *idx) {
     if (idx->rows_h) hipFree(idx->rows_h);
     if (idx->deleted) hipFree(idx->deleted);
     if (idx->stats) hipFree(idx->stats);
+    if (idx->g_deg) hipFree(idx->g_deg);
+    if (idx->g_nbr) hipFree(idx->g_nbr);
+    if (idx->g_visited) hipFree(idx->g_visited);
+    if (idx->g_overflow) hipFree(idx->g_overflow);
     delete idx;
 }
 
-static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out, hipMemcpyKind kind) {
+static VgGraph graph_of(const shodh_index *idx) {
+    return VgGraph{idx->rows, idx->cfg.dim, idx->g_deg, idx->g_nbr, idx->g_stride, idx->cfg.order};
+}
+
+// the walk keeps at most VG_C_CAP frontier entries; more can only be LIVE when thousands of rows tie with the worst of the beam
+static int check_graph_overflow(shodh_index *idx) {
+    uint32_t o = 0;
+    SHODH_HIP_TRY(hipMemcpy(&o, idx->g_overflow, 4, hipMemcpyDeviceToHost));
+    if (!o) return SHODH_OK;
+    hipMemset(idx->g_overflow, 0, 4);
+    set_error("graph walk: the frontier overflowed (thousands of equidistant rows); the answer may differ from the reference's");
+    return SHODH_ERR_UNSUPPORTED;
+}
+
+static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out, hipMemcpyKind kind, bool skip_graph = false) {
     if (!idx || (!rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (idx->cfg.kind != SHODH_INDEX_FLAT) { set_error("add is for FLAT indexes; IVF-PQ uses shodh_index_ivfpq_insert"); return SHODH_ERR_STATE; }
     std::unique_lock<std::shared_mutex> lk(idx->mu);
@@ -422,8 +486,18 @@ static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *f
     SHODH_TRY(grow(idx, idx->n + n));
     SHODH_HIP_TRY(hipMemcpy(idx->rows + idx->n * idx->cfg.dim, rows, n * idx->cfg.dim * 4, kind));
     SHODH_TRY(finish_append(idx, idx->n, n));
+    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !skip_graph) {
+        // add_vector (vamana.rs:853-974), one row after the other: each insert walks the graph the previous one left
+        if (idx->g_nodes != idx->n) { set_error("the graph does not cover the rows (%llu nodes, %llu rows): build it first", (unsigned long long)idx->g_nodes, (unsigned long long)idx->n); return SHODH_ERR_STATE; }
+        for (uint64_t at = 0; at < n; at += 4096) {               // bounded launches: one wave inserts row after row
+            VgInsertArgs a{graph_of(idx), (uint32_t)(idx->n + at), (uint32_t)std::min<uint64_t>(4096, n - at), idx->cfg.max_degree, idx->g_medoid, idx->g_visited, idx->g_overflow};
+            SHODH_TRY(vg_launch_insert(a, nullptr));
+        }
+        idx->g_nodes += n;
+    }
     SHODH_HIP_TRY(hipDeviceSynchronize());
     idx->n += n;
+    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !skip_graph) SHODH_TRY(check_graph_overflow(idx));
     return SHODH_OK;
 }
 
@@ -434,7 +508,7 @@ int shodh_index_add_device(shodh_index *idx, const float *d_rows, uint64_t n, ui
     return add_impl(idx, d_rows, n, first_id_out, hipMemcpyDeviceToDevice);
 }
 
-static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpyKind kind) {
+static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpyKind kind, bool construct_graph = true) {
     if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
     {
         std::unique_lock<std::shared_mutex> lk(idx->mu);
@@ -446,6 +520,13 @@ static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpy
         if (idx->deleted) SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
         std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
         SHODH_HIP_TRY(hipMemset(idx->stats, 0, 16));
+        idx->g_nodes = 0; idx->g_medoid = 0;
+    }
+    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
+        // VamanaIndex::build: store the rows, then construct the graph from a random start (vamana.rs:200-284); the start is drawn here
+        // from a fixed seed (the reference uses thread_rng) -- shodh_index_vamana_build takes an explicit start or another seed
+        SHODH_TRY(add_impl(idx, rows, n, nullptr, kind, true));
+        return construct_graph ? shodh_index_vamana_build(idx, 0x5EEDull, nullptr, nullptr, 0) : SHODH_OK;
     }
     return add_impl(idx, rows, n, nullptr, kind);
 }
@@ -495,7 +576,20 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
             d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
         }
-        if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma, sync_host);
+        if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
+            // VamanaIndex::search without SHODH_VECTOR_EXACT (vamana.rs:764-808)
+            if (idx->g_nodes != idx->n) { set_error("Vamana graph not built. Call build() first or add more vectors."); rc = SHODH_ERR_STATE; break; }
+            const uint64_t dc = idx->n_deleted;
+            const uint64_t search_k = dc > 0 ? (uint64_t)k + (dc < 2ull * k ? dc : 2ull * k) : k;
+            if (search_k > 1000) { set_error("graph search: k + tombstone over-fetch = %llu exceeds 1000", (unsigned long long)search_k); rc = SHODH_ERR_UNSUPPORTED; break; }
+            const uint32_t vis_words = (uint32_t)(idx->n / 32 + 1);
+            if ((rc = w->reserve((size_t)nq * vis_words * 4 + 256)) != SHODH_OK) break;
+            if (sync_host) hipEventRecord(w->ev[0], st);
+            VgSearchArgs a{graph_of(idx), (uint32_t)idx->n, idx->g_medoid, d_q, nq, k, (uint32_t)search_k, idx->n_deleted ? idx->deleted : nullptr,
+                           (uint32_t)idx->cfg.id_base, (uint32_t *)w->buf, vis_words, d_ids, d_dist, d_counts, idx->g_overflow};
+            rc = vg_launch_search(a, st);
+            if (sync_host) { hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st); }
+        } else if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma, sync_host);
         else {
             if ((rc = w->reserve(ivfpq_scratch_bytes(idx->ivfpq, idx->cfg, nq, k) + 256)) != SHODH_OK) break;
             if (sync_host) hipEventRecord(w->ev[0], st);
@@ -510,6 +604,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             collect_timings(idx, w, used_mfma, nullptr);
+            if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT && (rc = check_graph_overflow(idx)) != SHODH_OK) break;
             if (used_mfma) {
                 uint32_t st4[4] = {0, 0, 0, 0};
                 MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
@@ -666,6 +761,128 @@ int shodh_index_extract_live_rows(const shodh_index *idx, float *out_rows, uint3
 }
 
 uint32_t shodh_index_dim(const shodh_index *idx) { return idx ? idx->cfg.dim : 0; }
+
+int shodh_index_set_graph(shodh_index *idx, const uint32_t *deg, const uint32_t *nbr, uint32_t stride, uint32_t medoid) {
+    if (!idx || (idx->n && (!deg || !nbr))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    const uint64_t n = idx->n;
+    if (n && medoid >= n) { set_error("medoid %u out of range", medoid); return SHODH_ERR_INVALID; }
+    std::vector<uint32_t> hn((size_t)n * idx->g_stride, 0u);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (deg[i] > idx->cfg.max_degree + 1 || deg[i] > stride) { set_error("node %llu has %u neighbours (max_degree %u)", (unsigned long long)i, deg[i], idx->cfg.max_degree); return SHODH_ERR_INVALID; }
+        for (uint32_t j = 0; j < deg[i]; ++j) {
+            const uint32_t v = nbr[(size_t)i * stride + j];
+            if (v >= n) { set_error("node %llu: neighbour %u out of range", (unsigned long long)i, v); return SHODH_ERR_INVALID; }
+            hn[(size_t)i * idx->g_stride + j] = v;
+        }
+    }
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    if (n) {
+        SHODH_HIP_TRY(hipMemcpy(idx->g_deg, deg, n * 4, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(idx->g_nbr, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+    }
+    idx->g_medoid = medoid;
+    idx->g_nodes = n;
+    return SHODH_OK;
+}
+
+int shodh_index_get_graph(const shodh_index *idx, uint32_t *deg, uint32_t *nbr, uint32_t stride, uint32_t *medoid) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    if (idx->g_nodes != idx->n) { set_error("the graph does not cover the rows"); return SHODH_ERR_STATE; }
+    const uint64_t n = idx->n;
+    if (medoid) *medoid = idx->g_medoid;
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> hd(n);
+    if (n) SHODH_HIP_TRY(hipMemcpy(hd.data(), idx->g_deg, n * 4, hipMemcpyDeviceToHost));
+    if (deg && n) memcpy(deg, hd.data(), n * 4);
+    if (nbr && n) {
+        if (stride < idx->g_stride) { set_error("stride %u < max_degree + 1", stride); return SHODH_ERR_INVALID; }
+        std::vector<uint32_t> hn((size_t)n * idx->g_stride);
+        SHODH_HIP_TRY(hipMemcpy(hn.data(), idx->g_nbr, hn.size() * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i)                             // entries past a node's degree read 0, whatever the slots held before
+            for (uint32_t j = 0; j < stride; ++j) nbr[(size_t)i * stride + j] = j < hd[i] && j < idx->g_stride ? hn[(size_t)i * idx->g_stride + j] : 0u;
+    }
+    return SHODH_OK;
+}
+
+int shodh_index_build_with_graph(shodh_index *idx, const float *rows, uint64_t n, const uint32_t *deg, const uint32_t *nbr, uint32_t stride, uint32_t medoid) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
+    SHODH_TRY(build_impl(idx, rows, n, hipMemcpyHostToDevice, false));
+    return shodh_index_set_graph(idx, deg, nbr, stride, medoid);
+}
+
+int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *init_deg, const uint32_t *init_nbr, uint32_t init_stride) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
+    const uint64_t n = shodh_index_len(idx);
+    if (n == 0) { idx->g_nodes = 0; return SHODH_OK; }
+    const uint32_t R = idx->cfg.max_degree;
+    std::vector<uint32_t> deg(n), nbr((size_t)n * (R + 1), 0u);
+    if (init_deg && init_nbr) {
+        for (uint64_t i = 0; i < n; ++i) {
+            if (init_deg[i] > R || init_deg[i] > init_stride) { set_error("initial graph: node %llu has %u neighbours (max_degree %u)", (unsigned long long)i, init_deg[i], R); return SHODH_ERR_INVALID; }
+            deg[i] = init_deg[i];
+            for (uint32_t j = 0; j < deg[i]; ++j) nbr[(size_t)i * (R + 1) + j] = init_nbr[(size_t)i * init_stride + j];
+        }
+    } else {
+        // initialize_graph (vamana.rs:287-312): `degree = min(R, n - 1)` distinct random neighbours per node, never the node itself
+        uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+        auto next = [&]() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+        const uint32_t d = (uint32_t)std::min<uint64_t>(R, n - 1);
+        for (uint64_t i = 0; i < n; ++i) {
+            deg[i] = d;
+            uint32_t *row = nbr.data() + (size_t)i * (R + 1);
+            for (uint32_t j = 0; j < d;) {
+                uint64_t v = next() % (n - 1);
+                if (v >= i) ++v;
+                bool dup = false;
+                for (uint32_t t = 0; t < j; ++t) dup |= row[t] == (uint32_t)v;
+                if (!dup) row[j++] = (uint32_t)v;
+            }
+        }
+    }
+    // find_medoid (vamana.rs:407-441): mean vector, then the closest row with the first minimum winning == an exact search with k = 1
+    uint32_t medoid = 0;
+    {
+        float *d_c = nullptr; uint32_t *d_i = nullptr; float *d_d = nullptr; uint32_t *d_n = nullptr;
+        SHODH_TRY(set_device(idx));
+        SHODH_HIP_TRY(hipMalloc((void **)&d_c, (size_t)idx->cfg.dim * 4 + 64));
+        d_i = (uint32_t *)(d_c + idx->cfg.dim); d_d = (float *)(d_i + 1); d_n = (uint32_t *)(d_d + 1);
+        int rc = vg_launch_centroid(idx->rows, (uint32_t)n, idx->cfg.dim, d_c, nullptr);
+        if (rc == SHODH_OK) {
+            std::shared_lock<std::shared_mutex> lk(idx->mu);
+            const uint32_t gx = exact_grid_x(n, 1, 1, idx->cus);
+            unsigned char *part = nullptr;
+            if (hipMalloc((void **)&part, exact_partial_bytes(1, idx->cfg.dim, 1, gx) + 256) != hipSuccess) rc = SHODH_ERR_OOM;
+            else {
+                rc = launch_flat_exact(idx->rows, n, idx->cfg.dim, nullptr, d_c, 1, 1, idx->cfg.order, 0, (uint64_t *)part, gx, d_i, d_d, d_n, nullptr, nullptr, nullptr);
+                if (rc == SHODH_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&medoid, d_i, 4, hipMemcpyDeviceToHost) != hipSuccess)) { set_error("medoid search failed"); rc = SHODH_ERR_DEVICE; }
+                hipFree(part);
+            }
+        }
+        hipFree(d_c);
+        if (rc != SHODH_OK) return rc;
+    }
+    {
+        std::unique_lock<std::shared_mutex> lk(idx->mu);
+        SHODH_HIP_TRY(hipMemcpy(idx->g_deg, deg.data(), n * 4, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(idx->g_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
+        idx->g_medoid = medoid;
+        VgBuildArgs a{graph_of(idx), (uint32_t)n, R, idx->cfg.search_list_size, medoid, idx->cfg.alpha, idx->g_visited, idx->g_overflow};
+        SHODH_TRY(vg_launch_build(a, nullptr));
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { set_error("graph build failed on device: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
+        idx->g_nodes = n;
+        SHODH_TRY(check_graph_overflow(idx));
+    }
+    return SHODH_OK;
+}
 
 int shodh_topk_merge_device(const uint32_t *d_in_ids, const float *d_in_dist, uint32_t n_lists, uint32_t nq, uint32_t k,
                             uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream) {

@@ -1,0 +1,459 @@
+// vamana_graph.hip -- the Vamana GRAPH side of VamanaIndex on the device: the reference's default (non-exact) search path.
+//   greedy_search   src/vector_db/vamana.rs:576-657      search (ANN)  :764-808
+//   add_vector      :853-974 (incremental insert)        robust_prune  :665-746      find_medoid :407-441      build :200-284
+// Why it exists although the exact scan is faster up to ~10^7 rows per GPU: without SHODH_VECTOR_EXACT the reference answers from
+// the graph, and an index that only ever grows through add_vector (what `remember` does) has a fully DETERMINISTIC graph (no RNG
+// on that path, medoid 0). SHODH_SCAN_GRAPH reproduces that graph and that walk bit for bit, so a host that keeps the reference's
+// default mode gets the reference's answers -- including its misses.
+//
+// SearchCandidate's order is total, (distance total_cmp, id) (:1664-1673), and ids are unique, so the two BinaryHeaps of
+// greedy_search never show their internal order: here both are sorted arrays of 64-bit keys in LDS.
+//
+// One WAVE runs one search. State in LDS: the query, `w` (the k best so far, ascending), `cand` (the frontier, ascending, consumed
+// from the head), a staging area for 8 neighbour rows. Visited set: one bit per row in global memory (cleared by the wave before
+// the walk; test-and-set with atomicOr). A hop = pop the closest frontier node; its unvisited neighbours are found by the 64 lanes
+// in parallel, their rows are read 8 at a time (coalesced, all loads of a batch in flight), every distance is computed in the
+// reference's accumulation order (distance_inline.rs:67-173), and then the neighbours are offered to `w` / `cand` ONE BY ONE in
+// list order, exactly like the reference's loop: whether a neighbour is accepted depends on the worst entry of `w` at that moment.
+// Inserts and the build run the same walk from a single wave, node after node: every step reads the graph the previous one wrote.
+#include <cmath>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace shodh {
+
+constexpr int VG_W_CAP = 1024;     // beam: k (+ over-fetch for tombstones), search_list_size, max_degree
+constexpr int VG_C_CAP = 2048;     // frontier entries kept (only those not worse than the worst of `w` can ever be expanded)
+constexpr int VG_ROWS = 8;         // neighbour rows staged at a time
+constexpr int VG_MAXDEG = 128;     // neighbours per node the kernels handle (max_degree + 1 <= this)
+
+struct VgGraph {
+    const float *rows;      // [n][dim] f32 master rows
+    uint32_t dim;
+    uint32_t *deg;          // [cap_rows]
+    uint32_t *nbr;          // [cap_rows][stride]
+    uint32_t stride;        // >= max_degree + 1
+    uint32_t order;         // SHODH_ORDER_SCALAR4 / AVX2
+};
+
+struct VgLds {
+    float *q;               // [dim]
+    uint64_t *w;            // [VG_W_CAP]
+    uint64_t *cand;         // [VG_C_CAP]
+    float *stage;           // [VG_ROWS][dim + 4]  raw rows
+    float *tsum;            // [VG_ROWS][dim / 4 + 1] group sums (scalar-4) / [VG_ROWS][8] chain sums (AVX2)
+    uint32_t *newid;        // [VG_MAXDEG] unvisited neighbours of the current node, in list order
+    float *newd;            // [VG_MAXDEG] their distances
+    uint32_t *pr, *pr2;     // [VG_MAXDEG] pruned lists (build)
+    float *dne, *dne2;      // [VG_MAXDEG] node -> kept neighbour distances (build)
+};
+__host__ __device__ inline size_t vg_lds_bytes(uint32_t dim) {
+    return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + (size_t)VG_ROWS * (dim + 4) * 4 + (size_t)VG_ROWS * (dim / 4 + 1) * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
+}
+__device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim) {
+    VgLds l;
+    l.w = reinterpret_cast<uint64_t *>(smem);
+    l.cand = l.w + VG_W_CAP;
+    l.q = reinterpret_cast<float *>(l.cand + VG_C_CAP);
+    l.stage = l.q + dim;
+    l.tsum = l.stage + (size_t)VG_ROWS * (dim + 4);
+    l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)VG_ROWS * (dim / 4 + 1));
+    l.newd = reinterpret_cast<float *>(l.newid + VG_MAXDEG);
+    l.pr = reinterpret_cast<uint32_t *>(l.newd + VG_MAXDEG);
+    l.pr2 = l.pr + VG_MAXDEG;
+    l.dne = reinterpret_cast<float *>(l.pr2 + VG_MAXDEG);
+    l.dne2 = l.dne + VG_MAXDEG;
+    return l;
+}
+
+__device__ __forceinline__ float vg_key_dist(uint64_t k) { return order_key_inv((uint32_t)(k >> 32)); }
+
+// distances -dot(q, row) of m rows (ids in l.newid) in the reference's order -> l.newd. One wave; dim % 8 == 0.
+__device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane) {
+    const uint32_t dim = g.dim, d4 = dim >> 2, sp = dim + 4, tp = d4 + 1;
+    for (uint32_t b0 = 0; b0 < m; b0 += VG_ROWS) {
+        const uint32_t nb = m - b0 < (uint32_t)VG_ROWS ? m - b0 : (uint32_t)VG_ROWS;
+        // stage nb raw rows: nb * d4 float4, consecutive lanes along a row, every load of the batch in flight
+        for (uint32_t e0 = 0; e0 < nb * d4; e0 += 64 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = e0 + u * 64 + lane, ec = e < nb * d4 ? e : nb * d4 - 1;
+                v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.newid[b0 + ec / d4] * dim + (ec % d4) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = e0 + u * 64 + lane;
+                if (e < nb * d4) *reinterpret_cast<float4 *>(l.stage + (e / d4) * sp + (e % d4) * 4) = v[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (g.order == SHODH_ORDER_AVX2) {
+            // dot_product_avx2_inline (distance_inline.rs:67-111): 8 FMA chains over i = l, l + 8, ...; lanes 0..7 summed in order
+            const uint32_t r = lane >> 3, c = lane & 7;
+            if (r < nb) {
+                const float *row = l.stage + r * sp;
+                float acc = 0.0f;
+                for (uint32_t i = 0; i < dim; i += 8) acc = __builtin_fmaf(l.q[i + c], row[i + c], acc);
+                l.tsum[r * 8 + c] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < nb) {
+                const float *p8 = l.tsum + lane * 8;
+                float s = p8[0] + p8[1];
+                s = s + p8[2]; s = s + p8[3]; s = s + p8[4]; s = s + p8[5]; s = s + p8[6]; s = s + p8[7];
+                l.newd[b0 + lane] = -s;
+            }
+        } else {
+            // dot_product_scalar_inline (:157-173): t_g = ((a0 b0 + a1 b1) + a2 b2) + a3 b3 per group of four, sum += t_g in order
+            for (uint32_t e = lane; e < nb * d4; e += 64) {
+                const uint32_t r = e / d4, gq = e % d4;
+                const float4 a = *reinterpret_cast<const float4 *>(l.q + gq * 4), b = *reinterpret_cast<const float4 *>(l.stage + r * sp + gq * 4);
+                float t = a.x * b.x;
+                t = t + a.y * b.y; t = t + a.z * b.z; t = t + a.w * b.w;
+                l.tsum[r * tp + gq] = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < nb) {
+                const float *tr = l.tsum + lane * tp;
+                float s = 0.0f;
+                for (uint32_t gq = 0; gq < d4; ++gq) s = s + tr[gq];
+                l.newd[b0 + lane] = -s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// inserts key into the ascending array a[lo, n) (n < cap); returns the new n. One wave.
+__device__ uint32_t vg_sorted_insert(uint64_t *a, uint32_t lo, uint32_t n, uint64_t key, int lane) {
+    // position = lo + #keys in [lo, n) smaller than key
+    uint32_t pos = lo;
+    for (uint32_t i0 = lo; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool less = i < n && a[i] < key;
+        pos += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(less));
+    }
+    // shift [pos, n) up by one, highest chunk first (a chunk is read completely before it is written)
+    for (uint32_t hi = n; hi > pos;) {
+        const uint32_t cl = hi - pos < 64 ? hi - pos : 64, base = hi - cl;
+        const uint32_t i = base + lane;
+        uint64_t v = 0;
+        if ((uint32_t)lane < cl) v = a[i];
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < cl) a[i + 1] = v;
+        __builtin_amdgcn_wave_barrier();
+        hi = base;
+    }
+    if (lane == 0) a[pos] = key;
+    __builtin_amdgcn_wave_barrier();
+    return n + 1;
+}
+
+// greedy_search (vamana.rs:576-657) for the query in l.q over nodes [0, n): the k best end up in l.w[0, return value), ascending.
+// visited: n bits, private to this wave. *overflow is set if the frontier array was ever full (cannot happen unless thousands of
+// candidates tie with the worst of `w`).
+__device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint32_t k, uint32_t entry, uint32_t *visited, uint32_t *overflow, int lane) {
+    for (uint32_t i = lane; i < (n + 31) / 32; i += 64) visited[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { l.newid[0] = entry; visited[entry >> 5] = 1u << (entry & 31); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    vg_distances(g, l, 1, lane);
+    uint32_t wn = 1, ch = 0, cn = 1;             // |w|, frontier head, frontier end  (wave-uniform)
+    if (lane == 0) { const uint64_t key = make_key(l.newd[0], entry); l.w[0] = key; l.cand[0] = key; }
+    __builtin_amdgcn_wave_barrier();
+    while (ch < cn) {
+        const uint64_t cur = l.cand[ch++];
+        if (vg_key_dist(cur) > vg_key_dist(l.w[wn - 1])) break;          // current.distance > worst of w
+        const uint32_t cid = (uint32_t)cur;
+        if (cid >= n) continue;
+        const uint32_t dg = g.deg[cid];
+        // unvisited neighbours, in list order (up to VG_MAXDEG, two rounds of 64 lanes)
+        uint32_t m = 0;
+        for (uint32_t j0 = 0; j0 < dg; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            uint32_t nb = 0xFFFFFFFFu;
+            bool fresh = false;
+            if (j < dg) {
+                nb = g.nbr[(size_t)cid * g.stride + j];
+                if (nb < n) fresh = (atomicOr(visited + (nb >> 5), 1u << (nb & 31)) & (1u << (nb & 31))) == 0;
+            }
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(fresh);
+            if (fresh) l.newid[m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = nb;
+            m += (uint32_t)__builtin_popcountll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (m == 0) continue;
+        vg_distances(g, l, m, lane);
+        for (uint32_t i = 0; i < m; ++i) {                                // one by one, in list order, like the reference
+            const float d = l.newd[i];
+            const bool add = wn < k || d < vg_key_dist(l.w[wn - 1]);
+            if (!add) continue;
+            const uint64_t key = make_key(d, l.newid[i]);
+            if (cn == (uint32_t)VG_C_CAP) {
+                if (ch > 0) {                                             // reclaim the consumed head
+                    for (uint32_t t0 = 0; t0 < cn - ch; t0 += 64) {
+                        uint64_t v = 0;
+                        if (t0 + lane < cn - ch) v = l.cand[ch + t0 + lane];
+                        __builtin_amdgcn_wave_barrier();
+                        if (t0 + lane < cn - ch) l.cand[t0 + lane] = v;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    cn -= ch; ch = 0;
+                }
+                if (cn == (uint32_t)VG_C_CAP) { cn = VG_C_CAP - 1; if (lane == 0) *overflow = 1; }     // drop the worst frontier entry
+            }
+            cn = vg_sorted_insert(l.cand, ch, cn, key, lane);
+            wn = vg_sorted_insert(l.w, 0, wn, key, lane);
+            if (wn > k) wn = k;                                           // w.pop(): the largest key goes
+        }
+    }
+    return wn;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------------
+struct VgSearchArgs {
+    VgGraph g;
+    uint32_t n, medoid;
+    const float *q;           // [nq][dim]
+    uint32_t nq, k, search_k; // search_k = k + min(deleted, 2k)
+    const uint32_t *deleted;  // bitmask or null
+    uint32_t id_base;
+    uint32_t *visited;        // [nq][vis_words]
+    uint32_t vis_words;
+    uint32_t *ids; float *dist; uint32_t *counts;   // [nq][k]
+    uint32_t *overflow;
+};
+__global__ __launch_bounds__(64) void vg_search_kernel(VgSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const VgLds l = vg_carve(smem, a.g.dim);
+    const int lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    for (uint32_t i = lane; i < a.g.dim; i += 64) l.q[i] = a.q[(size_t)qi * a.g.dim + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wn = vg_greedy(a.g, l, a.n, a.search_k, a.medoid, a.visited + (size_t)qi * a.vis_words, a.overflow, lane);
+    // filter tombstones, take k (vamana.rs:797-804)
+    uint32_t o = 0;
+    for (uint32_t i0 = 0; i0 < wn && o < a.k; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool live = false;
+        uint64_t key = 0;
+        if (i < wn) { key = l.w[i]; const uint32_t id = (uint32_t)key; live = !(a.deleted && ((a.deleted[id >> 5] >> (id & 31)) & 1u)); }
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(live);
+        const uint32_t slot = o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (live && slot < a.k) { a.ids[(size_t)qi * a.k + slot] = a.id_base + (uint32_t)key; a.dist[(size_t)qi * a.k + slot] = vg_key_dist(key); }
+        o += (uint32_t)__builtin_popcountll(bal);
+    }
+    if (o > a.k) o = a.k;
+    for (uint32_t i = o + lane; i < a.k; i += 64) { a.ids[(size_t)qi * a.k + i] = 0xFFFFFFFFu; a.dist[(size_t)qi * a.k + i] = __builtin_inff(); }
+    if (lane == 0) a.counts[qi] = o;
+}
+
+// add_vector for rows [first, first + count), one after the other (vamana.rs:853-974). One wave.
+struct VgInsertArgs {
+    VgGraph g;
+    uint32_t first, count, R, medoid;
+    uint32_t *visited;        // [vis_words]
+    uint32_t *overflow;
+};
+__global__ __launch_bounds__(64) void vg_insert_kernel(VgInsertArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const VgLds l = vg_carve(smem, a.g.dim);
+    const int lane = threadIdx.x;
+    const uint32_t dim = a.g.dim;
+    for (uint32_t id = a.first; id < a.first + a.count; ++id) {
+        if (id == 0) { if (lane == 0) a.g.deg[0] = 0; continue; }          // the first vector: a node without neighbours
+        for (uint32_t i = lane; i < dim; i += 64) l.q[i] = a.g.rows[(size_t)id * dim + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t wn = vg_greedy(a.g, l, id, a.R, a.medoid, a.visited, a.overflow, lane);   // the graph holds nodes [0, id)
+        const uint32_t take = wn < a.R ? wn : a.R;
+        for (uint32_t i = lane; i < take; i += 64) a.g.nbr[(size_t)id * a.g.stride + i] = (uint32_t)l.w[i];
+        if (lane == 0) a.g.deg[id] = take;
+        // back edges, in neighbour order; a list that outgrows R keeps its R closest by (distance, id) (:925-957)
+        for (uint32_t i = 0; i < take; ++i) {
+            const uint32_t nb = (uint32_t)l.w[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            const uint32_t dg = a.g.deg[nb];
+            if (lane == 0) { a.g.nbr[(size_t)nb * a.g.stride + dg] = id; a.g.deg[nb] = dg + 1; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            if (dg + 1 > a.R) {
+                // distances from nb to each of its dg + 1 neighbours: the "query" is nb's row (w stays where it is)
+                const uint32_t cnt = dg + 1;
+                for (uint32_t t = lane; t < dim; t += 64) l.q[t] = a.g.rows[(size_t)nb * dim + t];
+                for (uint32_t t = lane; t < cnt; t += 64) l.newid[t] = a.g.nbr[(size_t)nb * a.g.stride + t];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                vg_distances(a.g, l, cnt, lane);
+                // rank by (distance total_cmp, id); ranks are unique (ids are): entry t goes to position rank(t) if rank < R
+                for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    if (t < cnt) {
+                        const uint64_t key = make_key(l.newd[t], l.newid[t]);
+                        uint32_t r = 0;
+                        for (uint32_t u = 0; u < cnt; ++u) r += make_key(l.newd[u], l.newid[u]) < key;
+                        if (r < a.R) a.g.nbr[(size_t)nb * a.g.stride + r] = l.newid[t];
+                    }
+                }
+                if (lane == 0) a.g.deg[nb] = a.R;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    }
+}
+
+// robust_prune of `node` over the candidates in l.w[0, nc) (keys: distance | id; sorted ascending == the reference's sort) -> pruned ids
+// in l.newid[?]... the pruned list is written to out[0, return). One wave. (vamana.rs:665-746)
+__device__ uint32_t vg_robust_prune(const VgGraph &g, const VgLds &l, uint32_t node, uint32_t nc, uint32_t R, float alpha, uint32_t *out /* LDS, R */,
+                                    float *out_dne /* LDS, R */, int lane) {
+    const uint32_t dim = g.dim;
+    uint32_t np = 0;
+    // node's row as the query for dist_nc
+    for (uint32_t i = 0; i < nc && np < R; ++i) {
+        const uint32_t cid = (uint32_t)l.w[i];
+        if (cid == node) continue;
+        // dist_nc = distance(node, c); dist_ce = distance(c, e_j) for the kept e_j: one batch of 1 + np rows against the query c... the
+        // reference evaluates dist_ce lazily and stops at the first hit; the values are the same, only evaluated eagerly here.
+        for (uint32_t t = lane; t < dim; t += 64) l.q[t] = g.rows[(size_t)cid * dim + t];
+        if (lane == 0) l.newid[0] = node;
+        for (uint32_t t = lane; t < np; t += 64) l.newid[1 + t] = out[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        vg_distances(g, l, 1 + np, lane);                                   // newd[0] = dist(c, node) == dist(node, c) term by term
+        const float dist_nc = l.newd[0];
+        bool hit = false;
+        for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool h = false;
+            if (j < np) { const float dist_ce = l.newd[1 + j]; h = alpha * (dist_ce + 1.0f) <= (dist_nc + 1.0f) && dist_ce <= out_dne[j]; }
+            hit = hit || __builtin_amdgcn_ballot_w64(h) != 0;
+        }
+        if (!hit) { if (lane == 0) { out[np] = cid; out_dne[np] = dist_nc; } ++np; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return np;
+}
+
+// build (vamana.rs:200-284) over the graph already in deg / nbr (the initial random graph). One wave, node after node, two passes.
+struct VgBuildArgs {
+    VgGraph g;
+    uint32_t n, R, L, medoid;
+    float alpha;
+    uint32_t *visited;
+    uint32_t *overflow;
+};
+__global__ __launch_bounds__(64) void vg_build_kernel(VgBuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const VgLds l = vg_carve(smem, a.g.dim);
+    const int lane = threadIdx.x;
+    const uint32_t dim = a.g.dim;
+    uint32_t *pr = l.pr, *pr2 = l.pr2;
+    float *dne = l.dne, *dne2 = l.dne2;
+    for (int iteration = 1;; ++iteration) {
+        uint32_t updates = 0;
+        for (uint32_t node = 0; node < a.n; ++node) {
+            for (uint32_t i = lane; i < dim; i += 64) l.q[i] = a.g.rows[(size_t)node * dim + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t m = vg_greedy(a.g, l, a.n, a.L, a.medoid, a.visited, a.overflow, lane);
+            const uint32_t np = vg_robust_prune(a.g, l, node, m, a.R, a.alpha, pr, dne, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            const uint32_t dg = a.g.deg[node];
+            bool same = np == dg;
+            if (same) {
+                bool diff = false;
+                for (uint32_t j = lane; j < np; j += 64) diff = diff || a.g.nbr[(size_t)node * a.g.stride + j] != pr[j];
+                same = __builtin_amdgcn_ballot_w64(diff) == 0;
+            }
+            if (same) continue;
+            ++updates;
+            for (uint32_t j = lane; j < np; j += 64) a.g.nbr[(size_t)node * a.g.stride + j] = pr[j];
+            if (lane == 0) a.g.deg[node] = np;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            for (uint32_t j = 0; j < np; ++j) {
+                const uint32_t nb = pr[j];
+                if (nb >= a.n) continue;
+                const uint32_t dn = a.g.deg[nb];
+                bool has = false;
+                for (uint32_t t = lane; t < dn; t += 64) has = has || a.g.nbr[(size_t)nb * a.g.stride + t] == node;
+                if (__builtin_amdgcn_ballot_w64(has) != 0) continue;
+                if (lane == 0) { a.g.nbr[(size_t)nb * a.g.stride + dn] = node; a.g.deg[nb] = dn + 1; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                if (dn + 1 > a.R) {
+                    // robust_prune(nb, its neighbours with distance 0.0): sorted by (0.0, id) = by id
+                    const uint32_t cnt = dn + 1;
+                    for (uint32_t t = lane; t < cnt; t += 64) l.newid[t] = a.g.nbr[(size_t)nb * a.g.stride + t];
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+                        const uint32_t t = t0 + lane;
+                        if (t < cnt) {
+                            const uint32_t idv = l.newid[t];
+                            uint32_t r = 0;
+                            for (uint32_t u = 0; u < cnt; ++u) r += l.newid[u] < idv;
+                            l.w[r] = make_key(0.0f, idv);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t q2 = vg_robust_prune(a.g, l, nb, cnt, a.R, a.alpha, pr2, dne2, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    for (uint32_t t = lane; t < q2; t += 64) a.g.nbr[(size_t)nb * a.g.stride + t] = pr2[t];
+                    if (lane == 0) a.g.deg[nb] = q2;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                }
+            }
+        }
+        if (updates == 0 || iteration >= 2) break;
+    }
+}
+
+// find_medoid (vamana.rs:407-441): the mean vector, coordinate sums in row order; then the closest row, first minimum wins.
+__global__ __launch_bounds__(256) void vg_centroid_kernel(const float *rows, uint32_t n, uint32_t dim, float *centroid) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= dim) return;
+    float s = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) s = s + rows[(size_t)i * dim + j];
+    centroid[j] = s / (float)n;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------
+int vg_launch_search(const VgSearchArgs &a, hipStream_t st) {
+    const size_t lds = vg_lds_bytes(a.g.dim);
+    SHODH_TRY(ensure_dynamic_lds((const void *)vg_search_kernel, lds));
+    hipLaunchKernelGGL(vg_search_kernel, dim3(a.nq), dim3(64), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int vg_launch_insert(const VgInsertArgs &a, hipStream_t st) {
+    const size_t lds = vg_lds_bytes(a.g.dim);
+    SHODH_TRY(ensure_dynamic_lds((const void *)vg_insert_kernel, lds));
+    hipLaunchKernelGGL(vg_insert_kernel, dim3(1), dim3(64), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int vg_launch_build(const VgBuildArgs &a, hipStream_t st) {
+    const size_t lds = vg_lds_bytes(a.g.dim);
+    SHODH_TRY(ensure_dynamic_lds((const void *)vg_build_kernel, lds));
+    hipLaunchKernelGGL(vg_build_kernel, dim3(1), dim3(64), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int vg_launch_centroid(const float *rows, uint32_t n, uint32_t dim, float *centroid, hipStream_t st) {
+    hipLaunchKernelGGL(vg_centroid_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, rows, n, dim, centroid);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+}  // namespace shodh

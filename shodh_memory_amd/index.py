@@ -39,10 +39,11 @@ class BackendType(Enum):
 
 @dataclass
 class VamanaConfig:
-    """vamana.rs VamanaConfig (graph parameters are accepted and ignored: the device index is flat)."""
+    """vamana.rs:56-90 VamanaConfig. The graph parameters matter under `scan_mode=SCAN_GRAPH` (the reference's default ANN
+    `search`, reproduced on the device); the exact scan modes -- SHODH_VECTOR_EXACT semantics, vamana.rs:1167-1188 -- ignore them."""
     dimension: int = 384
     max_degree: int = 32
-    search_list_size: int = 100
+    search_list_size: int = 75
     alpha: float = 1.2
     use_mmap: bool = False
     distance_metric: DistanceMetric = DistanceMetric.NormalizedDotProduct
@@ -107,7 +108,8 @@ class _Handle:
 
 
 class VamanaIndex:
-    """Flat exact index on one MI355X with the VamanaIndex method set."""
+    """The VamanaIndex method set on one MI355X: an exact scan by default (the reference under SHODH_VECTOR_EXACT), or the
+    reference's own graph walk -- same graph, same visits, same answers -- with `VamanaConfig(scan_mode=SCAN_GRAPH)`."""
 
     def __init__(self, config: VamanaConfig = None):
         self.config = config or VamanaConfig()
@@ -121,6 +123,9 @@ class VamanaIndex:
         cfg.scan_mode = self.config.scan_mode
         cfg.reserve_rows = self.config.reserve_rows
         cfg.id_base = self.config.id_base
+        cfg.max_degree = self.config.max_degree
+        cfg.search_list_size = self.config.search_list_size
+        cfg.alpha = self.config.alpha
         self._hd = _Handle(cfg)
         self._incremental = 0
         self._graph = None            # degree / neighbour arrays of a reference-built file (persist.load_vamana), while the rows are unchanged
@@ -165,6 +170,50 @@ class VamanaIndex:
         self._graph = None
 
     rebuild_from_vectors = build
+
+    # -- the graph itself (SCAN_GRAPH only) ---------------------------------------------------------------
+    @property
+    def graph_mode(self):
+        return self.config.scan_mode == L.SCAN_GRAPH
+
+    def vamana_build(self, seed=0, init_degree=None, init_neighbors=None):
+        """VamanaIndex::build's graph construction (vamana.rs:200-284) over the rows already stored. The reference draws its start
+        graph from thread_rng (:287-312); here it comes from `seed`, or is handed in as (`init_degree` [n] uint32,
+        `init_neighbors` [n, stride] uint32) -- which is how the parity tests pin the construction."""
+        if init_degree is not None:
+            d = np.ascontiguousarray(init_degree, np.uint32)
+            nb = np.ascontiguousarray(init_neighbors, np.uint32).reshape(d.shape[0], -1)
+            L.check(L.lib().shodh_index_vamana_build(self.handle, int(seed), d.ctypes.data, nb.ctypes.data, nb.shape[1]))
+        else:
+            L.check(L.lib().shodh_index_vamana_build(self.handle, int(seed), None, None, 0))
+        self._incremental = 0
+
+    def get_graph(self):
+        """-> (degree [n] uint32, neighbours [n, max_degree + 1] uint32, medoid); entries past a node's degree are 0"""
+        n, st = self.len(), self.config.max_degree + 1
+        deg = np.zeros(n, np.uint32); nb = np.zeros((n, st), np.uint32); med = C.c_uint32()
+        L.check(L.lib().shodh_index_get_graph(self.handle, deg.ctypes.data, nb.ctypes.data, st, C.byref(med)))
+        return deg, nb, int(med.value)
+
+    def set_graph(self, degree, neighbors, medoid, vectors=None):
+        """attach a graph built elsewhere (a reference-written VAMA file): `neighbors` [n, stride] or the flat concatenation.
+        With `vectors` the index contents are replaced by those rows first (load_from_file)."""
+        d = np.ascontiguousarray(degree, np.uint32)
+        nb = np.asarray(neighbors, np.uint32)
+        if nb.ndim == 1:                                               # flat adjacency lists, VAMA order
+            st = max(int(d.max()) if d.size else 0, 1)
+            sq = np.zeros((d.shape[0], st), np.uint32)
+            off = np.concatenate([[0], np.cumsum(d, dtype=np.int64)])
+            cols = np.arange(nb.shape[0], dtype=np.int64) - np.repeat(off[:-1], d)
+            sq[np.repeat(np.arange(d.shape[0]), d), cols] = nb
+            nb = sq
+        nb = np.ascontiguousarray(nb)
+        if vectors is not None:
+            a = _as_rows(vectors, self._hd.dim)
+            L.check(L.lib().shodh_index_build_with_graph(self.handle, a.ctypes.data, a.shape[0], d.ctypes.data, nb.ctypes.data, nb.shape[1], int(medoid)))
+            self._incremental = 0
+            return
+        L.check(L.lib().shodh_index_set_graph(self.handle, d.ctypes.data, nb.ctypes.data, nb.shape[1], int(medoid)))
 
     # -- add_vector (vamana.rs:853-974): returns the new id -------------------------------------------
     def add_vector(self, vector):

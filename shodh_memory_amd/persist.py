@@ -68,7 +68,11 @@ def load_vamana(path, device=0, scan_mode=L.SCAN_AUTO):
     idx = VamanaIndex(VamanaConfig(dimension=info["dimension"], max_degree=info["max_degree"], device=device, scan_mode=scan_mode,
                                    reserve_rows=max(int(info["num_vectors"]), 1)))
     if info["num_vectors"]:
-        idx.build(f["vectors"])
+        if scan_mode == L.SCAN_GRAPH:
+            # the file's graph IS the index: store the rows, attach the adjacency lists and the medoid as written
+            idx.set_graph(f["degree"].astype(np.uint32), f["neighbors"], int(info["medoid"]), vectors=f["vectors"])
+        else:
+            idx.build(f["vectors"])
     for i in f["deleted"]:
         idx.mark_deleted(int(i))
     idx._incremental = int(info["incremental_inserts"])
@@ -94,7 +98,12 @@ def save_vamana(index, path):
     base = int(index.config.id_base)
     deleted = [i for i in range(vec.shape[0]) if index.is_deleted(base + i)] if index.deleted_count() else []
     g = getattr(index, "_graph", None)
-    if g is not None and g["n"] == vec.shape[0]:
+    if getattr(index, "graph_mode", False) and vec.shape[0]:
+        deg, nb, medoid = index.get_graph()
+        flat = nb[np.arange(nb.shape[1])[None, :] < deg[:, None]]
+        write_vamana(path, vec, max_degree=index.config.max_degree, medoid=medoid, metric=0, deleted=deleted,
+                     incremental_inserts=index.incremental_insert_count(), degree=deg.astype(np.uint16), neighbors=np.ascontiguousarray(flat, np.uint32))
+    elif g is not None and g["n"] == vec.shape[0]:
         write_vamana(path, vec, max_degree=index.config.max_degree, medoid=g["medoid"], metric=0, deleted=deleted,
                      incremental_inserts=index.incremental_insert_count(), degree=g["degree"], neighbors=g["neighbors"])
     else:

@@ -42,11 +42,12 @@ def test_header_symbols_are_exported(shodh):
 
 def test_abi_version_and_structs(shodh):
     from shodh_memory_amd import _lib
-    assert _lib.lib().shodh_abi_version() == 1
+    assert _lib.lib().shodh_abi_version() == 2
     cfg = _lib.IndexCfg()
     _lib.lib().shodh_index_cfg_default(C.byref(cfg))
     assert (cfg.dim, cfg.metric, cfg.kind, cfg.order, cfg.nprobe) == (384, 0, 0, 0, 20)
-    assert C.sizeof(_lib.IndexCfg) == 48 and C.sizeof(_lib.Weights) == 32
+    assert (cfg.max_degree, cfg.search_list_size, round(cfg.alpha, 6)) == (32, 75, 1.2)        # VamanaConfig::default, vamana.rs:79-90
+    assert C.sizeof(_lib.IndexCfg) == 64 and C.sizeof(_lib.Weights) == 32
 
 
 def test_product_does_not_touch_the_oracle():

@@ -1,0 +1,107 @@
+"""Pins `oracle/vamana_oracle.c` (the CPU restatement of the Vamana graph walk) against what the reference's own unit tests assert
+(vamana.rs:1685-1830), run for MANY start graphs since the reference draws its start graph from thread_rng, and against
+definitions: greedy_search over a complete graph is the exact top-k, robust_prune keeps the nearest candidate first, a node never
+lists itself, no list exceeds max_degree, back edges exist.
+"""
+import numpy as np
+import pytest
+
+
+def random_init(n, R, rng):
+    """initialize_graph (vamana.rs:287-312): min(R, n - 1) distinct random neighbours per node, never the node itself"""
+    d = min(R, n - 1)
+    deg = np.full(n, d, np.uint32)
+    nbr = np.zeros((n, max(d, 1)), np.uint32)
+    for i in range(n):
+        others = np.delete(np.arange(n, dtype=np.uint32), i)
+        nbr[i, :d] = rng.choice(others, d, replace=False)
+    return deg, nbr
+
+
+REF_VECTORS_5 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [0.5, 0.5, 0, 0]], np.float32)
+REF_VECTORS_10 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [0.5, 0.5, 0, 0], [0.5, 0, 0.5, 0], [0, 0.5, 0.5, 0],
+                           [0, 0, 0.5, 0.5], [0.25, 0.25, 0.25, 0.25], [0.7, 0.3, 0, 0]], np.float32)
+
+
+def test_reference_test_vamana_construction(oracle):
+    """vamana.rs:1685-1713: 5 vectors, R=3, L=10; query [0.9, 0.1, 0, 0], k=2 -> 2 results, the first is id 0 -- for any start graph"""
+    for seed in range(200):
+        rng = np.random.default_rng(seed)
+        g = oracle.VamanaGraph(4, R=3, L=10, alpha=1.2)
+        g.build(REF_VECTORS_5, *random_init(5, 3, rng))
+        ids, dist = g.search(np.array([0.9, 0.1, 0, 0], np.float32), 2)
+        assert len(ids) == 2 and ids[0] == 0, (seed, ids)
+        assert dist[0] == np.float32(-0.9)
+
+
+def test_reference_test_estimate_recall(oracle):
+    """vamana.rs:1756-1789: 10 vectors, R=4, L=20: recall@3 of `search` against the brute force over 5 sampled rows >= 0.6"""
+    for seed in range(100):
+        rng = np.random.default_rng(1000 + seed)
+        g = oracle.VamanaGraph(4, R=4, L=20, alpha=1.2)
+        g.build(REF_VECTORS_10, *random_init(10, 4, rng))
+        hits = total = 0
+        for s in rng.choice(10, 5, replace=False):                  # estimate_recall queries with 5 shuffled rows (vamana.rs:1128-1165)
+            q = REF_VECTORS_10[s]
+            got, _ = g.search(q, 3)
+            exact = np.argsort(-(REF_VECTORS_10 @ q), kind="stable")[:3]
+            hits += len(set(got.tolist()) & set(exact.tolist()))
+            total += 3
+        assert hits / total >= 0.6, (seed, hits / total)
+
+
+def test_reference_test_incremental_inserts(oracle):
+    """vamana.rs:1715-1754: build 3, add 5 one by one: every vector becomes a node and can be found again"""
+    rng = np.random.default_rng(5)
+    g = oracle.VamanaGraph(4, R=3, L=10, alpha=1.2)
+    g.build(REF_VECTORS_5[:3], *random_init(3, 3, rng))
+    for i in range(5):
+        assert g.add_vector(np.array([0.1 * i, 0.1, 0.1, 0.1], np.float32)) == 3 + i
+    assert g.n == 8
+    assert (g.deg[:8] <= 3 + 1).all()                               # a back edge may leave R + 1 before the next prune (vamana.rs:938-966)
+
+
+def test_greedy_search_on_a_complete_graph_is_exact(oracle):
+    rng = np.random.default_rng(3)
+    n, dim = 40, 16
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    g = oracle.VamanaGraph(dim, R=n - 1, L=n)
+    g._grow(n); g.rows[:n] = rows; g.n = n
+    for i in range(n):
+        g.deg[i] = n - 1
+        g.nbr[i, :n - 1] = np.delete(np.arange(n, dtype=np.uint32), i)
+    for qi in range(10):
+        q = rng.standard_normal(dim).astype(np.float32)
+        ids, dist = g.greedy_search(q, 8, entry=qi)
+        ex_ids, ex_dist = oracle.brute_force_search(rows, q, 8)
+        assert ids.tolist() == list(ex_ids) and dist.tolist() == list(ex_dist)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_incremental_graph_invariants(oracle, order):
+    rng = np.random.default_rng(11)
+    n, dim, R = 300, 32, 8
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    g = oracle.VamanaGraph(dim, R=R, L=30, order=order)
+    for r in rows:
+        g.add_vector(r)
+    assert g.medoid == 0 and g.deg[0] > 0
+    for i in range(n):
+        nb = g.nbr[i, :g.deg[i]]
+        assert g.deg[i] <= R + 1 and i not in nb and len(set(nb.tolist())) == len(nb) and (nb < n).all()
+    # nearly every row is reachable from the entry point (pruning a full back-edge list may orphan a node: the reference's known drift,
+    # the reason for its repair / rebuild thresholds, vamana.rs:985-1016)
+    seen = {0}; todo = [0]
+    while todo:
+        u = todo.pop()
+        for v in g.nbr[u, :g.deg[u]].tolist():
+            if v not in seen:
+                seen.add(v); todo.append(v)
+    assert len(seen) >= 0.95 * n
+    # search with tombstones over-fetches (vamana.rs:789-806) and never returns a deleted id
+    deleted = np.zeros(n, np.uint8); deleted[rng.choice(n, 30, replace=False)] = 1
+    for qi in range(20):
+        ids, dist = g.search(rows[qi], 5, deleted=deleted)
+        assert len(ids) <= 5 and not deleted[ids].any() and (np.diff(dist) >= 0).all()
