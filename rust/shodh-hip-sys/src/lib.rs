@@ -26,7 +26,9 @@ fn cpath(p: &Path) -> Result<CString> {
     CString::new(p.to_string_lossy().as_bytes()).map_err(|e| anyhow!("path contains NUL: {e}"))
 }
 
-/// `VamanaConfig` (vamana.rs:120-166). Graph parameters are accepted and ignored: the device index is flat and exact.
+/// `VamanaConfig` (vamana.rs:56-90). With `graph_walk` the index answers like the reference WITHOUT `SHODH_VECTOR_EXACT`: it keeps
+/// the Vamana graph on the device and `search` is the reference's greedy walk (same graph, same visits, same answers as an index
+/// grown by `add_vector`); otherwise the graph parameters are ignored and `search` is the exact scan (`brute_force_search`).
 #[derive(Clone, Debug)]
 pub struct VamanaConfig {
     pub dimension: usize,
@@ -35,10 +37,11 @@ pub struct VamanaConfig {
     pub alpha: f32,
     pub use_mmap: bool,
     pub device: i32,
+    pub graph_walk: bool,
 }
 impl Default for VamanaConfig {
     fn default() -> Self {
-        Self { dimension: 384, max_degree: 32, search_list_size: 75, alpha: 1.2, use_mmap: false, device: 0 }
+        Self { dimension: 384, max_degree: 32, search_list_size: 75, alpha: 1.2, use_mmap: false, device: 0, graph_walk: false }
     }
 }
 
@@ -49,6 +52,7 @@ pub struct HipIndex {
     h: *mut ffi::shodh_index,
     dim: usize,
     max_degree: usize,
+    graph_walk: bool,
     incremental: std::sync::atomic::AtomicUsize,
 }
 // search may run concurrently on one handle; add / build / delete take the library's own lock
@@ -65,9 +69,13 @@ impl HipIndex {
         unsafe { ffi::shodh_index_cfg_default(&mut cfg) };
         cfg.dim = config.dimension as u32; // metric stays NormalizedDotProduct (retrieval.rs:188-193)
         cfg.device = config.device;
+        cfg.max_degree = config.max_degree as u32;
+        cfg.search_list_size = config.search_list_size as u32;
+        cfg.alpha = config.alpha;
+        if config.graph_walk { cfg.scan_mode = ffi::SHODH_SCAN_GRAPH as u32; }
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::shodh_index_create(&cfg, &mut h) })?;
-        Ok(Self { h, dim: config.dimension, max_degree: config.max_degree, incremental: Default::default() })
+        Ok(Self { h, dim: config.dimension, max_degree: config.max_degree, graph_walk: config.graph_walk, incremental: Default::default() })
     }
     /// vamana.rs:175-187: the storage path only tells the reference where to mmap its vectors; rows live in HBM here
     pub fn with_storage_path(config: VamanaConfig, _storage_path: Option<std::path::PathBuf>) -> Result<Self> { Self::new(config) }
@@ -184,13 +192,32 @@ impl HipIndex {
         flat.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect()
     }
 
-    /// `save_to_file` (vamana_persist.rs:175-284): VAMA v1 with empty adjacency lists (the graph is not built here)
+    /// the graph of a `graph_walk` index: (degree per node, adjacency lists concatenated in node order, medoid)
+    pub fn graph(&self) -> Result<(Vec<u16>, Vec<u32>, u32)> {
+        let (n, stride) = (self.len(), self.max_degree + 1);
+        let (mut deg, mut nbr, mut medoid) = (vec![0u32; n], vec![0u32; n * stride], 0u32);
+        check(unsafe { ffi::shodh_index_get_graph(self.h, deg.as_mut_ptr(), nbr.as_mut_ptr(), stride as u32, &mut medoid) })?;
+        let mut flat = Vec::with_capacity(deg.iter().map(|&d| d as usize).sum());
+        for (i, &d) in deg.iter().enumerate() { flat.extend_from_slice(&nbr[i * stride..i * stride + d as usize]); }
+        Ok((deg.into_iter().map(|d| d as u16).collect(), flat, medoid))
+    }
+
+    /// `save_to_file` (vamana_persist.rs:175-284): VAMA v1. A `graph_walk` index writes its graph; the exact index writes empty
+    /// adjacency lists (it builds no graph) and the caller keeps `incremental_inserts` at the rebuild threshold, see INTEGRATION.md
     pub fn save_to_file(&self, path: &Path) -> Result<()> {
         let n = self.len();
         let mut flat = vec![0f32; n * self.dim];
         check(unsafe { ffi::shodh_index_extract_rows(self.h, 0, n as u64, flat.as_mut_ptr()) })?;
         let deleted: Vec<u32> = (0..n as u32).filter(|&i| self.is_deleted(i)).collect();
         let p = cpath(path)?;
+        if self.graph_walk && n > 0 {
+            let (deg, nbr, medoid) = self.graph()?;
+            return check(unsafe {
+                ffi::shodh_vama_save(p.as_ptr(), flat.as_ptr(), n as u64, self.dim as u32, self.max_degree as u32, medoid, 0,
+                                     if deleted.is_empty() { std::ptr::null() } else { deleted.as_ptr() }, deleted.len() as u32,
+                                     self.incremental_insert_count() as u64, deg.as_ptr(), nbr.as_ptr())
+            });
+        }
         check(unsafe {
             ffi::shodh_vama_save(p.as_ptr(), flat.as_ptr(), n as u64, self.dim as u32, self.max_degree as u32, 0, 0,
                                  if deleted.is_empty() { std::ptr::null() } else { deleted.as_ptr() }, deleted.len() as u32,
@@ -207,6 +234,29 @@ impl HipIndex {
         check(unsafe { ffi::shodh_vama_load(p.as_ptr(), flat.as_mut_ptr(), deleted.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) })?;
         let idx = Self::new(VamanaConfig { dimension: d, max_degree: info.max_degree as usize, ..Default::default() })?;
         if n > 0 { check(unsafe { ffi::shodh_index_build(idx.h, flat.as_ptr(), n as u64) })?; }
+        for id in deleted { idx.mark_deleted(id); }
+        idx.incremental.store(info.incremental_inserts as usize, std::sync::atomic::Ordering::Release);
+        Ok(idx)
+    }
+    /// `load_from_file` keeping the file's graph: the index answers by walking it, like the reference that wrote it
+    pub fn load_from_file_with_graph(path: &Path) -> Result<Self> {
+        let p = cpath(path)?;
+        let mut info = ffi::shodh_vama_info::default();
+        check(unsafe { ffi::shodh_vama_info_read(p.as_ptr(), &mut info) })?;
+        let (n, d) = (info.num_vectors as usize, info.dimension as usize);
+        let (mut flat, mut deleted) = (vec![0f32; n * d], vec![0u32; info.deleted_count as usize]);
+        let (mut deg16, mut edges) = (vec![0u16; n], vec![0u32; info.graph_edges as usize]);
+        check(unsafe { ffi::shodh_vama_load(p.as_ptr(), flat.as_mut_ptr(), deleted.as_mut_ptr(), deg16.as_mut_ptr(), edges.as_mut_ptr()) })?;
+        let idx = Self::new(VamanaConfig { dimension: d, max_degree: info.max_degree as usize, graph_walk: true, ..Default::default() })?;
+        if n > 0 {
+            let stride = info.max_degree as usize + 1;
+            let (deg, mut nbr, mut at) = (deg16.iter().map(|&x| x as u32).collect::<Vec<u32>>(), vec![0u32; n * stride], 0usize);
+            for (i, &dg) in deg.iter().enumerate() {
+                nbr[i * stride..i * stride + dg as usize].copy_from_slice(&edges[at..at + dg as usize]);
+                at += dg as usize;
+            }
+            check(unsafe { ffi::shodh_index_build_with_graph(idx.h, flat.as_ptr(), n as u64, deg.as_ptr(), nbr.as_ptr(), stride as u32, info.medoid) })?;
+        }
         for id in deleted { idx.mark_deleted(id); }
         idx.incremental.store(info.incremental_inserts as usize, std::sync::atomic::Ordering::Release);
         Ok(idx)
