@@ -537,7 +537,11 @@ __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qk
 // product's C layout hands the keys to a lane (register r of half-wave h is key (r&3) + 8*(r>>2) + 4*h of the block), and
 // V^T is staged in that same order (position 16*(r>>3) + 8*h + (r&7)), so both operands agree without any shuffle.
 // Wave w takes the query blocks w, w+4, ... of the sequence; keys go in blocks of 32.
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const __bf16 *__restrict__ qkv, const int32_t *__restrict__ cu,
+// Launch bounds: the kernel is LATENCY-bound (~1 us of arithmetic per workgroup behind two HBM round trips), so what counts is how many
+// workgroups a CU holds: 6 waves per SIMD (<= 80 VGPRs; the LDS footprint allows 6 workgroups at 128 tokens) took a layer from 318
+// to 245 us. Tried and slower: a persistent launch prefetching the next item into registers (176 VGPRs, 2 workgroups per CU),
+// and the Q fragments fetched ahead of the staging loads.
+__global__ __launch_bounds__(256, 6) void attention_mfma_kernel(const __bf16 *__restrict__ qkv, const int32_t *__restrict__ cu,
                                                              __bf16 *__restrict__ ctx, int H, int heads, int s_pad /* multiple of 32 */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
@@ -850,11 +854,31 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
             static const bool unfused = getenv("SHODH_ENC_UNFUSED") && atoi(getenv("SHODH_ENC_UNFUSED"));     // speed only: the round-1 three-kernel form
             if (stream_gemm && I == FF_I && !unfused) {
                 // FFN up + GELU + FFN down + residual + LayerNorm in one kernel, in place (a workgroup reads and writes only its own rows)
-                SHODH_TRY(ensure_dynamic_lds((const void *)ffn_fused_kernel, FF_LDS));
                 const int n_tiles = (ntok + FF_TOK - 1) / FF_TOK;
-                hipLaunchKernelGGL(ffn_fused_kernel, dim3(n_tiles < e->cus ? n_tiles : e->cus), dim3(512), FF_LDS, st, (const __bf16 *)X, wp + (size_t)4 * H * H,
-                                   e->w2p16 + (size_t)li * I * H, w + l.ib, w + l.db, w + l.ln2g, w + l.ln2b, (__bf16 *)X, ntok, eps);
-                SHODH_HIP_TRY(hipGetLastError());
+                auto launch_ffn = [&](auto kern) -> int {
+                    SHODH_TRY(ensure_dynamic_lds((const void *)kern, FF_LDS));
+                    hipLaunchKernelGGL(kern, dim3(n_tiles < e->cus ? n_tiles : e->cus), dim3(512), FF_LDS, st, (const __bf16 *)X, wp + (size_t)4 * H * H,
+                                       e->w2p16 + (size_t)li * I * H, w + l.ib, w + l.db, w + l.ln2g, w + l.ln2b, (__bf16 *)X, ntok, eps);
+                    SHODH_HIP_TRY(hipGetLastError());
+                    return SHODH_OK;
+                };
+#ifdef SHODH_FFN_ABLATE
+                static const int abl = getenv("SHODH_FFN_ABLATE") ? atoi(getenv("SHODH_FFN_ABLATE")) : 0;
+                switch (abl) {
+                    case 1: SHODH_TRY(launch_ffn(ffn_fused_kernel<1>)); break;
+                    case 2: SHODH_TRY(launch_ffn(ffn_fused_kernel<2>)); break;
+                    case 4: SHODH_TRY(launch_ffn(ffn_fused_kernel<4>)); break;
+                    case 8: SHODH_TRY(launch_ffn(ffn_fused_kernel<8>)); break;
+                    case 12: SHODH_TRY(launch_ffn(ffn_fused_kernel<12>)); break;
+                    case 16: SHODH_TRY(launch_ffn(ffn_fused_kernel<16>)); break;
+                    case 32: SHODH_TRY(launch_ffn(ffn_fused_kernel<32>)); break;
+                    case 3: SHODH_TRY(launch_ffn(ffn_fused_kernel<3>)); break;
+                    case 63: SHODH_TRY(launch_ffn(ffn_fused_kernel<63>)); break;
+                    default: SHODH_TRY(launch_ffn(ffn_fused_kernel<0>)); break;
+                }
+#else
+                SHODH_TRY(launch_ffn(ffn_fused_kernel<0>));
+#endif
                 continue;
             }
             if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_GELU>(X, wp + (size_t)4 * H * H, w + l.ib, nullptr, FF, nullptr, ntok, I, e->cus, st));

@@ -73,6 +73,10 @@ __device__ __forceinline__ float ffn_gelu(float x) {
     return x * __builtin_fmaf(xc, p, 0.5f);
 }
 
+// ABL: diagnostics only (build with -DSHODH_FFN_ABLATE, pick with SHODH_FFN_ABLATE=<mask> at run time; results are INVALID for ABL != 0):
+//   1 no GELU arithmetic   2 no epilogue (residual / LayerNorm / stores)   4 no GEMM1 MFMAs   8 no GEMM2 MFMAs   16 no weight DMA
+//   32 no LDS reads of the weight fragments
+template <int ABL>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* may alias out: in place */, const __bf16 *__restrict__ W1p /* fragment-major FFN-up, chunk-major */,
                                                             const __bf16 *__restrict__ W2p /* pack_w2_kernel */, const float *__restrict__ b1,
                                                             const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
         p.dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (sq % (uint32_t)FF_SLOTS) * FF_PKG + (uint32_t)cw * 6u * 1024u));
         return p;
     };
-    auto issue_piece = [&](const Pkg &p, int i) { glds16(p.src, lane16 + i * 1024, p.dst + i * 1024); };
+    auto issue_piece = [&](const Pkg &p, int i) { if (!(ABL & 16)) glds16(p.src, lane16 + i * 1024, p.dst + i * 1024); };
     constexpr int NIT = FF_CHUNKS + 2;
     uint32_t gq = 0;                                     // stream index of Q(2 it) of the current iteration; continues across tiles
     int tile = blockIdx.x;
@@ -162,16 +166,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
                 constexpr int D = 4;
                 bf16x8f ring[8];
 #pragma unroll
-                for (int q = 0; q < D; ++q) ring[q] = a1[q * 64];
+                for (int q = 0; q < D; ++q) ring[q] = a1[(ABL & 32) ? 0 : q * 64];
                 bf16x8f hb[2];
 #pragma unroll
                 for (int st = 0; st < FF_KS; ++st) {
-                    if (st + D < FF_KS) ring[(st + D) & 7] = a1[(st + D) * 64];
+                    if (st + D < FF_KS && !(ABL & 32)) ring[(st + D) & 7] = a1[(st + D) * 64];
                     // two independent accumulator chains (even / odd k-steps): a chain of 24 dependent MFMAs waits for each predecessor
-                    if ((st & 1) == 0) h_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], bx[st], st == 0 ? zero16 : h_cur, 0, 0, 0);
+                    if (ABL & 4) { asm volatile("" : "+v"(ring[st & 7]), "+v"(bx[st])); }
+                    else if ((st & 1) == 0) h_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], bx[st], st == 0 ? zero16 : h_cur, 0, 0, 0);
                     else h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], bx[st], st == 1 ? zero16 : h_odd, 0, 0, 0);
                     if (st < 16) {      // gelu of h(it - 1) in the MFMA shadows; the empty asm pins the value to THIS step (the optimiser otherwise
-                        float gv = ffn_gelu(h_prev[st] + bv[st >> 2][st & 3]);      // sinks all sixteen evaluations below the loop, next to their only use)
+                        float gv = (ABL & 1) ? h_prev[st] + bv[st >> 2][st & 3] : ffn_gelu(h_prev[st] + bv[st >> 2][st & 3]);      // sinks all sixteen evaluations below the loop, next to their only use)
                         asm volatile("" : "+v"(gv));
                         hb[st >> 3][st & 7] = (__bf16)gv;
                     }
@@ -189,6 +194,22 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
             }
             FFP(1)
             __builtin_amdgcn_s_barrier();          // pairs with the consumers' post-loop barrier (the last iteration's ring slots become their scratch)
+            if (!(ABL & 2)) {
+                // The residual IS this wave's bx: it goes to the paired consumer's scratch in two halves of 192 features (a lane's 16-B
+                // fragment for k-step ks is chunk 2 ks + hi of its token's row) -- no second trip to HBM for it (the consumer used to
+                // stage the rows itself, four exposed HBM round trips per tile with no registers to spare for more loads in flight).
+                const uint32_t pfree0 = (gq + 3u) % (uint32_t)FF_SLOTS, pfree1 = (gq + 4u) % (uint32_t)FF_SLOTS;
+                unsigned char *pscr = smem + (tb < 2 ? pfree0 : pfree1) * FF_PKG + (tb & 1) * 12288;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j)
+                        *reinterpret_cast<bf16x8f *>(pscr + l31 * 384 + (((2 * j + hi) ^ (l31 & 7)) << 4)) = bx[half * 12 + j];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_s_barrier();      // half written
+                    if (half == 0) __builtin_amdgcn_s_barrier();      // half 0 consumed: the scratch can take half 1
+                }
+            }
         } else {
             // ---- consumer: GEMM2 + epilogue ------------------------------------------------------------------------------------
             // the accumulators start from b2 (lane = token, register r of block nb = feature 32 nb + (r & 3) + 8 (r >> 2) + 4 hi)
@@ -223,11 +244,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
                     constexpr int D = 6;
                     bf16x8f ring[8];
 #pragma unroll
-                    for (int q = 0; q < D; ++q) ring[q] = a2[q * 64];
+                    for (int q = 0; q < D; ++q) ring[q] = a2[(ABL & 32) ? 0 : q * 64];
 #pragma unroll
                     for (int st = 0; st < FF_KS; ++st) {       // st = 2 nb + ks
-                        if (st + D < FF_KS) ring[(st + D) & 7] = a2[(st + D) * 64];
-                        y[st >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], hb[st & 1], y[st >> 1], 0, 0, 0);
+                        if (st + D < FF_KS && !(ABL & 32)) ring[(st + D) & 7] = a2[(st + D) * 64];
+                        if (ABL & 8) { asm volatile("" : "+v"(ring[st & 7]), "+v"(hb[st & 1])); }
+                        else y[st >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], hb[st & 1], y[st >> 1], 0, 0, 0);
                         if ((st & 1) == 1) { if (st < 12) issue_piece(pa, st >> 1); else issue_piece(pb, (st >> 1) - 6); }     // one piece every second MFMA
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -248,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
             // (row & 7): global traffic is 16 B per lane along rows, the transposition happens in LDS.
             __builtin_amdgcn_s_barrier();
             FFP(5)
+            if (ABL & 2) { asm volatile("" : "+v"(y[0]), "+v"(y[5]), "+v"(y[11])); continue; }
             const uint32_t free0 = (gq + 3u) % (uint32_t)FF_SLOTS, free1 = (gq + 4u) % (uint32_t)FF_SLOTS;     // = slots of Q(gq - 2), Q(gq - 1): the last iteration's
             unsigned char *scr = smem + (cw < 2 ? free0 : free1) * FF_PKG + (cw & 1) * 12288;
             const int tok0 = tile * FF_TOK + tb * 32;
@@ -261,21 +284,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
             float s = 0.0f;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                // residual rows in: 32 rows x 24 chunks of 16 B = 768 chunks, 12 per lane, consecutive lanes along a row
-#pragma unroll
-                for (int i0 = 0; i0 < 12; i0 += 6) {
-                    u32x4 rin[6];
-                    const int ln = lane_now();
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const int idx = (i0 + i) * 64 + ln, row = idx / 24, ch = idx % 24;
-                        int t = tok0 + row; if (t >= M) t = M - 1;
-                        rin[i] = *reinterpret_cast<const u32x4 *>(X + (size_t)t * FF_H + half * 192 + ch * 8);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) { const int idx = (i0 + i) * 64 + ln; *reinterpret_cast<u32x4 *>(scr + sw(idx / 24, idx % 24)) = rin[i]; }
-                    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          // keep the batches apart: hoisting all the loads costs 100 registers the accumulators need
-                }
+                // residual rows: written by the paired producer from its registers (see there)
+                if (half == 1) __builtin_amdgcn_s_barrier();      // half 0 consumed
+                __builtin_amdgcn_s_barrier();                      // this half written
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
                 FFP(6)
 #pragma unroll
                 for (int nbh = 0; nbh < 6; ++nbh)
