@@ -55,7 +55,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
 }
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_RESID_B16 = 3 };   // _B16: bf16 out = bf16(acc + bias + residual), may be written over the residual
 
 // ---- bf16 MFMA GEMM: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue) ------------------------------------------
 // A, W bf16 row-major; K % 64 == 0, N % 128 == 0. 128 x 128 x 64 tiles, 4 waves x (2 x 2) 32x32 blocks,
@@ -259,6 +259,12 @@ __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *
                 }
             }
         } else if (EPI != EPI_BIAS_RESID_F32) {
+            bf16x4e r4[4];
+            if (EPI == EPI_BIAS_RESID_B16) {
+                const int mc = m < M ? m : M - 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const bf16x4e *>(resid + (size_t)mc * N + nblk * 32 + 8 * g + 4 * hi);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4e ob;
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *
                 for (int e = 0; e < 4; ++e) {
                     float x = c[4 * g + e] + bv[4 * g + e];
                     if (EPI == EPI_BIAS_GELU) x = gelu_erf_fast(x);
+                    if (EPI == EPI_BIAS_RESID_B16) x += (float)r4[g][e];
                     ob[e] = (__bf16)x;
                 }
                 // features 8g + 4hi .. +4 of token l31: chunk g (16 B), half hi
@@ -825,7 +832,9 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
         const float *bqkv = e->bqkv + (size_t)li * 3 * H;
         const __bf16 *wp = e->wp16 + (size_t)li * (4 * H + I) * H;      // fragment-major [qkv | o | ffn-up]
         const bool stream_gemm = (H == GS_DIM) && !(getenv("SHODH_ENC_TILED") && atoi(getenv("SHODH_ENC_TILED")));
-        (void)wp; (void)stream_gemm;
+        static const bool unfused = getenv("SHODH_ENC_UNFUSED") && atoi(getenv("SHODH_ENC_UNFUSED"));     // speed only: the round-1 three-kernel feed-forward
+        const bool ffn_fused = !std::is_same<T, float>::value && stream_gemm && I == FF_I && !unfused;
+        (void)wp; (void)stream_gemm; (void)ffn_fused;
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS>(X, e->wqkv32 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, ntok, 3 * H, H, st));
         } else {
@@ -842,23 +851,27 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(CTX, w + l.ow, w + l.ob, X, e->PRE, ntok, H, H, st));
         } else {
-            if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_RESID_F32>(CTX, wp + (size_t)3 * H * H, w + l.ob, X, nullptr, e->PRE, ntok, H, e->cus, st));
+            // fused form: the attention output projection writes the PRE-norm sum (bf16) over X, and the first LayerNorm happens in the FFN
+            // kernel as it loads its tokens (nobody else reads that LayerNorm's output): no f32 round trip, no LayerNorm launch
+            if (stream_gemm && ffn_fused) SHODH_TRY(gemm_k384_stream<EPI_BIAS_RESID_B16>(CTX, wp + (size_t)3 * H * H, w + l.ob, X, (__bf16 *)X, nullptr, ntok, H, e->cus, st));
+            else if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_RESID_F32>(CTX, wp + (size_t)3 * H * H, w + l.ob, X, nullptr, e->PRE, ntok, H, e->cus, st));
             else SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(CTX, e->w16 + l.ow, w + l.ob, X, nullptr, e->PRE, ntok, H, H, st));
         }
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
-        SHODH_HIP_TRY(hipGetLastError());
+        if (!ffn_fused) {
+            hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
+            SHODH_HIP_TRY(hipGetLastError());
+        }
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS_GELU>(X, w + l.iw, w + l.ib, nullptr, FF, ntok, I, H, st));
             SHODH_TRY(gemm_f32<EPI_BIAS_RESID_F32>(FF, w + l.dw, w + l.db, X, e->PRE, ntok, H, I, st));
         } else {
-            static const bool unfused = getenv("SHODH_ENC_UNFUSED") && atoi(getenv("SHODH_ENC_UNFUSED"));     // speed only: the round-1 three-kernel form
-            if (stream_gemm && I == FF_I && !unfused) {
+            if (ffn_fused) {
                 // FFN up + GELU + FFN down + residual + LayerNorm in one kernel, in place (a workgroup reads and writes only its own rows)
                 const int n_tiles = (ntok + FF_TOK - 1) / FF_TOK;
                 auto launch_ffn = [&](auto kern) -> int {
                     SHODH_TRY(ensure_dynamic_lds((const void *)kern, FF_LDS));
                     hipLaunchKernelGGL(kern, dim3(n_tiles < e->cus ? n_tiles : e->cus), dim3(512), FF_LDS, st, (const __bf16 *)X, wp + (size_t)4 * H * H,
-                                       e->w2p16 + (size_t)li * I * H, w + l.ib, w + l.db, w + l.ln2g, w + l.ln2b, (__bf16 *)X, ntok, eps);
+                                       e->w2p16 + (size_t)li * I * H, w + l.ib, w + l.db, w + l.ln2g, w + l.ln2b, w + l.ln1g, w + l.ln1b, (__bf16 *)X, ntok, eps);
                     SHODH_HIP_TRY(hipGetLastError());
                     return SHODH_OK;
                 };
@@ -874,6 +887,18 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
                     case 32: SHODH_TRY(launch_ffn(ffn_fused_kernel<32>)); break;
                     case 3: SHODH_TRY(launch_ffn(ffn_fused_kernel<3>)); break;
                     case 63: SHODH_TRY(launch_ffn(ffn_fused_kernel<63>)); break;
+                    case 64: SHODH_TRY(launch_ffn(ffn_fused_kernel<64>)); break;
+                    case 128: SHODH_TRY(launch_ffn(ffn_fused_kernel<128>)); break;
+                    case 192: SHODH_TRY(launch_ffn(ffn_fused_kernel<192>)); break;
+                    case 51: SHODH_TRY(launch_ffn(ffn_fused_kernel<51>)); break;
+                    case 31: SHODH_TRY(launch_ffn(ffn_fused_kernel<31>)); break;
+                    case 62: SHODH_TRY(launch_ffn(ffn_fused_kernel<62>)); break;
+                    case 47: SHODH_TRY(launch_ffn(ffn_fused_kernel<47>)); break;
+                    case 61: SHODH_TRY(launch_ffn(ffn_fused_kernel<61>)); break;
+                    case 19: SHODH_TRY(launch_ffn(ffn_fused_kernel<19>)); break;
+                    case 18: SHODH_TRY(launch_ffn(ffn_fused_kernel<18>)); break;
+                    case 50: SHODH_TRY(launch_ffn(ffn_fused_kernel<50>)); break;
+                    case 30: SHODH_TRY(launch_ffn(ffn_fused_kernel<30>)); break;
                     default: SHODH_TRY(launch_ffn(ffn_fused_kernel<0>)); break;
                 }
 #else

@@ -36,7 +36,7 @@ constexpr int FF_H = 384, FF_I = 1536, FF_KS = 24, FF_NB = 12, FF_CHUNKS = 48, F
 constexpr int FF_PKG = 24 * 1024;              // bytes of one package (W1 chunk: 24 k-steps x 1 KiB; W2 chunk: 12 n-blocks x 2 k-steps x 1 KiB)
 constexpr int FF_SLOTS = 5;
 constexpr int FF_HB = 2 * 4 * 2048;            // hb: 2 buffers x 4 token blocks x 2 KiB
-constexpr int FF_LDS = FF_SLOTS * FF_PKG + FF_HB + FF_I * 4 + 3 * FF_H * 4;      // + b1, b2, gamma, beta in LDS
+constexpr int FF_LDS = FF_SLOTS * FF_PKG + FF_HB + FF_I * 4 + 5 * FF_H * 4;      // + b1, b2, gamma, beta, and the input LayerNorm's gamma, beta in LDS
 
 // W2 [384][1536] row-major -> [chunk c][n-block nb][k-step ks][lane][8]: element = W2[32 nb + (lane & 31)][32 c + f(8 ks + j, lane >> 5)],
 // f(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi  -- the feature that register r of half-wave hi holds in the 32x32 C layout
@@ -59,7 +59,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // gelu(x) = x Phi(x) with Phi(x) = 0.5 + xc P(xc^2), xc = clamp(x, -4, 4), P of degree 7 (least-squares fit at Chebyshev nodes):
 // |error| <= 3e-4 absolute over all x (bf16 rounds the result to 2^-9 relative anyway), 12 VALU operations and no transcendental.
 // One wave per SIMD hides about six issue slots per MFMA: the erf form of the other kernels (~25 operations per value) made this
-// kernel VALU-issue-bound at 3460 cycles per iteration against 1536 of MFMA work.
+// kernel VALU-issue-bound at 3460 cycles per iteration against 1536 of MFMA work. (Tried: pairs of values on the packed FP32 pipe,
+// v_pk_fma_f32 -- 916 us per layer against 824: the constants need register pairs and the packed form issues no faster here.)
 __device__ __forceinline__ float ffn_gelu(float x) {
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
     const float u = xc * xc;
@@ -80,7 +81,8 @@ template <int ABL>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* may alias out: in place */, const __bf16 *__restrict__ W1p /* fragment-major FFN-up, chunk-major */,
                                                             const __bf16 *__restrict__ W2p /* pack_w2_kernel */, const float *__restrict__ b1,
                                                             const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            __bf16 *out, int M, float eps) {
+                                                            const float *__restrict__ in_gamma /* LayerNorm applied to X on the way in, or null */,
+                                                            const float *__restrict__ in_beta, __bf16 *out, int M, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     unsigned char *hbs = smem + FF_SLOTS * FF_PKG;
@@ -90,9 +92,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
     const bool producer = wave < 4;                      // wave-uniform
     const int tb = wave & 3;
     const int n_tiles = (M + FF_TOK - 1) / FF_TOK;
-    float *b2s = b1s + FF_I, *gms = b2s + FF_H, *bts = gms + FF_H;
+    float *b2s = b1s + FF_I, *gms = b2s + FF_H, *bts = gms + FF_H, *igs = bts + FF_H, *ibs = igs + FF_H;
+    const bool in_ln = in_gamma != nullptr;              // uniform
     for (int i = tid; i < FF_I; i += 512) b1s[i] = b1[i];
-    for (int i = tid; i < FF_H; i += 512) { b2s[i] = b2[i]; gms[i] = gamma[i]; bts[i] = beta[i]; }
+    for (int i = tid; i < FF_H; i += 512) { b2s[i] = b2[i]; gms[i] = gamma[i]; bts[i] = beta[i]; igs[i] = in_ln ? in_gamma[i] : 1.0f; ibs[i] = in_ln ? in_beta[i] : 0.0f; }
     __syncthreads();                                     // the consumers read b2 before the first pipeline barrier
 
     const unsigned char *w1b = reinterpret_cast<const unsigned char *>(W1p), *w2b = reinterpret_cast<const unsigned char *>(W2p);
@@ -149,6 +152,35 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
 #pragma unroll
                 for (int ks = 0; ks < FF_KS; ++ks) bx[ks] = xp[ks * 2];
             }
+            if (in_ln) {
+                // X holds the PRE-norm sum (attention output + residual): its LayerNorm happens here, on the fragments this lane holds
+                // (192 of its token's 384 values; the other half-wave has the rest). The normalised rows are both this kernel's input
+                // and its residual (handed to the consumer from these registers), and nobody else needs them.
+                float s1 = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < FF_KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s1 += (float)bx[ks][j];
+                s1 += __shfl_xor(s1, 32);
+                const float mean = s1 * (1.0f / (float)FF_H);
+                float vs = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < FF_KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = (float)bx[ks][j] - mean; vs += d * d; }
+                vs += __shfl_xor(vs, 32);
+                const float inv = 1.0f / __builtin_sqrtf(vs * (1.0f / (float)FF_H) + eps);
+#pragma unroll
+                for (int ks = 0; ks < FF_KS; ++ks) {
+                    const f32x4f g0 = *reinterpret_cast<const f32x4f *>(igs + 16 * ks + 8 * hi), g1 = *reinterpret_cast<const f32x4f *>(igs + 16 * ks + 8 * hi + 4);
+                    const f32x4f c0 = *reinterpret_cast<const f32x4f *>(ibs + 16 * ks + 8 * hi), c1 = *reinterpret_cast<const f32x4f *>(ibs + 16 * ks + 8 * hi + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bx[ks][j] = (__bf16)(((float)bx[ks][j] - mean) * inv * g0[j] + c0[j]);
+                        bx[ks][4 + j] = (__bf16)(((float)bx[ks][4 + j] - mean) * inv * g1[j] + c1[j]);
+                    }
+                }
+            }
             f32x16f h_cur = zero16, h_odd = zero16, h_prev = zero16;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -163,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
                 f32x4f bv[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4f *>(b1s + (ge ? it - 1 : 0) * 32 + 8 * g + 4 * hi);
-                constexpr int D = 4;
+                constexpr int D = (ABL & 128) ? 7 : 4;
                 bf16x8f ring[8];
 #pragma unroll
                 for (int q = 0; q < D; ++q) ring[q] = a1[(ABL & 32) ? 0 : q * 64];
@@ -244,12 +276,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const __bf16 *X /* ma
                     constexpr int D = 6;
                     bf16x8f ring[8];
 #pragma unroll
-                    for (int q = 0; q < D; ++q) ring[q] = a2[(ABL & 32) ? 0 : q * 64];
+                    for (int q = 0; q < D; ++q) ring[q] = a2[(ABL & 32) ? 0 : ((ABL & 64) ? ((q % FF_NB) * 2 + q / FF_NB) * 64 : q * 64)];
 #pragma unroll
                     for (int st = 0; st < FF_KS; ++st) {       // st = 2 nb + ks
-                        if (st + D < FF_KS && !(ABL & 32)) ring[(st + D) & 7] = a2[(st + D) * 64];
-                        if (ABL & 8) { asm volatile("" : "+v"(ring[st & 7]), "+v"(hb[st & 1])); }
-                        else y[st >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], hb[st & 1], y[st >> 1], 0, 0, 0);
+                        // (variant 64: all n-blocks of k-step 0, then of k-step 1 -- no MFMA depends on its predecessor)
+                        auto frag = [&](int s_) { return (ABL & 64) ? ((s_ % FF_NB) * 2 + s_ / FF_NB) * 64 : s_ * 64; };
+                        const int nb_ = (ABL & 64) ? st % FF_NB : st >> 1, ks_ = (ABL & 64) ? st / FF_NB : st & 1;
+                        if (st + D < FF_KS && !(ABL & 32)) ring[(st + D) & 7] = a2[frag(st + D)];
+                        if (ABL & 8) { asm volatile("" : "+v"(ring[st & 7]), "+v"(hb[ks_])); }
+                        else y[nb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[st & 7], hb[ks_], y[nb_], 0, 0, 0);
                         if ((st & 1) == 1) { if (st < 12) issue_piece(pa, st >> 1); else issue_piece(pb, (st >> 1) - 6); }     // one piece every second MFMA
                         __builtin_amdgcn_sched_barrier(0);
                     }
