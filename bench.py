@@ -288,6 +288,29 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         torch.cuda.empty_cache()
         done(e, t0)
 
+    # -- SHODH_TEXT_DIM 768 / 1024 (minilm.rs:313-322): the 256-thread pre-scan kernel, next to the exact-order scan it replaces ------
+    if want("flat_1M_d768_b256", "flat_1M_d1024_b256", "bigdim"):
+        for bd in (768, 1024):
+            t0 = time.perf_counter()
+            n = 1_000_000
+            qp = [synth_rows(torch, 256, bd, SEED + 40 + i, dev) for i in range(4)]
+            rows = synth_rows(torch, n, bd, SEED + 39, dev, adversarial_queries=qp[0])
+            idx = S.VamanaIndex(S.VamanaConfig(dimension=bd, reserve_rows=n))
+            idx.build(rows)
+            dead = tombstone(torch, idx, n, 0.05, SEED + 38, dev)
+            e = {"name": "flat_1M_d%d_b256" % bd, "workload": "1M memories x %d-d f32 (5 %% tombstoned), brute-force cosine top-10, batch 256" % bd,
+                 "rows": n, "rows_live": n - len(dead)}
+            e.update(run_flat_config(torch, dev, idx, qp, 10, 20, 4, n, n - len(dead), bd))
+            idx.close(); del idx
+            torch.cuda.empty_cache()
+            ex = S.VamanaIndex(S.VamanaConfig(dimension=bd, reserve_rows=n, scan_mode=L.SCAN_EXACT))      # what these dimensions ran before
+            ex.build(rows)
+            o = (torch.empty((256, 10), dtype=torch.int32, device=dev), torch.empty((256, 10), dtype=torch.float32, device=dev), torch.empty((256,), dtype=torch.int32, device=dev))
+            e["exact_order_scan_ms_per_step"] = round(timed_steps(torch, lambda i: ex.search_batch_device(qp[i % 4], 10, out=o), 3, 1) * 1e3, 3)
+            ex.close(); del ex, rows
+            torch.cuda.empty_cache()
+            done(e, t0)
+
     # -- the multi-GPU index behind the C ABI (shodh_sharded_index_*: RCCL all-gather + device merge inside the library), host-pointer API
     if want("sharded_c_abi_1M_b256"):
         t0 = time.perf_counter()

@@ -412,6 +412,216 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #endif
 }
 
+// ---- dimensions 768 and 1024 ---------------------------------------------------------------------------------------------------
+// 256 resident queries x 1024 dimensions of fp16 are 512 KiB -- the whole vector register file of a CU -- so the kernel above (a wave
+// = 32 queries resident as dim/16 B fragments next to a second wave on the same SIMD) stops at dim 512. Here a workgroup is FOUR waves,
+// one per SIMD with the full 512 registers: 128 queries per workgroup, and a 256-query pass is two workgroups (blockIdx.y = 2 * pass +
+// sub-pass) that walk the same tiles side by side -- the launch is sized so that both halves of a pass are resident together on the same
+// XCD (grid.x = CUs / 2), which makes the second reader of a tile an L2 hit rather than a second trip to HBM. A 64-row tile is 128 KiB at
+// dim 1024, so it goes through the LDS as two 32-row halves (two buffers). One wave per SIMD has nobody to hide an LDS-DMA's issue stall
+// behind (100-185 cycles each, see above), so the next half travels HBM -> registers (issued before the MFMA chain, 64 spare registers)
+// -> ds_write after the chain. Everything downstream (tile numbering, thresholds, candidate slots, final stage) is shared with the
+// 512-thread kernel: same tile = 64 rows, same 256-query pass layout.
+constexpr int MFB_TR = 32;
+template <int MODE, int KSTEPS>
+__global__ __launch_bounds__(256, 1) void mfma_scan_big_kernel(MfmaArgs a) {
+    constexpr int NT = 256;
+    constexpr int DIM = KSTEPS * 16;
+    constexpr int CPR = KSTEPS * 2;
+    constexpr int PITCH = DIM * 2;
+    constexpr int HALF_BYTES = MFB_TR * PITCH;
+    constexpr int NPC = MFB_TR * CPR / NT;     // 16-B pieces per thread and half tile (12 / 16)
+    constexpr int D = 6, RING = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + 2 * HALF_BYTES);
+    uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
+    uint32_t *qcount = eq_q + MF_EQ_CAP;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t pass = blockIdx.y >> 1, sub = blockIdx.y & 1;
+    const uint32_t q_local = sub * 128 + wave * 32 + l31;
+    const bool active = (uint32_t)(pass * MF_BPAD + sub * 128 + wave * 32) < a.nq;      // wave-uniform
+    if ((uint32_t)(pass * MF_BPAD + sub * 128) >= a.nq) {        // a sub-pass of nothing but padding: no reason to stream the corpus for it
+        if (MODE != MF_MODE_EMIT)                                 // (its sampled maxima still get defined values)
+            for (uint32_t sel = blockIdx.x; sel < a.n_sel_tiles; sel += gridDim.x)
+                if (tid < 128) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + sub * 128 + tid] = 0.0f;
+        return;
+    }
+    if (MODE == MF_MODE_EMIT) {
+        qcount[tid] = 0;
+        if (tid < 128) {
+            uint64_t *sl = a.slots + (((size_t)pass * MF_BPAD + sub * 128 + tid) * gridDim.x + blockIdx.x) * MF_SLOTS;
+#pragma unroll
+            for (int j = 0; j < MF_SLOTS; ++j) sl[j] = KEY_NONE;
+        }
+    }
+    // piece p = i * NT + tid of a half tile: LDS chunk (row, slot) <- global chunk (row, slot ^ (row & 15) within its group of 16)
+    uint32_t srcoff[NPC], dstoff[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int pc = i * NT + tid, row = pc / CPR, slot = pc % CPR;
+        const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
+        srcoff[i] = (uint32_t)(row * PITCH + c * 16);
+        dstoff[i] = (uint32_t)(row * PITCH + slot * 16);
+    }
+    const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
+    const size_t tile_bytes_g = (size_t)a.tile_stride * MF_TR * DIM * 2;
+
+    half8 bq[KSTEPS];
+    {
+        const half8 *qp = reinterpret_cast<const half8 *>(a.q_h) + ((size_t)pass * 8 + sub * 4 + wave) * KSTEPS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bq[ks] = qp[ks * 64];
+    }
+    float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
+    if (a.ablate & 8u) thr_l = __builtin_inff();
+    const int sw = l31 & 15;
+    int aoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4);
+
+    // survivors: the same wave-private queues and candidate slots as the 512-thread kernel
+    uint64_t *wq_key = eq_key + wave * MF_WQ_CAP;
+    uint32_t *wq_q = eq_q + wave * MF_WQ_CAP;
+    uint32_t wq_n = 0;
+    uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;
+    auto emit_direct = [&](uint64_t key, uint32_t ql) {
+        const uint32_t row = (uint32_t)key;
+        if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) return;      // tombstoned (vamana.rs:1175-1177)
+        const uint32_t s_ = atomicAdd(qcount + ql, 1u);
+        if (s_ < (uint32_t)MF_SLOTS) {
+            my_slots[(size_t)ql * gridDim.x * MF_SLOTS + s_] = key;
+        } else {
+            const size_t qi = (size_t)pass * MF_BPAD + ql;
+            const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
+            if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
+        }
+    };
+    auto drain = [&]() {
+        const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
+        for (uint32_t i = lane; i < n; i += 64) emit_direct(wq_key[i], wq_q[i]);
+        wq_n = 0;
+    };
+    auto emit_block = [&](const floatx16 &c, uint64_t brow0) {
+        const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
+        const uint32_t lim = left < 64 ? (uint32_t)left : 64u;
+        const uint32_t wq_n0 = wq_n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t roff = (r & 3) + 8 * (r >> 2);
+            const bool hit = c[r] >= thr_l && roff < lim;
+            const uint64_t b = __builtin_amdgcn_ballot_w64(hit);
+            if (__builtin_expect(b != 0, 0)) {
+                const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (hit && slot < (uint32_t)MF_WQ_CAP) {
+                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    wq_q[slot] = q_local;
+                }
+                wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
+            }
+        }
+        if (__builtin_expect(wq_n > (uint32_t)MF_WQ_CAP, 0)) {      // a dense block: straight to the candidate slots (see the kernel above)
+            wq_n = wq_n0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t roff = (r & 3) + 8 * (r >> 2);
+                if (c[r] >= thr_l && roff < lim) emit_direct(make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff)), q_local);
+            }
+        }
+    };
+
+    // The tiles of this workgroup: sel = blockIdx.x + i * gridDim.x, each as two 32-row halves (LDS buffer 0 / 1). Every half is
+    // fetched into registers TWO halves ahead (sets A and B, alternating) and written to its LDS buffer one half ahead: with a single
+    // half in flight the kernel ran at HBM latency, not bandwidth (64 KiB per CU per ~2.5 us round trip: 874 us per 256 queries
+    // at 1M x 1024).
+    const uint32_t step = gridDim.x;
+    const uint32_t n_mine = blockIdx.x < a.n_sel_tiles ? (a.n_sel_tiles - blockIdx.x + step - 1) / step : 0u;
+    const uint32_t n_half = 2 * n_mine;
+    u32x4 stg_a[NPC], stg_b[NPC];
+    auto src_of = [&](uint32_t u) -> const unsigned char * {
+        const uint32_t uc = u < n_half ? u : n_half - 1;              // past the end: a harmless repeat of the last half
+        const uint32_t sel = blockIdx.x + (uc >> 1) * step;
+        return rows_b + (size_t)sel * tile_bytes_g + (size_t)(uc & 1) * HALF_BYTES;      // the shadow slab is padded to whole tiles
+    };
+    auto stage = [&](uint32_t buf, const u32x4 *stg) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) *reinterpret_cast<u32x4 *>(smem + buf * HALF_BYTES + dstoff[i]) = stg[i];
+    };
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float tile_m = -__builtin_inff();
+    // one half tile: the MFMA chain over LDS buffer `h`, then its epilogue
+    auto compute = [&](uint32_t h, uint32_t sel) {
+        const unsigned char *buf = smem + h * HALF_BYTES;
+        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + h * MFB_TR;
+        if (active) {
+            // (two accumulator chains, even / odd k-steps, measured no faster at 768 and slower at 1024, where they spill)
+            floatx16 acc = zero16;
+            half8 ring[RING];
+#pragma unroll
+            for (int st = 0; st < D; ++st) ring[st % RING] = *reinterpret_cast<const half8 *>(buf + aoff[st & 7] + (st >> 3) * 256);
+#pragma unroll
+            for (int st = 0; st < KSTEPS; ++st) {
+                if (st + D < KSTEPS) ring[(st + D) % RING] = *reinterpret_cast<const half8 *>(buf + aoff[(st + D) & 7] + ((st + D) >> 3) * 256);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keeps the A fragments D steps ahead (without it the scheduler folds the ring into one register
+            }                                           // quad and every MFMA waits out its own LDS read)
+            if (MODE == MF_MODE_EMIT) {
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                if (__builtin_amdgcn_ballot_w64(m >= thr_l) != 0) emit_block(acc, row0);
+                if (wq_n >= (uint32_t)MF_WQ_CAP / 2) drain();
+            } else {
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t g0 = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (g0 < a.n_rows) m = fmaxf(m, acc[r]);
+                }
+                tile_m = fmaxf(tile_m, m);
+                if (h) {
+                    tile_m = fmaxf(tile_m, __shfl_xor(tile_m, 32));
+                    if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = tile_m * MF_INV_SCALE2;
+                    tile_m = -__builtin_inff();
+                }
+            }
+        } else if (MODE != MF_MODE_EMIT && h && lane < 32) {
+            a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;      // padding queries: defined values
+        }
+    };
+    if (n_mine) {
+        {
+            const unsigned char *s0 = src_of(0), *s1 = src_of(1);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) stg_a[i] = *reinterpret_cast<const u32x4 *>(s0 + srcoff[i]);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) stg_b[i] = *reinterpret_cast<const u32x4 *>(s1 + srcoff[i]);
+        }
+        stage(0, stg_a);
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < n_mine; ++i) {
+        const uint32_t sel = blockIdx.x + i * step;
+        {   // half 0 from buffer 0; set A takes half 0 of the next tile, set B (half 1 of this tile) goes to buffer 1
+            const unsigned char *sn = src_of(2 * i + 2);
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) stg_a[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
+            compute(0, sel);
+            stage(1, stg_b);
+            __syncthreads();
+        }
+        {   // half 1 from buffer 1; set B takes half 1 of the next tile, set A goes to buffer 0
+            const unsigned char *sn = src_of(2 * i + 3);
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) stg_b[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
+            compute(1, sel);
+            stage(0, stg_a);
+            __syncthreads();
+        }
+    }
+    if (MODE == MF_MODE_EMIT) drain();
+}
+
 // ---- conversions ------------------------------------------------------------------------------------
 // rows f32 -> fp16(256 x) shadow; also folds max row norm^2, max |x| and a non-finite flag into stats.
 // stats[0] = max norm^2 (float bits, atomicMax on uint works for non-negative floats)
@@ -683,9 +893,9 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     uint64_t kv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; kv[j] = slots_q[i < n_main ? i : 0]; }
-    float qv[2];
+    float qv[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const uint32_t i = j * 256 + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 512 on this path
+    for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 1024 on this path
     const uint32_t n_ovf = a.cand_cnt[q];
     bool bad = a.fallback[q] != 0 || n_ovf > a.cand_cap;
     const uint32_t n = n_main + (bad ? 0u : n_ovf);
@@ -695,7 +905,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     PROF_DECL
     if (!bad) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const uint32_t i = j * 256 + tid; if (i < a.dim) qs[i] = qv[j]; }
+        for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; if (i < a.dim) qs[i] = qv[j]; }
         if (tid == 0) { *fcnt = 0; *ecnt = 0; }
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
         uint64_t *list = a.cand + (size_t)q * a.cand_cap;
@@ -774,8 +984,11 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             const uint32_t dim = a.dim, d4 = dim >> 2;
             const f32x4 *qs4 = reinterpret_cast<const f32x4 *>(qs);
             const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            const f32x4 qa = ln < d4 ? qs4[ln] : z4, qb = ln + 64 < d4 ? qs4[ln + 64] : z4;      // dim <= 512: two float4 groups per lane
+            const f32x4 qa = ln < d4 ? qs4[ln] : z4, qb = ln + 64 < d4 ? qs4[ln + 64] : z4;      // two float4 groups per lane up to dim 512,
             const uint32_t ga = ln < d4 ? ln : 0u, gb = ln + 64 < d4 ? ln + 64 : 0u;
+            const bool wide = d4 > 128;                                                             // four up to dim 1024 (block-uniform)
+            const f32x4 qc = ln + 128 < d4 ? qs4[ln + 128] : z4, qd = ln + 192 < d4 ? qs4[ln + 192] : z4;
+            const uint32_t gc = ln + 128 < d4 ? ln + 128 : 0u, gd = ln + 192 < d4 ? ln + 192 : 0u;
             const uint32_t n_groups = (n + 63) >> 6;
             for (uint32_t g = wv; g < n_groups; g += 4) {
                 const uint32_t i = g * 64 + ln;
@@ -800,12 +1013,33 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                         const f32x4 *rp = reinterpret_cast<const f32x4 *>(a.rows + (size_t)r_u * dim);
                         va[u] = rp[ga]; vb[u] = rp[gb];
                     }
+                    float pp[R];
 #pragma unroll
                     for (int u = 0; u < R; ++u) {
                         float p = qa.x * va[u].x;
                         p = __builtin_fmaf(qa.y, va[u].y, p); p = __builtin_fmaf(qa.z, va[u].z, p); p = __builtin_fmaf(qa.w, va[u].w, p);
                         p = __builtin_fmaf(qb.x, vb[u].x, p); p = __builtin_fmaf(qb.y, vb[u].y, p);
                         p = __builtin_fmaf(qb.z, vb[u].z, p); p = __builtin_fmaf(qb.w, vb[u].w, p);
+                        pp[u] = p;
+                    }
+                    if (wide) {
+#pragma unroll
+                        for (int u = 0; u < R; ++u) {
+                            const uint32_t r_u = (uint32_t)__builtin_amdgcn_readlane((int)myrow, src[u]);
+                            const f32x4 *rp = reinterpret_cast<const f32x4 *>(a.rows + (size_t)r_u * dim);
+                            va[u] = rp[gc]; vb[u] = rp[gd];
+                        }
+#pragma unroll
+                        for (int u = 0; u < R; ++u) {
+                            float p = pp[u];
+                            p = __builtin_fmaf(qc.x, va[u].x, p); p = __builtin_fmaf(qc.y, va[u].y, p); p = __builtin_fmaf(qc.z, va[u].z, p); p = __builtin_fmaf(qc.w, va[u].w, p);
+                            p = __builtin_fmaf(qd.x, vb[u].x, p); p = __builtin_fmaf(qd.y, vb[u].y, p); p = __builtin_fmaf(qd.z, vb[u].z, p); p = __builtin_fmaf(qd.w, vb[u].w, p);
+                            pp[u] = p;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        float p = pp[u];
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
                         if ((uint32_t)u < cnt_r && (int)ln == src[u]) s2 = p;
@@ -983,7 +1217,7 @@ struct MfmaPlan {
 
 uint32_t topk_capacity(uint32_t k);   // flat_exact.hip
 
-bool mfma_supported(uint32_t dim) { return dim == 128 || dim == 256 || dim == 384 || dim == 512; }   // (final_stage_kernel loads the query with two loads per thread: dim <= 512)
+bool mfma_supported(uint32_t dim) { return dim == 128 || dim == 256 || dim == 384 || dim == 512 || dim == 768 || dim == 1024; }   // (768 / 1024: mfma_scan_big_kernel; final_stage_kernel holds the query in four loads per thread: dim <= 1024)
 
 MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus) {
     MfmaPlan p{};
@@ -1025,7 +1259,7 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     if (fc < 2048) fc = 2048;
     p.fcap = next_pow2(fc);
     p.topk_cap = topk_capacity(k);
-    p.grid_x = cus;
+    p.grid_x = dim > 512 ? (cus >= 2 ? cus / 2 : 1) : cus;      // big dimensions: two workgroups per pass and tile sequence (mfma_scan_big_kernel)
     return p;
 }
 
@@ -1057,6 +1291,25 @@ template <int MODE>
 // ev0 / ev1 (optional): start / stop timestamps of THIS dispatch (hipExtLaunchKernel attaches them to the kernel's own packet;
 // separate hipEventRecord calls are extra packets in the stream and cost 3-5 us each between two kernels)
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+    if (a.dim > 512) {
+        const size_t lds = 2ull * MFB_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
+        dim3 grid((uint32_t)p.grid_x, p.passes * 2);
+        if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
+#define SHODH_LAUNCH_BIG(KS)                                                                                        \
+    case KS:                                                                                                       \
+        SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big_kernel<MODE, KS>, lds));                           \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((mfma_scan_big_kernel<MODE, KS>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL((mfma_scan_big_kernel<MODE, KS>), grid, dim3(256), lds, st, a);                     \
+        break;
+        switch (p.ksteps) {
+            SHODH_LAUNCH_BIG(48)
+            SHODH_LAUNCH_BIG(64)
+            default: set_error("MFMA scan: unsupported dim %u", a.dim); return SHODH_ERR_UNSUPPORTED;
+        }
+#undef SHODH_LAUNCH_BIG
+        SHODH_HIP_TRY(hipGetLastError());
+        return SHODH_OK;
+    }
     const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
     const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);

@@ -210,6 +210,42 @@ def test_mfma_with_tombstones_and_dims(S, oracle):
     check_against_oracle(oracle, idx, rows, q, 10, 0, None)
 
 
+@pytest.mark.parametrize("dim,order", [(768, 0), (1024, 0), (768, 1), (1024, 1)])
+def test_mfma_prescan_at_dims_768_and_1024(S, oracle, dim, order):
+    """SHODH_TEXT_DIM 768 / 1024 (minilm.rs:313-322): the 256-thread pre-scan kernel (128 resident queries per workgroup, two
+    workgroups per pass). 300 queries = two passes, the second partly padding; the corpus ends inside a 64-row tile and inside
+    its first 32-row half; tombstones; then a corpus dense enough for the level-2 f32 filter (four float4 groups per lane)."""
+    n = 40000 + 17
+    q = synth.queries(300, dim)
+    rows = synth.corpus(n, dim, queries=q[:40])
+    idx = make_index(S, dim=dim, order=order, scan_mode=2)
+    idx.build(rows)
+    check_against_oracle(oracle, idx, rows, q[:64], 10, order)
+    st = idx.scan_stats()
+    assert st["sampled_rows"] > 0 and st["overflowed"] == 0
+    ids, dist, counts = idx.search_batch(q, 10)               # both passes, all sub-passes
+    for i in (0, 127, 128, 255, 256, 299):
+        e_ids, e_dist = oracle.brute_force_search(rows, q[i], 10, order=order, select=True)
+        assert ids[i].tolist() == e_ids.tolist() and dist[i].tobytes() == e_dist.tobytes(), i
+    deleted = synth.tombstones(n)
+    deleted[ids[:64, 0]] = 1
+    idx.mark_deleted_many(np.nonzero(deleted)[0].astype(np.uint32))
+    check_against_oracle(oracle, idx, rows, q[:48], 10, order, deleted)
+    check_against_oracle(oracle, idx, rows, q[:3], 120, order, deleted)
+    # dense corpus: every row within a narrow cone, thousands inside the fp16 window of each query
+    rng = np.random.default_rng(dim + order)
+    axis = rng.standard_normal(dim).astype(f32); axis /= np.linalg.norm(axis)
+    d = (axis[None, :] + f32(0.006) * rng.standard_normal((30000, dim)).astype(f32)).astype(f32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    qd = (axis[None, :] + f32(0.004) * rng.standard_normal((8, dim)).astype(f32)).astype(f32)
+    qd = (qd / np.linalg.norm(qd, axis=1, keepdims=True)).astype(f32)
+    idx2 = make_index(S, dim=dim, order=order, scan_mode=2)
+    idx2.build(d)
+    check_against_oracle(oracle, idx2, d, qd, 10, order)
+    st2 = idx2.scan_stats()
+    assert st2["level2"] >= 1, st2
+
+
 def test_mfma_adversarial_falls_back_to_exact(S, oracle):
     n = 20000
     base = synth.queries(1)[0]
