@@ -24,9 +24,24 @@
 
 namespace shodh {
 
+#ifdef SHODH_PROF
+#define VGP_DECL long long vp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vq_ = wall_clock64();
+#define VGP(i) { const long long t_ = wall_clock64(); vp_[i] += t_ - vq_; vq_ = t_; }
+#else
+#define VGP_DECL
+#define VGP(i)
+#endif
+#ifdef SHODH_PROF
+#define VGP_N vp_[7] += 1;
+#else
+#define VGP_N
+#endif
+
 constexpr int VG_W_CAP = 1024;     // beam: k (+ over-fetch for tombstones), search_list_size, max_degree
 constexpr int VG_C_CAP = 2048;     // frontier entries kept (only those not worse than the worst of `w` can ever be expanded)
-constexpr int VG_ROWS = 8;         // neighbour rows staged at a time
+constexpr int VG_ROWS = 32;        // neighbour rows scored at a time (dim <= 512; 8 above: the staging area of the 8-chain order has to fit the LDS)
+constexpr int VG_HASH = 8192;     // entries of the visited set kept in LDS (a walk that outgrows 60 % of it moves to the one-bit-per-row map in memory)
+constexpr int VG_U = 48;           // float4 loads per lane in flight in one round of vg_distances
 constexpr int VG_MAXDEG = 128;     // neighbours per node the kernels handle (max_degree + 1 <= this)
 
 struct VgGraph {
@@ -42,24 +57,30 @@ struct VgLds {
     float *q;               // [dim]
     uint64_t *w;            // [VG_W_CAP]
     uint64_t *cand;         // [VG_C_CAP]
-    float *stage;           // [VG_ROWS][dim + 4]  raw rows
-    float *tsum;            // [VG_ROWS][dim / 4 + 1] group sums (scalar-4) / [VG_ROWS][8] chain sums (AVX2)
+    float *stage;           // [rows per batch][dim + 4]  raw rows (8-chain order only)
+    float *tsum;            // [rows per batch][dim / 4 + 1] group sums (scalar-4) / [..][8] chain sums (AVX2)
+    uint32_t rpb;           // rows per batch
+    uint32_t *hset;         // [VG_HASH] visited set: open addressing, 0xFFFFFFFF = empty
     uint32_t *newid;        // [VG_MAXDEG] unvisited neighbours of the current node, in list order
     float *newd;            // [VG_MAXDEG] their distances
     uint32_t *pr, *pr2;     // [VG_MAXDEG] pruned lists (build)
     float *dne, *dne2;      // [VG_MAXDEG] node -> kept neighbour distances (build)
 };
-__host__ __device__ inline size_t vg_lds_bytes(uint32_t dim) {
-    return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + (size_t)VG_ROWS * (dim + 4) * 4 + (size_t)VG_ROWS * (dim / 4 + 1) * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
+__host__ __device__ inline uint32_t vg_rows_per_batch(uint32_t dim) { return dim <= 512 ? (uint32_t)VG_ROWS : 8u; }
+__host__ __device__ inline size_t vg_lds_bytes(uint32_t dim, uint32_t order) {
+    const size_t rpb = vg_rows_per_batch(dim), stage = order == SHODH_ORDER_AVX2 ? rpb * (dim + 4) * 4 : 0;      // scalar-4 sums straight from registers
+    return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + VG_HASH * 4 + stage + rpb * (dim / 4 + 1) * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
 }
-__device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim) {
+__device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t order) {
     VgLds l;
     l.w = reinterpret_cast<uint64_t *>(smem);
     l.cand = l.w + VG_W_CAP;
-    l.q = reinterpret_cast<float *>(l.cand + VG_C_CAP);
+    l.hset = reinterpret_cast<uint32_t *>(l.cand + VG_C_CAP);
+    l.q = reinterpret_cast<float *>(l.hset + VG_HASH);
+    l.rpb = vg_rows_per_batch(dim);
     l.stage = l.q + dim;
-    l.tsum = l.stage + (size_t)VG_ROWS * (dim + 4);
-    l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)VG_ROWS * (dim / 4 + 1));
+    l.tsum = l.stage + (order == SHODH_ORDER_AVX2 ? (size_t)l.rpb * (dim + 4) : 0);
+    l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)l.rpb * (dim / 4 + 1));
     l.newd = reinterpret_cast<float *>(l.newid + VG_MAXDEG);
     l.pr = reinterpret_cast<uint32_t *>(l.newd + VG_MAXDEG);
     l.pr2 = l.pr + VG_MAXDEG;
@@ -71,33 +92,73 @@ __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim) {
 __device__ __forceinline__ float vg_key_dist(uint64_t k) { return order_key_inv((uint32_t)(k >> 32)); }
 
 // distances -dot(q, row) of m rows (ids in l.newid) in the reference's order -> l.newd. One wave; dim % 8 == 0.
+// Up to 32 rows per batch, and every 16-byte piece of a batch is requested before the first is used (VG_U per lane and round: a hop of
+// the walk is a chain of dependent round trips, the rows are the longest of them and used to be fetched eight rows at a time).
 __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane) {
-    const uint32_t dim = g.dim, d4 = dim >> 2, sp = dim + 4, tp = d4 + 1;
-    for (uint32_t b0 = 0; b0 < m; b0 += VG_ROWS) {
-        const uint32_t nb = m - b0 < (uint32_t)VG_ROWS ? m - b0 : (uint32_t)VG_ROWS;
-        // stage nb raw rows: nb * d4 float4, consecutive lanes along a row, every load of the batch in flight
-        for (uint32_t e0 = 0; e0 < nb * d4; e0 += 64 * 4) {
-            float4 v[4];
+    const uint32_t dim = g.dim, d4 = dim >> 2, sp = dim + 4, tp = d4 + 1, rpb = l.rpb;
+    const bool avx = g.order == SHODH_ORDER_AVX2;
+    for (uint32_t b0 = 0; b0 < m; b0 += rpb) {
+        const uint32_t nb = m - b0 < rpb ? m - b0 : rpb, total = nb * d4;
+        // element e = e0 + 64 u + lane is float4 group gq = e % d4 of batch row r = e / d4. d4 is a run-time value: the quotient comes from a float
+        // multiply (exact for e < 2^13, d4 <= 256: (e + 0.5) / d4 stays 1 / (2 d4) away from every integer), an integer division per element
+        // cost more than the loads themselves. Rounds of eight loads; a round past the end of the batch is skipped (a walk's first call scores
+        // ONE row).
+        const float inv_d4 = 1.0f / (float)d4;
+        auto row_of = [&](uint32_t e) -> uint32_t { return (uint32_t)(((float)e + 0.5f) * inv_d4); };
+        for (uint32_t e0 = 0; e0 < total; e0 += 64 * VG_U) {
+            float4 v[VG_U];
+            const uint32_t e_first = e0 + lane;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t e = e0 + u * 64 + lane, ec = e < nb * d4 ? e : nb * d4 - 1;
-                v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.newid[b0 + ec / d4] * dim + (ec % d4) * 4);
+            for (int u0 = 0; u0 < VG_U; u0 += 8) {
+                if (e0 + u0 * 64 < total) {                       // wave-uniform
+#pragma unroll
+                    for (int u = u0; u < u0 + 8; ++u) {
+                        const uint32_t e = e_first + u * 64, ec = e < total ? e : total - 1;
+                        const uint32_t r = row_of(ec), gq = ec - r * d4;
+                        v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.newid[b0 + r] * dim + gq * 4);
+                    }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t e = e0 + u * 64 + lane;
-                if (e < nb * d4) *reinterpret_cast<float4 *>(l.stage + (e / d4) * sp + (e % d4) * 4) = v[u];
+            for (int u0 = 0; u0 < VG_U; u0 += 8) {
+                if (e0 + u0 * 64 < total) {
+#pragma unroll
+                    for (int u = u0; u < u0 + 8; ++u) {
+                        const uint32_t e = e_first + u * 64;
+                        if (e < total) {
+                            const uint32_t r = row_of(e), gq = e - r * d4;
+                            if (avx) {
+                                *reinterpret_cast<float4 *>(l.stage + r * sp + gq * 4) = v[u];
+                            } else {
+                                // dot_product_scalar_inline (distance_inline.rs:157-173): t_g = ((a0 b0 + a1 b1) + a2 b2) + a3 b3 per group of
+                                // four, straight from the registers the row arrived in
+                                const float4 qa = *reinterpret_cast<const float4 *>(l.q + gq * 4);
+                                float t = qa.x * v[u].x;
+                                t = t + qa.y * v[u].y; t = t + qa.z * v[u].z; t = t + qa.w * v[u].w;
+                                l.tsum[r * tp + gq] = t;
+                            }
+                        }
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (g.order == SHODH_ORDER_AVX2) {
-            // dot_product_avx2_inline (distance_inline.rs:67-111): 8 FMA chains over i = l, l + 8, ...; lanes 0..7 summed in order
-            const uint32_t r = lane >> 3, c = lane & 7;
-            if (r < nb) {
+        if (avx) {
+            // dot_product_avx2_inline (distance_inline.rs:67-111): 8 FMA chains over i = c, c + 8, ...; lanes 0..7 summed in order
+            for (uint32_t rc = lane; rc < nb * 8; rc += 64) {
+                const uint32_t r = rc >> 3, c = rc & 7;
                 const float *row = l.stage + r * sp;
                 float acc = 0.0f;
-                for (uint32_t i = 0; i < dim; i += 8) acc = __builtin_fmaf(l.q[i + c], row[i + c], acc);
+                uint32_t i = 0;
+                for (; i + 64 <= dim; i += 64) {                // eight steps of the chain per round of LDS reads
+                    float qa[8], ra[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { qa[u] = l.q[i + 8 * u + c]; ra[u] = row[i + 8 * u + c]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(qa[u], ra[u], acc);
+                }
+                for (; i < dim; i += 8) acc = __builtin_fmaf(l.q[i + c], row[i + c], acc);
                 l.tsum[r * 8 + c] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -109,20 +170,18 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 l.newd[b0 + lane] = -s;
             }
         } else {
-            // dot_product_scalar_inline (:157-173): t_g = ((a0 b0 + a1 b1) + a2 b2) + a3 b3 per group of four, sum += t_g in order
-            for (uint32_t e = lane; e < nb * d4; e += 64) {
-                const uint32_t r = e / d4, gq = e % d4;
-                const float4 a = *reinterpret_cast<const float4 *>(l.q + gq * 4), b = *reinterpret_cast<const float4 *>(l.stage + r * sp + gq * 4);
-                float t = a.x * b.x;
-                t = t + a.y * b.y; t = t + a.z * b.z; t = t + a.w * b.w;
-                l.tsum[r * tp + gq] = t;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < nb) {
+            if ((uint32_t)lane < nb) {            // sum += t_g in order
                 const float *tr = l.tsum + lane * tp;
                 float s = 0.0f;
-                for (uint32_t gq = 0; gq < d4; ++gq) s = s + tr[gq];
+                uint32_t gq = 0;
+                for (; gq + 8 <= d4; gq += 8) {                 // eight LDS reads in flight, then the eight additions in order
+                    float t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = tr[gq + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = s + t8[u];
+                }
+                for (; gq < d4; ++gq) s = s + tr[gq];
                 l.newd[b0 + lane] = -s;
             }
         }
@@ -160,13 +219,29 @@ __device__ uint32_t vg_sorted_insert(uint64_t *a, uint32_t lo, uint32_t n, uint6
 // visited: n bits, private to this wave. *overflow is set if the frontier array was ever full (cannot happen unless thousands of
 // candidates tie with the worst of `w`).
 __device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint32_t k, uint32_t entry, uint32_t *visited, uint32_t *overflow, int lane) {
-    for (uint32_t i = lane; i < (n + 31) / 32; i += 64) visited[i] = 0;
+    // visited set: a hash set in LDS (no trip to memory per hop, nothing to clear but 32 KiB of LDS); `visited` (one bit per row in
+    // memory, test-and-set with atomicOr) takes over only if a walk outgrows it
+    for (uint32_t i = lane * 4; i < (uint32_t)VG_HASH; i += 256) *reinterpret_cast<uint4 *>(l.hset + i) = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t hcount = 1;                 // wave-uniform
+    bool in_memory = false;              // wave-uniform
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { l.newid[0] = entry; visited[entry >> 5] = 1u << (entry & 31); }
+    if (lane == 0) { l.newid[0] = entry; l.hset[(entry * 2654435761u) >> 19] = entry; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    // true if id was not in the set before (and now is)
+    auto hash_insert = [&](uint32_t id) -> bool {
+        uint32_t h = (id * 2654435761u) >> 19;       // 13 bits
+        for (;;) {
+            const uint32_t old = atomicCAS(l.hset + h, 0xFFFFFFFFu, id);
+            if (old == 0xFFFFFFFFu) return true;
+            if (old == id) return false;
+            h = (h + 1) & (uint32_t)(VG_HASH - 1);
+        }
+    };
+    VGP_DECL
     vg_distances(g, l, 1, lane);
+    VGP(0)
     uint32_t wn = 1, ch = 0, cn = 1;             // |w|, frontier head, frontier end  (wave-uniform)
     if (lane == 0) { const uint64_t key = make_key(l.newd[0], entry); l.w[0] = key; l.cand[0] = key; }
     __builtin_amdgcn_wave_barrier();
@@ -175,25 +250,67 @@ __device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint
         if (vg_key_dist(cur) > vg_key_dist(l.w[wn - 1])) break;          // current.distance > worst of w
         const uint32_t cid = (uint32_t)cur;
         if (cid >= n) continue;
+        // the degree and the whole adjacency row in one round trip (the row is allocated to its full stride)
+        uint32_t nbv[VG_MAXDEG / 64];
+#pragma unroll
+        for (int t = 0; t < VG_MAXDEG / 64; ++t) { const uint32_t j = t * 64 + lane; nbv[t] = j < g.stride ? g.nbr[(size_t)cid * g.stride + j] : 0xFFFFFFFFu; }
         const uint32_t dg = g.deg[cid];
-        // unvisited neighbours, in list order (up to VG_MAXDEG, two rounds of 64 lanes)
+#ifdef SHODH_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        VGP(1)
+        // unvisited neighbours, in list order
         uint32_t m = 0;
-        for (uint32_t j0 = 0; j0 < dg; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            uint32_t nb = 0xFFFFFFFFu;
+#pragma unroll
+        for (int t = 0; t < VG_MAXDEG / 64; ++t) {
+            const uint32_t j = t * 64 + lane;
+            const uint32_t nb = nbv[t];
             bool fresh = false;
-            if (j < dg) {
-                nb = g.nbr[(size_t)cid * g.stride + j];
-                if (nb < n) fresh = (atomicOr(visited + (nb >> 5), 1u << (nb & 31)) & (1u << (nb & 31))) == 0;
-            }
+            if (j < dg && nb < n) fresh = in_memory ? (atomicOr(visited + (nb >> 5), 1u << (nb & 31)) & (1u << (nb & 31))) == 0 : hash_insert(nb);
             const uint64_t bal = __builtin_amdgcn_ballot_w64(fresh);
             if (fresh) l.newid[m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = nb;
             m += (uint32_t)__builtin_popcountll(bal);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        VGP(2)
+        hcount += m;
+        if (!in_memory && hcount > (uint32_t)(VG_HASH * 6 / 10)) {
+            // the set is filling up: everything seen so far goes to the bit map in memory, which serves the rest of the walk
+            for (uint32_t i = lane; i < (n + 31) / 32; i += 64) visited[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            for (uint32_t i = lane; i < (uint32_t)VG_HASH; i += 64) { const uint32_t id = l.hset[i]; if (id != 0xFFFFFFFFu) atomicOr(visited + (id >> 5), 1u << (id & 31)); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            in_memory = true;
+        }
         if (m == 0) continue;
         vg_distances(g, l, m, lane);
+        VGP(3)
+        VGP_N
+        // The neighbours are offered to `w` / the frontier one by one in list order, like the reference's loop. Once `w` is full its worst
+        // entry only ever improves, so a neighbour that does not beat the worst entry NOW never will: those are dropped up front, in
+        // parallel (late in a walk that is nearly all of them), and only the rest takes the sequential path.
+        if (wn == k) {
+            const float worst0 = vg_key_dist(l.w[wn - 1]);
+            uint32_t kept = 0;
+            for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const uint32_t idv = i < m ? l.newid[i] : 0u;
+                const float dv = i < m ? l.newd[i] : 0.0f;
+                const bool keep = i < m && dv < worst0;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(keep);
+                __builtin_amdgcn_wave_barrier();
+                if (keep) {
+                    const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    l.newid[pos] = idv; l.newd[pos] = dv;          // pos <= i: entries of later chunks are not overwritten before they are read
+                }
+                kept += (uint32_t)__builtin_popcountll(bal);
+                __builtin_amdgcn_wave_barrier();
+            }
+            m = kept;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
         for (uint32_t i = 0; i < m; ++i) {                                // one by one, in list order, like the reference
             const float d = l.newd[i];
             const bool add = wn < k || d < vg_key_dist(l.w[wn - 1]);
@@ -216,7 +333,11 @@ __device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint
             wn = vg_sorted_insert(l.w, 0, wn, key, lane);
             if (wn > k) wn = k;                                           // w.pop(): the largest key goes
         }
+        VGP(4)
     }
+#ifdef SHODH_PROF
+    if (blockIdx.x == 0 && lane == 0) printf("walk: entry %lld | adjacency %lld | visited %lld | distances %lld | offers %lld (10 ns ticks), hops %lld\n", vp_[0], vp_[1], vp_[2], vp_[3], vp_[4], vp_[7]);
+#endif
     return wn;
 }
 
@@ -235,7 +356,7 @@ struct VgSearchArgs {
 };
 __global__ __launch_bounds__(64) void vg_search_kernel(VgSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const VgLds l = vg_carve(smem, a.g.dim);
+    const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
     for (uint32_t i = lane; i < a.g.dim; i += 64) l.q[i] = a.q[(size_t)qi * a.g.dim + i];
@@ -268,7 +389,7 @@ struct VgInsertArgs {
 };
 __global__ __launch_bounds__(64) void vg_insert_kernel(VgInsertArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const VgLds l = vg_carve(smem, a.g.dim);
+    const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
     const uint32_t dim = a.g.dim;
     for (uint32_t id = a.first; id < a.first + a.count; ++id) {
@@ -356,7 +477,7 @@ struct VgBuildArgs {
 };
 __global__ __launch_bounds__(64) void vg_build_kernel(VgBuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const VgLds l = vg_carve(smem, a.g.dim);
+    const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
     const uint32_t dim = a.g.dim;
     uint32_t *pr = l.pr, *pr2 = l.pr2;
@@ -430,21 +551,21 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const float *rows, uin
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 int vg_launch_search(const VgSearchArgs &a, hipStream_t st) {
-    const size_t lds = vg_lds_bytes(a.g.dim);
+    const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_search_kernel, lds));
     hipLaunchKernelGGL(vg_search_kernel, dim3(a.nq), dim3(64), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
 int vg_launch_insert(const VgInsertArgs &a, hipStream_t st) {
-    const size_t lds = vg_lds_bytes(a.g.dim);
+    const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_insert_kernel, lds));
     hipLaunchKernelGGL(vg_insert_kernel, dim3(1), dim3(64), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
 int vg_launch_build(const VgBuildArgs &a, hipStream_t st) {
-    const size_t lds = vg_lds_bytes(a.g.dim);
+    const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_build_kernel, lds));
     hipLaunchKernelGGL(vg_build_kernel, dim3(1), dim3(64), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());

@@ -210,6 +210,26 @@ def test_vama_round_trip_carries_the_graph(S, oracle, tmp_path):
     assert (e[1][:, 0] <= a[1][:, 0]).all()
 
 
+def test_a_walk_that_outgrows_the_lds_visited_set(S, oracle):
+    """the visited set lives in LDS (8192 slots); a wide beam over a big enough graph visits more than 60 % of that and moves to the
+    bit map in memory mid-walk: same answers"""
+    dim, R, n = 64, 32, 9000
+    rows = unit_rows(n, dim, 91, clusters=4)
+    idx = gpu_index(S, dim, R, 75)
+    g = oracle.VamanaGraph(dim, R=R, L=75, capacity=n)
+    idx.add_vectors(rows)
+    for r in rows:
+        g.add_vector(r)
+    assert_graph_equal(idx, g)
+    queries = unit_rows(6, dim, 92, clusters=4)
+    assert_search_equal(idx, g, queries, 900)
+    ids, _, counts = idx.search_batch(queries, 900)
+    assert (counts == 900).all()
+    deleted = np.zeros(n, np.uint8); deleted[::3] = 1
+    idx.mark_deleted_many(np.nonzero(deleted)[0].astype(np.uint32))
+    assert_search_equal(idx, g, queries[:3], 300, deleted=deleted)       # search_k = 900
+
+
 def test_graph_mode_argument_checks(S):
     from shodh_memory_amd import _lib as L
     with pytest.raises(L.ShodhError):
