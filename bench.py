@@ -311,6 +311,48 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             torch.cuda.empty_cache()
             done(e, t0)
 
+    # -- SHODH_SCAN_GRAPH: the reference's default ANN path (greedy walk over the Vamana graph grown by add_vector), answers = reference's ---
+    if want("graph_ann_8k"):
+        t0 = time.perf_counter()
+        n = 8000
+        rows = synth_rows(torch, n, args.dim, SEED + 50, dev).cpu().numpy()
+        q = synth_rows(torch, 256, args.dim, SEED + 51, dev).cpu().numpy()
+        gi = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, scan_mode=L.SCAN_GRAPH, reserve_rows=n))
+        gi.add_vectors(rows[:64])
+        a = time.perf_counter(); gi.add_vectors(rows[64:]); ins = (time.perf_counter() - a) / (n - 64)
+        gi.search_batch(q, 10)
+        a = time.perf_counter()
+        for _ in range(5):
+            g_ids, g_dist, _ = gi.search_batch(q, 10)
+        tb = (time.perf_counter() - a) / 5
+        a = time.perf_counter()
+        for i in range(40):
+            gi.search(q[i], 10)
+        t1 = (time.perf_counter() - a) / 40
+        ex = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n)); ex.build(rows)
+        e_ids, _, _ = ex.search_batch(q, 10)
+        recall = float(np.mean([len(set(g_ids[i].tolist()) & set(e_ids[i].tolist())) / 10.0 for i in range(256)]))
+        e = {"name": "graph_ann_8k", "workload": "8000 memories x %d-d grown by add_vector (R = 32), greedy-walk top-10 (vamana.rs:764-808), host-pointer API" % args.dim,
+             "gpu_insert_us_each": round(ins * 1e6, 1), "gpu_search_b256_queries_per_s": round(256 / tb, 1), "gpu_search_single_us": round(t1 * 1e6, 1),
+             "recall_at_10_vs_exact": round(recall, 4)}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O      # CPU baseline leg: the restated reference walk, one thread
+            og = O.VamanaGraph(args.dim, R=32, L=75, capacity=n)
+            a = time.perf_counter()
+            for r in rows:
+                og.add_vector(r)
+            c_ins = (time.perf_counter() - a) / n
+            a = time.perf_counter()
+            same = True
+            for i in range(64):
+                c_ids, c_dist = og.search(q[i], 10)
+                same = same and c_ids.tolist() == g_ids[i, :len(c_ids)].tolist() and c_dist.tobytes() == g_dist[i, :len(c_ids)].tobytes()
+            c_s = (time.perf_counter() - a) / 64
+            e.update({"cpu_insert_us_each": round(c_ins * 1e6, 1), "cpu_search_single_us": round(c_s * 1e6, 1), "cpu_threads": 1,
+                      "gpu_matches_cpu_bit_exact": bool(same)})
+        gi.close(); ex.close()
+        done(e, t0)
+
     # -- the multi-GPU index behind the C ABI (shodh_sharded_index_*: RCCL all-gather + device merge inside the library), host-pointer API
     if want("sharded_c_abi_1M_b256"):
         t0 = time.perf_counter()
