@@ -763,11 +763,12 @@ int shodh_index_extract_live_rows(const shodh_index *idx, float *out_rows, uint3
 uint32_t shodh_index_dim(const shodh_index *idx) { return idx ? idx->cfg.dim : 0; }
 
 int shodh_index_set_graph(shodh_index *idx, const uint32_t *deg, const uint32_t *nbr, uint32_t stride, uint32_t medoid) {
-    if (!idx || (idx->n && (!deg || !nbr))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     SHODH_TRY(set_device(idx));
     const uint64_t n = idx->n;
+    if (n && (!deg || !nbr)) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (n && medoid >= n) { set_error("medoid %u out of range", medoid); return SHODH_ERR_INVALID; }
     std::vector<uint32_t> hn((size_t)n * idx->g_stride, 0u);
     for (uint64_t i = 0; i < n; ++i) {
@@ -820,7 +821,8 @@ int shodh_index_build_with_graph(shodh_index *idx, const float *rows, uint64_t n
 int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *init_deg, const uint32_t *init_nbr, uint32_t init_stride) {
     if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
-    const uint64_t n = shodh_index_len(idx);
+    std::unique_lock<std::shared_mutex> lk(idx->mu);      // a construction is a write from start to end (searches wait, like behind the reference's &mut self)
+    const uint64_t n = idx->n;
     if (n == 0) { idx->g_nodes = 0; return SHODH_OK; }
     const uint32_t R = idx->cfg.max_degree;
     std::vector<uint32_t> deg(n), nbr((size_t)n * (R + 1), 0u);
@@ -828,7 +830,11 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
         for (uint64_t i = 0; i < n; ++i) {
             if (init_deg[i] > R || init_deg[i] > init_stride) { set_error("initial graph: node %llu has %u neighbours (max_degree %u)", (unsigned long long)i, init_deg[i], R); return SHODH_ERR_INVALID; }
             deg[i] = init_deg[i];
-            for (uint32_t j = 0; j < deg[i]; ++j) nbr[(size_t)i * (R + 1) + j] = init_nbr[(size_t)i * init_stride + j];
+            for (uint32_t j = 0; j < deg[i]; ++j) {
+                const uint32_t v = init_nbr[(size_t)i * init_stride + j];
+                if (v >= n) { set_error("initial graph: node %llu lists neighbour %u (only %llu rows)", (unsigned long long)i, v, (unsigned long long)n); return SHODH_ERR_INVALID; }
+                nbr[(size_t)i * (R + 1) + j] = v;
+            }
         }
     } else {
         // initialize_graph (vamana.rs:287-312): `degree = min(R, n - 1)` distinct random neighbours per node, never the node itself
@@ -856,7 +862,6 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
         d_i = (uint32_t *)(d_c + idx->cfg.dim); d_d = (float *)(d_i + 1); d_n = (uint32_t *)(d_d + 1);
         int rc = vg_launch_centroid(idx->rows, (uint32_t)n, idx->cfg.dim, d_c, nullptr);
         if (rc == SHODH_OK) {
-            std::shared_lock<std::shared_mutex> lk(idx->mu);
             const uint32_t gx = exact_grid_x(n, 1, 1, idx->cus);
             unsigned char *part = nullptr;
             if (hipMalloc((void **)&part, exact_partial_bytes(1, idx->cfg.dim, 1, gx) + 256) != hipSuccess) rc = SHODH_ERR_OOM;
@@ -870,7 +875,6 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
         if (rc != SHODH_OK) return rc;
     }
     {
-        std::unique_lock<std::shared_mutex> lk(idx->mu);
         SHODH_HIP_TRY(hipMemcpy(idx->g_deg, deg.data(), n * 4, hipMemcpyHostToDevice));
         SHODH_HIP_TRY(hipMemcpy(idx->g_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
         idx->g_medoid = medoid;
