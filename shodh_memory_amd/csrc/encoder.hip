@@ -192,7 +192,12 @@ __global__ __launch_bounds__(512, 2) void gemm_k384_stream_kernel(const __bf16 *
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = blockIdx.x % n_groups, worker = blockIdx.x / n_groups, n_workers = gridDim.x / n_groups;
+    // XCD-aware block -> (feature group, worker) map: the n_groups workgroups that stream the SAME token tiles at the same time sit on the same
+    // XCD (consecutive workgroup ids go round the 8 XCDs), so a tile comes from HBM once and the other groups hit that XCD's L2. With the
+    // plain map (group = id % n_groups) every group of a tile sat behind a different L2 and X was fetched n_groups times (QKV: 5 x 214 MB).
+    const int n_workers = gridDim.x / n_groups;      // a multiple of 8 (the launcher's choice)
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int grp = rr % n_groups, worker = (rr / n_groups) * 8 + xcd;
     const int nblk = grp * 8 + wave;                 // this wave's 32-feature block
     const bool active = nblk * 32 < N;               // wave-uniform
     const int nblk_c = active ? nblk : 0;
@@ -787,10 +792,10 @@ template <int EPI>
 static int gemm_k384_stream(const __bf16 *X, const __bf16 *Wp, const float *bias, const __bf16 *resid, __bf16 *out_b, float *out_f,
                             int M, int N, int cus, hipStream_t st) {
     const int n_groups = (N + 255) / 256;
-    int n_workers = cus / n_groups;
-    if (n_workers < 1) n_workers = 1;
+    int n_workers = (cus / n_groups) & ~7;           // whole rounds of the 8 XCDs (see the kernel's block map)
+    if (n_workers < 8) n_workers = 8;
     const int n_tiles = (M + GS_TR - 1) / GS_TR;
-    if (n_workers > n_tiles) n_workers = n_tiles > 0 ? n_tiles : 1;
+    if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;      // workers beyond the tiles find nothing to do
     const size_t lds = (size_t)GS_NBUF * GS_TILE + 8 * 2048;      // + one 2 KiB epilogue scratch per wave = exactly 160 KiB
     SHODH_TRY(ensure_dynamic_lds((const void *)gemm_k384_stream_kernel<EPI>, lds));
 #ifdef SHODH_DIAG      // diagnostic build only (-DSHODH_DIAG): drops the GEMM stores to time the rest, results invalid
