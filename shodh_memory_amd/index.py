@@ -11,6 +11,7 @@ entry points without leaving HBM.
 """
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from enum import Enum
 
@@ -53,6 +54,33 @@ class VamanaConfig:
     scan_mode: int = L.SCAN_AUTO
     reserve_rows: int = 0
     id_base: int = 0
+
+
+def env_devices():
+    """SHODH_HIP_DEVICES="0,2,3" -> [0, 2, 3] (the HIP devices a process may use); unset -> [0]"""
+    v = os.environ.get("SHODH_HIP_DEVICES", "").strip()
+    return [int(x) for x in v.split(",") if x.strip() != ""] if v else [0]
+
+
+def env_dimension(default=384):
+    """SHODH_TEXT_DIM (minilm.rs:313-322): one of 128 / 256 / 384 / 512 / 768 / 1024, anything else falls back to the default"""
+    try:
+        d = int(os.environ.get("SHODH_TEXT_DIM", ""))
+    except ValueError:
+        return default
+    return d if d in (128, 256, 384, 512, 768, 1024) else default
+
+
+def vamana_config_from_env(**overrides):
+    """VamanaConfig the way a deployment configures the reference -- by environment:
+    SHODH_TEXT_DIM -> dimension; SHODH_HIP_DEVICES -> device (the first one listed);
+    SHODH_VECTOR_EXACT set (vamana.rs:770-777) -> the exact scan, which is ALSO this library's default when nothing is set;
+    SHODH_HIP_GRAPH_WALK=1 -> the reference's graph walk on the device (its behaviour WITHOUT SHODH_VECTOR_EXACT), unless
+    SHODH_VECTOR_EXACT is set as well (the reference's switch wins)."""
+    graph = os.environ.get("SHODH_HIP_GRAPH_WALK", "") not in ("", "0") and "SHODH_VECTOR_EXACT" not in os.environ
+    kw = dict(dimension=env_dimension(), device=env_devices()[0], scan_mode=L.SCAN_GRAPH if graph else L.SCAN_AUTO)
+    kw.update(overrides)
+    return VamanaConfig(**kw)
 
 
 @dataclass
@@ -580,6 +608,16 @@ class VectorIndexBackend:
     def auto(cls, config: BackendConfig, expected_vectors: int):
         bt = config.force_backend or (BackendType.Spann if expected_vectors >= SPANN_AUTO_THRESHOLD else BackendType.Vamana)
         return cls.new_vamana(config) if bt == BackendType.Vamana else cls.new_spann(config)
+
+    @classmethod
+    def from_env(cls, config: BackendConfig, expected_vectors: int):
+        """`auto`, unless SHODH_HIP_INDEX=flat|ivfpq forces one backend"""
+        forced = os.environ.get("SHODH_HIP_INDEX", "").strip().lower()
+        if forced == "flat":
+            return cls.new_vamana(config)
+        if forced == "ivfpq":
+            return cls.new_spann(config)
+        return cls.auto(config, expected_vectors)
 
     @classmethod
     def new_vamana(cls, config: BackendConfig):

@@ -258,3 +258,19 @@ def test_finalize_pooled_both_branches(oracle):
         assert np.abs(got - x).max() < 2e-6 and abs(np.linalg.norm(got) - 1) < 1e-6 and len(got) == min(n, out_dim or n)
     z = E.finalize_pooled(np.zeros(8, np.float32), apply_prenorm=True)          # constant input: var 0, denom = sqrt(1e-5) > EPSILON -> zeros stay zeros; norm 0 -> unchanged
     assert not z.any()
+
+
+def test_environment_switches(monkeypatch):
+    """SURVEY.md section 5 hooks: SHODH_TEXT_DIM, SHODH_HIP_DEVICES, SHODH_VECTOR_EXACT / SHODH_HIP_GRAPH_WALK (parsing only; no GPU)"""
+    from shodh_memory_amd import index as I, _lib as L
+    for k in ("SHODH_TEXT_DIM", "SHODH_HIP_DEVICES", "SHODH_VECTOR_EXACT", "SHODH_HIP_GRAPH_WALK"):
+        monkeypatch.delenv(k, raising=False)
+    c = I.vamana_config_from_env()
+    assert (c.dimension, c.device, c.scan_mode) == (384, 0, L.SCAN_AUTO)
+    monkeypatch.setenv("SHODH_TEXT_DIM", "768"); monkeypatch.setenv("SHODH_HIP_DEVICES", "3, 1"); monkeypatch.setenv("SHODH_HIP_GRAPH_WALK", "1")
+    c = I.vamana_config_from_env(max_degree=16)
+    assert (c.dimension, c.device, c.scan_mode, c.max_degree) == (768, 3, L.SCAN_GRAPH, 16) and I.env_devices() == [3, 1]
+    monkeypatch.setenv("SHODH_VECTOR_EXACT", "1")                   # the reference's switch wins
+    assert I.vamana_config_from_env().scan_mode == L.SCAN_AUTO
+    monkeypatch.setenv("SHODH_TEXT_DIM", "333")
+    assert I.env_dimension() == 384
