@@ -288,6 +288,29 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         torch.cuda.empty_cache()
         done(e, t0)
 
+    # -- the same dense regime at 10M rows (10 000 clusters of ~1000 members) --------------------------------------------------------
+    if want("flat_10M_clustered_b256") and not args.skip_10m:
+        t0 = time.perf_counter()
+        n = 10_000_000
+        rows, lab = synth_clustered(torch, n, args.dim, SEED + 33, dev, n_clusters=10_000)
+        del lab
+        g = torch.Generator(device=dev).manual_seed(SEED + 34)
+        qp = []
+        for i in range(4):
+            pick = torch.randint(0, n, (256,), generator=g, device=dev)
+            qp.append(torch.nn.functional.normalize(rows[pick] + 0.02 * torch.randn((256, args.dim), generator=g, device=dev), dim=1).contiguous())
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n))
+        idx.build(rows)
+        del rows
+        torch.cuda.empty_cache()
+        e = {"name": "flat_10M_clustered_b256", "workload": "10M memories in 10 000 vMF-like clusters, queries = noisy members, batch 256, top-10", "rows": n}
+        e.update(run_flat_config(torch, dev, idx, qp, 10, 12, 3, n, n, args.dim))
+        e120 = run_flat_config(torch, dev, idx, qp, 120, 8, 2, n, n, args.dim)
+        e["k120"] = {kk: e120[kk] for kk in ("ms_per_step", "survivors_emitted_per_query", "rescored_per_query", "level2_queries", "exact_fallback_queries")}
+        idx.close(); del idx
+        torch.cuda.empty_cache()
+        done(e, t0)
+
     # -- SHODH_TEXT_DIM 768 / 1024 (minilm.rs:313-322): the 256-thread pre-scan kernel, next to the exact-order scan it replaces ------
     if want("flat_1M_d768_b256", "flat_1M_d1024_b256", "bigdim"):
         for bd in (768, 1024):
