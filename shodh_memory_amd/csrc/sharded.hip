@@ -184,6 +184,10 @@ int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devi
     if (n_devices > 64) { set_error("at most 64 shards"); return SHODH_ERR_INVALID; }
     if (cfg->block_log2 < 6 || cfg->block_log2 > 26) { set_error("block_log2 %u out of range [6, 26]", cfg->block_log2); return SHODH_ERR_INVALID; }
     if (cfg->exchange > SHODH_EXCHANGE_COPY) { set_error("unknown exchange %u", cfg->exchange); return SHODH_ERR_INVALID; }
+    if (cfg->scan_mode == SHODH_SCAN_GRAPH) {        // one graph per shard would not be the reference's graph: the walk is a single-device mode
+        set_error("SHODH_SCAN_GRAPH is a single-device mode: a sharded index answers with the exact scan");
+        return SHODH_ERR_UNSUPPORTED;
+    }
     bool distinct = true;
     for (uint32_t i = 0; i < n_devices; ++i)
         for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
