@@ -601,10 +601,13 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (hipMemcpyAsync(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(dist, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(counts, d_counts, (size_t)nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+            uint32_t g_ovf = 0;
+            const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT;
+            if (graph_call) hipMemcpyAsync(&g_ovf, idx->g_overflow, 4, hipMemcpyDeviceToHost, st);      // rides along with the results: no second round trip
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             collect_timings(idx, w, used_mfma, nullptr);
-            if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT && (rc = check_graph_overflow(idx)) != SHODH_OK) break;
+            if (graph_call && g_ovf && (rc = check_graph_overflow(idx)) != SHODH_OK) break;
             if (used_mfma) {
                 uint32_t st4[4] = {0, 0, 0, 0};
                 MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
