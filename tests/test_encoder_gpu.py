@@ -221,3 +221,20 @@ def test_index_memory_chunks_long_content(S):
     assert res[0][0] == big and abs(res[0][1] - 1.0) < 1e-5 and [r[0] for r in res].count(big) == 1
     eng.index_memory(big, content="now it is short")                         # re-index: the old chunk vectors lose their mapping
     assert len(eng.id_mapping.get_vector_ids(big)) == 1 and all(eng.id_mapping.get_memory_id(v) is None for v in ids)
+
+
+def test_big_batches_run_as_sub_batches_with_identical_results(S):
+    """more than 8192 texts in one call are encoded as sub-batches inside the library (texts are independent in bf16 / fp32):
+    same bits as encoding the pieces one by one"""
+    from shodh_memory_amd import _lib as L
+    rng = np.random.default_rng(3)
+    b, ML = 8192 + 700, 256
+    lens = rng.integers(1, 40, b)
+    ids = np.zeros((b, ML), np.int32); mask = np.zeros((b, ML), np.uint8)
+    for i, n in enumerate(lens):
+        ids[i, :n] = rng.integers(1000, 30000, n); mask[i, :n] = 1
+    enc = S.MiniLMEmbedder(synthetic_seed=77, dtype=L.DTYPE_BF16)
+    whole = enc.encode_ids(ids, mask)
+    parts = np.concatenate([enc.encode_ids(ids[:8192], mask[:8192]), enc.encode_ids(ids[8192:], mask[8192:])])
+    assert whole.shape == (b, 384) and whole.tobytes() == parts.tobytes()
+    assert np.allclose(np.linalg.norm(whole, axis=1), 1.0, atol=1e-3)
