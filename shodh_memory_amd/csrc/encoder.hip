@@ -478,6 +478,47 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     int id = ids[(size_t)sq * max_len + p];
     if (id < 0) id = 0;
     if (id >= vocab) id = vocab - 1;
+    if constexpr (!std::is_same<T, float>::value) {
+        // bf16 mode: 16-byte loads and 8-byte stores (a lane takes float4 groups lane and lane + 64 of the row). The f32 / INT8 modes keep
+        // the scalar form below: their tests pin quantities that depend on the exact order of the LayerNorm sums.
+        if (!word_q && (H & 3) == 0 && H <= 512) {
+            const int h4 = H >> 2;
+            f32x4e xv[2];
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = lane + 64 * j;
+                if (g < h4) {
+                    const f32x4e w4 = *reinterpret_cast<const f32x4e *>(word + (size_t)id * H + g * 4), p4 = *reinterpret_cast<const f32x4e *>(pos + (size_t)p * H + g * 4),
+                                 t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xv[j][e] = w4[e] + p4[e] + t4[e]; s += xv[j][e]; }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)H;
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
+            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            const float inv = 1.0f / sqrtf(v / (float)H + eps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = lane + 64 * j;
+                if (g < h4) {
+                    const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
+                    bf16x4e o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (__bf16)((xv[j][e] - mean) * inv * g4[e] + b4[e]);
+                    *reinterpret_cast<bf16x4e *>(out + (size_t)tok * H + g * 4) = o4;
+                }
+            }
+            return;
+        }
+    }
     float x[16];
     int cnt = 0;
     float s = 0.0f;
@@ -669,7 +710,15 @@ __global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ x, cons
     int nv = 0;
     for (int d = threadIdx.x; d < H; d += 256) {
         float p = 0.0f;
-        for (int s = 0; s < S; ++s) p += to_f32(x[(size_t)(t0 + s) * H + d]);    // s ascending, like the reference loop
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {                                             // eight loads in flight, then the eight additions in order
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = to_f32(x[(size_t)(t0 + s + u) * H + d]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p += v8[u];
+        }
+        for (; s < S; ++s) p += to_f32(x[(size_t)(t0 + s) * H + d]);             // s ascending, like the reference loop
         if (S > 0) p = p / (float)S;
         if (!(fabsf(p) <= 3.4028235e38f)) p = 0.0f;                                // NaN / Inf scrub
         vals[nv++] = p;
