@@ -54,12 +54,18 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     const size_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 v = x4[i];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    auto fold = [&](const float4 &v) {
         const uint32_t k0 = order_key(v.x), k1 = order_key(v.y), k2 = order_key(v.z), k3 = order_key(v.w);
         lo = min(lo, min(min(k0, k1), min(k2, k3)));
         hi = max(hi, max(max(k0, k1), max(k2, k3)));
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads in flight per thread
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        fold(a); fold(b); fold(c); fold(d);
     }
+    for (; i < n4; i += stride) fold(x4[i]);
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const uint32_t k = order_key(x[i]); lo = min(lo, k); hi = max(hi, k); }
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
     __shared__ uint32_t slo[4], shi[4];
@@ -88,8 +94,9 @@ __global__ __launch_bounds__(256) void act_quant_kernel(const float *__restrict_
     const float zpf = (float)p.zp;
     const size_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 v = x4[i];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    auto quant4 = [&](const float4 &v) -> uint32_t {
         const float e[4] = {v.x, v.y, v.z, v.w};
         uint32_t pk = 0;
 #pragma unroll
@@ -98,8 +105,14 @@ __global__ __launch_bounds__(256) void act_quant_kernel(const float *__restrict_
             q = fminf(fmaxf(q, 0.0f), 255.0f);
             pk |= (uint32_t)(((int)q - 128) & 0xFF) << (8 * j);
         }
-        reinterpret_cast<uint32_t *>(out)[i] = pk;
+        return pk;
+    };
+    uint32_t *out4 = reinterpret_cast<uint32_t *>(out);
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads in flight per thread
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        out4[i] = quant4(a); out4[i + stride] = quant4(b); out4[i + 2 * stride] = quant4(c); out4[i + 3 * stride] = quant4(d);
     }
+    for (; i < n4; i += stride) out4[i] = quant4(x4[i]);
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float q = __builtin_rintf(x[i] / p.scale) + zpf;
         q = fminf(fmaxf(q, 0.0f), 255.0f);
