@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """libshodh_hip.so is (re)built before anything imports the package: importing shodh_memory_amd loads the library and fails loudly
+    when it is missing or stale, which is the state of a fresh checkout. The build script is loaded by path for the same reason."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_shodh_build", os.path.join(ROOT, "shodh_memory_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+
+
 def has_gpu():
     try:
         import torch
