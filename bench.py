@@ -571,6 +571,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # (re)build libshodh_hip.so if a source is newer -- incremental, a no-op on a built tree; loaded by path because importing the package
+    # needs the library. With several ranks only local rank 0 builds, the others wait for it.
+    if local_rank == 0:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_shodh_build", os.path.join(ROOT, "shodh_memory_amd", "build.py"))
+        bm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bm)
+        bm.build()
+    if world > 1:
+        dist.barrier()
     import shodh_memory_amd as S
     from shodh_memory_amd import _lib as L
     from shodh_memory_amd.distributed import ShardedFlatIndex, shard_range
