@@ -282,3 +282,25 @@ def test_ten_million_rows_ivfpq_full_size(S, oracle):
 def order_key_u32(d):
     b = np.ascontiguousarray(d, np.float32).view(np.uint32)
     return np.where(b & 0x80000000, ~b, b | 0x80000000).astype(np.uint32)
+
+
+def test_spann_at_768_dimensions(S, oracle):
+    """SHODH_TEXT_DIM = 768: 96 sub-quantisers; with 600 partitions the nearest-centroid searches of encode / search run on the
+    big-dimension MFMA pre-scan (SEQ_1M order) -- assignments, codes and search results must still match the oracle"""
+    rng = np.random.default_rng(13)
+    n, P, dim = 6000, 600, 768
+    M = dim // 8
+    rows = synth.corpus(n, dim, adversarial=False)
+    centroids = rows[rng.choice(n, P, replace=False)].copy()
+    codebook = np.stack([rows[rng.choice(n, 256, replace=False), m * 8:(m + 1) * 8] for m in range(M)]).astype(f32)
+    idx = S.SpannIndex(dim, num_probes=12)
+    idx.set_trained_state(centroids, codebook, np.zeros(P + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, M), np.uint8))
+    assign, codes = idx.encode(rows)
+    for i in rng.choice(n, 150, replace=False):
+        assert assign[i] == oracle.spann_find_nearest_centroid(rows[i], centroids)
+        assert codes[i].tolist() == oracle.pq_encode(codebook, rows[i]).tolist()
+    order = np.argsort(assign, kind="stable")
+    off = np.zeros(P + 1, np.uint64); off[1:] = np.cumsum(np.bincount(assign, minlength=P))
+    st = dict(centroids=centroids, codebook=codebook, list_off=off, ids=order.astype(np.uint32), codes=codes[order])
+    idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+    check(oracle, idx, st, synth.queries(40, dim), 10, 12)
