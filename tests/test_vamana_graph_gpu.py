@@ -55,7 +55,7 @@ def assert_search_equal(idx, g, queries, k, deleted=None):
         assert dist[qi, :m].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), qi
 
 
-@pytest.mark.parametrize("dim,R,order", [(384, 32, 0), (64, 8, 0), (384, 16, 1), (128, 4, 1)])
+@pytest.mark.parametrize("dim,R,order", [(384, 32, 0), (64, 8, 0), (384, 16, 1), (128, 4, 1), (768, 12, 0), (1024, 8, 1)])
 def test_incremental_inserts_build_the_reference_graph(S, oracle, dim, R, order):
     n = 700
     rows = unit_rows(n, dim, 100 + dim + R, clusters=8 if dim == 384 else 0)
