@@ -1,6 +1,6 @@
 """Randomised stress: many recall batches of random shapes through the MFMA pre-scan path, compared bit for bit with
 the exact-order scan path (itself checked against the CPU oracle by tests/) on the same device.
-usage: python tools/stress_parity.py [rounds] [rows]"""
+usage: python tools/stress_parity.py [rounds] [rows] [dims, e.g. 384,128,768,1024]"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
@@ -11,7 +11,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300_000
 rng = np.random.default_rng(123)
 bad = 0
-for dim in (384, 128):
+dims = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [384, 128]
+for dim in dims:
     rows = bench.synth_rows(torch, n, dim, 7, dev)
     rows[1000:1040] = rows[5]                                    # duplicates
     a = S.VamanaIndex(S.VamanaConfig(dimension=dim, scan_mode=2, reserve_rows=n)); a.build(rows)
@@ -30,5 +31,5 @@ for dim in (384, 128):
         if not (torch.equal(ia, ib) and torch.equal(da.view(torch.int32), db.view(torch.int32)) and torch.equal(ca, cb)):
             bad += 1
             print("MISMATCH dim %d round %d nq %d k %d" % (dim, r, nq, k), flush=True)
-print("stress: %d rounds x 2 dims, mismatches: %d" % (rounds, bad))
+print("stress: %d rounds x dims %s, mismatches: %d" % (rounds, dims, bad))
 sys.exit(1 if bad else 0)
