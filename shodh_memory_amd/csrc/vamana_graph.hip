@@ -61,6 +61,7 @@ struct VgLds {
     float *tsum;            // [rows per batch][dim / 4 + 1] group sums (scalar-4) / [..][8] chain sums (AVX2)
     uint32_t rpb;           // rows per batch
     uint32_t *hset;         // [VG_HASH] visited set: open addressing, 0xFFFFFFFF = empty
+    uint32_t *req;          // the walk's wave -> the three helper waves: rows to score (0xFFFFFFFF = done)
     uint32_t *newid;        // [VG_MAXDEG] unvisited neighbours of the current node, in list order
     float *newd;            // [VG_MAXDEG] their distances
     uint32_t *pr, *pr2;     // [VG_MAXDEG] pruned lists (build)
@@ -86,15 +87,20 @@ __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t ord
     l.pr2 = l.pr + VG_MAXDEG;
     l.dne = reinterpret_cast<float *>(l.pr2 + VG_MAXDEG);
     l.dne2 = l.dne + VG_MAXDEG;
+    l.req = reinterpret_cast<uint32_t *>(l.dne2 + VG_MAXDEG);
     return l;
 }
 
 __device__ __forceinline__ float vg_key_dist(uint64_t k) { return order_key_inv((uint32_t)(k >> 32)); }
 
-// distances -dot(q, row) of m rows (ids in l.newid) in the reference's order -> l.newd. One wave; dim % 8 == 0.
+// distances -dot(q, row) of m rows (ids in l.newid) in the reference's order -> l.newd. NT cooperating threads (the walk's wave plus three
+// helper waves: the batch is instruction-issue-bound for a single wave, ~1800 VALU / LDS instructions); dim % 8 == 0.
 // Up to 32 rows per batch, and every 16-byte piece of a batch is requested before the first is used (VG_U per lane and round: a hop of
 // the walk is a chain of dependent round trips, the rows are the longest of them and used to be fetched eight rows at a time).
-__device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane) {
+constexpr int VG_NT = 256;          // threads of a walk's workgroup: wave 0 walks, all four waves score rows
+__device__ __forceinline__ void vg_sync() { __syncthreads(); }
+__device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane /* 0 .. VG_NT - 1 */) {
+    constexpr int NT = VG_NT, VU = VG_U * 64 / NT;
     const uint32_t dim = g.dim, d4 = dim >> 2, sp = dim + 4, tp = d4 + 1, rpb = l.rpb;
     const bool avx = g.order == SHODH_ORDER_AVX2;
     for (uint32_t b0 = 0; b0 < m; b0 += rpb) {
@@ -105,26 +111,26 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
         // ONE row).
         const float inv_d4 = 1.0f / (float)d4;
         auto row_of = [&](uint32_t e) -> uint32_t { return (uint32_t)(((float)e + 0.5f) * inv_d4); };
-        for (uint32_t e0 = 0; e0 < total; e0 += 64 * VG_U) {
-            float4 v[VG_U];
+        for (uint32_t e0 = 0; e0 < total; e0 += NT * VU) {
+            float4 v[VU];
             const uint32_t e_first = e0 + lane;
 #pragma unroll
-            for (int u0 = 0; u0 < VG_U; u0 += 8) {
-                if (e0 + u0 * 64 < total) {                       // wave-uniform
+            for (int u0 = 0; u0 < VU; u0 += 4) {
+                if (e0 + u0 * NT < total) {                       // uniform
 #pragma unroll
-                    for (int u = u0; u < u0 + 8; ++u) {
-                        const uint32_t e = e_first + u * 64, ec = e < total ? e : total - 1;
+                    for (int u = u0; u < u0 + 4; ++u) {
+                        const uint32_t e = e_first + u * NT, ec = e < total ? e : total - 1;
                         const uint32_t r = row_of(ec), gq = ec - r * d4;
                         v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.newid[b0 + r] * dim + gq * 4);
                     }
                 }
             }
 #pragma unroll
-            for (int u0 = 0; u0 < VG_U; u0 += 8) {
-                if (e0 + u0 * 64 < total) {
+            for (int u0 = 0; u0 < VU; u0 += 4) {
+                if (e0 + u0 * NT < total) {
 #pragma unroll
-                    for (int u = u0; u < u0 + 8; ++u) {
-                        const uint32_t e = e_first + u * 64;
+                    for (int u = u0; u < u0 + 4; ++u) {
+                        const uint32_t e = e_first + u * NT;
                         if (e < total) {
                             const uint32_t r = row_of(e), gq = e - r * d4;
                             if (avx) {
@@ -142,11 +148,10 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        vg_sync();
         if (avx) {
             // dot_product_avx2_inline (distance_inline.rs:67-111): 8 FMA chains over i = c, c + 8, ...; lanes 0..7 summed in order
-            for (uint32_t rc = lane; rc < nb * 8; rc += 64) {
+            for (uint32_t rc = lane; rc < nb * 8; rc += NT) {
                 const uint32_t r = rc >> 3, c = rc & 7;
                 const float *row = l.stage + r * sp;
                 float acc = 0.0f;
@@ -161,8 +166,7 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 for (; i < dim; i += 8) acc = __builtin_fmaf(l.q[i + c], row[i + c], acc);
                 l.tsum[r * 8 + c] = acc;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            vg_sync();
             if ((uint32_t)lane < nb) {
                 const float *p8 = l.tsum + lane * 8;
                 float s = p8[0] + p8[1];
@@ -185,9 +189,31 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 l.newd[b0 + lane] = -s;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        vg_sync();
     }
+}
+
+// The walk itself runs on wave 0 of the workgroup; the other three waves wait for row batches to score.
+//   wave 0:   vg_dist_master(m)  =  request m rows -> barrier -> all four waves score -> barrier
+//   waves 1-3: vg_helper_loop()  =  barrier -> read the request (0xFFFFFFFF: the walk is over) -> score -> barrier
+__device__ void vg_dist_master(const VgGraph &g, const VgLds &l, uint32_t m, int lane) {
+    if (lane == 0) *l.req = m;
+    __syncthreads();
+    vg_distances(g, l, m, lane);
+    __syncthreads();
+}
+__device__ void vg_helper_loop(const VgGraph &g, const VgLds &l, int tid) {
+    for (;;) {
+        __syncthreads();
+        const uint32_t m = *l.req;
+        if (m == 0xFFFFFFFFu) break;
+        vg_distances(g, l, m, tid);
+        __syncthreads();
+    }
+}
+__device__ void vg_walk_done(const VgLds &l, int lane) {
+    if (lane == 0) *l.req = 0xFFFFFFFFu;
+    __syncthreads();
 }
 
 // inserts key into the ascending array a[lo, n) (n < cap); returns the new n. One wave.
@@ -240,7 +266,7 @@ __device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint
         }
     };
     VGP_DECL
-    vg_distances(g, l, 1, lane);
+    vg_dist_master(g, l, 1, lane);
     VGP(0)
     uint32_t wn = 1, ch = 0, cn = 1;             // |w|, frontier head, frontier end  (wave-uniform)
     if (lane == 0) { const uint64_t key = make_key(l.newd[0], entry); l.w[0] = key; l.cand[0] = key; }
@@ -284,7 +310,7 @@ __device__ uint32_t vg_greedy(const VgGraph &g, const VgLds &l, uint32_t n, uint
             in_memory = true;
         }
         if (m == 0) continue;
-        vg_distances(g, l, m, lane);
+        vg_dist_master(g, l, m, lane);
         VGP(3)
         VGP_N
         // The neighbours are offered to `w` / the frontier one by one in list order, like the reference's loop. Once `w` is full its worst
@@ -354,15 +380,17 @@ struct VgSearchArgs {
     uint32_t *ids; float *dist; uint32_t *counts;   // [nq][k]
     uint32_t *overflow;
 };
-__global__ __launch_bounds__(64) void vg_search_kernel(VgSearchArgs a) {
+__global__ __launch_bounds__(256) void vg_search_kernel(VgSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
+    if (threadIdx.x >= 64) { vg_helper_loop(a.g, l, (int)threadIdx.x); return; }      // waves 1-3 only score row batches for wave 0
     const uint32_t qi = blockIdx.x;
     for (uint32_t i = lane; i < a.g.dim; i += 64) l.q[i] = a.q[(size_t)qi * a.g.dim + i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const uint32_t wn = vg_greedy(a.g, l, a.n, a.search_k, a.medoid, a.visited + (size_t)qi * a.vis_words, a.overflow, lane);
+    vg_walk_done(l, lane);
     // filter tombstones, take k (vamana.rs:797-804)
     uint32_t o = 0;
     for (uint32_t i0 = 0; i0 < wn && o < a.k; i0 += 64) {
@@ -387,10 +415,11 @@ struct VgInsertArgs {
     uint32_t *visited;        // [vis_words]
     uint32_t *overflow;
 };
-__global__ __launch_bounds__(64) void vg_insert_kernel(VgInsertArgs a) {
+__global__ __launch_bounds__(256) void vg_insert_kernel(VgInsertArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
+    if (threadIdx.x >= 64) { vg_helper_loop(a.g, l, (int)threadIdx.x); return; }      // waves 1-3 only score row batches for wave 0
     const uint32_t dim = a.g.dim;
     for (uint32_t id = a.first; id < a.first + a.count; ++id) {
         if (id == 0) { if (lane == 0) a.g.deg[0] = 0; continue; }          // the first vector: a node without neighbours
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(64) void vg_insert_kernel(VgInsertArgs a) {
                 for (uint32_t t = lane; t < cnt; t += 64) l.newid[t] = a.g.nbr[(size_t)nb * a.g.stride + t];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                vg_distances(a.g, l, cnt, lane);
+                vg_dist_master(a.g, l, cnt, lane);
                 // rank by (distance total_cmp, id); ranks are unique (ids are): entry t goes to position rank(t) if rank < R
                 for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
                     const uint32_t t = t0 + lane;
@@ -432,6 +461,7 @@ __global__ __launch_bounds__(64) void vg_insert_kernel(VgInsertArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     }
+    vg_walk_done(l, lane);
 }
 
 // robust_prune of `node` over the candidates in l.w[0, nc) (keys: distance | id; sorted ascending == the reference's sort) -> pruned ids
@@ -451,7 +481,7 @@ __device__ uint32_t vg_robust_prune(const VgGraph &g, const VgLds &l, uint32_t n
         for (uint32_t t = lane; t < np; t += 64) l.newid[1 + t] = out[t];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        vg_distances(g, l, 1 + np, lane);                                   // newd[0] = dist(c, node) == dist(node, c) term by term
+        vg_dist_master(g, l, 1 + np, lane);                                   // newd[0] = dist(c, node) == dist(node, c) term by term
         const float dist_nc = l.newd[0];
         bool hit = false;
         for (uint32_t j0 = 0; j0 < np; j0 += 64) {
@@ -475,10 +505,11 @@ struct VgBuildArgs {
     uint32_t *visited;
     uint32_t *overflow;
 };
-__global__ __launch_bounds__(64) void vg_build_kernel(VgBuildArgs a) {
+__global__ __launch_bounds__(256) void vg_build_kernel(VgBuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
     const int lane = threadIdx.x;
+    if (threadIdx.x >= 64) { vg_helper_loop(a.g, l, (int)threadIdx.x); return; }      // waves 1-3 only score row batches for wave 0
     const uint32_t dim = a.g.dim;
     uint32_t *pr = l.pr, *pr2 = l.pr2;
     float *dne = l.dne, *dne2 = l.dne2;
@@ -538,6 +569,7 @@ __global__ __launch_bounds__(64) void vg_build_kernel(VgBuildArgs a) {
         }
         if (updates == 0 || iteration >= 2) break;
     }
+    vg_walk_done(l, lane);
 }
 
 // find_medoid (vamana.rs:407-441): the mean vector, coordinate sums in row order; then the closest row, first minimum wins.
@@ -553,21 +585,21 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const float *rows, uin
 int vg_launch_search(const VgSearchArgs &a, hipStream_t st) {
     const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_search_kernel, lds));
-    hipLaunchKernelGGL(vg_search_kernel, dim3(a.nq), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(vg_search_kernel, dim3(a.nq), dim3(VG_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
 int vg_launch_insert(const VgInsertArgs &a, hipStream_t st) {
     const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_insert_kernel, lds));
-    hipLaunchKernelGGL(vg_insert_kernel, dim3(1), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(vg_insert_kernel, dim3(1), dim3(VG_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
 int vg_launch_build(const VgBuildArgs &a, hipStream_t st) {
     const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_build_kernel, lds));
-    hipLaunchKernelGGL(vg_build_kernel, dim3(1), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(vg_build_kernel, dim3(1), dim3(VG_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
