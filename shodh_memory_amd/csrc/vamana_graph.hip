@@ -218,6 +218,19 @@ __device__ void vg_walk_done(const VgLds &l, int lane) {
 
 // inserts key into the ascending array a[lo, n) (n < cap); returns the new n. One wave.
 __device__ uint32_t vg_sorted_insert(uint64_t *a, uint32_t lo, uint32_t n, uint64_t key, int lane) {
+    if (n - lo < 64u) {
+        // the usual case (a beam of k <= 63, a frontier of a few dozen entries): one pass in registers -- lane i holds entry lo + i and its
+        // left neighbour, the ballot gives the position, every lane writes its new value
+        const uint32_t cnt = n - lo;
+        const uint64_t v = (uint32_t)lane < cnt ? a[lo + lane] : ~0ull;
+        const uint64_t left = (lane > 0 && (uint32_t)lane <= cnt) ? a[lo + lane - 1] : 0ull;
+        const uint32_t pos = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)lane < cnt && v < key));
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane <= cnt) a[lo + lane] = (uint32_t)lane < pos ? v : ((uint32_t)lane == pos ? key : left);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        return n + 1;
+    }
     // position = lo + #keys in [lo, n) smaller than key
     uint32_t pos = lo;
     for (uint32_t i0 = lo; i0 < n; i0 += 64) {
