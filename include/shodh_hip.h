@@ -115,6 +115,8 @@ int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n);
  * 0xFFFFFFFF / +inf. Empty index -> counts 0, SHODH_OK (vamana.rs:766-768). */
 int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts);
+/* SHODH_SCAN_GRAPH through the device-pointer entry point: bit 31 of d_counts[i] is set if walk i overflowed its frontier (thousands of
+ * equidistant rows; the answer may then differ from the reference's) -- mask it off; the host-pointer entry point reports it as an error */
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k,
                               uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */

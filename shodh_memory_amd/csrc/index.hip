@@ -109,8 +109,10 @@ struct Workspace {
     bool pending = false;                // ... and whether that search may still be running (device-pointer calls)
     unsigned char *buf = nullptr;
     size_t bytes = 0;
-    float *d_q = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr;
-    size_t q_floats = 0, out_elems = 0, nq_cap = 0;
+    // host-pointer calls: queries in, and ONE output block [ids | dist | counts] with a pinned host mirror, so that the results come back in
+    // a single copy (three small copies plus their API calls were a visible part of a single query's latency)
+    float *d_q = nullptr; uint32_t *d_out = nullptr, *h_out = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr;
+    size_t q_floats = 0, out_words = 0;
     // ring of (start, end) events around the dominant scan kernel of each search, for
     // shodh_index_kernel_timing (bench.py roofline): slot = ring_pos % RING
     static constexpr uint32_t RING = 256;
@@ -135,16 +137,17 @@ struct Workspace {
     }
     int reserve_io(size_t qf, size_t oe, size_t nq) {
         if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
-        if (oe > out_elems) {
-            if (d_ids) hipFree(d_ids); if (d_dist) hipFree(d_dist); d_ids = nullptr; d_dist = nullptr; out_elems = 0;
-            SHODH_HIP_TRY(hipMalloc((void **)&d_ids, oe * 4)); SHODH_HIP_TRY(hipMalloc((void **)&d_dist, oe * 4)); out_elems = oe;
+        const size_t words = 2 * oe + nq;
+        if (words > out_words) {
+            if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); d_out = nullptr; h_out = nullptr; out_words = 0;
+            SHODH_HIP_TRY(hipMalloc((void **)&d_out, words * 4)); SHODH_HIP_TRY(hipHostMalloc((void **)&h_out, words * 4)); out_words = words;
         }
-        if (nq > nq_cap) { if (d_counts) hipFree(d_counts); d_counts = nullptr; nq_cap = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_counts, nq * 4)); nq_cap = nq; }
+        d_ids = d_out; d_dist = reinterpret_cast<float *>(d_out + oe); d_counts = d_out + 2 * oe;      // contiguous for THIS call's sizes
         return SHODH_OK;
     }
     void destroy() {
         if (buf) hipFree(buf);
-        if (d_q) hipFree(d_q); if (d_ids) hipFree(d_ids); if (d_dist) hipFree(d_dist); if (d_counts) hipFree(d_counts);
+        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out);
         for (auto &e : ev) if (e) hipEventDestroy(e);
         if (last_use) hipEventDestroy(last_use);
         for (auto &r : ring) { if (r[0]) hipEventDestroy(r[0]); if (r[1]) hipEventDestroy(r[1]); }
@@ -598,16 +601,19 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         }
         if (rc != SHODH_OK) break;
         if (sync_host) {
-            if (hipMemcpyAsync(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(dist, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(counts, d_counts, (size_t)nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
-            uint32_t g_ovf = 0;
-            const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT;
-            if (graph_call) hipMemcpyAsync(&g_ovf, idx->g_overflow, 4, hipMemcpyDeviceToHost, st);      // rides along with the results: no second round trip
+            const size_t oe = (size_t)nq * k;
+            if (hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
+            memcpy(ids, w->h_out, oe * 4); memcpy(dist, w->h_out + oe, oe * 4); memcpy(counts, w->h_out + 2 * oe, (size_t)nq * 4);
+            const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT;
+            if (graph_call) {
+                // a walk whose frontier overflowed says so in the top bit of its count (vg_search_kernel)
+                bool ovf = false;
+                for (uint32_t i = 0; i < nq; ++i) { ovf = ovf || (counts[i] & 0x80000000u); counts[i] &= 0x7FFFFFFFu; }
+                if (ovf) { set_error("graph walk: the frontier overflowed (thousands of equidistant rows); the answer may differ from the reference's"); rc = SHODH_ERR_UNSUPPORTED; break; }
+            }
             collect_timings(idx, w, used_mfma, nullptr);
-            if (graph_call && g_ovf && (rc = check_graph_overflow(idx)) != SHODH_OK) break;
             if (used_mfma) {
                 uint32_t st4[4] = {0, 0, 0, 0};
                 MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);

@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void vg_search_kernel(VgSearchArgs a) {
     for (uint32_t i = lane; i < a.g.dim; i += 64) l.q[i] = a.q[(size_t)qi * a.g.dim + i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const uint32_t wn = vg_greedy(a.g, l, a.n, a.search_k, a.medoid, a.visited + (size_t)qi * a.vis_words, a.overflow, lane);
+    uint32_t *ovf = l.req + 1;                 // this walk's own overflow flag (LDS): reported in the top bit of counts[qi]
+    if (lane == 0) *ovf = 0;
+    const uint32_t wn = vg_greedy(a.g, l, a.n, a.search_k, a.medoid, a.visited + (size_t)qi * a.vis_words, ovf, lane);
     vg_walk_done(l, lane);
     // filter tombstones, take k (vamana.rs:797-804)
     uint32_t o = 0;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void vg_search_kernel(VgSearchArgs a) {
     }
     if (o > a.k) o = a.k;
     for (uint32_t i = o + lane; i < a.k; i += 64) { a.ids[(size_t)qi * a.k + i] = 0xFFFFFFFFu; a.dist[(size_t)qi * a.k + i] = __builtin_inff(); }
-    if (lane == 0) a.counts[qi] = o;
+    if (lane == 0) a.counts[qi] = o | (*ovf ? 0x80000000u : 0u);
 }
 
 // add_vector for rows [first, first + count), one after the other (vamana.rs:853-974). One wave.

@@ -305,6 +305,8 @@ class VamanaIndex:
         st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
         L.check(L.lib().shodh_index_search_device(self.handle, queries.data_ptr(), nq, k, ids.data_ptr(), dist.data_ptr(),
                                                   counts.data_ptr(), C.c_void_p(st)))
+        if self.graph_mode:
+            counts.bitwise_and_(0x7FFFFFFF)        # bit 31 = "this walk's frontier overflowed" (include/shodh_hip.h); the host-pointer API raises instead
         return ids, dist, counts
 
     # -- tombstones (vamana.rs:813-850) ------------------------------------------------------------------
