@@ -39,9 +39,10 @@ namespace shodh {
 
 constexpr int VG_W_CAP = 1024;     // beam: k (+ over-fetch for tombstones), search_list_size, max_degree
 constexpr int VG_C_CAP = 2048;     // frontier entries kept (only those not worse than the worst of `w` can ever be expanded)
-constexpr int VG_ROWS = 32;        // neighbour rows scored at a time (dim <= 512; 8 above: the staging area of the 8-chain order has to fit the LDS)
+constexpr int VG_ROWS = 64;        // neighbour rows scored at a time (scalar-4 order, dim <= 512: a back-edge list of R + 1 = 33 rows is ONE batch; 32 in the
+                                   // 8-chain order, 8 above 512 dimensions: the staging area has to fit the LDS)
 constexpr int VG_HASH = 8192;     // entries of the visited set kept in LDS (a walk that outgrows 60 % of it moves to the one-bit-per-row map in memory)
-constexpr int VG_U = 48;           // float4 loads per lane in flight in one round of vg_distances
+constexpr int VG_U = 96;           // float4 loads per lane in flight in one round of vg_distances
 constexpr int VG_MAXDEG = 128;     // neighbours per node the kernels handle (max_degree + 1 <= this)
 
 struct VgGraph {
@@ -67,9 +68,9 @@ struct VgLds {
     uint32_t *pr, *pr2;     // [VG_MAXDEG] pruned lists (build)
     float *dne, *dne2;      // [VG_MAXDEG] node -> kept neighbour distances (build)
 };
-__host__ __device__ inline uint32_t vg_rows_per_batch(uint32_t dim) { return dim <= 512 ? (uint32_t)VG_ROWS : 8u; }
+__host__ __device__ inline uint32_t vg_rows_per_batch(uint32_t dim, uint32_t order) { return dim <= 512 ? (order == SHODH_ORDER_AVX2 ? 32u : (uint32_t)VG_ROWS) : 8u; }
 __host__ __device__ inline size_t vg_lds_bytes(uint32_t dim, uint32_t order) {
-    const size_t rpb = vg_rows_per_batch(dim), stage = order == SHODH_ORDER_AVX2 ? rpb * (dim + 4) * 4 : 0;      // scalar-4 sums straight from registers
+    const size_t rpb = vg_rows_per_batch(dim, order), stage = order == SHODH_ORDER_AVX2 ? rpb * (dim + 4) * 4 : 0;      // scalar-4 sums straight from registers
     return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + VG_HASH * 4 + stage + rpb * (dim / 4 + 1) * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
 }
 __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t order) {
@@ -78,7 +79,7 @@ __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t ord
     l.cand = l.w + VG_W_CAP;
     l.hset = reinterpret_cast<uint32_t *>(l.cand + VG_C_CAP);
     l.q = reinterpret_cast<float *>(l.hset + VG_HASH);
-    l.rpb = vg_rows_per_batch(dim);
+    l.rpb = vg_rows_per_batch(dim, order);
     l.stage = l.q + dim;
     l.tsum = l.stage + (order == SHODH_ORDER_AVX2 ? (size_t)l.rpb * (dim + 4) : 0);
     l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)l.rpb * (dim / 4 + 1));
