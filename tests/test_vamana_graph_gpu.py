@@ -248,3 +248,34 @@ def test_graph_mode_argument_checks(S):
         idx.set_graph(np.full(50, 2, np.uint32), np.zeros((50, 2), np.uint32), 50)                     # medoid out of range
     with pytest.raises(L.ShodhError):
         S.VamanaIndex(S.VamanaConfig(dimension=64)).get_graph()                                        # not a graph index
+
+
+def test_concurrent_graph_searches_on_one_handle(S, oracle):
+    """`search` takes &self in the reference (concurrent under a read lock): eight host threads walk the same graph at once, each
+    call with its own visited set and result block; every answer equals the oracle's"""
+    import threading
+    dim, R, n = 384, 32, 2000
+    rows = unit_rows(n, dim, 61, clusters=10)
+    idx = gpu_index(S, dim, R, 75)
+    g = oracle.VamanaGraph(dim, R=R, L=75, capacity=n)
+    idx.add_vectors(rows)
+    for r in rows:
+        g.add_vector(r)
+    queries = unit_rows(64, dim, 62, clusters=10)
+    expect = [g.search(q, 10) for q in queries]
+    errs = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                sl = slice(t * 8, t * 8 + 8)
+                ids, dist, counts = idx.search_batch(queries[sl], 10)
+                for j in range(8):
+                    e_ids, e_dist = expect[t * 8 + j]
+                    m = int(counts[j])
+                    assert ids[j, :m].tolist() == e_ids.tolist() and dist[j, :m].tobytes() == e_dist.tobytes()
+        except Exception as ex:   # noqa
+            errs.append(ex)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
