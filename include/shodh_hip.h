@@ -115,6 +115,10 @@ int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n);
  * 0xFFFFFFFF / +inf. Empty index -> counts 0, SHODH_OK (vamana.rs:766-768). */
 int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts);
+/* VamanaIndex::brute_force_search (vamana.rs:1167-1188) whatever the scan mode: the exact scan of a FLAT index, graph mode included
+ * (what the reference's estimate_recall compares its ANN answers with, vamana.rs:1128-1165) */
+int shodh_index_brute_force_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k,
+                                   uint32_t *ids, float *dist, uint32_t *counts);
 /* SHODH_SCAN_GRAPH through the device-pointer entry point: bit 31 of d_counts[i] is set if walk i overflowed its frontier (thousands of
  * equidistant rows; the answer may then differ from the reference's) -- mask it off; the host-pointer entry point reports it as an error */
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k,

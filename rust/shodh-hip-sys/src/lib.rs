@@ -156,8 +156,36 @@ impl HipIndex {
         self.incremental.store(inserts.saturating_sub(REPAIR_THRESHOLD), std::sync::atomic::Ordering::Release);   // vamana.rs:1108-1111
         Ok(0)
     }
-    pub fn quality_degraded(&self) -> Result<bool> { Ok(false) }
-    pub fn estimate_recall(&self, _sample_size: usize, _k: usize) -> Result<f32> { Ok(1.0) }   // search IS the brute-force search
+    /// vamana.rs:1194-1208
+    pub fn quality_degraded(&self) -> Result<bool> {
+        if self.len() < 100 || self.incremental_insert_count() == 0 { return Ok(false); }
+        Ok(self.estimate_recall(50, 10)? < 0.85)
+    }
+    /// `brute_force_search` (vamana.rs:1167-1188) whatever the scan mode
+    pub fn brute_force_search(&self, query: &[f32], k: usize) -> Result<Vec<(u32, f32)>> {
+        if query.len() != self.dim { return Err(anyhow!("Query dimension {} doesn't match index dimension {}", query.len(), self.dim)); }
+        let (mut ids, mut dist, mut cnt) = (vec![0u32; k.max(1)], vec![0f32; k.max(1)], 0u32);
+        check(unsafe { ffi::shodh_index_brute_force_search(self.h, query.as_ptr(), 1, k as u32, ids.as_mut_ptr(), dist.as_mut_ptr(), &mut cnt) })?;
+        Ok((0..cnt as usize).map(|i| (ids[i], dist[i])).collect())
+    }
+    /// `estimate_recall` (vamana.rs:1128-1165). The exact index answers with the brute-force scan itself (1.0 by construction); a
+    /// `graph_walk` index compares its walk with `brute_force_search` over `sample_size` stored vectors (every `n / sample_size`-th
+    /// row here; the reference shuffles with thread_rng).
+    pub fn estimate_recall(&self, sample_size: usize, k: usize) -> Result<f32> {
+        let n = self.len();
+        if n < 2 || !self.graph_walk { return Ok(1.0); }
+        let (sample_size, k) = (sample_size.min(n / 2).max(1), k.min(n - 1));
+        let mut row = vec![0f32; self.dim];
+        let mut total = 0f32;
+        for s in 0..sample_size {
+            let i = s * (n / sample_size);
+            check(unsafe { ffi::shodh_index_extract_rows(self.h, i as u64, 1, row.as_mut_ptr()) })?;
+            let ann: std::collections::HashSet<u32> = self.search(&row, k)?.into_iter().map(|(id, _)| id).collect();
+            let exact = self.brute_force_search(&row, k)?;
+            total += exact.iter().filter(|(id, _)| ann.contains(id)).count() as f32 / k as f32;
+        }
+        Ok(total / sample_size as f32)
+    }
     pub fn auto_maintain(&self) -> Result<String> {
         if self.needs_rebuild() {
             return Ok(if self.auto_rebuild_if_needed()? { "full_rebuild" } else { "rebuild_skipped" }.to_string());

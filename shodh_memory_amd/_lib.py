@@ -99,6 +99,7 @@ SYMBOLS = {
     "shodh_index_build": (C.c_int, [_vp, _fp, C.c_uint64]),
     "shodh_index_build_device": (C.c_int, [_vp, _fp, C.c_uint64]),
     "shodh_index_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "shodh_index_brute_force_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "shodh_index_search_device": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
     "shodh_index_mark_deleted_batch": (C.c_int, [_vp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -537,7 +537,7 @@ int shodh_index_build(shodh_index *idx, const float *rows, uint64_t n) { return 
 int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n) { return build_impl(idx, d_rows, n, hipMemcpyDeviceToDevice); }
 
 static int search_common(shodh_index *idx, const float *q, bool q_on_device, uint32_t nq, uint32_t k,
-                         uint32_t *ids, float *dist, uint32_t *counts, hipStream_t user_stream, bool sync_host) {
+                         uint32_t *ids, float *dist, uint32_t *counts, hipStream_t user_stream, bool sync_host, bool force_exact = false) {
     if (!idx || (nq && (!q || !counts)) || (nq && k && (!ids || !dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (nq == 0) return SHODH_OK;
     std::shared_lock<std::shared_mutex> lk(idx->mu);
@@ -579,7 +579,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
             d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
         }
-        if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
+        if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !force_exact) {
             // VamanaIndex::search without SHODH_VECTOR_EXACT (vamana.rs:764-808)
             if (idx->g_nodes != idx->n) { set_error("Vamana graph not built. Call build() first or add more vectors."); rc = SHODH_ERR_STATE; break; }
             const uint64_t dc = idx->n_deleted;
@@ -606,7 +606,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             memcpy(ids, w->h_out, oe * 4); memcpy(dist, w->h_out + oe, oe * 4); memcpy(counts, w->h_out + 2 * oe, (size_t)nq * 4);
-            const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT;
+            const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT && !force_exact;
             if (graph_call) {
                 // a walk whose frontier overflowed says so in the top bit of its count (vg_search_kernel)
                 bool ovf = false;
@@ -637,6 +637,10 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
 
 int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
     return search_common(idx, q, false, nq, k, ids, dist, counts, nullptr, true);
+}
+int shodh_index_brute_force_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+    if (idx && idx->cfg.kind != SHODH_INDEX_FLAT) { set_error("brute_force_search is for FLAT indexes"); return SHODH_ERR_STATE; }
+    return search_common(idx, q, false, nq, k, ids, dist, counts, nullptr, true, true);
 }
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k, uint32_t *d_ids, float *d_dist,
                               uint32_t *d_counts, void *stream) {

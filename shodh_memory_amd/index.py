@@ -20,6 +20,7 @@ import numpy as np
 from . import _lib as L
 
 # vamana.rs:103-117
+MIN_ACCEPTABLE_RECALL = 0.85            # vamana.rs:115
 REBUILD_THRESHOLD = 10_000
 REPAIR_THRESHOLD = 1_000
 DELETION_RATIO_THRESHOLD = 0.30
@@ -361,12 +362,41 @@ class VamanaIndex:
         self._incremental = max(0, self._incremental - REPAIR_THRESHOLD)
         return 0
 
-    def estimate_recall(self, sample_size=100, k=10):
-        """vamana.rs:1128-1165 compares `search` with `brute_force_search`; here they are the same scan"""
-        return 1.0
+    def brute_force_search_batch(self, queries, k):
+        """VamanaIndex::brute_force_search (vamana.rs:1167-1188) whatever the scan mode -> (ids, dist, counts)"""
+        q = _as_rows(queries, self._hd.dim)
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        L.check(L.lib().shodh_index_brute_force_search(self.handle, q.ctypes.data, nq, k, ids.ctypes.data, dist.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], dist[:, :k], counts
+
+    def estimate_recall(self, sample_size=100, k=10, rng=None):
+        """vamana.rs:1128-1165: recall@k of `search` against `brute_force_search` over randomly sampled stored vectors. With the exact
+        scan the two are the same scan (1.0 by construction); in graph mode both run on the device and are compared."""
+        n = self.len()
+        if n < 2 or not self.graph_mode:
+            return 1.0
+        sample_size = max(min(sample_size, n // 2), 1)
+        k = min(k, n - 1)
+        rng = rng or np.random.default_rng()
+        pick = rng.permutation(n)[:sample_size]                                  # the reference shuffles with thread_rng
+        rows = np.empty((sample_size, self._hd.dim), np.float32)
+        for j, i in enumerate(pick):
+            L.check(L.lib().shodh_index_extract_rows(self.handle, int(i), 1, rows[j].ctypes.data))
+        a_ids, _, a_cnt = self.search_batch(rows, k)
+        e_ids, _, e_cnt = self.brute_force_search_batch(rows, k)
+        total = 0.0
+        for j in range(sample_size):
+            total += len(set(a_ids[j, :int(a_cnt[j])].tolist()) & set(e_ids[j, :int(e_cnt[j])].tolist())) / float(k)
+        return total / sample_size
 
     def quality_degraded(self):
-        return False
+        """vamana.rs:1194-1210: too small / no incremental inserts -> False; else estimated recall@10 over 50 samples below MIN_ACCEPTABLE_RECALL"""
+        if self.len() < 100 or self._incremental == 0:
+            return False
+        return self.estimate_recall(50, 10) < MIN_ACCEPTABLE_RECALL
 
     def auto_maintain(self):
         """vamana.rs:1217-1232"""

