@@ -163,6 +163,11 @@ int shodh_index_get_graph(const shodh_index *idx, uint32_t *deg, uint32_t *nbr, 
  * drawn from thread_rng (:287-312): pass it as init_deg / init_nbr [len][init_stride] (each list <= max_degree) to reproduce a
  * given run bit for bit, or NULL to draw one here from `seed`. */
 int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *init_deg, const uint32_t *init_nbr, uint32_t init_stride);
+/* VamanaIndex::incremental_repair (vamana.rs:1033-1115) for nodes [first_node, first_node + count): walk(search_list_size) from the
+ * medoid, robust_prune(alpha), and where a list changed its stale back edges are removed and the new ones pushed (truncated to max_degree).
+ * repaired_out = nodes whose list changed. Which nodes to repair and the insert counter are the caller's (the reference: the last
+ * min(inserts, 1000) nodes once 1000 inserts have accumulated). */
+int shodh_index_incremental_repair(shodh_index *idx, uint32_t first_node, uint32_t count, uint32_t *repaired_out);
 
 /* ---- multi-GPU: merge of per-shard results ------------------------------------------------------- */
 /* Row-sharded corpora: every rank searches its shard (ids carry id_base), the

@@ -113,6 +113,7 @@ def lib():
         "so_vamana_add_vector": (None, [fp, sz, sz, u32p, u32p, sz, sz, C.c_uint32, C.c_int]),
         "so_vamana_robust_prune": (sz, [fp, sz, C.c_uint32, u32p, fp, sz, sz, C.c_float, C.c_int, u32p]),
         "so_vamana_find_medoid": (C.c_uint32, [fp, sz, sz, C.c_int]),
+        "so_vamana_incremental_repair": (sz, [fp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, C.c_float, C.c_uint32, C.c_uint32, C.c_int]),
         "so_vamana_build": (C.c_uint32, [fp, sz, sz, u32p, u32p, sz, sz, sz, C.c_float, C.c_int]),
         "so_bench_brute_force": (C.c_double, [fp, sz, sz, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
         "so_bench_brute_force_del": (C.c_double, [fp, sz, sz, u8p, fp, sz, sz, C.c_int, C.c_int, C.c_int, u32p, fp]),
@@ -458,6 +459,11 @@ class VamanaGraph:
         self.medoid = int(lib().so_vamana_build(_p(self.rows, C.c_float), n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32),
                                                 self.cap, self.R, self.L, self.alpha, self.order))
         return self.medoid
+
+    def incremental_repair(self, start):
+        """VamanaIndex::incremental_repair (vamana.rs:1033-1115) for nodes [start, n) -> nodes whose list changed"""
+        return int(lib().so_vamana_incremental_repair(_p(self.rows, C.c_float), self.n, self.dim, _p(self.deg, C.c_uint32), _p(self.nbr, C.c_uint32),
+                                                      self.cap, self.R, self.L, self.alpha, self.medoid, start, self.order))
 
     def greedy_search(self, q, k, entry=None):
         q, pq = _f(q)

@@ -187,6 +187,8 @@ void so_vamana_add_vector(const float *vecs, size_t n_before, size_t dim, uint32
 size_t so_vamana_robust_prune(const float *vecs, size_t dim, uint32_t node, const uint32_t *c_ids, const float *c_dist, size_t n_c,
                               size_t R, float alpha, int order, uint32_t *out);
 uint32_t so_vamana_find_medoid(const float *vecs, size_t n, size_t dim, int order);
+size_t so_vamana_incremental_repair(const float *vecs, size_t n, size_t dim, uint32_t *deg, uint32_t *nbr, size_t cap, size_t R, size_t L,
+                                    float alpha, uint32_t medoid, uint32_t start, int order);
 uint32_t so_vamana_build(const float *vecs, size_t n, size_t dim, uint32_t *deg, uint32_t *nbr, size_t cap, size_t R, size_t L, float alpha,
                          int order);
 

@@ -220,3 +220,46 @@ uint32_t so_vamana_build(const float *vecs, size_t n, size_t dim, uint32_t *deg,
     free(ids); free(pr); free(pr2); free(dist); free(zero);
     return medoid;
 }
+
+/* incremental_repair (vamana.rs:1033-1115) for nodes [start, n): greedy_search(L) from the medoid, robust_prune, and when the list
+ * changed: stale back edges removed (retain), new back edges pushed and truncated to R. Returns the number of nodes whose list changed. */
+size_t so_vamana_incremental_repair(const float *vecs, size_t n, size_t dim, uint32_t *deg, uint32_t *nbr, size_t cap, size_t R, size_t L,
+                                    float alpha, uint32_t medoid, uint32_t start, int order) {
+    if (n == 0) return 0;
+    uint32_t *ids = (uint32_t *)malloc((L ? L : 1) * 4), *pr = (uint32_t *)malloc((R + 1) * 4), *old = (uint32_t *)malloc((cap + 1) * 4);
+    float *dist = (float *)malloc((L ? L : 1) * 4);
+    size_t repaired = 0;
+    for (uint32_t node = start; node < (uint32_t)n; ++node) {
+        const size_t m = so_vamana_greedy_search(vecs, n, dim, deg, nbr, cap, vecs + (size_t)node * dim, L, medoid, order, ids, dist);
+        const size_t np = so_vamana_robust_prune(vecs, dim, node, ids, dist, m, R, alpha, order, pr);
+        const uint32_t od = deg[node];
+        int same = (np == od);
+        for (size_t j = 0; same && j < np; ++j) same = nbr[(size_t)node * cap + j] == pr[j];
+        if (same) continue;
+        for (uint32_t j = 0; j < od; ++j) old[j] = nbr[(size_t)node * cap + j];
+        for (size_t j = 0; j < np; ++j) nbr[(size_t)node * cap + j] = pr[j];
+        deg[node] = (uint32_t)np;
+        ++repaired;
+        for (uint32_t j = 0; j < od; ++j) {                       /* back edges of neighbours that are gone */
+            const uint32_t o = old[j];
+            int kept = 0;
+            for (size_t t = 0; t < np; ++t) kept |= pr[t] == o;
+            if (kept || o >= n) continue;
+            uint32_t w = 0;
+            for (uint32_t t = 0; t < deg[o]; ++t) { const uint32_t x = nbr[(size_t)o * cap + t]; if (x != node) nbr[(size_t)o * cap + w++] = x; }
+            deg[o] = w;
+        }
+        for (size_t j = 0; j < np; ++j) {                         /* back edges to the new neighbours: push, truncate to R */
+            const uint32_t p = pr[j];
+            if (p >= n) continue;
+            int has = 0;
+            for (uint32_t t = 0; t < deg[p]; ++t) has |= nbr[(size_t)p * cap + t] == node;
+            if (has) continue;
+            if (deg[p] < cap) nbr[(size_t)p * cap + deg[p]] = node;
+            deg[p] += 1;
+            if (deg[p] > R) deg[p] = (uint32_t)R;
+        }
+    }
+    free(ids); free(pr); free(old); free(dist);
+    return repaired;
+}

@@ -151,11 +151,19 @@ impl HipIndex {
     pub fn needs_rebuild(&self) -> bool { self.incremental_insert_count() >= REBUILD_THRESHOLD || self.needs_compaction() }
     pub fn needs_repair(&self) -> bool { (REPAIR_THRESHOLD..REBUILD_THRESHOLD).contains(&self.incremental_insert_count()) }
     pub fn incremental_repair(&self) -> Result<usize> {
-        let inserts = self.incremental_insert_count();
-        if self.is_empty() || inserts < REPAIR_THRESHOLD { return Ok(0); }
-        self.incremental.store(inserts.saturating_sub(REPAIR_THRESHOLD), std::sync::atomic::Ordering::Release);   // vamana.rs:1108-1111
-        Ok(0)
+        // vamana.rs:1033-1115: the last min(inserts, REPAIR_THRESHOLD) nodes are re-pruned once REPAIR_THRESHOLD inserts have accumulated
+        // (on the device for a `graph_walk` index; the exact index has no graph: 0 nodes); the counter moves as the reference's does
+        let (n, inserts) = (self.len(), self.incremental_insert_count());
+        if n == 0 || inserts < REPAIR_THRESHOLD { return Ok(0); }
+        let mut repaired = 0u32;
+        if self.graph_walk {
+            let count = inserts.min(REPAIR_THRESHOLD).min(n);
+            check(unsafe { ffi::shodh_index_incremental_repair(self.h, (n - count) as u32, count as u32, &mut repaired) })?;
+        }
+        self.incremental.store(inserts.saturating_sub(REPAIR_THRESHOLD), std::sync::atomic::Ordering::Relaxed);
+        Ok(repaired as usize)
     }
+
     /// vamana.rs:1194-1208
     pub fn quality_degraded(&self) -> Result<bool> {
         if self.len() < 100 || self.incremental_insert_count() == 0 { return Ok(false); }

@@ -118,6 +118,7 @@ SYMBOLS = {
     "shodh_index_set_graph": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, C.c_uint32]),
     "shodh_index_get_graph": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "shodh_index_build_with_graph": (C.c_int, [_vp, _fp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32]),
+    "shodh_index_incremental_repair": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "shodh_index_vamana_build": (C.c_int, [_vp, C.c_uint64, _u32p, _u32p, C.c_uint32]),
     "shodh_topk_merge_device": (C.c_int, [_u32p, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_topk_merge_strided_device": (C.c_int, [_u32p, _fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),

@@ -88,6 +88,8 @@ struct VgSearchArgs { VgGraph g; uint32_t n, medoid; const float *q; uint32_t nq
                       uint32_t *visited; uint32_t vis_words; uint32_t *ids; float *dist; uint32_t *counts; uint32_t *overflow; };
 struct VgInsertArgs { VgGraph g; uint32_t first, count, R, medoid; uint32_t *visited; uint32_t *overflow; };
 struct VgBuildArgs { VgGraph g; uint32_t n, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; };
+struct VgRepairArgs { VgGraph g; uint32_t n, first, count, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; uint32_t *repaired; };
+int vg_launch_repair(const VgRepairArgs &a, hipStream_t st);
 int vg_launch_search(const VgSearchArgs &a, hipStream_t st);
 int vg_launch_insert(const VgInsertArgs &a, hipStream_t st);
 int vg_launch_build(const VgBuildArgs &a, hipStream_t st);
@@ -829,6 +831,30 @@ int shodh_index_build_with_graph(shodh_index *idx, const float *rows, uint64_t n
     if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
     SHODH_TRY(build_impl(idx, rows, n, hipMemcpyHostToDevice, false));
     return shodh_index_set_graph(idx, deg, nbr, stride, medoid);
+}
+
+int shodh_index_incremental_repair(shodh_index *idx, uint32_t first_node, uint32_t count, uint32_t *repaired_out) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (idx->cfg.scan_mode != SHODH_SCAN_GRAPH) { set_error("not a SHODH_SCAN_GRAPH index"); return SHODH_ERR_STATE; }
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    SHODH_TRY(set_device(idx));
+    if (repaired_out) *repaired_out = 0;
+    if (idx->g_nodes != idx->n) { set_error("the graph does not cover the rows: build it first"); return SHODH_ERR_STATE; }
+    if (count == 0 || first_node >= idx->n) return SHODH_OK;
+    uint32_t total = 0;
+    for (uint64_t at = first_node; at < (uint64_t)first_node + count && at < idx->n; at += 1024) {       // bounded launches
+        const uint32_t m = (uint32_t)std::min<uint64_t>(1024, std::min<uint64_t>((uint64_t)first_node + count, idx->n) - at);
+        VgRepairArgs a{graph_of(idx), (uint32_t)idx->n, (uint32_t)at, m, idx->cfg.max_degree, idx->cfg.search_list_size, idx->g_medoid, idx->cfg.alpha,
+                       idx->g_visited, idx->g_overflow, idx->g_overflow + 8};
+        SHODH_TRY(vg_launch_repair(a, nullptr));
+        uint32_t r = 0;
+        const hipError_t e = hipMemcpy(&r, idx->g_overflow + 8, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("graph repair failed on device: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
+        total += r;
+    }
+    SHODH_TRY(check_graph_overflow(idx));
+    if (repaired_out) *repaired_out = total;
+    return SHODH_OK;
 }
 
 int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *init_deg, const uint32_t *init_nbr, uint32_t init_stride) {

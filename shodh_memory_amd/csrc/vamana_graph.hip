@@ -588,6 +588,91 @@ __global__ __launch_bounds__(256) void vg_build_kernel(VgBuildArgs a) {
     vg_walk_done(l, lane);
 }
 
+// incremental_repair (vamana.rs:1033-1115) for nodes [first, first + count): walk with beam L from the medoid, robust_prune, and where the
+// list changed: remove the stale back edges (retain), push the new ones and truncate to R. One workgroup, node after node.
+struct VgRepairArgs {
+    VgGraph g;
+    uint32_t n, first, count, R, L, medoid;
+    float alpha;
+    uint32_t *visited;
+    uint32_t *overflow;
+    uint32_t *repaired;       // out: nodes whose list changed
+};
+__global__ __launch_bounds__(256) void vg_repair_kernel(VgRepairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const VgLds l = vg_carve(smem, a.g.dim, a.g.order);
+    const int lane = threadIdx.x;
+    if (threadIdx.x >= 64) { vg_helper_loop(a.g, l, (int)threadIdx.x); return; }
+    const uint32_t dim = a.g.dim;
+    uint32_t *pr = l.pr, *old = l.pr2;
+    float *dne = l.dne;
+    uint32_t repaired = 0;
+    for (uint32_t node = a.first; node < a.first + a.count && node < a.n; ++node) {
+        for (uint32_t i = lane; i < dim; i += 64) l.q[i] = a.g.rows[(size_t)node * dim + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t m = vg_greedy(a.g, l, a.n, a.L, a.medoid, a.visited, a.overflow, lane);
+        const uint32_t np = vg_robust_prune(a.g, l, node, m, a.R, a.alpha, pr, dne, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        const uint32_t od = a.g.deg[node];
+        bool same = np == od;
+        if (same) {
+            bool diff = false;
+            for (uint32_t j = lane; j < np; j += 64) diff = diff || a.g.nbr[(size_t)node * a.g.stride + j] != pr[j];
+            same = __builtin_amdgcn_ballot_w64(diff) == 0;
+        }
+        if (same) continue;
+        ++repaired;
+        for (uint32_t j = lane; j < od; j += 64) old[j] = a.g.nbr[(size_t)node * a.g.stride + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = lane; j < np; j += 64) a.g.nbr[(size_t)node * a.g.stride + j] = pr[j];
+        if (lane == 0) a.g.deg[node] = np;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        for (uint32_t j = 0; j < od; ++j) {                      // back edges of neighbours that are gone: retain(|x| x != node)
+            const uint32_t o = old[j];
+            bool kept = false;
+            for (uint32_t t = lane; t < np; t += 64) kept = kept || pr[t] == o;
+            if (__builtin_amdgcn_ballot_w64(kept) != 0 || o >= a.n) continue;
+            const uint32_t dg = a.g.deg[o];
+            // lists hold at most VG_MAXDEG entries: two rounds of 64 lanes, the entries after the removed one move up by one
+            uint32_t vals[VG_MAXDEG / 64];
+            uint32_t pos = 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = 0; t < VG_MAXDEG / 64; ++t) {
+                const uint32_t i = t * 64 + lane;
+                vals[t] = i < dg ? a.g.nbr[(size_t)o * a.g.stride + i] : 0xFFFFFFFFu;
+                const uint64_t hit = __builtin_amdgcn_ballot_w64(i < dg && vals[t] == node);
+                if (hit && pos == 0xFFFFFFFFu) pos = t * 64 + (uint32_t)__builtin_ctzll(hit);
+            }
+            if (pos == 0xFFFFFFFFu) continue;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < VG_MAXDEG / 64; ++t) {
+                const uint32_t i = t * 64 + lane;
+                if (i < dg && i > pos) a.g.nbr[(size_t)o * a.g.stride + i - 1] = vals[t];
+            }
+            if (lane == 0) a.g.deg[o] = dg - 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+        for (uint32_t j = 0; j < np; ++j) {                      // back edges to the new neighbours: push, truncate to R
+            const uint32_t p = pr[j];
+            if (p >= a.n) continue;
+            const uint32_t dg = a.g.deg[p];
+            bool has = false;
+            for (uint32_t t = lane; t < dg; t += 64) has = has || a.g.nbr[(size_t)p * a.g.stride + t] == node;
+            if (__builtin_amdgcn_ballot_w64(has) != 0) continue;
+            if (lane == 0) {
+                if (dg < a.R) { a.g.nbr[(size_t)p * a.g.stride + dg] = node; a.g.deg[p] = dg + 1; }
+                else a.g.deg[p] = a.R;                            // the pushed entry (and anything beyond R) falls to the truncation
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+    }
+    if (lane == 0) *a.repaired = repaired;
+    vg_walk_done(l, lane);
+}
+
 // find_medoid (vamana.rs:407-441): the mean vector, coordinate sums in row order; then the closest row, first minimum wins.
 __global__ __launch_bounds__(256) void vg_centroid_kernel(const float *rows, uint32_t n, uint32_t dim, float *centroid) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -616,6 +701,13 @@ int vg_launch_build(const VgBuildArgs &a, hipStream_t st) {
     const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
     SHODH_TRY(ensure_dynamic_lds((const void *)vg_build_kernel, lds));
     hipLaunchKernelGGL(vg_build_kernel, dim3(1), dim3(VG_NT), lds, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+int vg_launch_repair(const VgRepairArgs &a, hipStream_t st) {
+    const size_t lds = vg_lds_bytes(a.g.dim, a.g.order);
+    SHODH_TRY(ensure_dynamic_lds((const void *)vg_repair_kernel, lds));
+    hipLaunchKernelGGL(vg_repair_kernel, dim3(1), dim3(VG_NT), lds, st, a);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }

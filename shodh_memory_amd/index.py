@@ -355,12 +355,20 @@ class VamanaIndex:
         return REPAIR_THRESHOLD <= self._incremental < REBUILD_THRESHOLD             # vamana.rs:1010-1016
 
     def incremental_repair(self):
-        """vamana.rs:1033-1115. There is no graph to re-prune in the exact index: 0 nodes repaired, the counter moves as
-        the reference's does."""
-        if self.is_empty() or self._incremental < REPAIR_THRESHOLD:
+        """vamana.rs:1033-1115: once REPAIR_THRESHOLD inserts have accumulated, the last min(inserts, REPAIR_THRESHOLD) nodes are
+        re-pruned (walk + robust_prune + back edges) -- on the device in graph mode; the exact index has no graph to repair (0 nodes).
+        The counter moves as the reference's does. Returns the number of nodes whose list changed."""
+        n = self.len()
+        if n == 0 or self._incremental < REPAIR_THRESHOLD:
             return 0
+        repaired = 0
+        if self.graph_mode:
+            count = min(self._incremental, REPAIR_THRESHOLD, n)
+            r = C.c_uint32()
+            L.check(L.lib().shodh_index_incremental_repair(self.handle, n - count, count, C.byref(r)))
+            repaired = int(r.value)
         self._incremental = max(0, self._incremental - REPAIR_THRESHOLD)
-        return 0
+        return repaired
 
     def brute_force_search_batch(self, queries, k):
         """VamanaIndex::brute_force_search (vamana.rs:1167-1188) whatever the scan mode -> (ids, dist, counts)"""

@@ -309,3 +309,23 @@ def test_estimate_recall_and_brute_force_in_graph_mode(S, oracle):
     assert idx.quality_degraded() == (r < 0.85) or True            # (quality_degraded draws its own sample)
     exact = S.VamanaIndex(S.VamanaConfig(dimension=dim)); exact.build(rows)
     assert exact.estimate_recall(20, 5) == 1.0 and exact.quality_degraded() is False
+
+
+@pytest.mark.parametrize("dim,R,Ls,order", [(64, 8, 30, 0), (384, 16, 40, 0), (128, 6, 20, 1)])
+def test_incremental_repair_matches_the_oracle(S, oracle, dim, R, Ls, order):
+    """vamana.rs:1033-1115 after 1300 add_vector calls: the last 1000 nodes re-pruned on the device, lists and degrees equal to the oracle's"""
+    n = 1300
+    rows = unit_rows(n, dim, 81 + dim, clusters=6)
+    idx = gpu_index(S, dim, R, Ls, order)
+    g = oracle.VamanaGraph(dim, R=R, L=Ls, order=order, capacity=n)
+    idx.add_vectors(rows)
+    for r in rows:
+        g.add_vector(r)
+    assert idx.incremental_insert_count() == n - 1 and idx.needs_repair()
+    rep = idx.incremental_repair()
+    assert rep == g.incremental_repair(n - 1000) and rep > 0
+    assert_graph_equal(idx, g)
+    assert idx.incremental_insert_count() == n - 1 - 1000 and not idx.needs_repair()
+    assert idx.incremental_repair() == 0                               # below the threshold again: nothing happens
+    assert_search_equal(idx, g, unit_rows(24, dim, 5, clusters=6), 10)
+    assert idx.auto_maintain() == "no_action"
