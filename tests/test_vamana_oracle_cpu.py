@@ -105,3 +105,22 @@ def test_incremental_graph_invariants(oracle, order):
     for qi in range(20):
         ids, dist = g.search(rows[qi], 5, deleted=deleted)
         assert len(ids) <= 5 and not deleted[ids].any() and (np.diff(dist) >= 0).all()
+
+
+def test_incremental_repair_invariants(oracle):
+    """vamana.rs:1033-1115 restated: after re-pruning the last 1000 nodes every list is duplicate-free, within max_degree, never lists its
+    own node, and a second repair of the same range changes far fewer nodes (the lists are already alpha-pruned)"""
+    rng = np.random.default_rng(21)
+    n, dim, R = 1400, 32, 8
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    g = oracle.VamanaGraph(dim, R=R, L=30, capacity=n)
+    for r in rows:
+        g.add_vector(r)
+    first = g.incremental_repair(n - 1000)
+    assert first > 0
+    for i in range(n):
+        nb = g.nbr[i, :g.deg[i]]
+        assert g.deg[i] <= R and i not in nb and len(set(nb.tolist())) == len(nb) and (nb < n).all()
+    second = g.incremental_repair(n - 1000)
+    assert second < first
