@@ -99,9 +99,15 @@ __device__ __forceinline__ float vg_key_dist(uint64_t k) { return order_key_inv(
 // Up to 32 rows per batch, and every 16-byte piece of a batch is requested before the first is used (VG_U per lane and round: a hop of
 // the walk is a chain of dependent round trips, the rows are the longest of them and used to be fetched eight rows at a time).
 constexpr int VG_NT = 256;          // threads of a walk's workgroup: wave 0 walks, all four waves score rows
-__device__ __forceinline__ void vg_sync() { __syncthreads(); }
-__device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane /* 0 .. VG_NT - 1 */) {
-    constexpr int NT = VG_NT, VU = VG_U * 64 / NT;
+template <int NT> __device__ __forceinline__ void vg_sync() {
+    if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+// NT = 256: the whole workgroup on the walk's own buffers; NT = 64: ONE wave on private buffers (the back-edge lists of an insert are
+// re-ranked four at a time, one per wave). VU = float4 loads per thread in flight per round.
+struct VgDistBuf { const float *q; float *tsum; float *stage; const uint32_t *ids; float *out; uint32_t rpb; };
+template <int NT, int VU>
+__device__ void vg_dist_core(const VgGraph &g, const VgDistBuf &l, uint32_t m, int lane /* 0 .. NT - 1 */) {
     const uint32_t dim = g.dim, d4 = dim >> 2, sp = dim + 4, tp = d4 + 1, rpb = l.rpb;
     const bool avx = g.order == SHODH_ORDER_AVX2;
     for (uint32_t b0 = 0; b0 < m; b0 += rpb) {
@@ -122,7 +128,7 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                     for (int u = u0; u < u0 + 4; ++u) {
                         const uint32_t e = e_first + u * NT, ec = e < total ? e : total - 1;
                         const uint32_t r = row_of(ec), gq = ec - r * d4;
-                        v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.newid[b0 + r] * dim + gq * 4);
+                        v[u] = *reinterpret_cast<const float4 *>(g.rows + (size_t)l.ids[b0 + r] * dim + gq * 4);
                     }
                 }
             }
@@ -149,7 +155,7 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 }
             }
         }
-        vg_sync();
+        vg_sync<NT>();
         if (avx) {
             // dot_product_avx2_inline (distance_inline.rs:67-111): 8 FMA chains over i = c, c + 8, ...; lanes 0..7 summed in order
             for (uint32_t rc = lane; rc < nb * 8; rc += NT) {
@@ -167,12 +173,12 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                 for (; i < dim; i += 8) acc = __builtin_fmaf(l.q[i + c], row[i + c], acc);
                 l.tsum[r * 8 + c] = acc;
             }
-            vg_sync();
+            vg_sync<NT>();
             if ((uint32_t)lane < nb) {
                 const float *p8 = l.tsum + lane * 8;
                 float s = p8[0] + p8[1];
                 s = s + p8[2]; s = s + p8[3]; s = s + p8[4]; s = s + p8[5]; s = s + p8[6]; s = s + p8[7];
-                l.newd[b0 + lane] = -s;
+                l.out[b0 + lane] = -s;
             }
         } else {
             if ((uint32_t)lane < nb) {            // sum += t_g in order
@@ -187,11 +193,16 @@ __device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int l
                     for (int u = 0; u < 8; ++u) s = s + t8[u];
                 }
                 for (; gq < d4; ++gq) s = s + tr[gq];
-                l.newd[b0 + lane] = -s;
+                l.out[b0 + lane] = -s;
             }
         }
-        vg_sync();
+        vg_sync<NT>();
     }
+}
+
+__device__ void vg_distances(const VgGraph &g, const VgLds &l, uint32_t m, int lane /* 0 .. VG_NT - 1 */) {
+    const VgDistBuf b{l.q, l.tsum, l.stage, l.newid, l.newd, l.rpb};
+    vg_dist_core<VG_NT, VG_U * 64 / VG_NT>(g, b, m, lane);
 }
 
 // The walk itself runs on wave 0 of the workgroup; the other three waves wait for row batches to score.
@@ -203,12 +214,53 @@ __device__ void vg_dist_master(const VgGraph &g, const VgLds &l, uint32_t m, int
     vg_distances(g, l, m, lane);
     __syncthreads();
 }
+// The back edges of one insert (vamana.rs:925-957): every neighbour nb of the new node `id` gets `id` appended; a list that outgrows R keeps
+// its R closest entries by (distance from nb, id). The lists belong to different nodes, so they are independent: wave w takes neighbours
+// w, w + 4, ... with private buffers carved from the regions a finished walk no longer needs (frontier + visited set: three slices of
+// 16 KiB; the group-sum area for the fourth wave). Scalar-4 order only (the 8-chain order would need 50 KiB of raw rows per wave).
+constexpr uint32_t VG_REQ_EXIT = 0xFFFFFFFFu, VG_REQ_BACKEDGE = 0xFFFFFFFEu;
+__host__ __device__ inline bool vg_parallel_backedges(uint32_t dim, uint32_t order, uint32_t R) {
+    return order != SHODH_ORDER_AVX2 && dim <= 512 && R + 1 <= 64 && (size_t)dim * 4 + (size_t)(R + 1) * (dim / 4 + 1) * 4 + 512 <= 16384;
+}
+__device__ void vg_backedge_task(const VgGraph &g, const VgLds &l, int wave, int lane) {
+    const uint32_t id = l.req[2], take = l.req[3], R = l.req[4];
+    const uint32_t dim = g.dim, tp = dim / 4 + 1;
+    unsigned char *base = wave < 3 ? reinterpret_cast<unsigned char *>(l.cand) + (size_t)wave * 16384 : reinterpret_cast<unsigned char *>(l.tsum);
+    float *qw = reinterpret_cast<float *>(base);
+    float *tsw = qw + dim;
+    uint32_t *idw = reinterpret_cast<uint32_t *>(tsw + (size_t)(R + 1) * tp);
+    float *dw = reinterpret_cast<float *>(idw + 64);
+    for (uint32_t i = wave; i < take; i += 4) {
+        const uint32_t nb = l.pr[i];
+        const uint32_t dg = g.deg[nb];
+        if (lane == 0) { g.nbr[(size_t)nb * g.stride + dg] = id; g.deg[nb] = dg + 1; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        if (dg + 1 > R) {
+            const uint32_t cnt = dg + 1;
+            for (uint32_t t = lane; t < dim; t += 64) qw[t] = g.rows[(size_t)nb * dim + t];
+            if ((uint32_t)lane < cnt) idw[lane] = g.nbr[(size_t)nb * g.stride + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const VgDistBuf b{qw, tsw, nullptr, idw, dw, 64u};
+            vg_dist_core<64, 32>(g, b, cnt, lane);
+            if ((uint32_t)lane < cnt) {
+                const uint64_t key = make_key(dw[lane], idw[lane]);
+                uint32_t r = 0;
+                for (uint32_t u = 0; u < cnt; ++u) r += make_key(dw[u], idw[u]) < key;
+                if (r < R) g.nbr[(size_t)nb * g.stride + r] = idw[lane];
+            }
+            if (lane == 0) g.deg[nb] = R;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+    }
+}
 __device__ void vg_helper_loop(const VgGraph &g, const VgLds &l, int tid) {
     for (;;) {
         __syncthreads();
         const uint32_t m = *l.req;
-        if (m == 0xFFFFFFFFu) break;
-        vg_distances(g, l, m, tid);
+        if (m == VG_REQ_EXIT) break;
+        if (m == VG_REQ_BACKEDGE) vg_backedge_task(g, l, tid >> 6, tid & 63);
+        else vg_distances(g, l, m, tid);
         __syncthreads();
     }
 }
@@ -446,7 +498,15 @@ __global__ __launch_bounds__(256) void vg_insert_kernel(VgInsertArgs a) {
         const uint32_t take = wn < a.R ? wn : a.R;
         for (uint32_t i = lane; i < take; i += 64) a.g.nbr[(size_t)id * a.g.stride + i] = (uint32_t)l.w[i];
         if (lane == 0) a.g.deg[id] = take;
-        // back edges, in neighbour order; a list that outgrows R keeps its R closest by (distance, id) (:925-957)
+        // back edges; a list that outgrows R keeps its R closest by (distance, id) (:925-957)
+        if (vg_parallel_backedges(dim, a.g.order, a.R)) {
+            for (uint32_t i = lane; i < take; i += 64) l.pr[i] = (uint32_t)l.w[i];
+            if (lane == 0) { l.req[2] = id; l.req[3] = take; l.req[4] = a.R; *l.req = VG_REQ_BACKEDGE; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");           // the new node's own list is out before anybody lists it
+            __syncthreads();
+            vg_backedge_task(a.g, l, 0, lane);
+            __syncthreads();
+        } else
         for (uint32_t i = 0; i < take; ++i) {
             const uint32_t nb = (uint32_t)l.w[i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
