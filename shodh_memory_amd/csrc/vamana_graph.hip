@@ -1,6 +1,7 @@
 // vamana_graph.hip -- the Vamana GRAPH side of VamanaIndex on the device: the reference's default (non-exact) search path.
 //   greedy_search   src/vector_db/vamana.rs:576-657      search (ANN)  :764-808
 //   add_vector      :853-974 (incremental insert)        robust_prune  :665-746      find_medoid :407-441      build :200-284
+//   incremental_repair :1033-1115
 // Why it exists although the exact scan is faster up to ~10^7 rows per GPU: without SHODH_VECTOR_EXACT the reference answers from
 // the graph, and an index that only ever grows through add_vector (what `remember` does) has a fully DETERMINISTIC graph (no RNG
 // on that path, medoid 0). SHODH_SCAN_GRAPH reproduces that graph and that walk bit for bit, so a host that keeps the reference's
@@ -9,13 +10,16 @@
 // SearchCandidate's order is total, (distance total_cmp, id) (:1664-1673), and ids are unique, so the two BinaryHeaps of
 // greedy_search never show their internal order: here both are sorted arrays of 64-bit keys in LDS.
 //
-// One WAVE runs one search. State in LDS: the query, `w` (the k best so far, ascending), `cand` (the frontier, ascending, consumed
-// from the head), a staging area for 8 neighbour rows. Visited set: one bit per row in global memory (cleared by the wave before
-// the walk; test-and-set with atomicOr). A hop = pop the closest frontier node; its unvisited neighbours are found by the 64 lanes
-// in parallel, their rows are read 8 at a time (coalesced, all loads of a batch in flight), every distance is computed in the
-// reference's accumulation order (distance_inline.rs:67-173), and then the neighbours are offered to `w` / `cand` ONE BY ONE in
-// list order, exactly like the reference's loop: whether a neighbour is accepted depends on the worst entry of `w` at that moment.
-// Inserts and the build run the same walk from a single wave, node after node: every step reads the graph the previous one wrote.
+// One WORKGROUP of four waves runs one walk: wave 0 walks (the control flow is serial by nature), all four waves score each batch of
+// neighbour rows (waves 1-3 wait in a request loop). State in LDS: the query, `w` (the k best so far, ascending), `cand` (the frontier,
+// ascending, consumed from the head), the group sums of a distance batch, the visited set (an 8192-slot hash set; one bit per row in
+// memory only when a walk outgrows it). A hop = pop the closest frontier node; its degree and adjacency row arrive in one round trip;
+// its unvisited neighbours are found by the 64 lanes in parallel; their rows are read up to 64 at a time (every 16-byte piece of a batch
+// in flight before the first is used); every distance is computed in the reference's accumulation order (distance_inline.rs:67-173);
+// neighbours that cannot beat the worst of a full `w` are dropped in parallel, the rest are offered to `w` / `cand` ONE BY ONE in list
+// order, exactly like the reference's loop: whether a neighbour is accepted depends on the worst entry of `w` at that moment.
+// Inserts, repairs and the build run the same walk node after node: every step reads the graph the previous one wrote. The back-edge lists
+// of one insert are independent of each other and are re-ranked four at a time, one per wave.
 #include <cmath>
 
 #include "common.h"
