@@ -75,7 +75,8 @@ struct VgLds {
 __host__ __device__ inline uint32_t vg_rows_per_batch(uint32_t dim, uint32_t order) { return dim <= 512 ? (order == SHODH_ORDER_AVX2 ? 32u : (uint32_t)VG_ROWS) : 8u; }
 __host__ __device__ inline size_t vg_lds_bytes(uint32_t dim, uint32_t order) {
     const size_t rpb = vg_rows_per_batch(dim, order), stage = order == SHODH_ORDER_AVX2 ? rpb * (dim + 4) * 4 : 0;      // scalar-4 sums straight from registers
-    return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + VG_HASH * 4 + stage + rpb * (dim / 4 + 1) * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
+    const size_t tcols = dim / 4 + 1 > 8 ? dim / 4 + 1 : 8;       // group sums per row (scalar-4) or the eight chain sums (8-chain order)
+    return (size_t)dim * 4 + VG_W_CAP * 8 + VG_C_CAP * 8 + VG_HASH * 4 + stage + rpb * tcols * 4 + VG_MAXDEG * 8 + VG_MAXDEG * 16 + 64;
 }
 __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t order) {
     VgLds l;
@@ -86,7 +87,7 @@ __device__ inline VgLds vg_carve(unsigned char *smem, uint32_t dim, uint32_t ord
     l.rpb = vg_rows_per_batch(dim, order);
     l.stage = l.q + dim;
     l.tsum = l.stage + (order == SHODH_ORDER_AVX2 ? (size_t)l.rpb * (dim + 4) : 0);
-    l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)l.rpb * (dim / 4 + 1));
+    l.newid = reinterpret_cast<uint32_t *>(l.tsum + (size_t)l.rpb * (dim / 4 + 1 > 8 ? dim / 4 + 1 : 8));
     l.newd = reinterpret_cast<float *>(l.newid + VG_MAXDEG);
     l.pr = reinterpret_cast<uint32_t *>(l.newd + VG_MAXDEG);
     l.pr2 = l.pr + VG_MAXDEG;
