@@ -112,7 +112,8 @@ int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n);
 /* search (vamana.rs:764-808 under SHODH_VECTOR_EXACT -> brute_force_search :1167-1188;
  * spann.rs:574-693 for IVFPQ). q: [nq][dim]. ids/dist: [nq][k], row i holds counts[i] valid
  * entries in ascending (dist by f32::total_cmp, id) order; the rest is filled with
- * 0xFFFFFFFF / +inf. Empty index -> counts 0, SHODH_OK (vamana.rs:766-768). */
+ * 0xFFFFFFFF / +inf. Empty index -> counts 0, SHODH_OK (vamana.rs:766-768). k up to 7936 (the per-query selection buffers live
+ * in LDS; the reference's callers ask for limit * 12 at most, retrieval.rs:913-918): more is SHODH_ERR_UNSUPPORTED. */
 int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts);
 /* VamanaIndex::brute_force_search (vamana.rs:1167-1188) whatever the scan mode: the exact scan of a FLAT index, graph mode included
