@@ -80,7 +80,7 @@ typedef struct {
     uint32_t scan_mode;     /* SHODH_SCAN_* */
     uint64_t reserve_rows;  /* rows of HBM to reserve up front (grows by doubling) */
     uint64_t id_base;       /* global id of local row 0 (row-sharded multi-GPU corpora); ids returned = id_base + local */
-    uint32_t nprobe;        /* IVFPQ: SpannConfig.num_probes (default 10; BackendConfig 20) */
+    uint32_t nprobe;        /* IVFPQ: SpannConfig.num_probes (default 10; BackendConfig 20); capped at the partition count; at most 1024 lists per query */
     uint32_t reserved;
     /* SHODH_SCAN_GRAPH only (VamanaConfig, vamana.rs:120-166): */
     uint32_t max_degree;        /* 32 */

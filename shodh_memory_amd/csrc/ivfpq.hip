@@ -124,7 +124,7 @@ struct AdcArgs {
 constexpr int ADC_U = 1;        // postings per thread and iteration
 constexpr int ADC_NT = 1024;    // threads per workgroup: the 48 KiB table allows two workgroups per CU; 2 x 16 waves keep the LDS gathers busy
                                 // (measured at 10M rows, batch 1024: 256 threads x 2 postings 2.36 ms, 512 x 2 1.87 ms, 1024 x 1 1.73 ms)
-constexpr int ADC_MAXP = 256;   // probed lists per query (nprobe is capped at P and at this)
+constexpr int ADC_MAXP = 1024;  // probed lists per query (nprobe is capped at P and at this; the reference's default is 20)
 // FULL256: 256 codewords per sub-quantiser (always the case for a reference-built index, pq.rs:27): an 8-bit code cannot
 // leave the table, so the range check disappears and the table row becomes an immediate offset of the LDS read.
 template <bool FULL256, int NT>
@@ -161,12 +161,12 @@ __global__ __launch_bounds__(NT) void adc_scan_kernel(AdcArgs a) {
     // requested before the current one is scored (the loads used to be issued and awaited inside every 256-posting
     // iteration: 122 exposed round trips per block at 4M rows). Scoring order does not matter: the result is the k
     // smallest (distance, id) keys and every distance is its own fixed-order sum.
-    if (tid < np) {
-        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + tid];
+    for (uint32_t i = tid; i < np; i += NT) {
+        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + i];
         const uint64_t lo = a.list_off[p], len = a.list_off[p + 1] - lo;
         const uint64_t b0 = lo + len * part / a.split, b1 = lo + len * (part + 1) / a.split;
-        seg_base[tid] = b0;
-        seg_start[tid] = (uint32_t)(b1 - b0);       // length for now; scanned below
+        seg_base[i] = b0;
+        seg_start[i] = (uint32_t)(b1 - b0);         // length for now; scanned below
     }
     __syncthreads();
     if (tid == 0) {
