@@ -428,12 +428,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 
 // ---- LayerNorm over the hidden dim, f32 in -> T out. Half a wave per token: lane l owns the float4 groups l, l+32, ...
 // (512 contiguous bytes per load instruction); the row is read once and stays in registers. H % 128 == 0, H <= 512.
+// DynamicQuantizeLinear needs the min / max of a whole tensor before its first byte can be written. The producers of the INT8 path fold
+// them into their own stores (mm[0] = smallest order key, mm[1] = largest; reset by the host before the producer runs) instead of a
+// separate pass over the tensor: every wave reduces its values and touches the two global words only when it would change them.
+__device__ __forceinline__ void minmax_commit(uint32_t lo, uint32_t hi, uint32_t *mm) {
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo < __atomic_load_n(mm, __ATOMIC_RELAXED)) atomicMin(mm, lo);
+        if (hi > __atomic_load_n(mm + 1, __ATOMIC_RELAXED)) atomicMax(mm + 1, hi);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
-                                                        const float *__restrict__ beta, T *__restrict__ out, int ntok, int H, float eps) {
+                                                        const float *__restrict__ beta, T *__restrict__ out, int ntok, int H, float eps,
+                                                        uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */) {
     const int l = threadIdx.x & 31;
-    const int tok = (blockIdx.x * 256 + threadIdx.x) >> 5;
-    if (tok >= ntok) return;
+    const int tok_raw = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool valid = tok_raw < ntok;       // a half-wave past the end redoes the last token and stores nothing (the wave stays together for the
+    const int tok = valid ? tok_raw : ntok - 1;      // min / max exchange at the end)
+    if (!valid && !mm) return;
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
     const f32x4e *x4 = reinterpret_cast<const f32x4e *>(in + (size_t)tok * H);
     const int ng = H >> 7;                  // float4 groups per lane (3 at H = 384)
     f32x4e xv[4];
@@ -456,11 +471,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         const f32x4e g = g4[j * 32 + l], b = b4[j * 32 + l];
         T o4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>((xv[j][e] - mean) * inv * g[e] + b[e]);
+        for (int e = 0; e < 4; ++e) {
+            const float v_ = (xv[j][e] - mean) * inv * g[e] + b[e];
+            o4[e] = from_f32<T>(v_);
+            if (mm && valid) { const uint32_t kk = order_key(v_); klo = min(klo, kk); khi = max(khi, kk); }
+        }
         T *dst = out + (size_t)tok * H + (size_t)(j * 32 + l) * 4;
+        if (valid) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = o4[e];
+            for (int e = 0; e < 4; ++e) dst[e] = o4[e];
+        }
     }
+    if (mm) minmax_commit(klo, khi, mm);
 }
 
 // ---- embeddings: word + position + token_type(0), then LayerNorm ------------------------------------------
@@ -470,10 +492,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
                                                        const float *__restrict__ pos, const float *__restrict__ type0,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        T *__restrict__ out, int ntok, int H, int max_len, int vocab, float eps,
-                                                       const int8_t *__restrict__ word_q /* INT8 mode: the 8-bit word table, else null */, const float *__restrict__ word_scale) {
+                                                       const int8_t *__restrict__ word_q /* INT8 mode: the 8-bit word table, else null */, const float *__restrict__ word_scale,
+                                                       uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */) {
     const int lane = threadIdx.x & 63;
     const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (tok >= ntok) return;
+    if (tok >= ntok) return;                 // wave-uniform: one wave per token
     const int sq = tok_seq[tok], p = tok_pos[tok];
     int id = ids[(size_t)sq * max_len + p];
     if (id < 0) id = 0;
@@ -534,7 +557,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const float inv = 1.0f / sqrtf(v / (float)H + eps);
     cnt = 0;
-    for (int i = lane; i < H; i += 64) { out[(size_t)tok * H + i] = from_f32<T>((x[cnt] - mean) * inv * gamma[i] + beta[i]); ++cnt; }
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+    for (int i = lane; i < H; i += 64) {
+        const float v_ = (x[cnt] - mean) * inv * gamma[i] + beta[i];
+        out[(size_t)tok * H + i] = from_f32<T>(v_);
+        if (mm) { const uint32_t kk = order_key(v_); klo = min(klo, kk); khi = max(khi, kk); }
+        ++cnt;
+    }
+    if (mm) minmax_commit(klo, khi, mm);
 }
 
 // ---- attention: one workgroup per (sequence, head); d_head = 32; online softmax per query row ---------------
@@ -542,10 +572,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 // are KEYS: HF BERT adds finfo.min to masked keys, which is the restriction to the real ones)
 template <class T>
 __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qkv, const int32_t *__restrict__ cu, T *__restrict__ ctx,
-                                                        int H, int heads, const int32_t *__restrict__ klen) {
+                                                        int H, int heads, const int32_t *__restrict__ klen, uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of ctx */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
     const int t0 = cu[seq], Sq = cu[seq + 1] - t0;
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
     const int S = klen ? klen[seq] : Sq;
     float *Ks = reinterpret_cast<float *>(smem);          // [S][32]
     float *Vs = Ks + (size_t)S * 32;                       // [S][32]
@@ -577,8 +608,13 @@ __global__ __launch_bounds__(128) void attention_kernel(const T *__restrict__ qk
         }
         const float invl = 1.0f / l;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) ctx[(size_t)(t0 + i) * H + head * 32 + d] = from_f32<T>(o[d] * invl);
+        for (int d = 0; d < 32; ++d) {
+            const float v_ = o[d] * invl;
+            ctx[(size_t)(t0 + i) * H + head * 32 + d] = from_f32<T>(v_);
+            if (mm) { const uint32_t kk = order_key(v_); klo = min(klo, kk); khi = max(khi, kk); }
+        }
     }
+    if (mm) minmax_commit(klo, khi, mm);       // every thread of the block gets here (the query loop above has no early exit)
 }
 
 // ---- attention on the matrix cores (bf16 path): one workgroup per (sequence, head), d_head = 32 -----------------
@@ -983,28 +1019,35 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     const float *w = e->w32;
     const int tok_blocks = (ntok * 64 + 255) / 256;
     const int ln_blocks = (ntok * 32 + 255) / 256;
+    // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it (minmax_commit), not from a pass of
+    // its own: three pairs of keys -- X (LayerNorm outputs), CTX (attention output), FF (GELU output) -- reset before their producer runs.
+    uint32_t *mmX = e->qscratch + 4, *mmC = e->qscratch + 6, *mmF = e->qscratch + 8;
+    SHODH_TRY(reset_range(mmX, st));
     hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
-                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale);
+                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_keys * 32 * 4 * 2;
     SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
-    uint32_t *mm = e->qscratch;
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
         const float *bqkv = e->bqkv + (size_t)li * 3 * H;
-        SHODH_TRY(dynamic_quantize(X, (size_t)ntok * H, e->XQ, e->act_params, mm, st));                 // one quantisation feeds q, k and v (same tensor)
+        SHODH_TRY(quantize_known_range(X, (size_t)ntok * H, e->XQ, e->act_params, mmX, st));              // one quantisation feeds q, k and v (same tensor)
         SHODH_TRY(gemm_i8<EPI8_BIAS>(e->XQ, e->q_qkv[li], 0, 3 * H, e->act_params, bqkv, nullptr, QKV, nullptr, ntok, st));
-        hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen);
+        SHODH_TRY(reset_range(mmC, st));
+        hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen, mmC);
         SHODH_HIP_TRY(hipGetLastError());
-        SHODH_TRY(dynamic_quantize(CTX, (size_t)ntok * H, e->XQ, e->act_params, mm, st));
+        SHODH_TRY(quantize_known_range(CTX, (size_t)ntok * H, e->XQ, e->act_params, mmC, st));
         SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_o[li], 0, H, e->act_params, w + l.ob, X, e->PRE, nullptr, ntok, st));
-        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps);
+        SHODH_TRY(reset_range(mmX, st));
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps, mmX);
         SHODH_HIP_TRY(hipGetLastError());
-        SHODH_TRY(dynamic_quantize(X, (size_t)ntok * H, e->XQ, e->act_params, mm, st));
-        SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, e->q_up[li], 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st));
-        SHODH_TRY(dynamic_quantize(FF, (size_t)ntok * I, e->XQ, e->act_params, mm, st));
+        SHODH_TRY(quantize_known_range(X, (size_t)ntok * H, e->XQ, e->act_params, mmX, st));
+        SHODH_TRY(reset_range(mmF, st));
+        SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, e->q_up[li], 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st, mmF));
+        SHODH_TRY(quantize_known_range(FF, (size_t)ntok * I, e->XQ, e->act_params, mmF, st));
         SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_dn[li], 0, H, e->act_params, w + l.db, X, e->PRE, nullptr, ntok, st));
-        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
+        SHODH_TRY(reset_range(mmX, st));
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps, mmX);
         SHODH_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((pool_kernel<float>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H, klen, orow);

@@ -133,7 +133,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ W, const float *__restrict__ act_params /* {scale, zp} */,
                                                       const float *__restrict__ wscale /*[N]*/, const int32_t *__restrict__ rowsum /*[N]*/,
                                                       const float *__restrict__ bias /*[N] or null*/, const float *__restrict__ resid /*[M][N]*/,
-                                                      float *__restrict__ out, int32_t *__restrict__ acc_out /* [M][N] or null */, int M, int N, int K) {
+                                                      float *__restrict__ out, int32_t *__restrict__ acc_out /* [M][N] or null */, int M, int N, int K,
+                                                      uint32_t *__restrict__ mm = nullptr /* min / max keys of the output (the next layer's DynamicQuantizeLinear) */) {
     constexpr int TB = 128 * 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
     }
     const float a_scale = act_params[0];
     const int corr = 128 - (int)act_params[1];        // the stored activation is a - 128: sum (a - zp) w = sum (a - 128) w + (128 - zp) rowsum(w)
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wr * 64 + i * 32 + l31;
@@ -230,8 +232,19 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
                     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                 }
                 *reinterpret_cast<float4 *>(out + (size_t)m * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+                if (mm) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const uint32_t kk = order_key(v[e]); klo = min(klo, kk); khi = max(khi, kk); }
+                }
                 if (acc_out) *reinterpret_cast<int4 *>(acc_out + (size_t)m * N + nb) = make_int4(ai[0], ai[1], ai[2], ai[3]);
             }
+    }
+    if (mm) {          // (the rows loop may have skipped lanes past M: they carry the neutral keys)
+        for (int o = 32; o > 0; o >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, o)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, o)); }
+        if (lane == 0) {
+            if (klo < __atomic_load_n(mm, __ATOMIC_RELAXED)) atomicMin(mm, klo);
+            if (khi > __atomic_load_n(mm + 1, __ATOMIC_RELAXED)) atomicMax(mm + 1, khi);
+        }
     }
 }
 
@@ -266,11 +279,24 @@ static int dynamic_quantize(const float *x, size_t n, int8_t *xq, float *params,
     return SHODH_OK;
 }
 
+// the min / max keys are already in mm (folded into the producer's stores): only the byte pass
+static int quantize_known_range(const float *x, size_t n, int8_t *xq, float *params, const uint32_t *mm, hipStream_t st) {
+    const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div(n, 4096), 1), 2048);
+    hipLaunchKernelGGL(act_quant_kernel, dim3(blocks), dim3(256), 0, st, x, n, mm, xq, params);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+static int reset_range(uint32_t *mm, hipStream_t st) {
+    SHODH_HIP_TRY(hipMemsetAsync(mm, 0xFF, 4, st));        // min key
+    SHODH_HIP_TRY(hipMemsetAsync(mm + 1, 0, 4, st));       // max key
+    return SHODH_OK;
+}
+
 template <int EPI>
 static int gemm_i8(const int8_t *A, const QWeight &W, int row0, int N, const float *act_params, const float *bias, const float *resid,
-                   float *out, int32_t *acc_out, int M, hipStream_t st) {
+                   float *out, int32_t *acc_out, int M, hipStream_t st, uint32_t *mm = nullptr) {
     dim3 grid(N / 128, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_i8_kernel<EPI>), grid, dim3(256), 0, st, A, W.q + (size_t)row0 * W.K, act_params, W.scale + row0, W.rowsum + row0, bias, resid, out, acc_out, M, N, W.K);
+    hipLaunchKernelGGL((gemm_i8_kernel<EPI>), grid, dim3(256), 0, st, A, W.q + (size_t)row0 * W.K, act_params, W.scale + row0, W.rowsum + row0, bias, resid, out, acc_out, M, N, W.K, mm);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
