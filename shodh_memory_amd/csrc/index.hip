@@ -71,11 +71,16 @@ struct MfmaPlan {
 bool mfma_supported(uint32_t dim);
 MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus);
 size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs);
+bool solo_supported(uint32_t nq, uint32_t k);
+int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
+                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext);
 int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
                          uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1);
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext);
 int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
 int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStream_t st);
 int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st);
@@ -111,9 +116,10 @@ struct Workspace {
     bool pending = false;                // ... and whether that search may still be running (device-pointer calls)
     unsigned char *buf = nullptr;
     size_t bytes = 0;
+    uint32_t *solo_cnt = nullptr;        // single-query scan: its overflow counter, zero between calls (scan_mfma.hip, launch_solo_pipeline)
     // host-pointer calls: queries in, and ONE output block [ids | dist | counts] with a pinned host mirror, so that the results come back in
     // a single copy (three small copies plus their API calls were a visible part of a single query's latency)
-    float *d_q = nullptr; uint32_t *d_out = nullptr, *h_out = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr;
+    float *d_q = nullptr; uint32_t *d_out = nullptr, *h_out = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr, *d_stats = nullptr;
     size_t q_floats = 0, out_words = 0;
     // ring of (start, end) events around the dominant scan kernel of each search, for
     // shodh_index_kernel_timing (bench.py roofline): slot = ring_pos % RING
@@ -127,6 +133,8 @@ struct Workspace {
         SHODH_HIP_TRY(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
         for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }
         for (auto &r : ring) { SHODH_HIP_TRY(hipEventCreate(&r[0])); SHODH_HIP_TRY(hipEventCreate(&r[1])); }
+        SHODH_HIP_TRY(hipMalloc((void **)&solo_cnt, 256));
+        SHODH_HIP_TRY(hipMemset(solo_cnt, 0, 256));
         return SHODH_OK;
     }
     int reserve(size_t need) {
@@ -139,16 +147,18 @@ struct Workspace {
     }
     int reserve_io(size_t qf, size_t oe, size_t nq) {
         if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
-        const size_t words = 2 * oe + nq;
+        const size_t words = 2 * oe + nq + 4;          // + the four pipeline statistics (scan_stats), so that they come back in the same copy
         if (words > out_words) {
             if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); d_out = nullptr; h_out = nullptr; out_words = 0;
             SHODH_HIP_TRY(hipMalloc((void **)&d_out, words * 4)); SHODH_HIP_TRY(hipHostMalloc((void **)&h_out, words * 4)); out_words = words;
         }
         d_ids = d_out; d_dist = reinterpret_cast<float *>(d_out + oe); d_counts = d_out + 2 * oe;      // contiguous for THIS call's sizes
+        d_stats = d_out + 2 * oe + nq;
         return SHODH_OK;
     }
     void destroy() {
         if (buf) hipFree(buf);
+        if (solo_cnt) hipFree(solo_cnt);
         if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out);
         for (auto &e : ev) if (e) hipEventDestroy(e);
         if (last_use) hipEventDestroy(last_use);
@@ -307,9 +317,32 @@ static bool use_mfma(const shodh_index *idx, uint32_t nq, uint32_t k) {
     return true;
 }
 
-// enqueue a FLAT search on `st` using workspace w (device in/out pointers)
+// What enqueue_flat did, for the caller's bookkeeping after the stream has been synchronised
+struct FlatCall {
+    bool used_mfma = false;      // fp16 pre-scan pipeline (statistics exist)
+    bool solo = false;           // ... its single-query form
+    bool lean_events = false;    // stage timings come from the scan kernel's own event pair + ev[3] (no packets between the kernels)
+    bool deferred = false;       // the exact scan of unresolved queries has NOT been enqueued: statistics word 2 says whether it is needed
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    size_t ws_bytes = 0; size_t offs[16]; uint32_t gx = 0;
+    uint32_t sampled_rows = 0;
+};
+
+// the exact scan of the queries the pre-scan pipeline left in its fallback list (normally none)
+static int enqueue_flat_fallback(shodh_index *idx, Workspace *w, const FlatCall &fc, const float *d_q, uint32_t nq, uint32_t k,
+                                 uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st) {
+    const uint32_t *fb_list = (const uint32_t *)(w->buf + fc.offs[6]);
+    const uint32_t *fb_count = (const uint32_t *)(w->buf + fc.offs[7]);
+    uint64_t *partial = (uint64_t *)(w->buf + ((fc.ws_bytes + 255) & ~(size_t)255));
+    return launch_flat_exact(idx->rows, idx->n, idx->cfg.dim, idx->n_deleted ? idx->deleted : nullptr, d_q, nq, k, idx->cfg.order, (uint32_t)idx->cfg.id_base,
+                             partial, fc.gx, d_ids, d_dist, d_counts, fb_list, fb_count, st);
+}
+
+// enqueue a FLAT search on `st` using workspace w (device in/out pointers). host_call: the caller synchronises the stream and reads
+// `stats_ext` (four words in its output block) afterwards, so the stage events are recorded and a single query's exact fallback can wait
+// for that look at the statistics instead of costing two empty launches on every call.
 static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32_t nq, uint32_t k,
-                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, bool *used_mfma, bool stage_events) {
+                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, FlatCall *fc, bool host_call, uint32_t *stats_ext) {
     // events: the per-stage ones only for host-pointer calls (their timings are read back after the call's own
     // synchronisation); the pair around the scan kernel unless SHODH_KERNEL_EVENTS=0. Each record is a packet in the
     // stream between two kernels.
@@ -317,27 +350,34 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     const uint32_t dim = idx->cfg.dim;
     const uint32_t idb = (uint32_t)idx->cfg.id_base;
     const uint32_t *del = idx->n_deleted ? idx->deleted : nullptr;
-    *used_mfma = use_mfma(idx, nq, k);
+    fc->used_mfma = use_mfma(idx, nq, k);
+    fc->solo = fc->used_mfma && solo_supported(nq, k);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
     hipEvent_t rk0 = nullptr, rk1 = nullptr;
     if (kernel_events) { rk0 = rk[0]; rk1 = rk[1]; w->ring_pos++; }
+    fc->k0 = rk0; fc->k1 = rk1;
+    fc->lean_events = host_call && fc->solo && kernel_events;
+    const bool stage_events = host_call && !fc->lean_events;
     if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
-    if (*used_mfma) {
+    if (fc->used_mfma) {
         MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-        size_t offs[16];
-        const size_t ws_bytes = mfma_workspace_bytes(p, dim, offs);
-        const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
-        const size_t part_bytes = exact_partial_bytes(nq, dim, k, gx);
-        SHODH_TRY(w->reserve(ws_bytes + part_bytes + 256));
-        SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
-                                       idx->maxnorm, p, w->buf, offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
-                                       stage_events ? w->ev[2] : nullptr, rk0, rk1));
+        fc->ws_bytes = mfma_workspace_bytes(p, dim, fc->offs);
+        fc->gx = exact_grid_x(idx->n, nq, k, idx->cus);
+        fc->sampled_rows = fc->solo ? 0u : p.n_sel_tiles * 64u;
+        const size_t part_bytes = exact_partial_bytes(nq, dim, k, fc->gx);
+        SHODH_TRY(w->reserve(fc->ws_bytes + part_bytes + 256));
+        if (fc->solo) {     // one query: a single pass over the shadow copy with workgroup-local thresholds
+            SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, p, w->buf, fc->offs,
+                                           w->solo_cnt, idx->cus, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
+                                           stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
+            fc->deferred = host_call && stats_ext != nullptr;
+        } else {
+            SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
+                                           idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
+                                           stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
+        }
         // exact scan of whatever the pre-scan could not settle (device-side list; normally empty)
-        const uint32_t *fb_list = (const uint32_t *)(w->buf + offs[6]);
-        const uint32_t *fb_count = (const uint32_t *)(w->buf + offs[7]);
-        uint64_t *partial = (uint64_t *)(w->buf + ((ws_bytes + 255) & ~(size_t)255));
-        SHODH_TRY(launch_flat_exact(idx->rows, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb, partial, gx,
-                                    d_ids, d_dist, d_counts, fb_list, fb_count, st));
+        if (!fc->deferred) SHODH_TRY(enqueue_flat_fallback(idx, w, *fc, d_q, nq, k, d_ids, d_dist, d_counts, st));
     } else {
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
         SHODH_TRY(w->reserve(exact_partial_bytes(nq, dim, k, gx) + 256));
@@ -347,21 +387,26 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
         if (rk1) SHODH_HIP_TRY(hipEventRecord(rk1, st));     // scan + merge (the merge is a few microseconds)
         if (stage_events) { SHODH_HIP_TRY(hipEventRecord(w->ev[1], st)); SHODH_HIP_TRY(hipEventRecord(w->ev[2], st)); }
     }
-    if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[3], st));
+    if (host_call) SHODH_HIP_TRY(hipEventRecord(w->ev[3], st));
     return SHODH_OK;
 }
 
-static void collect_timings(shodh_index *idx, Workspace *w, bool used_mfma, const size_t *offs_or_null) {
+static void collect_timings(shodh_index *idx, Workspace *w, const FlatCall *fc) {
     float scan = 0, sel = 0, tot = 0;
-    hipEventElapsedTime(&scan, w->ev[0], w->ev[1]);
-    hipEventElapsedTime(&sel, w->ev[1], w->ev[2]);
-    hipEventElapsedTime(&tot, w->ev[0], w->ev[3]);
+    if (fc && fc->lean_events) {
+        hipEventElapsedTime(&scan, fc->k0, fc->k1);
+        hipEventElapsedTime(&tot, fc->k0, w->ev[3]);
+        sel = tot - scan;
+    } else {
+        hipEventElapsedTime(&scan, w->ev[0], w->ev[1]);
+        hipEventElapsedTime(&sel, w->ev[1], w->ev[2]);
+        hipEventElapsedTime(&tot, w->ev[0], w->ev[3]);
+    }
     std::lock_guard<std::mutex> g(idx->stat_mu);
     idx->last_us[0] = scan * 1000.0f;
     idx->last_us[1] = sel * 1000.0f;
     idx->last_us[2] = (tot - scan - sel) * 1000.0f;
     idx->last_us[3] = tot * 1000.0f;
-    (void)used_mfma; (void)offs_or_null;
 }
 
 }  // namespace shodh
@@ -565,7 +610,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
     if (!w) return SHODH_ERR_DEVICE;
     hipStream_t st = sync_host ? w->stream : user_stream;
     int rc = SHODH_OK;
-    bool used_mfma = false;
+    FlatCall fc;
     do {
         if (w->pending && w->last_stream != st) {
             // the previous user may still be running on another stream
@@ -594,7 +639,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
                            (uint32_t)idx->cfg.id_base, (uint32_t *)w->buf, vis_words, d_ids, d_dist, d_counts, idx->g_overflow};
             rc = vg_launch_search(a, st);
             if (sync_host) { hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st); }
-        } else if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &used_mfma, sync_host);
+        } else if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &fc, sync_host, sync_host ? w->d_stats : nullptr);
         else {
             if ((rc = w->reserve(ivfpq_scratch_bytes(idx->ivfpq, idx->cfg, nq, k) + 256)) != SHODH_OK) break;
             if (sync_host) hipEventRecord(w->ev[0], st);
@@ -604,9 +649,17 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         if (rc != SHODH_OK) break;
         if (sync_host) {
             const size_t oe = (size_t)nq * k;
-            if (hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+            const size_t out_bytes = (2 * oe + nq + 4) * 4;
+            if (hipMemcpyAsync(w->h_out, w->d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
+            if (fc.deferred && w->h_out[2 * oe + nq + 2] != 0) {
+                // the single query could not be settled by the pre-scan (non-finite / unquantisable values, thousands of near-duplicates): exact scan now
+                if ((rc = enqueue_flat_fallback(idx, w, fc, d_q, nq, k, d_ids, d_dist, d_counts, st)) != SHODH_OK) break;
+                if (hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+                e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
+            }
             memcpy(ids, w->h_out, oe * 4); memcpy(dist, w->h_out + oe, oe * 4); memcpy(counts, w->h_out + 2 * oe, (size_t)nq * 4);
             const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT && !force_exact;
             if (graph_call) {
@@ -615,19 +668,14 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
                 for (uint32_t i = 0; i < nq; ++i) { ovf = ovf || (counts[i] & 0x80000000u); counts[i] &= 0x7FFFFFFFu; }
                 if (ovf) { set_error("graph walk: the frontier overflowed (thousands of equidistant rows); the answer may differ from the reference's"); rc = SHODH_ERR_UNSUPPORTED; break; }
             }
-            collect_timings(idx, w, used_mfma, nullptr);
-            if (used_mfma) {
-                uint32_t st4[4] = {0, 0, 0, 0};
-                MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
-                size_t offs[16];
-                mfma_workspace_bytes(p, dim, offs);
-                hipMemcpy(st4, w->buf + offs[8], 16, hipMemcpyDeviceToHost);
+            collect_timings(idx, w, idx->cfg.kind == SHODH_INDEX_FLAT && !graph_call ? &fc : nullptr);
+            {
+                const uint32_t *st4 = w->h_out + 2 * oe + nq;
                 std::lock_guard<std::mutex> g(idx->stat_mu);
-                idx->last_stats[0] = (uint64_t)p.n_sel_tiles * 64; idx->last_stats[1] = st4[0]; idx->last_stats[2] = st4[1]; idx->last_stats[3] = st4[2];
-                idx->last_stats[4] = st4[3];
-            } else {
-                std::lock_guard<std::mutex> g(idx->stat_mu);
-                idx->last_stats[0] = idx->last_stats[1] = idx->last_stats[2] = idx->last_stats[3] = idx->last_stats[4] = 0;
+                if (fc.used_mfma) {
+                    idx->last_stats[0] = fc.sampled_rows; idx->last_stats[1] = st4[0]; idx->last_stats[2] = st4[1]; idx->last_stats[3] = st4[2];
+                    idx->last_stats[4] = st4[3];
+                } else idx->last_stats[0] = idx->last_stats[1] = idx->last_stats[2] = idx->last_stats[3] = idx->last_stats[4] = 0;
             }
         }
     } while (0);

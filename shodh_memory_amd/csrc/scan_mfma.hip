@@ -821,6 +821,7 @@ struct FinalArgs {
     float *dist;
     uint32_t *counts;
     uint32_t *stats;          // [0] emitted, [1] rescored, [2] overflowed queries, [3] queries that went through level 2
+    uint32_t *cnt_reset;      // single-query path: its overflow counter lives across calls and is handed back zeroed (nullptr otherwise)
 };
 
 template <int ORDER>
@@ -897,6 +898,10 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 1024 on this path
     const uint32_t n_ovf = a.cand_cnt[q];
+    if (a.cnt_reset) {                  // block-uniform; every thread has read the counter before it is handed back
+        __syncthreads();
+        if (tid == 0) a.cnt_reset[q] = 0;
+    }
     bool bad = a.fallback[q] != 0 || n_ovf > a.cand_cap;
     const uint32_t n = n_main + (bad ? 0u : n_ovf);
     uint32_t *ecnt = sel32 + KTH_SCRATCH_U32 - 1;    // number of real candidates (statistics)
@@ -1332,55 +1337,10 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
     return SHODH_OK;
 }
 
-// Enqueues the whole pre-scan + re-score pipeline. Queries that could not be resolved here
-// (list overflow, unusable threshold, unquantisable query) are left in ws.fb_list / ws.fb_count
-// for the exact scan, which the caller enqueues right after (flat_exact.hip, device-side count).
-int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
-                         const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
-                         uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
-                         uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1) {
-    MfmaWorkspace w;
-    w.q_h = (_Float16 *)(ws_base + offs[0]); w.qnorm = (float *)(ws_base + offs[1]); w.thr = (float *)(ws_base + offs[2]);
-    w.eps = (float *)(ws_base + offs[3]); w.cand_cnt = (uint32_t *)(ws_base + offs[4]); w.fallback = (uint32_t *)(ws_base + offs[5]);
-    w.fb_list = (uint32_t *)(ws_base + offs[6]); w.fb_count = (uint32_t *)(ws_base + offs[7]); w.stats = (uint32_t *)(ws_base + offs[8]);
-    w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]); w.slots = (uint64_t *)(ws_base + offs[11]);
-    w.eps2 = (float *)(ws_base + offs[12]);
-
-    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
-    hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
-    SHODH_HIP_TRY(hipGetLastError());
-
-#ifdef SHODH_DIAG      // diagnostic build only (-DSHODH_DIAG): switches parts of the emit scan off to time the rest, results invalid
-    static const uint32_t ablate = getenv("SHODH_ABLATE") ? (uint32_t)atoi(getenv("SHODH_ABLATE")) : 0u;
-#else
-    const uint32_t ablate = 0u;
-#endif
-    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u, nq};
-    SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
-
-    // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
-    // dim * 2^-23, reference rounding ~1e-5; absolute term for flushed/denormal fp16 after the 2^8 scale
-    const float eps_rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
-    const float eps_abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f + (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);   // SEQ_1M: + the rounding of `1 - dot` (<= 2^-24 |1 - dot|, |dot| <= qn*maxnorm), charged generously
-    // level 2 (final stage, dense corpora only): s2 = f32 FMA dot in any order. Both s2 and the reference's sum are within
-    // gamma_dim * |q||c| of the exact dot (gamma_n = n 2^-24 / (1 - n 2^-24)), so |s2 - dot_ref| <= dim * 2^-23 * |q| * maxnorm
-    const float eps2_rel = (float)dim * 1.1921e-7f * 1.01f;
-    const float eps2_abs_a = (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);
-    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps,
-              eps2_rel * maxnorm, eps2_abs_a, w.eps2};
-    const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
-    (void)tlds;
-    hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), 0, st, t);
-    SHODH_HIP_TRY(hipGetLastError());
-
-    a.tile_stride = 1;
-    a.n_sel_tiles = (uint32_t)p.n_tiles;
-    a.ablate = ablate;
-    SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st, ev_emit0, ev_emit1));
-    if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
-
-    const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
+// one workgroup per query: k-th best approximate score, window, reference-order re-score, sort, write (final_stage_kernel)
+static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                              const MfmaPlan &p, const MfmaWorkspace &w, uint32_t nb_emit, const uint32_t *cand_cnt, uint32_t *cnt_reset,
+                              uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st) {
     // LDS of the final stage. One workgroup per query: with a few hundred queries every workgroup has a CU to itself and the
     // generous sizes cost nothing; with thousands of queries (nearest-centroid searches of k-means / IVF encoding) the
     // workgroups per CU are what counts, so the re-score list, the key staging and the row staging shrink to what such
@@ -1394,8 +1354,8 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
         ch_rows = next_pow2(k ? k : 1);
         ch_rows = ch_rows < 4u ? 4u : (ch_rows > (uint32_t)FS_CH ? (uint32_t)FS_CH : ch_rows);
     }
-    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, w.cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
-                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats};
+    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
+                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset};
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
     const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
                         final_stage_region_bytes(dim, order, ch_rows) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
@@ -1410,6 +1370,275 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
         hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SCALAR4>), dim3(nq), dim3(256), flds, st, f);
     }
     SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+
+
+// ---- single-query scan ------------------------------------------------------------------------------------------------
+// `recall` asks the index one query at a time (mod.rs:2875-2904): a batch-shaped pipeline spends a third of such a call on launches
+// (query conversion, sampled scan, threshold, emit scan, final stage). For ONE query the scores of a workgroup's slice of the corpus fit
+// in LDS, so a single pass does it all: every workgroup streams its slice of the fp16 shadow (a row = 16 lanes, f32 query in registers,
+// f32 FMA: the error bound of the MFMA scan without the query's rounding), keeps the order keys of the scores in LDS, selects its LOCAL
+// k-th best and hands every live row within 2 eps of it to the final stage. The global k-th best is at least the local one, so the union
+// of the local windows contains the global window {s~ >= kth(s~) - 2 eps}: the same proof, the same final stage, the same results.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SOLO_NT = 1024;
+constexpr int SOLO_MAX_SLICE = 16384;      // rows per workgroup (their keys: 64 KiB of LDS)
+constexpr int SOLO_EM = 1024;              // survivors of a workgroup staged in LDS before they are handed over with ONE global atomic
+constexpr uint32_t SOLO_MAX_K = 32;        // nb * k candidates reach the final stage: larger k goes through the sampled threshold
+struct SoloArgs {
+    const _Float16 *rows_h; uint64_t n_rows; uint32_t dim;
+    const float *q;            // [dim]
+    const uint32_t *deleted;
+    uint32_t k, slice;         // slice: rows per workgroup
+    float eps_rel_maxnorm, eps_abs_a, maxnorm, eps2_rel_maxnorm, eps2_abs_a;
+    uint64_t *slots;           // [gridDim.x][MF_SLOTS]
+    uint64_t *cand; uint32_t *cand_cnt; uint32_t cand_cap;      // cand_cnt: zero on entry (the final stage hands it back zeroed)
+    float *eps, *eps2; uint32_t *fallback, *fb_count, *stats;   // written by workgroup 0 for the final stage
+    uint32_t ablate;           // diagnostic builds (-DSHODH_DIAG): 1 = no selection / hand-over, 2 = no arithmetic (results invalid)
+};
+
+template <int DIM>
+__global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
+    constexpr int EPL = DIM / 16;          // halfs per lane
+    constexpr int LPL = EPL / 8;           // 16-byte loads per lane and row
+    constexpr int U = EPL <= 24 ? 4 : (EPL <= 32 ? 2 : 1);   // groups of 4 rows in flight per wave (12 KiB per wave and 16 waves per CU at 384-d)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *skey = reinterpret_cast<uint32_t *>(smem);                       // [slice] order_key(-score), 0xFFFFFFFF = tombstoned
+    uint64_t *em = reinterpret_cast<uint64_t *>(skey + a.slice + (a.slice & 1u));   // [SOLO_EM]
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(em + SOLO_EM);            // [KTH_SCRATCH_U32]
+    uint32_t *ctl = scratch + KTH_SCRATCH_U32;                                 // [2]
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sr = lane >> 4, seg = lane & 15;
+    // the query: this lane's EPL values -- the 16-byte chunks seg, 16 + seg, ... of a row, so that the 16 lanes of a row read 256
+    // contiguous bytes per load instruction (whole cache lines; one lane = one contiguous piece of the row made every line the business
+    // of three instructions); norm, largest magnitude and finiteness over the 16 lanes of a row group
+    float qv[EPL];
+    float ss = 0.0f, mx = 0.0f;
+    uint32_t badv = 0;
+#pragma unroll
+    for (int c = 0; c < LPL; ++c) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(a.q + (c * 16 + seg) * 8), v1 = *reinterpret_cast<const float4 *>(a.q + (c * 16 + seg) * 8 + 4);
+        qv[c * 8] = v0.x; qv[c * 8 + 1] = v0.y; qv[c * 8 + 2] = v0.z; qv[c * 8 + 3] = v0.w;
+        qv[c * 8 + 4] = v1.x; qv[c * 8 + 5] = v1.y; qv[c * 8 + 6] = v1.z; qv[c * 8 + 7] = v1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        if (!(__builtin_fabsf(qv[j]) <= 3.0e38f)) badv++;
+        mx = fmaxf(mx, __builtin_fabsf(qv[j]));
+        ss = __builtin_fmaf(qv[j], qv[j], ss);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        badv += __shfl_xor(badv, off);
+    }
+    const float qn = __builtin_sqrtf(ss) * 1.00001f;
+    const bool bad_q = badv != 0 || mx * MF_SCALE > 60000.0f;       // the conditions of convert_queries_kernel
+    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;
+    if (blockIdx.x == 0) {
+        if (tid < 4) a.stats[tid] = 0;
+        if (tid == 4) *a.fb_count = 0;
+        if (tid == 5) { a.eps[0] = eps; a.eps2[0] = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f; a.fallback[0] = bad_q ? 1u : 0u; }
+    }
+    uint64_t *my_slots = a.slots + (size_t)blockIdx.x * MF_SLOTS;
+    const uint64_t row0 = (uint64_t)blockIdx.x * a.slice;
+    const uint32_t n_loc = row0 >= a.n_rows ? 0u : (a.n_rows - row0 < a.slice ? (uint32_t)(a.n_rows - row0) : a.slice);
+    if (bad_q || n_loc == 0) {          // block-uniform
+        if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE;
+        return;
+    }
+    // ---- scores of the slice ------------------------------------------------------------------------------------------
+    const _Float16 *base = a.rows_h + row0 * DIM + (size_t)seg * 8;
+    for (uint32_t r0 = 0; r0 < n_loc; r0 += 64 * U) {
+        u32x4 h[U][LPL];
+        uint32_t dw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t rl = r0 + u * 64 + wave * 4 + sr;
+            const uint32_t rc = rl < n_loc ? rl : n_loc - 1;        // unconditional loads on clamped rows: all of them in flight at once
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(base + (size_t)rc * DIM);
+#pragma unroll
+            for (int c = 0; c < LPL; ++c) h[u][c] = rp[c * 16];
+            dw[u] = a.deleted ? a.deleted[(row0 + rc) >> 5] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t rl = r0 + u * 64 + wave * 4 + sr;
+            float p0 = 0.0f, p1 = 0.0f;
+            if (a.ablate & 2u) { p0 = __uint_as_float(h[u][0].x ^ h[u][LPL - 1].w); }
+            else
+#pragma unroll
+            for (int c = 0; c < LPL; ++c) {
+                const _Float16 *hv = reinterpret_cast<const _Float16 *>(&h[u][c]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    p0 = __builtin_fmaf(qv[c * 8 + e], (float)hv[e], p0);
+                    p1 = __builtin_fmaf(qv[c * 8 + e + 1], (float)hv[e + 1], p1);
+                }
+            }
+            float pr = p0 + p1;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) pr += __shfl_xor(pr, off);
+            if (seg == 0 && rl < n_loc) {
+                const uint32_t row = (uint32_t)(row0 + rl);
+                const bool del = (dw[u] >> (row & 31)) & 1u;
+                skey[rl] = del ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
+            }
+        }
+    }
+    if (tid == 0) ctl[0] = 0;
+    __syncthreads();
+    if (a.ablate & 1u) { if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE; return; }
+    // ---- local k-th best, window, hand-over ---------------------------------------------------------------------------
+    auto key_at = [&](uint32_t i) -> uint32_t { return skey[i]; };
+    bool ovf = false;
+    const uint32_t kk = block_kth_u32<SOLO_NT>(key_at, n_loc, a.k, scratch, &ovf);
+    uint32_t klim = 0xFFFFFFFEu;           // fewer than k live rows in the slice: all of them
+    if (kk != 0xFFFFFFFFu) {
+        const float kth = -order_key_inv(kk);
+        const float lo = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth));
+        klim = order_key(-lo);
+    }
+    for (uint32_t i = tid; i < n_loc; i += SOLO_NT) {
+        const uint32_t key = skey[i];
+        if (key != 0xFFFFFFFFu && key <= klim) {
+            const uint64_t k64 = ((uint64_t)key << 32) | (uint32_t)(row0 + i);
+            const uint32_t idx = atomicAdd(&ctl[0], 1u);
+            if (idx < (uint32_t)SOLO_EM) em[idx] = k64;
+            else {                           // a dense slice: straight to the shared list
+                const uint32_t slot = atomicAdd(a.cand_cnt, 1u);
+                if (slot < a.cand_cap) a.cand[slot] = k64;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = ctl[0] < (uint32_t)SOLO_EM ? ctl[0] : (uint32_t)SOLO_EM;
+    const uint32_t extra = total > (uint32_t)MF_SLOTS ? total - MF_SLOTS : 0u;
+    if (tid == 0) ctl[1] = extra ? atomicAdd(a.cand_cnt, extra) : 0u;
+    __syncthreads();
+    const uint32_t lbase = ctl[1];
+    const uint32_t n_out = total > (uint32_t)MF_SLOTS ? total : (uint32_t)MF_SLOTS;
+    for (uint32_t i = tid; i < n_out; i += SOLO_NT) {
+        if (i < (uint32_t)MF_SLOTS) my_slots[i] = i < total ? em[i] : KEY_NONE;
+        else if (lbase + (i - MF_SLOTS) < a.cand_cap) a.cand[lbase + (i - MF_SLOTS)] = em[i];
+    }
+}
+
+static void unpack_workspace(MfmaWorkspace &w, unsigned char *ws_base, const size_t *offs) {
+    w.q_h = (_Float16 *)(ws_base + offs[0]); w.qnorm = (float *)(ws_base + offs[1]); w.thr = (float *)(ws_base + offs[2]);
+    w.eps = (float *)(ws_base + offs[3]); w.cand_cnt = (uint32_t *)(ws_base + offs[4]); w.fallback = (uint32_t *)(ws_base + offs[5]);
+    w.fb_list = (uint32_t *)(ws_base + offs[6]); w.fb_count = (uint32_t *)(ws_base + offs[7]); w.stats = (uint32_t *)(ws_base + offs[8]);
+    w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]); w.slots = (uint64_t *)(ws_base + offs[11]);
+    w.eps2 = (float *)(ws_base + offs[12]);
+}
+
+// eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
+// dim * 2^-23, reference rounding ~1e-5; absolute term for flushed/denormal fp16 after the 2^8 scale
+struct EpsCoef { float rel, abs_a, rel2, abs2_a; };
+static EpsCoef eps_coefficients(uint32_t dim, uint32_t order) {
+    EpsCoef c;
+    c.rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
+    c.abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f + (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);   // SEQ_1M: + the rounding of `1 - dot` (<= 2^-24 |1 - dot|, |dot| <= qn*maxnorm), charged generously
+    // level 2 (final stage, dense corpora only): s2 = f32 FMA dot in any order. Both s2 and the reference's sum are within
+    // gamma_dim * |q||c| of the exact dot (gamma_n = n 2^-24 / (1 - n 2^-24)), so |s2 - dot_ref| <= dim * 2^-23 * |q| * maxnorm
+    c.rel2 = (float)dim * 1.1921e-7f * 1.01f;
+    c.abs2_a = (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);
+    return c;
+}
+
+bool solo_supported(uint32_t nq, uint32_t k) {
+    static const bool off = getenv("SHODH_SOLO") && atoi(getenv("SHODH_SOLO")) == 0;
+    return !off && nq == 1 && k >= 1 && k <= SOLO_MAX_K;
+}
+
+// The single-query pipeline: solo_scan_kernel + final stage; like launch_mfma_pipeline it leaves an unresolved query in fb_list / fb_count.
+// `solo_cnt`: one u32 that is zero between calls (allocated zeroed by the caller, handed back zeroed by the final stage).
+int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
+                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext) {
+    MfmaWorkspace w;
+    unpack_workspace(w, ws_base, offs);
+    if (stats_ext) w.stats = stats_ext;
+    uint64_t nb = (uint64_t)(cus > 0 ? cus : 1);
+    if (nb > ceil_div(n_rows, 64)) nb = ceil_div(n_rows, 64);
+    if (nb < 1) nb = 1;
+    uint64_t slice = ceil_div(n_rows, nb);
+    if (slice > (uint64_t)SOLO_MAX_SLICE) { slice = SOLO_MAX_SLICE; nb = ceil_div(n_rows, slice); }
+    if (slice < 1) slice = 1;
+    if (nb > (uint64_t)p.grid_x * MF_BPAD) { set_error("single-query scan: %llu workgroups do not fit the slot table", (unsigned long long)nb); return SHODH_ERR_UNSUPPORTED; }
+    const EpsCoef c = eps_coefficients(dim, order);
+    SoloArgs a{rows_h, n_rows, dim, d_q, deleted, k, (uint32_t)slice, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a,
+               w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u};
+#ifdef SHODH_DIAG
+    a.ablate = getenv("SHODH_SOLO_ABLATE") ? (uint32_t)atoi(getenv("SHODH_SOLO_ABLATE")) : 0u;
+#endif
+    const size_t lds = ((size_t)slice + (slice & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16;
+#define SHODH_LAUNCH_SOLO(D)                                                                                          \
+    case D:                                                                                                           \
+        SHODH_TRY(ensure_dynamic_lds((const void *)solo_scan_kernel<D>, lds));                                        \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((solo_scan_kernel<D>), dim3((uint32_t)nb), dim3(SOLO_NT), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL((solo_scan_kernel<D>), dim3((uint32_t)nb), dim3(SOLO_NT), lds, st, a);                \
+        break;
+    switch (dim) {
+        SHODH_LAUNCH_SOLO(128)
+        SHODH_LAUNCH_SOLO(256)
+        SHODH_LAUNCH_SOLO(384)
+        SHODH_LAUNCH_SOLO(512)
+        SHODH_LAUNCH_SOLO(768)
+        SHODH_LAUNCH_SOLO(1024)
+        default: set_error("single-query scan: unsupported dim %u", dim); return SHODH_ERR_UNSUPPORTED;
+    }
+#undef SHODH_LAUNCH_SOLO
+    SHODH_HIP_TRY(hipGetLastError());
+    if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
+    SHODH_TRY(launch_final_stage(rows, dim, d_q, 1, k, order, id_base, p, w, (uint32_t)nb, solo_cnt, solo_cnt, d_ids, d_dist, d_counts, st));
+    if (ev_select_done) SHODH_HIP_TRY(hipEventRecord(ev_select_done, st));
+    return SHODH_OK;
+}
+
+// Enqueues the whole pre-scan + re-score pipeline. Queries that could not be resolved here
+// (list overflow, unusable threshold, unquantisable query) are left in ws.fb_list / ws.fb_count
+// for the exact scan, which the caller enqueues right after (flat_exact.hip, device-side count).
+int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
+                         const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
+                         uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext) {
+    MfmaWorkspace w;
+    unpack_workspace(w, ws_base, offs);
+    if (stats_ext) w.stats = stats_ext;      // host-pointer calls: the statistics words of the caller's output block
+
+    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
+    hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
+    SHODH_HIP_TRY(hipGetLastError());
+
+#ifdef SHODH_DIAG      // diagnostic build only (-DSHODH_DIAG): switches parts of the emit scan off to time the rest, results invalid
+    static const uint32_t ablate = getenv("SHODH_ABLATE") ? (uint32_t)atoi(getenv("SHODH_ABLATE")) : 0u;
+#else
+    const uint32_t ablate = 0u;
+#endif
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u, nq};
+    SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
+
+    const EpsCoef c = eps_coefficients(dim, order);
+    const float eps_rel = c.rel, eps_abs_a = c.abs_a, eps2_rel = c.rel2, eps2_abs_a = c.abs2_a;
+    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps,
+              eps2_rel * maxnorm, eps2_abs_a, w.eps2};
+    const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
+    (void)tlds;
+    hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), 0, st, t);
+    SHODH_HIP_TRY(hipGetLastError());
+
+    a.tile_stride = 1;
+    a.n_sel_tiles = (uint32_t)p.n_tiles;
+    a.ablate = ablate;
+    SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st, ev_emit0, ev_emit1));
+    if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
+
+    const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
+    SHODH_TRY(launch_final_stage(rows, dim, d_q, nq, k, order, id_base, p, w, nb_emit, w.cand_cnt, nullptr, d_ids, d_dist, d_counts, st));
     if (ev_select_done) SHODH_HIP_TRY(hipEventRecord(ev_select_done, st));
     return SHODH_OK;
 }
