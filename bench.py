@@ -701,7 +701,22 @@ def main():
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - a)
         ts = sorted(ts[10:])
-        lat = {"nq": 1, "p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "p95_ms": round(ts[int(len(ts) * 0.95)] * 1e3, 4)}
+        lat = {"nq": 1, "p50_ms": round(ts[len(ts) // 2] * 1e3, 4), "p95_ms": round(ts[int(len(ts) * 0.95)] * 1e3, 4),
+               "api": "device pointers (shodh_index_search_device + stream synchronise)"}
+        # the same through host pointers (shodh_index_search: what VamanaIndex::search costs a caller holding a Vec<f32>): query H2D,
+        # results D2H and the synchronisation included; device-side stage timings of the last call beside it
+        hq = [qpool[i % len(qpool)][i % args.nq:i % args.nq + 1].cpu().numpy() for i in range(16)]
+        th = []
+        for i in range(80):
+            a = time.perf_counter()
+            index.search_batch(hq[i % 16], args.k)
+            th.append(time.perf_counter() - a)
+        th = sorted(th[10:])
+        stg = index.stage_timings_us()
+        lat.update({"host_pointers_p50_ms": round(th[len(th) // 2] * 1e3, 4), "host_pointers_p95_ms": round(th[int(len(th) * 0.95)] * 1e3, 4),
+                    "scan_kernel_us": round(stg["scan"], 1), "device_total_us": round(stg["total"], 1),
+                    "scan_kernel_hbm_frac_fp16_bytes": round(rows_local * args.dim * 2 / (stg["scan"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4) if stg["scan"] > 0 else None,
+                    "path": "single pass over the fp16 shadow with workgroup-local thresholds (solo_scan_kernel) + final stage" if args.k <= 32 else "batch pipeline"})
 
     cpu = None
     cpu_info = host_cpu_info() if rank == 0 else None

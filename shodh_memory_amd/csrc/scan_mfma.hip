@@ -1549,7 +1549,8 @@ static EpsCoef eps_coefficients(uint32_t dim, uint32_t order) {
 
 bool solo_supported(uint32_t nq, uint32_t k) {
     static const bool off = getenv("SHODH_SOLO") && atoi(getenv("SHODH_SOLO")) == 0;
-    return !off && nq == 1 && k >= 1 && k <= SOLO_MAX_K;
+    static const uint32_t max_k = getenv("SHODH_SOLO_MAX_K") ? (uint32_t)atoi(getenv("SHODH_SOLO_MAX_K")) : SOLO_MAX_K;
+    return !off && nq == 1 && k >= 1 && k <= max_k;
 }
 
 // The single-query pipeline: solo_scan_kernel + final stage; like launch_mfma_pipeline it leaves an unresolved query in fb_list / fb_count.
