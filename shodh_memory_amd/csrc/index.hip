@@ -370,13 +370,14 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
             SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, p, w->buf, fc->offs,
                                            w->solo_cnt, idx->cus, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
                                            stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
-            fc->deferred = host_call && stats_ext != nullptr;
         } else {
             SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
                                            idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
                                            stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
         }
-        // exact scan of whatever the pre-scan could not settle (device-side list; normally empty)
+        // exact scan of whatever the pre-scan could not settle (device-side list; normally empty). A host-pointer call looks at the
+        // statistics after its synchronisation and enqueues it only then, if at all.
+        fc->deferred = host_call && stats_ext != nullptr;
         if (!fc->deferred) SHODH_TRY(enqueue_flat_fallback(idx, w, *fc, d_q, nq, k, d_ids, d_dist, d_counts, st));
     } else {
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
@@ -654,7 +655,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             if (fc.deferred && w->h_out[2 * oe + nq + 2] != 0) {
-                // the single query could not be settled by the pre-scan (non-finite / unquantisable values, thousands of near-duplicates): exact scan now
+                // some query could not be settled by the pre-scan (unquantisable values, thousands of near-duplicates, an unusable threshold): exact scan now
                 if ((rc = enqueue_flat_fallback(idx, w, fc, d_q, nq, k, d_ids, d_dist, d_counts, st)) != SHODH_OK) break;
                 if (hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
                 e = hipStreamSynchronize(st);

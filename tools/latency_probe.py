@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import shodh_memory_amd as S  # noqa: E402
 from tests import synth  # noqa: E402
 

@@ -31,4 +31,8 @@ python $ROOT/tools/stats_to_md.py /tmp/pi "round 2 -- rocprofv3 --kernel-trace -
 rm -rf /tmp/pmc_iv; rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_iv -- $IV > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py /tmp/pmc_iv > $OUT/${R}_ivfpq_pmc_sq.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pmci_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmci_$C -- $IV > /dev/null 2>&1; python $ROOT/tools/pmc_summary.py /tmp/pmci_$C >> $OUT/${R}_ivfpq_pmc_sq.txt 2>&1; done
+# 7. single-query path (solo_scan_kernel + final stage): host-pointer latency and kernel stats
+python $ROOT/tools/latency_probe.py > $OUT/${R}_single_query_line.json 2>/dev/null
+rm -rf /tmp/psq; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psq -- python $ROOT/tools/latency_probe.py > /dev/null 2>&1
+python $ROOT/tools/stats_to_md.py /tmp/psq "round 2 -- rocprofv3 --kernel-trace --stats of \`python tools/latency_probe.py\` (1M x 384, 5 % tombstones, one query per call through host pointers: 320 calls at k = 10 on the single-pass scan, 320 at k = 120 on the batch pipeline)" | head -20 > $OUT/${R}_single_query_kernel_stats.md
 ls -la $OUT | tail -20; tail -c 300 $OUT/${R}_bench_line.json; echo; cat $OUT/${R}_bench_pmc_sq.txt | head; cat $OUT/${R}_ivfpq_pmc_sq.txt | head -20
