@@ -71,7 +71,7 @@ struct MfmaPlan {
 bool mfma_supported(uint32_t dim);
 MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus);
 size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs);
-bool solo_supported(uint32_t nq, uint32_t k);
+bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const MfmaPlan &p);
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
                          uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
@@ -351,7 +351,9 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     const uint32_t idb = (uint32_t)idx->cfg.id_base;
     const uint32_t *del = idx->n_deleted ? idx->deleted : nullptr;
     fc->used_mfma = use_mfma(idx, nq, k);
-    fc->solo = fc->used_mfma && solo_supported(nq, k);
+    MfmaPlan p{};
+    if (fc->used_mfma) p = mfma_plan(idx->n, dim, nq, k, idx->cus);
+    fc->solo = fc->used_mfma && solo_supported(nq, k, idx->n, idx->cus, p);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
     hipEvent_t rk0 = nullptr, rk1 = nullptr;
     if (kernel_events) { rk0 = rk[0]; rk1 = rk[1]; w->ring_pos++; }
@@ -360,7 +362,6 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     const bool stage_events = host_call && !fc->lean_events;
     if (stage_events) SHODH_HIP_TRY(hipEventRecord(w->ev[0], st));
     if (fc->used_mfma) {
-        MfmaPlan p = mfma_plan(idx->n, dim, nq, k, idx->cus);
         fc->ws_bytes = mfma_workspace_bytes(p, dim, fc->offs);
         fc->gx = exact_grid_x(idx->n, nq, k, idx->cus);
         fc->sampled_rows = fc->solo ? 0u : p.n_sel_tiles * 64u;

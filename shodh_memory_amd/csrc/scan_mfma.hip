@@ -1385,7 +1385,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SOLO_NT = 1024;
 constexpr int SOLO_MAX_SLICE = 16384;      // rows per workgroup (their keys: 64 KiB of LDS)
 constexpr int SOLO_EM = 1024;              // survivors of a workgroup staged in LDS before they are handed over with ONE global atomic
-constexpr uint32_t SOLO_MAX_K = 32;        // nb * k candidates reach the final stage: larger k goes through the sampled threshold
+constexpr uint32_t SOLO_MAX_K = 32;        // local thresholds: nb * k candidates reach the final stage. Above it (recall's own k = 120, retrieval.rs:927):
+// GLOBAL threshold mode -- the scan writes every row's order key to HBM (4 bytes per row) and each wave its best key; a second, tiny
+// kernel takes the k-th best of those nb * 16 wave maxima (scores of distinct rows, so a lower bound of the true k-th best, exactly
+// the argument of the batch pipeline's sampled tile maxima -- only that here the maxima cover the whole corpus and the bound is nearly
+// tight) and hands over the rows within 2 eps of it: about k of them instead of nb * k.
+constexpr uint32_t SOLO_MAX_K_GLOBAL = 2048;
+constexpr int SOLO_WAVES = 16;             // waves per workgroup of the scan = maxima per workgroup
 struct SoloArgs {
     const _Float16 *rows_h; uint64_t n_rows; uint32_t dim;
     const float *q;            // [dim]
@@ -1396,9 +1402,11 @@ struct SoloArgs {
     uint64_t *cand; uint32_t *cand_cnt; uint32_t cand_cap;      // cand_cnt: zero on entry (the final stage hands it back zeroed)
     float *eps, *eps2; uint32_t *fallback, *fb_count, *stats;   // written by workgroup 0 for the final stage
     uint32_t ablate;           // diagnostic builds (-DSHODH_DIAG): 1 = no selection / hand-over, 2 = no arithmetic (results invalid)
+    uint32_t *skeys;           // global threshold mode: [n_rows] order keys of the scores (0xFFFFFFFF = tombstoned)
+    uint32_t *tops;            // global threshold mode: [gridDim.x][SOLO_WAVES] best key of each wave
 };
 
-template <int DIM>
+template <int DIM, bool GLOBAL_THR = false>
 __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     constexpr int EPL = DIM / 16;          // halfs per lane
     constexpr int LPL = EPL / 8;           // 16-byte loads per lane and row
@@ -1445,9 +1453,11 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     const uint64_t row0 = (uint64_t)blockIdx.x * a.slice;
     const uint32_t n_loc = row0 >= a.n_rows ? 0u : (a.n_rows - row0 < a.slice ? (uint32_t)(a.n_rows - row0) : a.slice);
     if (bad_q || n_loc == 0) {          // block-uniform
-        if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE;
+        if (GLOBAL_THR) { if (lane == 0) a.tops[blockIdx.x * SOLO_WAVES + wave] = 0xFFFFFFFFu; }
+        else if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE;
         return;
     }
+    uint32_t best = 0xFFFFFFFFu;        // (GLOBAL_THR) smallest key = best score among this lane's rows
     // ---- scores of the slice ------------------------------------------------------------------------------------------
     const _Float16 *base = a.rows_h + row0 * DIM + (size_t)seg * 8;
     for (uint32_t r0 = 0; r0 < n_loc; r0 += 64 * U) {
@@ -1455,16 +1465,19 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
         uint32_t dw[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t rl = r0 + u * 64 + wave * 4 + sr;
+            // local mode: group u of the iteration is 64 consecutive rows over the 16 waves; global mode: a wave takes 4 U consecutive rows,
+            // so that their keys leave in one store instruction
+            const uint32_t rl = GLOBAL_THR ? r0 + wave * (4 * U) + u * 4 + sr : r0 + u * 64 + wave * 4 + sr;
             const uint32_t rc = rl < n_loc ? rl : n_loc - 1;        // unconditional loads on clamped rows: all of them in flight at once
             const u32x4 *rp = reinterpret_cast<const u32x4 *>(base + (size_t)rc * DIM);
 #pragma unroll
             for (int c = 0; c < LPL; ++c) h[u][c] = rp[c * 16];
             dw[u] = a.deleted ? a.deleted[(row0 + rc) >> 5] : 0u;
         }
+        uint32_t keyu[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t rl = r0 + u * 64 + wave * 4 + sr;
+            const uint32_t rl = GLOBAL_THR ? r0 + wave * (4 * U) + u * 4 + sr : r0 + u * 64 + wave * 4 + sr;
             float p0 = 0.0f, p1 = 0.0f;
             if (a.ablate & 2u) { p0 = __uint_as_float(h[u][0].x ^ h[u][LPL - 1].w); }
             else
@@ -1480,12 +1493,31 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
             float pr = p0 + p1;
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) pr += __shfl_xor(pr, off);
-            if (seg == 0 && rl < n_loc) {
+            if (GLOBAL_THR) {           // (the butterfly left the sum in all 16 lanes of the row)
+                const uint32_t row = (uint32_t)(row0 + (rl < n_loc ? rl : n_loc - 1));
+                const bool del = (dw[u] >> (row & 31)) & 1u;
+                keyu[u] = (del || rl >= n_loc) ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
+                best = keyu[u] < best ? keyu[u] : best;
+            } else if (seg == 0 && rl < n_loc) {
                 const uint32_t row = (uint32_t)(row0 + rl);
                 const bool del = (dw[u] >> (row & 31)) & 1u;
                 skey[rl] = del ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
             }
         }
+        if (GLOBAL_THR) {
+            // lane (sr, seg = u) stores the key of row 4 u + sr of the wave's block: 4 U dwords of one 16 U-byte segment in ONE instruction
+            uint32_t mykey = keyu[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) mykey = (int)seg == u ? keyu[u] : mykey;
+            const uint32_t rs = r0 + wave * (4 * U) + seg * 4 + sr;
+            if (seg < (uint32_t)U && rs < n_loc) a.skeys[row0 + rs] = mykey;
+        }
+    }
+    if (GLOBAL_THR) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, off); best = o < best ? o : best; }
+        if (lane == 0) a.tops[blockIdx.x * SOLO_WAVES + wave] = best;
+        return;
     }
     if (tid == 0) ctl[0] = 0;
     __syncthreads();
@@ -1525,6 +1557,66 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     }
 }
 
+// global threshold mode, second kernel: threshold from the wave maxima, then every workgroup hands over its slice's survivors
+struct SoloEmitArgs {
+    const uint32_t *skeys; const uint32_t *tops; uint32_t n_tops;
+    uint64_t n_rows; uint32_t slice, k;
+    const float *eps; const uint32_t *fallback;
+    uint64_t *slots; uint64_t *cand; uint32_t *cand_cnt; uint32_t cand_cap;
+};
+__global__ __launch_bounds__(256) void solo_emit_kernel(SoloEmitArgs a) {
+    __shared__ uint32_t scratch[KTH_SCRATCH_U32];
+    __shared__ uint64_t em[SOLO_EM];
+    __shared__ uint32_t ctl[2];
+    const uint32_t tid = threadIdx.x;
+    uint64_t *my_slots = a.slots + (size_t)blockIdx.x * MF_SLOTS;
+    const uint64_t row0 = (uint64_t)blockIdx.x * a.slice;
+    const uint32_t n_loc = row0 >= a.n_rows ? 0u : (a.n_rows - row0 < a.slice ? (uint32_t)(a.n_rows - row0) : a.slice);
+    if (a.fallback[0] || n_loc == 0) {          // block-uniform
+        if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE;
+        return;
+    }
+    if (tid == 0) ctl[0] = 0;
+    auto top_at = [&](uint32_t i) -> uint32_t { return a.tops[i]; };
+    bool ovf = false;
+    const uint32_t kk = block_kth_u32<256>(top_at, a.n_tops, a.k, scratch, &ovf);      // (starts with a barrier: ctl is visible after it)
+    uint32_t klim = 0xFFFFFFFEu;           // fewer than k waves saw a live row: every live row goes on
+    if (kk != 0xFFFFFFFFu) {
+        const float kth = -order_key_inv(kk);
+        const float lo = kth - (2.001f * a.eps[0] + 1e-7f * __builtin_fabsf(kth));
+        klim = order_key(-lo);
+    }
+    for (uint32_t i0 = 0; i0 < n_loc; i0 += 1024) {          // four loads in flight per thread (clamped index)
+        uint32_t kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 256 + tid; kv[u] = a.skeys[row0 + (i < n_loc ? i : n_loc - 1)]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * 256 + tid;
+            if (i < n_loc && kv[u] != 0xFFFFFFFFu && kv[u] <= klim) {
+                const uint64_t k64 = ((uint64_t)kv[u] << 32) | (uint32_t)(row0 + i);
+                const uint32_t idx = atomicAdd(&ctl[0], 1u);
+                if (idx < (uint32_t)SOLO_EM) em[idx] = k64;
+                else {
+                    const uint32_t slot = atomicAdd(a.cand_cnt, 1u);
+                    if (slot < a.cand_cap) a.cand[slot] = k64;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = ctl[0] < (uint32_t)SOLO_EM ? ctl[0] : (uint32_t)SOLO_EM;
+    const uint32_t extra = total > (uint32_t)MF_SLOTS ? total - MF_SLOTS : 0u;
+    if (tid == 0) ctl[1] = extra ? atomicAdd(a.cand_cnt, extra) : 0u;
+    __syncthreads();
+    const uint32_t lbase = ctl[1];
+    const uint32_t n_out = total > (uint32_t)MF_SLOTS ? total : (uint32_t)MF_SLOTS;
+    for (uint32_t i = tid; i < n_out; i += 256) {
+        if (i < (uint32_t)MF_SLOTS) my_slots[i] = i < total ? em[i] : KEY_NONE;
+        else if (lbase + (i - MF_SLOTS) < a.cand_cap) a.cand[lbase + (i - MF_SLOTS)] = em[i];
+    }
+}
+
 static void unpack_workspace(MfmaWorkspace &w, unsigned char *ws_base, const size_t *offs) {
     w.q_h = (_Float16 *)(ws_base + offs[0]); w.qnorm = (float *)(ws_base + offs[1]); w.thr = (float *)(ws_base + offs[2]);
     w.eps = (float *)(ws_base + offs[3]); w.cand_cnt = (uint32_t *)(ws_base + offs[4]); w.fallback = (uint32_t *)(ws_base + offs[5]);
@@ -1547,14 +1639,27 @@ static EpsCoef eps_coefficients(uint32_t dim, uint32_t order) {
     return c;
 }
 
-bool solo_supported(uint32_t nq, uint32_t k) {
+// room for the global threshold mode's keys and wave maxima behind query 0's overflow list (the lists of the other 255 query slots of a
+// pass are unused by a single-query call)
+static bool solo_global_fits(const MfmaPlan &p, uint64_t n_rows, uint64_t nb) {
+    const uint64_t room = ((uint64_t)p.n_slots - 1) * p.cand_cap * 8;
+    return n_rows * 4 + nb * SOLO_WAVES * 4 + 512 <= room;
+}
+static uint64_t solo_workgroups(uint64_t n_rows, int cus) {
+    uint64_t nb = (uint64_t)(cus > 0 ? cus : 1);
+    if (nb > ceil_div(n_rows, 64)) nb = ceil_div(n_rows, 64);
+    return nb < 1 ? 1 : nb;
+}
+bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const MfmaPlan &p) {
     static const bool off = getenv("SHODH_SOLO") && atoi(getenv("SHODH_SOLO")) == 0;
     static const uint32_t max_k = getenv("SHODH_SOLO_MAX_K") ? (uint32_t)atoi(getenv("SHODH_SOLO_MAX_K")) : SOLO_MAX_K;
-    return !off && nq == 1 && k >= 1 && k <= max_k;
+    if (off || nq != 1 || k < 1) return false;
+    if (k <= max_k) return true;
+    return k <= SOLO_MAX_K_GLOBAL && solo_global_fits(p, n_rows, solo_workgroups(n_rows, cus));
 }
 
-// The single-query pipeline: solo_scan_kernel + final stage; like launch_mfma_pipeline it leaves an unresolved query in fb_list / fb_count.
-// `solo_cnt`: one u32 that is zero between calls (allocated zeroed by the caller, handed back zeroed by the final stage).
+// The single-query pipeline: solo_scan_kernel [+ solo_emit_kernel] + final stage; like launch_mfma_pipeline it leaves an unresolved query in
+// fb_list / fb_count. `solo_cnt`: one u32 that is zero between calls (allocated zeroed by the caller, handed back zeroed by the final stage).
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
                          uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
@@ -1562,25 +1667,29 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     MfmaWorkspace w;
     unpack_workspace(w, ws_base, offs);
     if (stats_ext) w.stats = stats_ext;
-    uint64_t nb = (uint64_t)(cus > 0 ? cus : 1);
-    if (nb > ceil_div(n_rows, 64)) nb = ceil_div(n_rows, 64);
-    if (nb < 1) nb = 1;
+    static const uint32_t max_k_local = getenv("SHODH_SOLO_MAX_K") ? (uint32_t)atoi(getenv("SHODH_SOLO_MAX_K")) : SOLO_MAX_K;
+    const bool global_thr = k > max_k_local;
+    uint64_t nb = solo_workgroups(n_rows, cus);
     uint64_t slice = ceil_div(n_rows, nb);
-    if (slice > (uint64_t)SOLO_MAX_SLICE) { slice = SOLO_MAX_SLICE; nb = ceil_div(n_rows, slice); }
+    if (!global_thr && slice > (uint64_t)SOLO_MAX_SLICE) { slice = SOLO_MAX_SLICE; nb = ceil_div(n_rows, slice); }    // (the slice's keys live in LDS)
     if (slice < 1) slice = 1;
     if (nb > (uint64_t)p.grid_x * MF_BPAD) { set_error("single-query scan: %llu workgroups do not fit the slot table", (unsigned long long)nb); return SHODH_ERR_UNSUPPORTED; }
     const EpsCoef c = eps_coefficients(dim, order);
+    uint32_t *skeys = reinterpret_cast<uint32_t *>(w.cand + p.cand_cap);          // behind query 0's list (solo_global_fits)
+    uint32_t *tops = skeys + ((n_rows + 63) & ~(uint64_t)63);
     SoloArgs a{rows_h, n_rows, dim, d_q, deleted, k, (uint32_t)slice, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a,
-               w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u};
+               w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u, skeys, tops};
 #ifdef SHODH_DIAG
     a.ablate = getenv("SHODH_SOLO_ABLATE") ? (uint32_t)atoi(getenv("SHODH_SOLO_ABLATE")) : 0u;
 #endif
-    const size_t lds = ((size_t)slice + (slice & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16;
+    const size_t lds = global_thr ? 0 : ((size_t)slice + (slice & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16;
+#define SHODH_LAUNCH_SOLO_K(KERN)                                                                                     \
+        SHODH_TRY(ensure_dynamic_lds((const void *)KERN, lds));                                                       \
+        if (ev0 && ev1) hipExtLaunchKernelGGL(KERN, dim3((uint32_t)nb), dim3(SOLO_NT), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL(KERN, dim3((uint32_t)nb), dim3(SOLO_NT), lds, st, a);
 #define SHODH_LAUNCH_SOLO(D)                                                                                          \
     case D:                                                                                                           \
-        SHODH_TRY(ensure_dynamic_lds((const void *)solo_scan_kernel<D>, lds));                                        \
-        if (ev0 && ev1) hipExtLaunchKernelGGL((solo_scan_kernel<D>), dim3((uint32_t)nb), dim3(SOLO_NT), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
-        else hipLaunchKernelGGL((solo_scan_kernel<D>), dim3((uint32_t)nb), dim3(SOLO_NT), lds, st, a);                \
+        if (global_thr) { SHODH_LAUNCH_SOLO_K((solo_scan_kernel<D, true>)) } else { SHODH_LAUNCH_SOLO_K((solo_scan_kernel<D, false>)) }  \
         break;
     switch (dim) {
         SHODH_LAUNCH_SOLO(128)
@@ -1592,7 +1701,13 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
         default: set_error("single-query scan: unsupported dim %u", dim); return SHODH_ERR_UNSUPPORTED;
     }
 #undef SHODH_LAUNCH_SOLO
+#undef SHODH_LAUNCH_SOLO_K
     SHODH_HIP_TRY(hipGetLastError());
+    if (global_thr) {
+        SoloEmitArgs e{skeys, tops, (uint32_t)(nb * SOLO_WAVES), n_rows, (uint32_t)slice, k, w.eps, w.fallback, w.slots, w.cand, solo_cnt, p.cand_cap};
+        hipLaunchKernelGGL(solo_emit_kernel, dim3((uint32_t)nb), dim3(256), 0, st, e);
+        SHODH_HIP_TRY(hipGetLastError());
+    }
     if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
     SHODH_TRY(launch_final_stage(rows, dim, d_q, 1, k, order, id_base, p, w, (uint32_t)nb, solo_cnt, solo_cnt, d_ids, d_dist, d_counts, st));
     if (ev_select_done) SHODH_HIP_TRY(hipEventRecord(ev_select_done, st));

@@ -34,7 +34,7 @@ def check_one(oracle, idx, rows, q, k, order, deleted=None):
 @pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("dim", [128, 256, 384, 512, 768, 1024])
 def test_single_query_matches_oracle(S, oracle, dim, order):
-    n = 20011 if dim <= 512 else 16999
+    n = 20011
     q = synth.queries(5, dim, seed=50 + dim)
     rows = synth.corpus(n, dim, seed=60 + dim, queries=q)
     deleted = synth.tombstones(n, 0.05, seed=70 + dim)
@@ -48,9 +48,12 @@ def test_single_query_matches_oracle(S, oracle, dim, order):
     check_one(oracle, idx, rows, rows[n // 3], 10, order, deleted)                              # a stored row: itself (or its duplicates) first
     t = idx.stage_timings_us()
     assert t["total"] > 0 and t["scan"] > 0
-    # k beyond the single-pass limit (32) takes the sampled-threshold pipeline: same answer
-    check_one(oracle, idx, rows, q[0], 33, order, deleted)
-    assert idx.scan_stats()["sampled_rows"] > 0
+    # k beyond the local-threshold limit (32): global threshold from the wave maxima (scan + emit + final stage); about k rows are
+    # handed over instead of 256 x k
+    for i, k in enumerate((33, 120, 300)):
+        check_one(oracle, idx, rows, q[i], k, order, deleted)
+        st = idx.scan_stats()
+        assert st["sampled_rows"] == 0 and k <= st["emitted"] <= 3 * k + 64 and st["overflowed"] == 0, st
     idx.close()
 
 
@@ -84,7 +87,10 @@ def test_negative_scores_few_live_rows_and_ties(S, oracle):
         e_ids, e_dist = oracle.brute_force_search(same, qq, 10, select=True)
         assert ids[0].tolist() == e_ids.tolist() == list(range(10)) and dist[0].tobytes() == e_dist.tobytes()
         assert idx2.scan_stats()["overflowed"] == 1
-    # ... and the next call on a healthy index handle starts from a clean counter
+        ids, dist, counts = idx2.search_batch(np.ascontiguousarray(qq[None, :]), 120)      # the same through the global-threshold mode
+        e_ids, e_dist = oracle.brute_force_search(same, qq, 120, select=True)
+        assert ids[0].tolist() == e_ids.tolist() and dist[0].tobytes() == e_dist.tobytes()
+        assert idx2.scan_stats()["overflowed"] == 1
     idx2.close()
 
 
@@ -109,6 +115,10 @@ def test_crowded_corpus_and_interleaved_batches(S, oracle, order):
         assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes()
     check_one(oracle, idx, rows, base, 10, order)
     assert idx.scan_stats()["level2"] == 1
+    for i in range(len(qs)):                                             # global-threshold mode on the crowded corpus
+        check_one(oracle, idx, rows, qs[i], 120, order)
+        assert idx.scan_stats()["overflowed"] == 0
+    check_one(oracle, idx, rows, qs[0], 10, order)
     idx.close()
 
 
@@ -124,6 +134,10 @@ def test_device_pointer_single_query(S, oracle):
         torch.cuda.synchronize()
         e_ids, e_dist = oracle.brute_force_search(rows, q[i], 10, select=True)
         assert ids.cpu().numpy().view(np.uint32)[0].tolist() == e_ids.tolist() and dist.cpu().numpy()[0].tobytes() == e_dist.tobytes()
+    ids, dist, counts = idx.search_batch(torch.from_numpy(q[2:3]).cuda(), 120)
+    torch.cuda.synchronize()
+    e_ids, e_dist = oracle.brute_force_search(rows, q[2], 120, select=True)
+    assert ids.cpu().numpy().view(np.uint32)[0].tolist() == e_ids.tolist() and dist.cpu().numpy()[0].tobytes() == e_dist.tobytes()
     # a query the fp16 pre-scan cannot take (component beyond the fp16 range after scaling): device-side exact fallback
     big = (q[0] * f32(3000.0)).astype(f32)
     ids, dist, counts = idx.search_batch(torch.from_numpy(big[None, :]).cuda(), 10)
@@ -154,4 +168,7 @@ def test_slice_cap_many_workgroups(S, oracle):
         check_one(oracle, idx, rows, q[i], 10, 0)
         st = idx.scan_stats()
         assert st["sampled_rows"] == 0 and st["overflowed"] == 0, st
+        check_one(oracle, idx, rows, q[i], 120, 0)                       # no slice cap in the global-threshold mode: 256 slices of 16 797 rows
+        st = idx.scan_stats()
+        assert st["sampled_rows"] == 0 and st["overflowed"] == 0 and st["emitted"] < 1000, st
     idx.close()
