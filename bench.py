@@ -716,7 +716,25 @@ def main():
         lat.update({"host_pointers_p50_ms": round(th[len(th) // 2] * 1e3, 4), "host_pointers_p95_ms": round(th[int(len(th) * 0.95)] * 1e3, 4),
                     "scan_kernel_us": round(stg["scan"], 1), "device_total_us": round(stg["total"], 1),
                     "scan_kernel_hbm_frac_fp16_bytes": round(rows_local * args.dim * 2 / (stg["scan"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4) if stg["scan"] > 0 else None,
-                    "path": "single pass over the fp16 shadow with workgroup-local thresholds (solo_scan_kernel) + final stage" if args.k <= 32 else "batch pipeline"})
+                    "path": "single pass over the fp16 shadow with workgroup-local thresholds (solo_scan_kernel) + final stage" if args.k <= 32 else "single-query scan, global threshold"})
+        # ... and at the index-level k of a top-10 recall (k = 120, retrieval.rs:927): single-query scan with the global threshold
+        o120 = (torch.empty((1, 120), dtype=torch.int32, device=dev), torch.empty((1, 120), dtype=torch.float32, device=dev),
+                torch.empty((1,), dtype=torch.int32, device=dev))
+        t120, h120 = [], []
+        for i in range(60):
+            q1 = qpool[i % len(qpool)][i % args.nq:i % args.nq + 1]
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            index.search_batch_device(q1, 120, out=o120)
+            torch.cuda.synchronize()
+            t120.append(time.perf_counter() - a)
+            a = time.perf_counter()
+            index.search_batch(hq[i % 16], 120)
+            h120.append(time.perf_counter() - a)
+        t120, h120 = sorted(t120[10:]), sorted(h120[10:])
+        stg = index.stage_timings_us()
+        lat["k120"] = {"p50_ms": round(t120[len(t120) // 2] * 1e3, 4), "host_pointers_p50_ms": round(h120[len(h120) // 2] * 1e3, 4),
+                       "scan_kernel_us": round(stg["scan"], 1), "device_total_us": round(stg["total"], 1)}
 
     cpu = None
     cpu_info = host_cpu_info() if rank == 0 else None
