@@ -681,6 +681,8 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
             }
         }
     } while (0);
+    // a single-query call that failed half way may have left its list counter non-zero (the final stage hands it back zeroed)
+    if (rc != SHODH_OK && fc.solo) (void)hipMemsetAsync(w->solo_cnt, 0, 4, st);
     w->last_stream = st;
     w->pending = !(sync_host && rc == SHODH_OK);       // successful host-pointer calls end with a stream synchronisation
     ws_release(idx, w);
