@@ -83,8 +83,10 @@ def load_vamana(path, device=0, scan_mode=L.SCAN_AUTO):
 def save_vamana(index, path):
     """VamanaIndex::save_to_file (vamana_persist.rs:175-284) for an index of this library.
 
-    This library never builds a Vamana graph. Two cases:
-    * the index was loaded from a reference-written file and its rows are unchanged (`index._graph`): the loaded degree /
+    Three cases:
+    * graph mode (`SHODH_SCAN_GRAPH`): the index holds the reference's graph (grown by `add_vector`, built by `vamana_build` or loaded);
+      degree / neighbour arrays and medoid are read back from the device and written;
+    * exact-scan modes, index loaded from a reference-written file and its rows unchanged (`index._graph`): the loaded degree /
       neighbour arrays and medoid are written back, so the file round-trips with its graph;
     * otherwise every node gets an EMPTY adjacency list, and `incremental_inserts` is raised to REBUILD_THRESHOLD in the
       header: the reference's default (non-exact) `search` would walk a graph without edges and return one hit per query
