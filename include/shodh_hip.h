@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SHODH_HIP_ABI_VERSION 2
+#define SHODH_HIP_ABI_VERSION 3
 
 typedef enum {
     SHODH_OK = 0,
@@ -262,9 +262,10 @@ int shodh_top_k_similar(int device, const float *query, uint32_t query_dim, cons
 /* ---- embedder: trait Embedder / MiniLMEmbedder (src/embeddings/mod.rs:52-88, minilm.rs) ------- */
 enum { SHODH_DTYPE_FP32 = 0, SHODH_DTYPE_BF16 = 1,
        /* the reference's DEFAULT model is the ONNX Runtime dynamic-quantisation export model_quint8_avx2.onnx (downloader.rs:31,
-        * minilm.rs:212-220): 8-bit per-tensor weights (and word table), DynamicQuantizeLinear uint8 activations per dense layer,
-        * MatMulInteger int32 accumulation on v_mfma_i32_32x32x32_i8, fp32 softmax / GELU / LayerNorm. Parity with that file is
-        * unpinned (no ONNX Runtime / checkpoint offline): what is implemented is the published semantics of those ONNX operators */
+        * minilm.rs:212-220): 8-bit weights and word table with the file's own scales and zero points (per tensor or per channel; see
+        * shodh_embedder_load_file), DynamicQuantizeLinear uint8 activations per dense layer, MatMulInteger int32 accumulation on
+        * v_mfma_i32_32x32x32_i8, fp32 softmax / GELU / LayerNorm. Parity with that file is unpinned (no ONNX Runtime / checkpoint
+        * offline): what is implemented is the published semantics of those ONNX operators */
        SHODH_DTYPE_INT8 = 2 };
 typedef struct {
     int32_t  device;
@@ -275,6 +276,8 @@ typedef struct {
     uint32_t compute_padded; /* 0: only real tokens (exact in fp32/bf16, minilm.rs:153-154); 1 (INT8 only): all max_len positions of every
                               * non-empty text, as the reference's tensor has them -- DynamicQuantizeLinear takes its range over
                               * the padded tensor, so the padding is part of the INT8 embedding function (minilm.rs:588-593) */
+    const char *weights_path; /* NULL, or the model file shodh_embedder_create loads (EmbeddingConfig.model_path, minilm.rs:212-220): model.safetensors,
+                              * model.onnx, or the dynamic-quantisation export model_quantized.onnx -- see shodh_embedder_load_file */
 } shodh_embed_cfg;
 void shodh_embed_cfg_default(shodh_embed_cfg *cfg);
 int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out);   /* MiniLMEmbedder::new minilm.rs:652-690 */
@@ -283,6 +286,41 @@ void shodh_embedder_destroy(shodh_embedder *e);
  * (see DESIGN.md "encoder weight blob") */
 uint64_t shodh_embedder_param_count(const shodh_embedder *e);
 int shodh_embedder_load_weights(shodh_embedder *e, const float *blob, uint64_t n_floats);
+/* ---- weights as the reference's files hold them (minilm.rs:96-98 hands the .onnx file to ONNX Runtime; downloader.rs:29-53 names the
+ * files: onnx/model.onnx, onnx/model_quint8_avx2.onnx; the checkpoint itself is model.safetensors) -------------------------------------
+ * shodh_embedder_load_file reads
+ *   .safetensors  F32 / F16 / BF16 tensors under their HF BertModel names (any "prefix." in front, pooler ignored);
+ *   .onnx         the fp32 export, or the onnxruntime dynamic-quantisation export: initialisers by HF name where the exporter kept them,
+ *                 MatMul / MatMulInteger constants ([K][N], anonymous) by the bias their result is added to, <w>_quantized / <w>_scale /
+ *                 <w>_zero_point triples per tensor or per output channel, uint8 or int8.
+ * With SHODH_DTYPE_INT8 an export's quantised tensors are used AS THEY ARE (bytes, scales, zero points: MatMulInteger's
+ * sum (a - a_zp)(b - b_zp) with b_zp of any value); tensors that arrive as floats are quantised by this library (per tensor, symmetric:
+ * scale = 2 max|w| / 255) -- a fallback for checkpoints without an export, not the export's arithmetic. fp32 / bf16 modes take
+ * the dequantised values of quantised tensors. */
+int shodh_embedder_load_file(shodh_embedder *e, const char *path);
+/* the same hand-over one tensor at a time (a host that parses the model file itself): names are HF BertModel parameter names
+ * ("embeddings.word_embeddings.weight", "encoder.layer.0.attention.self.query.weight", ...; see shodh_weight_file_* for the list).
+ * load_tensor: f32, [rows][cols] as HF stores it, or [cols][rows] with transposed != 0 (ONNX MatMul constants are [K][N]).
+ * load_quantized: uint8 (is_signed = 0) or int8 bytes in the same layouts, n_scale = 1 (per tensor) or N (per output channel) scales and
+ * zero points (zero_point NULL = 0; same integer type as the bytes); allowed for the six dense weights per layer and the word table.
+ * finish_weights checks that every parameter arrived and builds the device copies; encode calls fail with SHODH_ERR_STATE before it. */
+int shodh_embedder_load_tensor(shodh_embedder *e, const char *name, const float *data, uint64_t n, uint32_t transposed);
+int shodh_embedder_load_quantized(shodh_embedder *e, const char *name, const void *q, uint32_t is_signed, uint32_t transposed,
+                                  const float *scale, const void *zero_point, uint32_t n_scale);
+int shodh_embedder_finish_weights(shodh_embedder *e);
+/* where a parameter's device copy came from: ABSENT (nothing loaded), F32, EXPORT_Q8 (INT8 mode multiplies the file's own bytes),
+ * SELF_Q8 (INT8 mode quantised f32 values itself) */
+enum { SHODH_WEIGHT_ABSENT = 0, SHODH_WEIGHT_F32 = 1, SHODH_WEIGHT_EXPORT_Q8 = 2, SHODH_WEIGHT_SELF_Q8 = 3 };
+int shodh_embedder_weight_source(const shodh_embedder *e, const char *name, uint32_t *source_out);
+/* host-only view of a weight file (no device needed; what shodh_embedder_load_file parses): the f32 blob in shodh_embedder_load_weights
+ * order (quantised tensors dequantised, (q - zp) * scale), and per name the quantised form in this library's storage convention --
+ * signed bytes [N][K] (uint8 sources minus 128), n_scale scales, zero points in the same signed terms. n_scale_out = 0: stored as floats. */
+typedef struct shodh_weight_file shodh_weight_file;
+int shodh_weight_file_open(const char *path, const shodh_embed_cfg *cfg, shodh_weight_file **out);
+void shodh_weight_file_close(shodh_weight_file *f);
+int shodh_weight_file_blob(const shodh_weight_file *f, float *blob_out, uint64_t n_floats);
+int shodh_weight_file_quantized(const shodh_weight_file *f, const char *name, int8_t *q_out, uint64_t q_len, float *scale_out,
+                                int32_t *zero_point_out, uint32_t scale_cap, uint32_t *n_scale_out);
 /* deterministic synthetic weights (normal std 0.02, LayerNorm gamma 1 beta 0) from a seed; the
  * same blob is returned to the host when blob_out != NULL so a checker can mirror it */
 int shodh_embedder_init_synthetic(shodh_embedder *e, uint64_t seed, float *blob_out, uint64_t n_floats);
@@ -304,6 +342,11 @@ int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /
  * quantisation parameters, w_scale the weight scale. The building block of SHODH_DTYPE_INT8. */
 int shodh_int8_dense(int device, const float *x, const float *w, const float *bias, uint32_t M, uint32_t N, uint32_t K,
                      float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale);
+/* the same layer on a weight that is ALREADY quantised (an export's tensor): wq uint8 (is_signed = 0) or int8 [N][K], n_scale = 1 or N
+ * scales and zero points (w_zero_point NULL = 0, same integer type as wq). acc_out = sum_k (a - a_zp)(wq - w_zp), exact (MatMulInteger). */
+int shodh_int8_dense_quantized(int device, const float *x, const void *wq, uint32_t is_signed, const float *w_scale, const void *w_zero_point,
+                               uint32_t n_scale, const float *bias, uint32_t M, uint32_t N, uint32_t K, float *y, int32_t *acc_out,
+                               float *a_scale, int32_t *a_zp);
 
 /* ---- host-side glue of the same path (string / uuid work: stays on the host by design) ------------------ */
 /* MiniLMEmbedder::new_simplified / generate_embedding_simplified (minilm.rs:777-831): SipHash-1-3

@@ -11,9 +11,12 @@ graph of SURVEY.md Appendix E:
       zp = round_half_even(clip(0 - rmin / scale, 0, 255));  q = clip(round_half_even(x / scale) + zp, 0, 255)
       -- over the WHOLE tensor [B, max_len, H], padding included (minilm.rs:588-593: "derives its activation scale from
          the whole tensor, padding included, so the tensor length is part of the embedding function")
-  weights: per tensor, symmetric, 8 bit (quantize_dynamic, avx2 config): scale = 2 max|w| / 255, zp = 128 (uint8), i.e. the
-      signed value clip(round_half_even(w / scale), -128, 127)
-  MatMulInteger: int32 sum of (a - a_zp) * (b - b_zp), exact
+  weights: whatever the export holds -- uint8 or int8 bytes with a scale and a zero point per tensor or per output channel
+      (`quantize_weight_ort` restates the onnxruntime quantiser's rule for producing them: symmetric or asymmetric, optional 7-bit
+      "reduce_range"; WHICH of these model_quint8_avx2.onnx uses cannot be checked offline, so the restatement and the HIP path take the
+      tensors as given). The default when only f32 weights exist: per tensor, symmetric, scale = 2 max|w| / 255, zero point 128 in
+      uint8 terms, i.e. the signed value clip(round_half_even(w / scale), -128, 127) with zero point 0 (`quantize_weight`).
+  MatMulInteger: int32 sum of (a - a_zp) * (b - b_zp), exact, b_zp a scalar or one value per output channel
   dequantise: float(acc) * (a_scale * b_scale) + bias            (MatMulIntegerToFloat)
   only MatMuls with a constant weight are quantised (MatMulConstBOnly, the dynamic-mode default): Q, K, V, attention output,
   FFN up, FFN down; QK^T, softmax, PV, GELU (erf), LayerNorm stay fp32. The word-embedding table is stored 8-bit (Gather) and
@@ -38,6 +41,50 @@ def quantize_weight(w):
     return q, f32(scale)
 
 
+def quantize_weight_ort(w, per_channel=False, symmetric=False, reduce_range=False, signed=False):
+    """The onnxruntime quantiser's weight rule (onnxruntime/python/tools/quantization/quant_utils.py: compute_scale_zp + quantize_nparray),
+    restated: the range is widened to contain 0 (and made symmetric if asked), scale = (rmax - rmin) / (qmax - qmin),
+    zero_point = round_half_even(qmin - rmin / scale), q = clip(round_half_even(w / scale) + zero_point, qmin, qmax).
+    w [N, K] (HF layout); per_channel = one (scale, zero point) per output feature n. -> (q uint8|int8 [N, K], scale f32 [1|N], zp same dtype [1|N])"""
+    w = np.asarray(w, f32)
+    if signed:
+        qmin, qmax = (-64, 64) if reduce_range else (-128, 127)
+        if symmetric:
+            qmin = -qmax if not reduce_range else qmin
+    else:
+        qmin, qmax = (0, 127) if reduce_range else (0, 255)
+    rows = w if per_channel else w.reshape(1, -1)
+    rmin = np.minimum(rows.min(1), f32(0)).astype(f32); rmax = np.maximum(rows.max(1), f32(0)).astype(f32)
+    if symmetric:
+        am = np.maximum(np.abs(rmin), np.abs(rmax)).astype(f32)
+        rmin, rmax = -am, am
+    scale = ((rmax - rmin) / f32(qmax - qmin)).astype(f32)
+    tiny = scale < np.finfo(f32).tiny
+    scale = np.where(tiny, f32(1), scale).astype(f32)
+    zp = np.where(tiny, 0, np.rint(f32(qmin) - rmin / scale)).astype(np.int64)
+    sc_full = scale[:, None] if per_channel else scale[0]
+    zp_full = zp[:, None] if per_channel else zp[0]
+    q = np.clip(np.rint(w / sc_full) + zp_full, qmin, qmax)
+    dt = np.int8 if signed else np.uint8
+    return q.astype(dt), scale.astype(f32), zp.astype(dt)
+
+
+def as_triple(q, scale, zp=None):
+    """(bytes, scales, zero points) with array-shaped scale / zero point"""
+    q = np.asarray(q)
+    scale = np.atleast_1d(np.asarray(scale, f32))
+    zp = np.zeros(scale.shape, q.dtype) if zp is None else np.atleast_1d(np.asarray(zp)).astype(q.dtype)
+    return q, scale, zp
+
+
+def dequantize(q, scale, zp):
+    """DequantizeLinear: (q - zp) * scale, per tensor or per row"""
+    q, scale, zp = as_triple(q, scale, zp)
+    sc = scale[:, None] if scale.size > 1 else scale[0]
+    z = zp.astype(np.int32)[:, None] if zp.size > 1 else int(zp[0])
+    return ((q.astype(np.int32) - z).astype(f32) * sc).astype(f32)
+
+
 def dynamic_quantize_params(x):
     rmin = min(f32(0), f32(x.min())) if x.size else f32(0)
     rmax = max(f32(0), f32(x.max())) if x.size else f32(0)
@@ -55,19 +102,24 @@ def dynamic_quantize(x):
     return q, scale, zp
 
 
-def matmul_integer(a_u8, a_zp, w_s8):
-    """exact int32 accumulators of sum_k (a - a_zp) * w   (a [M,K] uint8, w [N,K] signed)"""
+def matmul_integer(a_u8, a_zp, w_q, w_zp=None):
+    """MatMulInteger: exact int32 accumulators of sum_k (a - a_zp) * (w - w_zp)   (a [M,K] uint8, w [N,K] uint8 or int8, w_zp scalar or [N])"""
     # float64 BLAS is exact here (|acc| < 2^53) and far faster than numpy's integer matmul
-    acc = (a_u8.astype(np.float64) - float(a_zp)) @ w_s8.astype(np.float64).T
+    wz = w_q.astype(np.float64)
+    if w_zp is not None:
+        z = np.atleast_1d(np.asarray(w_zp)).astype(np.float64)
+        wz = wz - (z[:, None] if z.size > 1 else z[0])
+    acc = (a_u8.astype(np.float64) - float(a_zp)) @ wz.T
     return acc.astype(np.int64).astype(np.int32)
 
 
-def dense_int8(x, w_q, w_scale, bias):
-    """one quantised dense layer; x [..., K] f32. -> (y f32, acc int32, a_scale, a_zp)"""
+def dense_int8(x, w_q, w_scale, bias, w_zp=None):
+    """one quantised dense layer; x [..., K] f32; w_scale / w_zp scalars or [N]. -> (y f32, acc int32, a_scale, a_zp)"""
     shp = x.shape
     a, sa, zp = dynamic_quantize(x)
-    acc = matmul_integer(a.reshape(-1, shp[-1]), zp, w_q)
-    y = acc.astype(f32) * f32(sa * w_scale) + bias.astype(f32)
+    acc = matmul_integer(a.reshape(-1, shp[-1]), zp, w_q, w_zp)
+    ws = np.atleast_1d(np.asarray(w_scale, f32))
+    y = acc.astype(f32) * (f32(sa) * (ws[None, :] if ws.size > 1 else ws[0])).astype(f32) + bias.astype(f32)
     return y.reshape(shp[:-1] + (w_q.shape[0],)), acc, sa, zp
 
 
@@ -86,17 +138,22 @@ def gelu_erf(x):
     return (f32(0.5) * x * (f32(1.0) + _erf(x.astype(np.float64) * 0.7071067811865476).astype(f32))).astype(f32)
 
 
-def quantize_model(sd, layers):
-    """-> dict of quantised tensors (name -> (int8 values, scale)) for the word table and the six dense weights per layer"""
-    q = {"embeddings.word_embeddings.weight": quantize_weight(sd["embeddings.word_embeddings.weight"])}
+QUANTISED_NAMES = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
+
+
+def quantize_model(sd, layers, rule=quantize_weight, word_rule=None):
+    """-> dict name -> (bytes, scales, zero points) for the word table and the six dense weights per layer. `rule` maps an f32 matrix to
+    (q, scale[, zp]): `quantize_weight` (this library's fallback for f32 checkpoints) or e.g. lambda w: quantize_weight_ort(w, per_channel=True)"""
+    word_rule = word_rule or rule
+    q = {"embeddings.word_embeddings.weight": as_triple(*word_rule(sd["embeddings.word_embeddings.weight"]))}
     for l in range(layers):
         p = "encoder.layer.%d." % l
-        for nm in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense"):
-            q[p + nm + ".weight"] = quantize_weight(sd[p + nm + ".weight"])
+        for nm in QUANTISED_NAMES:
+            q[p + nm + ".weight"] = as_triple(*rule(sd[p + nm + ".weight"]))
     return q
 
 
-def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None):
+def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None, qmodel=None):
     """ids/mask [B, S] (S = the padded tensor length, max_len). Rows with an empty mask are left out of the tensor (the
     reference never runs empty texts, minilm.rs:1123-1125, :1319-1350) and come back as zeros. -> unit vectors [B, H].
     `trace` (dict) receives the int32 accumulators and quantisation parameters of layer 0's query projection."""
@@ -109,9 +166,9 @@ def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None):
         return out
     ids, mask = ids[keep], mask[keep]
     Bk = len(keep)
-    qm = quantize_model(sd, layers)
-    wq, ws = qm["embeddings.word_embeddings.weight"]
-    word = wq[np.clip(ids, 0, wq.shape[0] - 1)].astype(f32) * ws                       # Gather + DequantizeLinear
+    qm = qmodel if qmodel is not None else quantize_model(sd, layers)                   # an export's tensors, or the f32 weights quantised by the fallback rule
+    wq, ws, wz = qm["embeddings.word_embeddings.weight"]
+    word = (wq[np.clip(ids, 0, wq.shape[0] - 1)].astype(np.int32) - int(wz[0])).astype(f32) * ws[0]     # Gather + DequantizeLinear
     x = word + sd["embeddings.position_embeddings.weight"][None, :S].astype(f32) + sd["embeddings.token_type_embeddings.weight"][0][None, None].astype(f32)
     x = layer_norm(x, sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], eps).astype(f32)
     dh = H // heads
@@ -121,11 +178,11 @@ def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None):
         p = "encoder.layer.%d." % l
 
         def dense(name, t):
-            w_q, w_s = qm[p + name + ".weight"]
-            return dense_int8(t, w_q, w_s, sd[p + name + ".bias"])
+            w_q, w_s, w_z = qm[p + name + ".weight"]
+            return dense_int8(t, w_q, w_s, sd[p + name + ".bias"], w_z)
         q, acc_q, sa, zp = dense("attention.self.query", x)
         if trace is not None and l == 0:
-            trace.update(acc_q=acc_q, a_scale=sa, a_zp=zp, w_scale=qm[p + "attention.self.query.weight"][1])
+            trace.update(acc_q=acc_q, a_scale=sa, a_zp=zp, w_scale=qm[p + "attention.self.query.weight"][1][0])
         k = dense("attention.self.key", x)[0]
         v = dense("attention.self.value", x)[0]
         qh = q.reshape(Bk, S, heads, dh).transpose(0, 2, 1, 3)

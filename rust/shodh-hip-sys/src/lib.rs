@@ -403,21 +403,39 @@ pub trait Tokenize: Send + Sync {
 /// `impl Embedder` (src/embeddings/mod.rs:52-88). Tokenisation stays on the host; `session.run` + pooling
 /// (minilm.rs:939-981) run on the device. Add `impl crate::embeddings::Embedder for HipEmbedder<T>` in the reference
 /// tree forwarding to these inherent methods (the trait lives in that crate).
+/// GEMM operand type of the encoder. `Int8` is the reference's default model (SHODH_USE_QUANTIZED_MODEL unset, minilm.rs:205-220).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum EncoderDtype { Fp32, Bf16, Int8 }
 pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize }
 unsafe impl<T: Tokenize> Send for HipEmbedder<T> {}
 unsafe impl<T: Tokenize> Sync for HipEmbedder<T> {}
 impl<T: Tokenize> HipEmbedder<T> {
-    /// `weights`: the f32 blob in HF `BertModel` parameter order (embedder.py::state_dict_to_blob documents every slice)
-    pub fn new(tok: T, weights: &[f32], device: i32, bf16: bool) -> Result<Self> {
+    /// `weights`: the f32 blob in HF `BertModel` parameter order (embedder.py::state_dict_to_blob documents every slice). With
+    /// `EncoderDtype::Int8` a blob is quantised by the library (per tensor, symmetric); to run the reference's own quantised
+    /// export use `from_model_file`.
+    pub fn new(tok: T, weights: &[f32], device: i32, dtype: EncoderDtype) -> Result<Self> {
+        let e = Self::create(tok, device, dtype, None)?;
+        check(unsafe { ffi::shodh_embedder_load_weights(e.h, weights.as_ptr(), weights.len() as u64) })?;
+        Ok(e)
+    }
+    /// The model file the reference hands to ONNX Runtime (`EmbeddingConfig.model_path`, minilm.rs:212-220): `model_quantized.onnx`
+    /// (= onnx/model_quint8_avx2.onnx, the default: its uint8 tensors, scales and zero points are multiplied as they are under
+    /// `EncoderDtype::Int8`), `model.onnx`, or the checkpoint's `model.safetensors`.
+    pub fn from_model_file(tok: T, model_path: &std::path::Path, device: i32, dtype: EncoderDtype) -> Result<Self> {
+        let p = std::ffi::CString::new(model_path.to_string_lossy().as_bytes()).map_err(|_| anyhow!("model path contains NUL"))?;
+        Self::create(tok, device, dtype, Some(&p))
+    }
+    fn create(tok: T, device: i32, dtype: EncoderDtype, path: Option<&std::ffi::CString>) -> Result<Self> {
         let mut cfg = ffi::shodh_embed_cfg::default();
         unsafe { ffi::shodh_embed_cfg_default(&mut cfg) };
         cfg.device = device;
-        cfg.dtype = if bf16 { ffi::SHODH_DTYPE_BF16 as u32 } else { ffi::SHODH_DTYPE_FP32 as u32 };
+        cfg.dtype = match dtype { EncoderDtype::Fp32 => ffi::SHODH_DTYPE_FP32, EncoderDtype::Bf16 => ffi::SHODH_DTYPE_BF16, EncoderDtype::Int8 => ffi::SHODH_DTYPE_INT8 } as u32;
+        // the reference's INT8 tensor is padded to max_length and DynamicQuantizeLinear ranges span it (minilm.rs:588-593)
+        cfg.compute_padded = if dtype == EncoderDtype::Int8 { 1 } else { 0 };
+        cfg.weights_path = path.map_or(std::ptr::null(), |p| p.as_ptr());
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::shodh_embedder_create(&cfg, &mut h) })?;
-        let e = Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize };
-        check(unsafe { ffi::shodh_embedder_load_weights(e.h, weights.as_ptr(), weights.len() as u64) })?;
-        Ok(e)
+        Ok(Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize })
     }
     pub fn dimension(&self) -> usize { self.dim }
     pub fn encode(&self, text: &str) -> Result<Vec<f32>> {

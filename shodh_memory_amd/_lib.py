@@ -26,6 +26,7 @@ ORDER_SCALAR4, ORDER_AVX2, ORDER_SEQ_1M = 0, 1, 2
 INDEX_FLAT, INDEX_IVFPQ = 0, 1
 SCAN_AUTO, SCAN_EXACT, SCAN_MFMA, SCAN_GRAPH = 0, 1, 2, 3
 DTYPE_FP32, DTYPE_BF16, DTYPE_INT8 = 0, 1, 2
+WEIGHT_ABSENT, WEIGHT_F32, WEIGHT_EXPORT_Q8, WEIGHT_SELF_Q8 = 0, 1, 2, 3
 
 
 class ShodhError(RuntimeError):
@@ -44,7 +45,8 @@ class IndexCfg(C.Structure):
 class EmbedCfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("dtype", C.c_uint32), ("max_len", C.c_uint32), ("vocab", C.c_uint32),
                 ("hidden", C.c_uint32), ("layers", C.c_uint32), ("heads", C.c_uint32), ("intermediate", C.c_uint32),
-                ("max_pos", C.c_uint32), ("type_vocab", C.c_uint32), ("ln_eps", C.c_float), ("compute_padded", C.c_uint32)]
+                ("max_pos", C.c_uint32), ("type_vocab", C.c_uint32), ("ln_eps", C.c_float), ("compute_padded", C.c_uint32),
+                ("weights_path", C.c_char_p)]
 
 
 class Weights(C.Structure):
@@ -154,6 +156,17 @@ SYMBOLS = {
     "shodh_embedder_param_count": (C.c_uint64, [_vp]),
     "shodh_embedder_load_weights": (C.c_int, [_vp, _fp, C.c_uint64]),
     "shodh_embedder_init_synthetic": (C.c_int, [_vp, C.c_uint64, _fp, C.c_uint64]),
+    "shodh_embedder_load_file": (C.c_int, [_vp, C.c_char_p]),
+    "shodh_embedder_load_tensor": (C.c_int, [_vp, C.c_char_p, _fp, C.c_uint64, C.c_uint32]),
+    "shodh_embedder_load_quantized": (C.c_int, [_vp, C.c_char_p, _vp, C.c_uint32, C.c_uint32, _fp, _vp, C.c_uint32]),
+    "shodh_embedder_finish_weights": (C.c_int, [_vp]),
+    "shodh_embedder_weight_source": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "shodh_weight_file_open": (C.c_int, [C.c_char_p, C.POINTER(EmbedCfg), C.POINTER(C.c_void_p)]),
+    "shodh_weight_file_close": (None, [_vp]),
+    "shodh_weight_file_blob": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "shodh_weight_file_quantized": (C.c_int, [_vp, C.c_char_p, _vp, C.c_uint64, _fp, _i32p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "shodh_int8_dense_quantized": (C.c_int, [C.c_int, _fp, _vp, C.c_uint32, _fp, _vp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _fp, _i32p,
+                                             C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "shodh_embed_param_count": (C.c_uint64, [C.POINTER(EmbedCfg)]),
     "shodh_embedder_synthetic_weights": (C.c_int, [C.POINTER(EmbedCfg), C.c_uint64, _fp, C.c_uint64]),
     "shodh_hash_embed": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, _fp]),

@@ -19,14 +19,18 @@
 //  * weights stay resident in HBM as bf16 (45 MB) next to the f32 master copy.
 // dtype FP32 runs the same graph with f32 storage and a plain tiled f32 GEMM (validation path).
 #include <cmath>
+#include <memory>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <vector>
 
 #include "common.h"
 #include "glds.h"
 #include "encoder_int8.h"
+#include "encoder_int8_fast.h"
 #include "encoder_ffn.h"
+#include "weights_io.h"
 
 namespace shodh {
 
@@ -545,9 +549,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     float x[16];
     int cnt = 0;
     float s = 0.0f;
-    const float wsc = word_q ? *word_scale : 0.0f;
+    const float wsc = word_q ? word_scale[0] : 0.0f;
+    const int wzp = word_q ? (int)word_scale[1] : 0;          // zero point in signed-storage terms
     for (int i = lane; i < H; i += 64) {
-        const float wv = word_q ? (float)word_q[(size_t)id * H + i] * wsc : word[(size_t)id * H + i];      // Gather + DequantizeLinear
+        const float wv = word_q ? (float)((int)word_q[(size_t)id * H + i] - wzp) * wsc : word[(size_t)id * H + i];      // Gather + DequantizeLinear: (q - zp) * scale
         const float v = wv + pos[(size_t)p * H + i] + type0[i]; x[cnt++] = v; s += v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -797,8 +802,18 @@ struct shodh_embedder {
     // [I][H], FFN down [H][I] as signed 8-bit values with one scale per output feature (per-tensor scales, repeated) and row sums;
     // the word table 8-bit as well
     std::vector<QWeight> q_qkv, q_o, q_up, q_dn;
-    int8_t *word_q = nullptr; float *word_scale = nullptr;
+    int8_t *word_q = nullptr; float *word_scale = nullptr;      // word_scale = {scale, zero point (signed-storage terms)}
+    bool word_from_export = false;
+    std::unique_ptr<WeightSet> ws;       // tensors handed over by file / one by one, until shodh_embedder_finish_weights
+    std::vector<QTensor> qexp;           // per tensor slot: a quantised export's own bytes, scales and zero points (INT8 mode multiplies these)
+    std::string weights_path;
     int8_t *XQ = nullptr;                // quantised activations of the current dense layer [tok_cap][max(H, I)]
+    int8_t *HQ = nullptr;                // quantised GELU output [tok_cap][I] (fast INT8 path: the f32 intermediate never exists)
+    int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
+    bool need_rs = false;
+    uint32_t int8_stages = 0xF;          // bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
+    bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
+    uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][2]
     float *act_params = nullptr;         // {scale, zp} of the current activation tensor
     uint32_t *qscratch = nullptr;        // min/max keys, absmax
     int32_t *d_klen = nullptr, *d_orow = nullptr;   // padded mode: real tokens per computed sequence, output row of each computed sequence
@@ -838,13 +853,23 @@ static int reserve(shodh_embedder *e, size_t ntok, size_t nseq) {
     const size_t es = e->cfg.dtype == SHODH_DTYPE_BF16 ? 2 : 4;
     if (ntok > e->tok_cap) {
         hipFree(e->X); hipFree(e->QKV); hipFree(e->CTX); hipFree(e->FF); hipFree(e->PRE); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->XQ);
-        e->X = e->QKV = e->CTX = e->FF = nullptr; e->PRE = nullptr; e->d_tok_seq = e->d_tok_pos = nullptr; e->XQ = nullptr; e->tok_cap = 0;
+        hipFree(e->HQ); hipFree(e->rsX); hipFree(e->rsH);
+        e->X = e->QKV = e->CTX = e->FF = nullptr; e->PRE = nullptr; e->d_tok_seq = e->d_tok_pos = nullptr; e->XQ = nullptr; e->HQ = nullptr; e->rsX = e->rsH = nullptr; e->tok_cap = 0;
         size_t cap = ntok + ntok / 4 + 256;
-        if (e->cfg.dtype == SHODH_DTYPE_INT8) SHODH_HIP_TRY(hipMalloc((void **)&e->XQ, cap * std::max(H, I)));
+        const bool int8 = e->cfg.dtype == SHODH_DTYPE_INT8;
+        if (int8) {
+            SHODH_HIP_TRY(hipMalloc((void **)&e->XQ, cap * std::max(H, I)));
+            SHODH_HIP_TRY(hipMalloc((void **)&e->HQ, cap * I));
+            SHODH_HIP_TRY(hipMalloc((void **)&e->rsX, cap * 4));
+            SHODH_HIP_TRY(hipMalloc((void **)&e->rsH, cap * 4));
+        }
+        // the fast INT8 layer keeps neither the q|k|v tensor nor the f32 GELU output (encoder_int8_fast.h); they exist only for the stages
+        // switched back to the round-2 kernels (SHODH_INT8_STAGES) or for shapes the fused kernels do not take
+        const bool need_wide = !int8 || !e->int8_all_fast;
         SHODH_HIP_TRY(hipMalloc(&e->X, cap * H * es));
-        SHODH_HIP_TRY(hipMalloc(&e->QKV, cap * 3 * H * es));
+        if (need_wide) SHODH_HIP_TRY(hipMalloc(&e->QKV, cap * 3 * H * es));
         SHODH_HIP_TRY(hipMalloc(&e->CTX, cap * H * es));
-        SHODH_HIP_TRY(hipMalloc(&e->FF, cap * I * es));
+        if (need_wide) SHODH_HIP_TRY(hipMalloc(&e->FF, cap * I * es));
         SHODH_HIP_TRY(hipMalloc((void **)&e->PRE, cap * H * 4));
         SHODH_HIP_TRY(hipMalloc((void **)&e->d_tok_seq, cap * 4));
         SHODH_HIP_TRY(hipMalloc((void **)&e->d_tok_pos, cap * 4));
@@ -1008,10 +1033,37 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
     return SHODH_OK;
 }
 
-// INT8 mode: the fp32 graph with every constant-weight MatMul replaced by DynamicQuantizeLinear -> MatMulInteger -> dequantise
-// (encoder_int8.h). `klen` / `orow` (device, may be null): real tokens per computed sequence and the output row of each -- the padded
-// tensor computes all max_len positions of every non-empty text (compute_padded = 1, the reference's tensor), keys and pooling stay
-// restricted to the real tokens.
+// INT8 mode: the fp32 graph with every constant-weight MatMul replaced by DynamicQuantizeLinear -> MatMulInteger -> dequantise.
+// `klen` / `orow` (device, may be null): real tokens per computed sequence and the output row of each -- the padded tensor computes all
+// max_len positions of every non-empty text (compute_padded = 1, the reference's tensor), keys and pooling stay restricted to the real
+// tokens. Four stages per layer, each either the round-3 fused kernel (encoder_int8_fast.h) or the round-2 kernels (encoder_int8.h;
+// SHODH_INT8_STAGES is a bit mask of the fused ones, default all) -- same tensors between the stages either way:
+//   X f32 -> [quantise] XQ -> A: q|k|v + attention -> CTX f32 (+ range) -> [quantise] XQ -> B: attention output + residual + LayerNorm -> X
+//   -> [quantise] XQ -> C: FFN up + GELU -> HQ bytes (range pass, then quantising pass | f32 tensor, then a quantising pass over it)
+//   -> D: FFN down + residual + LayerNorm -> X
+__global__ void init_ranges_kernel(uint32_t *mm, int n_pairs) {
+    for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+template <int EPI>
+static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
+    int n_workers = (cus / a.n_groups) & ~7;           // whole rounds of the 8 XCDs (see the kernel's block map)
+    if (n_workers < 8) n_workers = 8;
+    const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
+    if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
+    SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI>, S8_LDS));
+    hipLaunchKernelGGL((i8_stream_kernel<EPI>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
+static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t *xq, const uint32_t *mm, int32_t *rs, hipStream_t st) {
+    if (e->need_rs) {
+        const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div((size_t)M * 32, 256), 1), 4096);
+        hipLaunchKernelGGL(act_quant_rows_kernel, dim3(blocks), dim3(256), 0, st, x, M, K, mm, xq, e->act_params, rs);
+        SHODH_HIP_TRY(hipGetLastError());
+        return SHODH_OK;
+    }
+    return quantize_known_range(x, (size_t)M * K, xq, e->act_params, mm, st);
+}
 static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, const int32_t *klen, const int32_t *orow, float *d_out, hipStream_t st) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
     const float eps = e->cfg.ln_eps;
@@ -1019,36 +1071,79 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     const float *w = e->w32;
     const int tok_blocks = (ntok * 64 + 255) / 256;
     const int ln_blocks = (ntok * 32 + 255) / 256;
-    // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it (minmax_commit), not from a pass of
-    // its own: three pairs of keys -- X (LayerNorm outputs), CTX (attention output), FF (GELU output) -- reset before their producer runs.
-    uint32_t *mmX = e->qscratch + 4, *mmC = e->qscratch + 6, *mmF = e->qscratch + 8;
-    SHODH_TRY(reset_range(mmX, st));
+    const bool shape_ok = H == S8_NF && I == 4 * S8_NF && heads * 32 == H;
+    const int nkb_max = (max_keys + 31) / 32;
+    const size_t att_fused_lds = (size_t)nkb_max * 8192 + 4 * 4096;
+    const uint32_t stages = shape_ok ? e->int8_stages : 0u;
+    const bool fA = (stages & 1u) && att_fused_lds <= 160 * 1024, fB = stages & 2u, fC = stages & 4u, fD = stages & 8u;
+    if ((!fA && !QKV) || (!fC && !FF)) { set_error("INT8 encoder: this batch needs the round-2 kernels' buffers (keys per text %d); create the embedder with SHODH_INT8_STAGES=0", max_keys); return SHODH_ERR_UNSUPPORTED; }
+    // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it, not from a pass of its own:
+    // one pair of order keys per tensor of the forward, all initialised by one launch.
+    const int n_pairs = 4 * (int)e->cfg.layers + 2;
+    hipLaunchKernelGGL(init_ranges_kernel, dim3(1), dim3(64), 0, st, e->mmr, n_pairs);
+    uint32_t *mmX = e->mmr;                               // range of the current layer input
     hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
                        w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_keys * 32 * 4 * 2;
-    SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
+    if (!fA) SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
+    else SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_i8_kernel, att_fused_lds));
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
         const float *bqkv = e->bqkv + (size_t)li * 3 * H;
-        SHODH_TRY(quantize_known_range(X, (size_t)ntok * H, e->XQ, e->act_params, mmX, st));              // one quantisation feeds q, k and v (same tensor)
-        SHODH_TRY(gemm_i8<EPI8_BIAS>(e->XQ, e->q_qkv[li], 0, 3 * H, e->act_params, bqkv, nullptr, QKV, nullptr, ntok, st));
-        SHODH_TRY(reset_range(mmC, st));
-        hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen, mmC);
+        uint32_t *mmC = e->mmr + 2 * (4 * li + 1), *mmX1 = e->mmr + 2 * (4 * li + 2), *mmF = e->mmr + 2 * (4 * li + 3), *mmXn = e->mmr + 2 * (4 * li + 4);
+        const QWeight &wq = e->q_qkv[li], &wo = e->q_o[li], &wu = e->q_up[li], &wd = e->q_dn[li];
+        // ---- A: q | k | v projections + attention
+        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));              // one quantisation feeds q, k and v (same tensor)
+        if (fA) {
+            const int blocks = ((nseq + 7) / 8) * 8 * heads;
+            hipLaunchKernelGGL(qkv_attn_i8_kernel, dim3(blocks), dim3(256), att_fused_lds, st, (const int8_t *)e->XQ, (const int32_t *)e->rsX, (const uint32_t *)mmX, (const int8_t *)wq.qp,
+                               (const float *)wq.scale, (const int32_t *)wq.rsz, (const int32_t *)wq.zw, bqkv, (const int32_t *)e->d_cu, klen, CTX, mmC, nseq, heads, H, nkb_max * 8192);
+        } else {
+            SHODH_TRY(gemm_i8<EPI8_BIAS>(e->XQ, wq, 0, 3 * H, e->act_params, bqkv, nullptr, QKV, nullptr, ntok, st, nullptr, e->rsX));
+            hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen, mmC);
+        }
         SHODH_HIP_TRY(hipGetLastError());
-        SHODH_TRY(quantize_known_range(CTX, (size_t)ntok * H, e->XQ, e->act_params, mmC, st));
-        SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_o[li], 0, H, e->act_params, w + l.ob, X, e->PRE, nullptr, ntok, st));
-        SHODH_TRY(reset_range(mmX, st));
-        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps, mmX);
-        SHODH_HIP_TRY(hipGetLastError());
-        SHODH_TRY(quantize_known_range(X, (size_t)ntok * H, e->XQ, e->act_params, mmX, st));
-        SHODH_TRY(reset_range(mmF, st));
-        SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, e->q_up[li], 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st, mmF));
-        SHODH_TRY(quantize_known_range(FF, (size_t)ntok * I, e->XQ, e->act_params, mmF, st));
-        SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, e->q_dn[li], 0, H, e->act_params, w + l.db, X, e->PRE, nullptr, ntok, st));
-        SHODH_TRY(reset_range(mmX, st));
-        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps, mmX);
-        SHODH_HIP_TRY(hipGetLastError());
+        // ---- B: attention output + residual + LayerNorm
+        SHODH_TRY(quantize_act(e, CTX, ntok, H, e->XQ, mmC, e->rsX, st));
+        if (fB) {
+            S8Args a{};
+            a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmC; a.Wp = wo.qp; a.wscale = wo.scale; a.rsz = wo.rsz; a.zw = wo.zw; a.bias = w + l.ob;
+            a.resid = X; a.gamma = w + l.ln1g; a.beta = w + l.ln1b; a.eps = eps; a.out_f = X; a.mm_out = mmX1; a.M = ntok; a.N = H; a.n_groups = 1;
+            SHODH_TRY(launch_i8_stream<SEPI_RESID_LN>(a, e->cus, st));
+        } else {
+            SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->XQ, wo, 0, H, e->act_params, w + l.ob, X, e->PRE, nullptr, ntok, st, nullptr, e->rsX));
+            hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln1g, w + l.ln1b, X, ntok, H, eps, mmX1);
+            SHODH_HIP_TRY(hipGetLastError());
+        }
+        // ---- C: FFN up + GELU -> quantised bytes (HQ) and their range (mmF)
+        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX1, e->rsX, st));
+        if (fC) {
+            S8Args a{};
+            a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmX1; a.Wp = wu.qp; a.wscale = wu.scale; a.rsz = wu.rsz; a.zw = wu.zw; a.bias = w + l.ib;
+            a.M = ntok; a.N = I; a.n_groups = I / S8_NF;
+            a.mm_out = mmF;
+            SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));                // pass 1: the range of gelu(up(x)), nothing stored
+            a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw) ? e->rsH : nullptr;
+            if (a.rs_out) SHODH_HIP_TRY(hipMemsetAsync(e->rsH, 0, (size_t)ntok * 4, st));
+            SHODH_TRY(launch_i8_stream<SEPI_GELU_QUANT>(a, e->cus, st));                // pass 2: the same values again, quantised on the way out
+        } else {
+            SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, wu, 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st, mmF, e->rsX));
+            SHODH_TRY(quantize_act(e, FF, ntok, I, e->HQ, mmF, e->rsH, st));
+        }
+        // ---- D: FFN down + residual + LayerNorm
+        if (fD) {
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel, KT_LDS));
+            hipLaunchKernelGGL(i8_ktile_ln_kernel, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)e->rsH, (const uint32_t *)mmF,
+                               (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+            SHODH_HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(params_from_range_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)mmF, e->act_params);
+            SHODH_TRY(gemm_i8<EPI8_BIAS_RESID>(e->HQ, wd, 0, H, e->act_params, w + l.db, X, e->PRE, nullptr, ntok, st, nullptr, e->rsH));
+            hipLaunchKernelGGL((layernorm_kernel<float>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps, mmXn);
+            SHODH_HIP_TRY(hipGetLastError());
+        }
+        mmX = mmXn;
     }
     hipLaunchKernelGGL((pool_kernel<float>), dim3(nseq), dim3(256), 0, st, X, e->d_cu, d_out, H, klen, orow);
     SHODH_HIP_TRY(hipGetLastError());
@@ -1060,9 +1155,46 @@ static int alloc_qweight(QWeight &q, int N, int K) {
     SHODH_HIP_TRY(hipMalloc((void **)&q.q, (size_t)N * K));
     SHODH_HIP_TRY(hipMalloc((void **)&q.scale, (size_t)N * 4));
     SHODH_HIP_TRY(hipMalloc((void **)&q.rowsum, (size_t)N * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&q.qp, (size_t)N * K));
+    SHODH_HIP_TRY(hipMalloc((void **)&q.rsz, (size_t)N * 4));
+    SHODH_HIP_TRY(hipMalloc((void **)&q.zw_buf, (size_t)N * 4));
+    SHODH_HIP_TRY(hipMemset(q.zw_buf, 0, (size_t)N * 4));
     return SHODH_OK;
 }
-static void free_qweight(QWeight &q) { hipFree(q.q); hipFree(q.scale); hipFree(q.rowsum); q = QWeight(); }
+static void free_qweight(QWeight &q) { hipFree(q.q); hipFree(q.qp); hipFree(q.scale); hipFree(q.rowsum); hipFree(q.rsz); hipFree(q.zw_buf); q = QWeight(); }
+
+// rows [row0, row0 + N) of a quantised matrix: the export's own tensor `t` when there is one (bytes, scales, zero points as the file
+// holds them), else the f32 rows `w` quantised here per tensor, symmetric (scale = 2 max|w| / 255, zero point 128 in uint8 terms) --
+// the LABELLED FALLBACK for weights that arrive as floats; it follows the onnxruntime quantiser's symmetric uint8 rule but is this
+// library's choice, not a file's.
+static int install_qweight_rows(QWeight &q, int row0, int N, const QTensor *t, const float *w, uint32_t *scratch_u32) {
+    const int K = q.K;
+    if (t && t->present) {
+        if ((int)t->N != N || (int)t->K != K) { set_error("quantised tensor is %u x %u, expected %d x %d", t->N, t->K, N, K); return SHODH_ERR_INVALID; }
+        std::vector<float> sc(N);
+        std::vector<int32_t> zp(N);
+        bool any = false;
+        for (int n = 0; n < N; ++n) { sc[n] = t->scale[t->n_scale == 1 ? 0 : n]; zp[n] = t->zp[t->n_scale == 1 ? 0 : n]; any |= zp[n] != 0; }
+        SHODH_HIP_TRY(hipMemcpy(q.q + (size_t)row0 * K, t->q.data(), (size_t)N * K, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(q.scale + row0, sc.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(q.zw_buf + row0, zp.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        if (any) q.zw = q.zw_buf;
+        q.from_export = true;
+        hipLaunchKernelGGL(rowsum_s8_kernel, dim3((uint32_t)N), dim3(64), 0, nullptr, q.q + (size_t)row0 * K, K, q.rowsum + row0);
+        SHODH_HIP_TRY(hipGetLastError());
+    } else {
+        SHODH_TRY(quantize_weight_into(w, N, K, q.q + (size_t)row0 * K, q.scale + row0, q.rowsum + row0, scratch_u32, nullptr));
+    }
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    return SHODH_OK;
+}
+static int finish_qweight(QWeight &q) {
+    hipLaunchKernelGGL(rsz_kernel, dim3((uint32_t)ceil_div(q.N, 256)), dim3(256), 0, nullptr, (const int32_t *)q.rowsum, (const int32_t *)q.zw, q.rsz, q.N, q.K);
+    hipLaunchKernelGGL(pack_i8_frag_kernel, dim3((uint32_t)ceil_div((size_t)q.N * q.K, 256)), dim3(256), 0, nullptr, (const int8_t *)q.q, q.qp, q.N, q.K);
+    SHODH_HIP_TRY(hipGetLastError());
+    SHODH_HIP_TRY(hipDeviceSynchronize());
+    return SHODH_OK;
+}
 
 static int finish_weights_int8(shodh_embedder *e) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate;
@@ -1071,34 +1203,40 @@ static int finish_weights_int8(shodh_embedder *e) {
         SHODH_HIP_TRY(hipMalloc((void **)&e->word_q, (size_t)e->cfg.vocab * H));
         SHODH_HIP_TRY(hipMalloc((void **)&e->word_scale, 256 * 4));
     }
-    {   // word table: its row sums are not needed; borrow a scratch row-sum buffer
+    auto exported = [&](int slot) -> const QTensor * { return (slot >= 0 && slot < (int)e->qexp.size() && e->qexp[slot].present) ? &e->qexp[slot] : nullptr; };
+    // tensor slots in blob order (weights_io.h): 0 word table, then per layer 16 slots: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b up.w up.b down.w down.b ln2.g ln2.b
+    if (const QTensor *t = exported(0)) {
+        const float par[2] = {t->scale[0], (float)t->zp[0]};
+        SHODH_HIP_TRY(hipMemcpy(e->word_q, t->q.data(), (size_t)e->cfg.vocab * H, hipMemcpyHostToDevice));
+        SHODH_HIP_TRY(hipMemcpy(e->word_scale, par, 8, hipMemcpyHostToDevice));
+        e->word_from_export = true;
+    } else {   // word table self-quantised: its row sums are not needed; borrow scratch buffers
         int32_t *tmp = nullptr;
         SHODH_HIP_TRY(hipMalloc((void **)&tmp, (size_t)e->cfg.vocab * 4));
         float *sc = nullptr;
         SHODH_HIP_TRY(hipMalloc((void **)&sc, (size_t)e->cfg.vocab * 4));
         int rc = quantize_weight_into(e->w32 + e->o_word, (int)e->cfg.vocab, H, e->word_q, sc, tmp, e->qscratch + 2, nullptr);
-        if (rc == SHODH_OK && hipMemcpy(e->word_scale, sc, 4, hipMemcpyDeviceToDevice) != hipSuccess) rc = SHODH_ERR_DEVICE;
+        const float zero = 0.0f;
+        if (rc == SHODH_OK && (hipMemcpy(e->word_scale, sc, 4, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(e->word_scale + 1, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)) rc = SHODH_ERR_DEVICE;
         hipFree(tmp); hipFree(sc);
         if (rc != SHODH_OK) return rc;
+        e->word_from_export = false;
     }
+    e->need_rs = false;
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
+        const int s0 = 5 + 16 * (int)li;
         SHODH_TRY(alloc_qweight(e->q_qkv[li], 3 * H, H));
         SHODH_TRY(alloc_qweight(e->q_o[li], H, H));
         SHODH_TRY(alloc_qweight(e->q_up[li], I, H));
         SHODH_TRY(alloc_qweight(e->q_dn[li], H, I));
         const size_t qkv_off[3] = {l.qw, l.kw, l.vw};
-        for (int j = 0; j < 3; ++j) {      // q, k and v are separate tensors in the graph: one scale each
-            QWeight &q = e->q_qkv[li];
-            SHODH_TRY(quantize_weight_into(e->w32 + qkv_off[j], H, H, q.q + (size_t)j * H * H, q.scale + j * H, q.rowsum + j * H, e->qscratch + 2, nullptr));
-            SHODH_HIP_TRY(hipDeviceSynchronize());
-        }
-        SHODH_TRY(quantize_weight_into(e->w32 + l.ow, H, H, e->q_o[li].q, e->q_o[li].scale, e->q_o[li].rowsum, e->qscratch + 2, nullptr));
-        SHODH_HIP_TRY(hipDeviceSynchronize());
-        SHODH_TRY(quantize_weight_into(e->w32 + l.iw, I, H, e->q_up[li].q, e->q_up[li].scale, e->q_up[li].rowsum, e->qscratch + 2, nullptr));
-        SHODH_HIP_TRY(hipDeviceSynchronize());
-        SHODH_TRY(quantize_weight_into(e->w32 + l.dw, H, I, e->q_dn[li].q, e->q_dn[li].scale, e->q_dn[li].rowsum, e->qscratch + 2, nullptr));
-        SHODH_HIP_TRY(hipDeviceSynchronize());
+        for (int j = 0; j < 3; ++j)        // q, k and v are separate tensors in the graph: their own scales / zero points
+            SHODH_TRY(install_qweight_rows(e->q_qkv[li], j * H, H, exported(s0 + 2 * j), e->w32 + qkv_off[j], e->qscratch + 2));
+        SHODH_TRY(install_qweight_rows(e->q_o[li], 0, H, exported(s0 + 6), e->w32 + l.ow, e->qscratch + 2));
+        SHODH_TRY(install_qweight_rows(e->q_up[li], 0, I, exported(s0 + 10), e->w32 + l.iw, e->qscratch + 2));
+        SHODH_TRY(install_qweight_rows(e->q_dn[li], 0, H, exported(s0 + 12), e->w32 + l.dw, e->qscratch + 2));
+        for (QWeight *q : {&e->q_qkv[li], &e->q_o[li], &e->q_up[li], &e->q_dn[li]}) { SHODH_TRY(finish_qweight(*q)); e->need_rs |= q->zw != nullptr; }
     }
     return SHODH_OK;
 }
@@ -1156,6 +1294,7 @@ void shodh_embed_cfg_default(shodh_embed_cfg *cfg) {
     cfg->max_pos = 512; cfg->type_vocab = 2;
     cfg->ln_eps = 1e-12f;
     cfg->compute_padded = 0;
+    cfg->weights_path = nullptr;
 }
 
 int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
@@ -1174,6 +1313,10 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     SHODH_HIP_TRY(hipSetDevice(cfg->device));
     shodh_embedder *e = new shodh_embedder();
     e->cfg = *cfg;
+    if (cfg->weights_path) e->weights_path = cfg->weights_path;
+    e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
+    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0xFu;       // speed only: which stages run the fused kernels
+    e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && e->int8_stages == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);
     if (hipMalloc((void **)&e->w32, e->n_params * 4) != hipSuccess || hipMalloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
@@ -1184,12 +1327,17 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         hipMalloc((void **)&e->w2p16, (size_t)cfg->layers * cfg->intermediate * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
-    if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess)) {
+    if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess ||
+                                           hipMalloc((void **)&e->mmr, (size_t)(4 * cfg->layers + 2) * 8) != hipSuccess)) {
         shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
     }
     SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     SHODH_HIP_TRY(hipEventCreate(&e->ev0));
     SHODH_HIP_TRY(hipEventCreate(&e->ev1));
+    if (!e->weights_path.empty()) {      // shodh_embed_cfg.weights_path: MiniLMEmbedder::new loads the model file itself (minilm.rs:652-690)
+        const int rc = shodh_embedder_load_file(e, e->weights_path.c_str());
+        if (rc != SHODH_OK) { shodh_embedder_destroy(e); return rc; }
+    }
     *out = e;
     return SHODH_OK;
 }
@@ -1202,6 +1350,7 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
     for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) for (auto &q : *v) free_qweight(q);
     hipFree(e->word_q); hipFree(e->word_scale); hipFree(e->XQ); hipFree(e->act_params); hipFree(e->qscratch); hipFree(e->d_klen); hipFree(e->d_orow);
+    hipFree(e->HQ); hipFree(e->rsX); hipFree(e->rsH); hipFree(e->mmr);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -1217,7 +1366,68 @@ int shodh_embedder_load_weights(shodh_embedder *e, const float *blob, uint64_t n
     std::lock_guard<std::mutex> g(e->mu);
     SHODH_HIP_TRY(hipSetDevice(e->cfg.device));
     SHODH_HIP_TRY(hipMemcpy(e->w32, blob, n_floats * 4, hipMemcpyHostToDevice));
+    e->qexp.clear(); e->ws.reset();      // a plain f32 blob: INT8 mode quantises it itself (the labelled fallback, install_qweight_rows)
     return finish_weights(e);
+}
+
+// a WeightSet (file or tensor-by-tensor hand-over) -> device: the f32 view of every parameter, plus -- INT8 mode -- the export's own 8-bit tensors
+static int apply_weightset(shodh_embedder *e, WeightSet &ws) {
+    SHODH_TRY(ws.check_complete());
+    if (ws.blob.size() != e->n_params) { set_error("weight set has %llu floats, expected %llu", (unsigned long long)ws.blob.size(), (unsigned long long)e->n_params); return SHODH_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(e->mu);
+    SHODH_HIP_TRY(hipSetDevice(e->cfg.device));
+    SHODH_HIP_TRY(hipMemcpy(e->w32, ws.blob.data(), e->n_params * 4, hipMemcpyHostToDevice));
+    e->qexp.clear();
+    if (e->cfg.dtype == SHODH_DTYPE_INT8) e->qexp = std::move(ws.q);
+    const int rc = finish_weights(e);
+    if (e->cfg.dtype == SHODH_DTYPE_INT8) for (auto &t : e->qexp) { t.q.clear(); t.q.shrink_to_fit(); }      // the bytes live on the device now; keep the (small) scales for shodh_embedder_weight_source
+    return rc;
+}
+
+int shodh_embedder_load_file(shodh_embedder *e, const char *path) {
+    if (!e || !path) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    WeightSet ws;
+    SHODH_TRY(load_weight_file(path, e->cfg, ws));
+    return apply_weightset(e, ws);
+}
+
+static WeightSet *pending(shodh_embedder *e) {
+    if (!e->ws) { e->ws.reset(new WeightSet()); e->ws->init(e->cfg); }
+    return e->ws.get();
+}
+int shodh_embedder_load_tensor(shodh_embedder *e, const char *name, const float *data, uint64_t n, uint32_t transposed) {
+    if (!e || !name || !data) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    WeightSet *ws = pending(e);
+    const int si = ws->find(name);
+    if (si < 0) { set_error("unknown parameter %s (HF BertModel names, e.g. encoder.layer.0.attention.self.query.weight)", name); return SHODH_ERR_INVALID; }
+    return ws->set_f32(si, data, n, transposed != 0);
+}
+int shodh_embedder_load_quantized(shodh_embedder *e, const char *name, const void *q, uint32_t is_signed, uint32_t transposed, const float *scale,
+                                  const void *zero_point, uint32_t n_scale) {
+    if (!e || !name || !q || !scale) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    WeightSet *ws = pending(e);
+    const int si = ws->find(name);
+    if (si < 0) { set_error("unknown parameter %s", name); return SHODH_ERR_INVALID; }
+    return ws->set_quantized(si, q, is_signed != 0, transposed != 0, scale, zero_point, n_scale);
+}
+int shodh_embedder_finish_weights(shodh_embedder *e) {
+    if (!e) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (!e->ws) { set_error("no tensors were handed over (shodh_embedder_load_tensor / shodh_embedder_load_quantized)"); return SHODH_ERR_STATE; }
+    const int rc = apply_weightset(e, *e->ws);
+    if (rc == SHODH_OK) e->ws.reset();
+    return rc;
+}
+int shodh_embedder_weight_source(const shodh_embedder *e, const char *name, uint32_t *source_out) {
+    if (!e || !name || !source_out) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    uint64_t np = 0;
+    const std::vector<TensorSlot> slots = tensor_table(e->cfg, &np);
+    int si = -1;
+    for (size_t i = 0; i < slots.size(); ++i) if (slots[i].name == name) { si = (int)i; break; }
+    if (si < 0) { set_error("unknown parameter %s", name); return SHODH_ERR_INVALID; }
+    if (!e->loaded) *source_out = SHODH_WEIGHT_ABSENT;
+    else if (e->cfg.dtype == SHODH_DTYPE_INT8 && slots[si].quantisable) *source_out = (si < (int)e->qexp.size() && e->qexp[si].present) ? SHODH_WEIGHT_EXPORT_Q8 : SHODH_WEIGHT_SELF_Q8;
+    else *source_out = SHODH_WEIGHT_F32;
+    return SHODH_OK;
 }
 
 // host-only: the parameter layout and the synthetic generator need no device
@@ -1378,27 +1588,43 @@ int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, co
 }
 // One dynamically quantised dense layer on host data: the building block of the INT8 mode, exposed so that its integer
 // arithmetic can be checked bit for bit (tests/test_encoder_int8_gpu.py) and reused by callers that quantise their own layers.
-int shodh_int8_dense(int device, const float *x, const float *w, const float *bias, uint32_t M, uint32_t N, uint32_t K,
-                     float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale) {
-    if (!x || !w || !y || M == 0) { set_error("null argument"); return SHODH_ERR_INVALID; }
+// wq == null: `w` (f32) is quantised here (per tensor, symmetric); else wq is an export's tensor (uint8 / int8 [N][K], scale / zero point per
+// tensor or per output channel).
+static int int8_dense_impl(int device, const float *x, const float *w, const void *wq, uint32_t is_signed, const float *wq_scale, const void *wq_zp, uint32_t n_scale,
+                           const float *bias, uint32_t M, uint32_t N, uint32_t K, float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale) {
+    if (!x || (!w && !wq) || !y || M == 0) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (N % 128 != 0 || K % 128 != 0) { set_error("shodh_int8_dense needs N %% 128 == 0 and K %% 128 == 0 (got N %u, K %u)", N, K); return SHODH_ERR_UNSUPPORTED; }
     SHODH_HIP_TRY(hipSetDevice(device));
     float *d_x = nullptr, *d_w = nullptr, *d_b = nullptr, *d_y = nullptr, *d_par = nullptr;
-    int32_t *d_acc = nullptr; int8_t *d_xq = nullptr; uint32_t *d_scr = nullptr;
+    int32_t *d_acc = nullptr, *d_rs = nullptr; int8_t *d_xq = nullptr; uint32_t *d_scr = nullptr;
     QWeight qw;
+    QTensor qt;
     int rc = SHODH_OK;
     auto fail = [&](const char *what) { set_error("shodh_int8_dense: %s", what); rc = SHODH_ERR_DEVICE; };
     do {
-        if (hipMalloc((void **)&d_x, (size_t)M * K * 4) != hipSuccess || hipMalloc((void **)&d_w, (size_t)N * K * 4) != hipSuccess ||
-            hipMalloc((void **)&d_y, (size_t)M * N * 4) != hipSuccess || hipMalloc((void **)&d_par, 64) != hipSuccess ||
+        if (wq) {      // the same conversion a weight file goes through (WeightSet::set_quantized): signed storage, zero points in the same terms
+            if (!wq_scale || (n_scale != 1 && n_scale != N)) { set_error("shodh_int8_dense_quantized: n_scale must be 1 or N"); rc = SHODH_ERR_INVALID; break; }
+            qt.present = true; qt.N = N; qt.K = K; qt.n_scale = n_scale;
+            qt.q.resize((size_t)N * K); qt.scale.assign(wq_scale, wq_scale + n_scale); qt.zp.resize(n_scale);
+            for (uint32_t c = 0; c < n_scale; ++c) { const int z = wq_zp ? (is_signed ? (int)((const int8_t *)wq_zp)[c] : (int)((const uint8_t *)wq_zp)[c]) : 0; qt.zp[c] = is_signed ? z : z - 128; }
+            for (size_t i = 0; i < (size_t)N * K; ++i) qt.q[i] = is_signed ? ((const int8_t *)wq)[i] : (int8_t)((int)((const uint8_t *)wq)[i] - 128);
+        }
+        if (hipMalloc((void **)&d_x, (size_t)M * K * 4) != hipSuccess || (w && hipMalloc((void **)&d_w, (size_t)N * K * 4) != hipSuccess) ||
+            hipMalloc((void **)&d_y, (size_t)M * N * 4) != hipSuccess || hipMalloc((void **)&d_par, 64) != hipSuccess || hipMalloc((void **)&d_rs, (size_t)M * 4) != hipSuccess ||
             hipMalloc((void **)&d_xq, (size_t)M * K) != hipSuccess || hipMalloc((void **)&d_scr, 64) != hipSuccess ||
             (bias && hipMalloc((void **)&d_b, (size_t)N * 4) != hipSuccess) || (acc_out && hipMalloc((void **)&d_acc, (size_t)M * N * 4) != hipSuccess)) { fail("out of HBM"); rc = SHODH_ERR_OOM; break; }
         if ((rc = alloc_qweight(qw, (int)N, (int)K)) != SHODH_OK) break;
-        if (hipMemcpy(d_x, x, (size_t)M * K * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_w, w, (size_t)N * K * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(d_x, x, (size_t)M * K * 4, hipMemcpyHostToDevice) != hipSuccess || (w && hipMemcpy(d_w, w, (size_t)N * K * 4, hipMemcpyHostToDevice) != hipSuccess) ||
             (bias && hipMemcpy(d_b, bias, (size_t)N * 4, hipMemcpyHostToDevice) != hipSuccess)) { fail("H2D copy"); break; }
-        if ((rc = quantize_weight_into(d_w, (int)N, (int)K, qw.q, qw.scale, qw.rowsum, d_scr + 2, nullptr)) != SHODH_OK) break;
-        if ((rc = dynamic_quantize(d_x, (size_t)M * K, d_xq, d_par, d_scr, nullptr)) != SHODH_OK) break;
-        if ((rc = gemm_i8<EPI8_BIAS>(d_xq, qw, 0, (int)N, d_par, d_b, nullptr, d_y, d_acc, (int)M, nullptr)) != SHODH_OK) break;
+        if ((rc = install_qweight_rows(qw, 0, (int)N, wq ? &qt : nullptr, d_w, d_scr + 2)) != SHODH_OK) break;
+        if ((rc = finish_qweight(qw)) != SHODH_OK) break;
+        if (hipMemsetAsync(d_scr, 0xFF, 4, nullptr) != hipSuccess || hipMemsetAsync(d_scr + 1, 0, 4, nullptr) != hipSuccess) { fail("memset"); break; }
+        {
+            const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div((size_t)M * K, 4096), 1), 2048);
+            hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, nullptr, d_x, (size_t)M * K, d_scr);
+            hipLaunchKernelGGL(act_quant_rows_kernel, dim3((uint32_t)std::min<size_t>(ceil_div((size_t)M * 32, 256), 2048)), dim3(256), 0, nullptr, (const float *)d_x, (int)M, (int)K, (const uint32_t *)d_scr, d_xq, d_par, d_rs);
+        }
+        if ((rc = gemm_i8<EPI8_BIAS>(d_xq, qw, 0, (int)N, d_par, d_b, nullptr, d_y, d_acc, (int)M, nullptr, nullptr, d_rs)) != SHODH_OK) break;
         if (hipDeviceSynchronize() != hipSuccess) { fail("kernel execution"); break; }
         float par[2] = {0, 0}, ws = 0;
         if (hipMemcpy(y, d_y, (size_t)M * N * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(par, d_par, 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1408,9 +1634,19 @@ int shodh_int8_dense(int device, const float *x, const float *w, const float *bi
         if (a_zp) *a_zp = (int32_t)par[1];
         if (w_scale) *w_scale = ws;
     } while (0);
-    hipFree(d_x); hipFree(d_w); hipFree(d_b); hipFree(d_y); hipFree(d_par); hipFree(d_acc); hipFree(d_xq); hipFree(d_scr);
+    hipFree(d_x); hipFree(d_w); hipFree(d_b); hipFree(d_y); hipFree(d_par); hipFree(d_acc); hipFree(d_xq); hipFree(d_scr); hipFree(d_rs);
     free_qweight(qw);
     return rc;
+}
+int shodh_int8_dense(int device, const float *x, const float *w, const float *bias, uint32_t M, uint32_t N, uint32_t K,
+                     float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp, float *w_scale) {
+    if (!w) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    return int8_dense_impl(device, x, w, nullptr, 0, nullptr, nullptr, 0, bias, M, N, K, y, acc_out, a_scale, a_zp, w_scale);
+}
+int shodh_int8_dense_quantized(int device, const float *x, const void *wq, uint32_t is_signed, const float *w_scale, const void *w_zero_point, uint32_t n_scale,
+                               const float *bias, uint32_t M, uint32_t N, uint32_t K, float *y, int32_t *acc_out, float *a_scale, int32_t *a_zp) {
+    if (!wq) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    return int8_dense_impl(device, x, nullptr, wq, is_signed, w_scale, w_zero_point, n_scale, bias, M, N, K, y, acc_out, a_scale, a_zp, nullptr);
 }
 
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2) {

@@ -131,10 +131,12 @@ enum { EPI8_BIAS = 0, EPI8_BIAS_GELU = 1, EPI8_BIAS_RESID = 2 };
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ W, const float *__restrict__ act_params /* {scale, zp} */,
-                                                      const float *__restrict__ wscale /*[N]*/, const int32_t *__restrict__ rowsum /*[N]*/,
+                                                      const float *__restrict__ wscale /*[N]*/, const int32_t *__restrict__ rowsum /*[N]: rowsum_w[n] - K * zw[n]*/,
                                                       const float *__restrict__ bias /*[N] or null*/, const float *__restrict__ resid /*[M][N]*/,
                                                       float *__restrict__ out, int32_t *__restrict__ acc_out /* [M][N] or null */, int M, int N, int K,
-                                                      uint32_t *__restrict__ mm = nullptr /* min / max keys of the output (the next layer's DynamicQuantizeLinear) */) {
+                                                      uint32_t *__restrict__ mm = nullptr /* min / max keys of the output (the next layer's DynamicQuantizeLinear) */,
+                                                      const int32_t *__restrict__ zw = nullptr /*[N] weight zero points in signed-storage terms, or null = all 0*/,
+                                                      const int32_t *__restrict__ rsA = nullptr /*[M] row sums of the stored activations (needed with zw)*/) {
     constexpr int TB = 128 * 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wr * 64 + i * 32 + l31;
         if (m >= M) continue;
+        const int rsa = (zw && rsA) ? rsA[m] : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -214,15 +217,18 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
                 const int nb = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
                 const float4 ws = *reinterpret_cast<const float4 *>(wscale + nb);
                 const int4 rs = *reinterpret_cast<const int4 *>(rowsum + nb);
+                int4 zz = make_int4(0, 0, 0, 0);
+                if (zw) zz = *reinterpret_cast<const int4 *>(zw + nb);
                 const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
                 const int rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const int zwv[4] = {zz.x, zz.y, zz.z, zz.w};
                 float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (bias) { const float4 b4 = *reinterpret_cast<const float4 *>(bias + nb); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
                 float v[4];
                 int ai[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ai[e] = acc[j][i][4 * g + e] + corr * rsv[e];
+                    ai[e] = acc[j][i][4 * g + e] + corr * rsv[e] - zwv[e] * rsa;      // sum (a - a_zp)(w' - z) = sum a'w' + c (rowsum_w - K z) - z rowsum_a
                     float x = (float)ai[e] * (a_scale * wsv[e]) + bv[e];       // MatMulIntegerToFloat: float(acc) * (a_scale * b_scale) + bias
                     if (EPI == EPI8_BIAS_GELU) x = gelu_erf_exact(x);
                     v[e] = x;
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
 }
 
 // one quantised weight matrix on the device
-struct QWeight { int8_t *q = nullptr; float *scale = nullptr; int32_t *rowsum = nullptr; int N = 0, K = 0; };
+// q: row-major [N][K] signed storage; qp: the same bytes fragment-major (pack_i8_frag_kernel); scale[N]; rowsum[N] = sum_k q; zw[N] = zero points
+// in signed-storage terms (null when all zero: the symmetric case); rsz[N] = rowsum - K * zw; from_export: the bytes are a file's own
+struct QWeight { int8_t *q = nullptr, *qp = nullptr; float *scale = nullptr; int32_t *rowsum = nullptr, *rsz = nullptr, *zw = nullptr /* = zw_buf when any entry is non-zero */, *zw_buf = nullptr; int N = 0, K = 0; bool from_export = false; };
 
 // quantises rows [0, N) of `w` (f32 [N][K], device) into dst rows starting at row `row0` (a fused matrix may hold several tensors,
 // each with its own per-tensor scale: the scale array has one entry per output feature)
@@ -294,9 +302,10 @@ static int reset_range(uint32_t *mm, hipStream_t st) {
 
 template <int EPI>
 static int gemm_i8(const int8_t *A, const QWeight &W, int row0, int N, const float *act_params, const float *bias, const float *resid,
-                   float *out, int32_t *acc_out, int M, hipStream_t st, uint32_t *mm = nullptr) {
+                   float *out, int32_t *acc_out, int M, hipStream_t st, uint32_t *mm = nullptr, const int32_t *rsA = nullptr) {
     dim3 grid(N / 128, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_i8_kernel<EPI>), grid, dim3(256), 0, st, A, W.q + (size_t)row0 * W.K, act_params, W.scale + row0, W.rowsum + row0, bias, resid, out, acc_out, M, N, W.K, mm);
+    hipLaunchKernelGGL((gemm_i8_kernel<EPI>), grid, dim3(256), 0, st, A, W.q + (size_t)row0 * W.K, act_params, W.scale + row0, W.rsz + row0, bias, resid, out, acc_out, M, N, W.K, mm,
+                       W.zw ? W.zw + row0 : (const int32_t *)nullptr, rsA);
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }

@@ -1,0 +1,722 @@
+// encoder_int8_fast.h -- the INT8 encoder layer without f32 round trips (round 3; included by encoder.hip only).
+//
+// Same function as encoder_int8.h's path (the dynamic-quantisation export's graph, minilm.rs:212-220, :588-593): every constant-weight
+// MatMul is DynamicQuantizeLinear(whole tensor) -> MatMulInteger -> float(acc) * (a_scale * w_scale[n]) + bias, everything else fp32.
+// What changed is where the tensors live. Round 2 wrote QKV (4.8 GB at 4096 padded texts), the GELU output (6.4 GB) and two pre-norm
+// sums (1.6 GB each) to HBM in f32 and read them back, per layer; here
+//   qkv_attn_i8_kernel     one workgroup per (sequence, head): Q/K/V projections on v_mfma_i32_32x32x32_i8 straight into the MFMA
+//                          operand layouts of the attention (K and V^T fragments through LDS, Q and P in registers), softmax in f32,
+//                          both attention products as three f16 MFMAs on (hi, lo) splits of the f32 operands (error <= 2^-21 relative,
+//                          see f16_split). K and V are projected for the real keys only -- masked keys are never read.
+//   i8_stream_kernel       weight-stationary int8 GEMM for K = 384 (attention output, FFN up): 12 waves hold 384 output features as
+//                          resident fragments, the quantised activations stream through LDS by LDS-DMA (gemm_k384_stream_kernel's
+//                          structure). Epilogues: + residual + LayerNorm (whole rows in the workgroup) | GELU -> range only |
+//                          GELU -> quantised bytes (the range is known from the first pass; the f32 intermediate never exists).
+//   i8_ktile_ln_kernel     tiled int8 GEMM for K = 1536 (FFN down) over all 384 features + residual + LayerNorm.
+// Weight zero points are general (per tensor or per output channel, any value): with a' = a - 128, w' the signed storage and
+// z[n] its zero point, sum_k (a - a_zp)(w' - z[n]) = sum a'w' + c * (rowsum_w[n] - K z[n]) - z[n] * rowsum_a[m],  c = 128 - a_zp.
+#pragma once
+#include "common.h"
+#include "glds.h"
+#include "encoder_int8.h"
+
+namespace shodh {
+
+typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+typedef int i32x4q __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4qq __attribute__((ext_vector_type(4)));
+typedef int i32x16l __attribute__((ext_vector_type(16)));
+// LDS hand-over between the waves of a workgroup WITHOUT touching vmcnt: __syncthreads() would also wait for the LDS-DMA in flight
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7 (+ ~1e-7 from v_rcp / v_exp), so
+// |gelu error| <= 1.3e-7 |x| -- against a quantisation step of (max - min) / 255 of the tensor it feeds. Exact erff costs ~40 VALU
+// operations per value, this ~16; the INT8 FFN evaluates 1.6e9 of them per layer and pass.
+__device__ __forceinline__ float gelu_i8(float x) {
+    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = 1.0f - p * t * e;
+    return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
+}
+
+// W_q[N][K] signed bytes -> fragment-major [N/32][K/32][64 lanes][16]: lane = ((k % 32) / 16) * 32 + n % 32 holds bytes k % 16
+__global__ void pack_i8_frag_kernel(const int8_t *__restrict__ W, int8_t *__restrict__ out, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const size_t frag = ((size_t)(n / 32) * (K / 32) + k / 32) * 64 + ((k % 32) / 16) * 32 + n % 32;
+    out[frag * 16 + k % 16] = W[i];
+}
+// rsz[n] = rowsum_w[n] - K * z[n]
+__global__ void rsz_kernel(const int32_t *__restrict__ rowsum, const int32_t *__restrict__ zw /* or null */, int32_t *__restrict__ rsz, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) rsz[n] = rowsum[n] - (zw ? K * zw[n] : 0);
+}
+
+// DynamicQuantizeLinear bytes + per-row sums of the stored (signed) values: half a wave per row
+__global__ __launch_bounds__(256) void act_quant_rows_kernel(const float *__restrict__ x, int M, int K, const uint32_t *__restrict__ mm,
+                                                             int8_t *__restrict__ out, float *__restrict__ params_out, int32_t *__restrict__ rowsum) {
+    const ActQ p = act_params(mm);
+    const float zpf = (float)p.zp;
+    const int l = threadIdx.x & 31;
+    const int k4 = K >> 2;
+    for (int row = (blockIdx.x * 256 + threadIdx.x) >> 5; row < M; row += (gridDim.x * 256) >> 5) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)row * K);
+        uint32_t *o4 = reinterpret_cast<uint32_t *>(out + (size_t)row * K);
+        int s = 0;
+        for (int g = l; g < k4; g += 32) {
+            const float4 v = x4[g];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float q = __builtin_rintf(e[j] / p.scale) + zpf;
+                q = fminf(fmaxf(q, 0.0f), 255.0f);
+                const int qi = (int)q - 128;
+                s += qi;
+                pk |= (uint32_t)(qi & 0xFF) << (8 * j);
+            }
+            o4[g] = pk;
+        }
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (l == 0) rowsum[row] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { params_out[0] = p.scale; params_out[1] = zpf; }
+}
+
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): |x - (hi + lo)| <= 2^-22 |x| (+ 2^-25 absolute where lo is subnormal), so
+// a.b ~ ah.bh + ah.bl + al.bh drops only al.bl: relative error <= 2^-21 per product, f32 accumulation in the MFMA as for any f32 dot.
+__device__ __forceinline__ void f16_split8(const float *v, f16x8q &h, f16x8q &l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const _Float16 a = (_Float16)v[j]; h[j] = a; l[j] = (_Float16)(v[j] - (float)a); }
+}
+
+// ---- fused Q/K/V projection + attention --------------------------------------------------------------------------------------
+// grid: ceil(nseq / 8) * 8 * heads workgroups of 4 waves; workgroup id -> (XCD, sequence, head) so that the `heads` workgroups of a
+// sequence run on ONE XCD (consecutive ids go round the 8 XCDs): its quantised rows come from HBM once and then from that L2.
+// Layouts (f(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi is the row that register r of half-wave hi holds in a 32x32 MFMA result):
+//   Q  = Wq . X^T   A = weight fragments (rows = features), B = token fragments  -> lane = query, registers = features f(r, hi)
+//                   == the B operand of S^T = K . Q^T with k-slot (hi, j) of step s bound to feature f(8 s + j, hi)
+//   K  likewise (lane = key): the same registers are the A operand of S^T under the same k-slot rule -> LDS, fragment-major
+//   V^T = X . Wv^T  A = token fragments, B = weight fragments -> lane = feature d, registers = keys f(r, hi) of the block
+//                   == the A operand of O^T = V^T . P^T with k-slot (hi, j) of step s bound to key f(8 s + j, hi), which is the
+//                   order in which S^T's result hands the keys (and so P) to a lane: P never leaves its registers.
+// LDS: K / V fragments [key block][K | V][step 0..1][hi | lo part][64 lanes][16 B] = 8 KiB per 32 keys, then 4 KiB of output
+// scratch per wave.
+__global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__restrict__ XQ, const int32_t *__restrict__ rsA /* row sums of XQ, or null */,
+                                                             const uint32_t *__restrict__ mmA /* range keys of the quantised tensor */,
+                                                             const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const float *__restrict__ wscale,
+                                                             const int32_t *__restrict__ rsz, const int32_t *__restrict__ zw /* or null */, const float *__restrict__ bias,
+                                                             const int32_t *__restrict__ cu, const int32_t *__restrict__ klen /* or null */, float *__restrict__ ctx,
+                                                             uint32_t *__restrict__ mm_out, int nseq, int heads, int H, int kv_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int seq = (rr / heads) * 8 + xcd, head = rr % heads;
+    if (seq >= nseq) return;                              // the whole workgroup
+    const int t0 = cu[seq], P = cu[seq + 1] - t0;
+    const int S = klen ? klen[seq] : P;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkb = (S + 31) >> 5, nqb = (P + 31) >> 5;
+    const ActQ ap = act_params(mmA);
+    const float a_scale = ap.scale;
+    const int corr = 128 - ap.zp;
+    const i32x4q *wp4 = reinterpret_cast<const i32x4q *>(Wp);
+    const int nblk_h = H >> 5;                            // 32-feature blocks per q / k / v section (12)
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+
+    // ---- phase 1: K and V^T fragments of the real keys -> LDS
+    for (int task = wave; task < 2 * nkb; task += 4) {
+        const int kb = task >> 1, isv = task & 1;
+        int tok = kb * 32 + l31; if (tok >= P) tok = P - 1;
+        const int8_t *xr = XQ + (size_t)(t0 + tok) * 384 + hi * 16;
+        const i32x4q *wf = wp4 + ((size_t)((isv ? 2 : 1) * nblk_h + head) * 12) * 64 + lane;
+        i32x16l acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            const i32x4q xf = *reinterpret_cast<const i32x4q *>(xr + ks * 32);
+            const i32x4q w = wf[ks * 64];
+            acc = isv ? __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(w, xf, acc, 0, 0, 0);
+        }
+        float v[16];
+        if (!isv) {                                       // lane = key `tok`, registers = features
+            const int rsa = (rsA && zw) ? rsA[t0 + tok] : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = H + head * 32 + 8 * g + 4 * hi;
+                const f32x4q ws = *reinterpret_cast<const f32x4q *>(wscale + nb), b4 = *reinterpret_cast<const f32x4q *>(bias + nb);
+                const i32x4q rz = *reinterpret_cast<const i32x4q *>(rsz + nb);
+                i32x4q z4 = {0, 0, 0, 0};
+                if (zw) z4 = *reinterpret_cast<const i32x4q *>(zw + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = (float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e];
+            }
+        } else {                                          // lane = feature d, registers = keys f(r, hi) of the block
+            const int n = 2 * H + head * 32 + l31;
+            const float ws1 = wscale[n], b1 = bias[n];
+            const int rz1 = rsz[n], z1 = zw ? zw[n] : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int tk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; if (tk >= P) tk = P - 1;
+                const int rsa = (rsA && zw) ? rsA[t0 + tk] : 0;
+                v[r] = (float)(acc[r] + corr * rz1 - z1 * rsa) * (a_scale * ws1) + b1;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8q fh, fl;
+            f16_split8(v + 8 * s2, fh, fl);
+            unsigned char *dst = smem + (size_t)((kb * 2 + isv) * 2 + s2) * 2048 + lane * 16;
+            *reinterpret_cast<f16x8q *>(dst) = fh;
+            *reinterpret_cast<f16x8q *>(dst + 1024) = fl;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: per 32-query block: Q projection, online softmax over the key blocks, O^T, row-wise stores
+    const float sc = 0.17677669529663688110f * 1.44269504088896340736f;      // 1/sqrt(32) * log2(e): softmax in base 2
+    unsigned char *scr = smem + kv_bytes + wave * 4096;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int q = qb * 32 + l31;
+        const int qc = q < P ? q : P - 1;
+        const int8_t *xr = XQ + (size_t)(t0 + qc) * 384 + hi * 16;
+        const i32x4q *wf = wp4 + ((size_t)head * 12) * 64 + lane;
+        i32x16l acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            const i32x4q xf = *reinterpret_cast<const i32x4q *>(xr + ks * 32);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks * 64], xf, acc, 0, 0, 0);
+        }
+        f16x8q bqh[2], bql[2];
+        {
+            float v[16];
+            const int rsa = (rsA && zw) ? rsA[t0 + qc] : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = head * 32 + 8 * g + 4 * hi;
+                const f32x4q ws = *reinterpret_cast<const f32x4q *>(wscale + nb), b4 = *reinterpret_cast<const f32x4q *>(bias + nb);
+                const i32x4q rz = *reinterpret_cast<const i32x4q *>(rsz + nb);
+                i32x4q z4 = {0, 0, 0, 0};
+                if (zw) z4 = *reinterpret_cast<const i32x4q *>(zw + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = ((float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e]) * sc;
+            }
+            f16_split8(v, bqh[0], bql[0]);
+            f16_split8(v + 8, bqh[1], bql[1]);
+        }
+        f32x16q o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        float mx = -3.0e38f, l = 0.0f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16q st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+            const unsigned char *kf = smem + (size_t)(kb * 2) * 4096 + lane * 16;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f16x8q kh = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048), kl = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048 + 1024);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bqh[s2], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bql[s2], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, bqh[s2], st, 0, 0, 0);
+            }
+            float bm = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                st[r] = key < S ? st[r] : -3.0e38f;
+                bm = fmaxf(bm, st[r]);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = fmaxf(mx, bm);
+            const float cf = __builtin_amdgcn_exp2f(mx - mn);
+            float ps = 0.0f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(st[r] - mn); ps += pv[r]; }      // masked keys: exp2(-3e38 - mn) = 0
+            ps += __shfl_xor(ps, 32);
+            l = l * cf + ps;
+            mx = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= cf;
+            const unsigned char *vf = smem + (size_t)(kb * 2 + 1) * 4096 + lane * 16;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8q ph, pl;
+                f16_split8(pv + 8 * s2, ph, pl);
+                const f16x8q vh = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048), vl = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048 + 1024);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+            }
+        }
+        // O^T: this lane = query q, register r = feature f(r, hi). Through the wave's scratch (16-byte chunks XOR-swizzled by
+        // token & 7) so that a token's 32 features leave as one 128-byte row.
+        const float invl = 1.0f / l;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4q ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ov[e] = o[4 * g + e] * invl;
+                if (q < P) { const uint32_t kk = order_key(ov[e]); klo = min(klo, kk); khi = max(khi, kk); }
+            }
+            *reinterpret_cast<f32x4q *>(scr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = ov;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+            const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+            if (qb * 32 + tl < P) *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + qb * 32 + tl) * H + head * 32 + ch * 4) = v4;
+        }
+    }
+    if (mm_out) {
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
+        if (lane == 0) {
+            if (klo < __atomic_load_n(mm_out, __ATOMIC_RELAXED)) atomicMin(mm_out, klo);
+            if (khi > __atomic_load_n(mm_out + 1, __ATOMIC_RELAXED)) atomicMax(mm_out + 1, khi);
+        }
+    }
+}
+
+// ---- weight-stationary int8 GEMM, K = 384, 384 output features per workgroup ---------------------------------------------------
+constexpr int S8_TR = 64, S8_PITCH = 384, S8_TILE = S8_TR * S8_PITCH, S8_NBUF = 3, S8_KS = 12, S8_NT = 768, S8_NPC = 6, S8_NF = 384;
+constexpr int S8_CONST = S8_NBUF * S8_TILE;               // wscale | rsz | bias | zw | gamma | beta: 6 x 384 x 4 B
+constexpr int S8_RED = S8_CONST + 6 * S8_NF * 4;          // [2][12 waves][64 tokens] f32
+constexpr int S8_SCR = S8_RED + 2 * 12 * 64 * 4;          // 12 x 4 KiB wave scratch (LayerNorm epilogue) / 2 x 24 KiB output tiles (quantising epilogue)
+constexpr int S8_LDS = S8_SCR + 12 * 4096;
+enum { SEPI_RESID_LN = 0, SEPI_GELU_RANGE = 1, SEPI_GELU_QUANT = 2 };
+
+struct S8Args {
+    const int8_t *XQ; const int32_t *rsA; const uint32_t *mmA;        // quantised activations [M + pad][384], their row sums (or null), their range keys
+    const int8_t *Wp; const float *wscale; const int32_t *rsz; const int32_t *zw; const float *bias;      // fragment-major weight + per-feature constants [N]
+    const float *resid; const float *gamma; const float *beta; float eps; float *out_f;                    // SEPI_RESID_LN: out_f may alias resid (in place)
+    const uint32_t *mmO; int8_t *out_q; int32_t *rs_out;              // SEPI_GELU_QUANT: the output's range (from the RANGE pass), bytes [M][N], row sums (atomicAdd; or null)
+    uint32_t *mm_out;                                                  // SEPI_RESID_LN / SEPI_GELU_RANGE: range keys of the output
+    int M, N, n_groups;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
+    constexpr int KS = S8_KS, NS = 2 * KS, D = 5, RING = 6, PF = S8_NBUF - 1, NPC = S8_NPC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.M;
+    // XCD-aware block -> (feature group, worker): the n_groups workgroups streaming the same token tiles share an XCD (see gemm_k384_stream_kernel)
+    const int n_workers = gridDim.x / a.n_groups;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int grp = rr % a.n_groups, worker = (rr / a.n_groups) * 8 + xcd;
+    const int nbase = grp * S8_NF;                        // this workgroup's first feature
+    const int nblk = grp * 12 + wave;                     // this wave's 32-feature block
+
+    float *c_ws = reinterpret_cast<float *>(smem + S8_CONST);
+    int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + S8_NF);
+    float *c_b = reinterpret_cast<float *>(c_rz + S8_NF);
+    int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + S8_NF);
+    float *c_g = reinterpret_cast<float *>(c_zw + S8_NF), *c_be = c_g + S8_NF;
+    for (int i = tid; i < S8_NF; i += S8_NT) {
+        c_ws[i] = a.wscale[nbase + i]; c_rz[i] = a.rsz[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
+        if (EPI == SEPI_RESID_LN) { c_g[i] = a.gamma[i]; c_be[i] = a.beta[i]; }
+    }
+    const ActQ ap = act_params(a.mmA);
+    const float a_scale = ap.scale;
+    const int corr = 128 - ap.zp;
+    float o_scale = 1.0f, o_zpf = 0.0f;
+    if (EPI == SEPI_GELU_QUANT) { const ActQ op = act_params(a.mmO); o_scale = op.scale; o_zpf = (float)op.zp; }
+
+    uint32_t srcoff[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int p = i * 256 + (tid & 255);
+        const int row = p / 24, slot = p % 24;
+        const int c = (slot & ~7) | ((slot & 7) ^ (row & 7));
+        srcoff[i] = (uint32_t)(row * S8_PITCH + c * 16);
+    }
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(a.XQ);
+    const uint32_t wave_lds = smem_lds + (uint32_t)(wave & 3) * 1024u;
+    const int n_tiles = (M + S8_TR - 1) / S8_TR;         // the last tile may read up to 63 rows past M (the buffer is padded); they are not stored
+    int t = worker;
+#pragma unroll
+    for (int b = 0; b < PF; ++b) {
+        const int tt = t + b * n_workers < n_tiles ? t + b * n_workers : (t < n_tiles ? t : 0);
+        const unsigned char *src = uniform_ptr(xb + (size_t)tt * S8_TILE);
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * S8_TILE + i * 4096);
+        }
+    }
+    // resident weight fragments (A operand: row = feature l31 of the block, bytes 32 ks + 16 hi ..)
+    i32x4q bw[KS];
+    {
+        const i32x4q *wp = reinterpret_cast<const i32x4q *>(a.Wp) + (size_t)nblk * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[ks] = wp[ks * 64];
+    }
+    int aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[j] = l31 * S8_PITCH + (((2 * j + hi) ^ (l31 & 7)) << 4);
+
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+    float *red = reinterpret_cast<float *>(smem + S8_RED);
+    unsigned char *scr = smem + S8_SCR + wave * 4096;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) for hipcc's own loads (weights): not re-waited inside the loop
+    lds_barrier();
+    const i32x16l zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    i32x16l acc0 = zero16, acc1 = zero16;
+    uint32_t cur = 0;
+    int it = 0, t_prev = 0;
+    auto store_out_tile = [&](int tile, int buf) {        // SEPI_GELU_QUANT: rows of the finished output tile -> HBM, 16 B per lane, 384 B per token
+        const unsigned char *ot = smem + S8_SCR + buf * S8_TILE;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int p = pass * S8_NT + tid;
+            const int row = p / 24, c = p % 24;
+            const u32x4qq v4 = *reinterpret_cast<const u32x4qq *>(ot + row * S8_PITCH + (((c & ~7) | ((c & 7) ^ (row & 7))) << 4));
+            const int m = tile * S8_TR + row;
+            if (m < M) *reinterpret_cast<u32x4qq *>(a.out_q + (size_t)m * a.N + nbase + c * 16) = v4;
+        }
+    };
+    for (; t < n_tiles; t += n_workers, ++it) {
+        if (EPI == SEPI_GELU_QUANT) { if (it > 0) store_out_tile(t_prev, (it - 1) & 1); }
+        const unsigned char *buf = smem + cur * S8_TILE;
+        const uint32_t pfb = cur + PF >= S8_NBUF ? cur + PF - S8_NBUF : cur + PF;
+        const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
+        const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * S8_TILE);
+        const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * S8_TILE));
+        i32x4q ring[RING];
+        auto rd = [&](int st) {
+            const int rb = st / KS, ks = st % KS;
+            ring[st % RING] = *reinterpret_cast<const i32x4q *>(buf + rb * 32 * S8_PITCH + aoff[ks & 3] + (ks >> 2) * 128);
+        };
+#pragma unroll
+        for (int st = 0; st < D; ++st) rd(st);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            rd(st + D);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bw[st], ring[st % RING], st == 0 ? zero16 : acc0, 0, 0, 0);
+            if ((st & 3) == 2 && (st >> 2) < NPC) { if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int st = KS; st < NS; ++st) {
+            if (st + D < NS) rd(st + D);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bw[st - KS], ring[st % RING], st == KS ? zero16 : acc1, 0, 0, 0);
+            if ((st & 3) == 2 && (st >> 2) < NPC) { if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next tile must have landed before the barrier: counted wait before this tile's own loads / stores are issued (see
+        // gemm_k384_stream_kernel: everything younger than that tile's DMA is this tile's NPC pieces plus older, finished work)
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+
+        // ---- epilogue: lane = token (blk * 32 + l31 of the tile), registers = features 32 wave + f(r, hi); one 32-token block at a time
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const i32x16l &acc = blk ? acc1 : acc0;
+            const int m = t * S8_TR + blk * 32 + l31;
+            const int mc = m < M ? m : M - 1;
+            const bool valid = m < M;
+            const int rsa = (a.rsA && a.zw) ? a.rsA[mc] : 0;
+            if (EPI == SEPI_GELU_RANGE || EPI == SEPI_GELU_QUANT) {
+                unsigned char *ot = smem + S8_SCR + (it & 1) * S8_TILE + (blk * 32 + l31) * S8_PITCH;
+                int ssum = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wave * 32 + 8 * g + 4 * hi;
+                    const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+                    const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = (float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e];
+                        const float v = gelu_i8(x);
+                        if (EPI == SEPI_GELU_RANGE) {
+                            if (valid) { const uint32_t kk = order_key(v); klo = min(klo, kk); khi = max(khi, kk); }
+                        } else {
+                            float q = __builtin_rintf(v / o_scale) + o_zpf;
+                            q = fminf(fmaxf(q, 0.0f), 255.0f);
+                            const int qi = (int)q - 128;
+                            ssum += qi;
+                            pk |= (uint32_t)(qi & 0xFF) << (8 * e);
+                        }
+                    }
+                    if (EPI == SEPI_GELU_QUANT) {
+                        const int c = nl >> 4;
+                        *reinterpret_cast<uint32_t *>(ot + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;      // (32 + l31) & 7 == l31 & 7
+                    }
+                }
+                if (EPI == SEPI_GELU_QUANT && a.rs_out) {
+                    ssum += __shfl_xor(ssum, 32);
+                    if (hi == 0 && valid) atomicAdd(a.rs_out + m, ssum);
+                }
+            } else {
+                // + residual, then LayerNorm over the 384 features of a token: 16 here, 16 in the other half-wave, the rest in the other 11 waves
+                float v[16];
+                float s = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wave * 32 + 8 * g + 4 * hi;
+                    const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+                    const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+                    const f32x4q r4 = *reinterpret_cast<const f32x4q *>(a.resid + (size_t)mc * S8_NF + nl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[4 * g + e] = (float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e] + r4[e];
+                        s += v[4 * g + e];
+                    }
+                }
+                float *rs_ = red + blk * 768, *rq_ = red + 384 + blk * 768;      // [12 waves][32 tokens] sums | squares of this block
+                s += __shfl_xor(s, 32);
+                if (hi == 0) rs_[wave * 32 + l31] = s;
+                lds_barrier();
+                float mean = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 12; ++w) mean += rs_[w * 32 + l31];
+                mean *= (1.0f / (float)S8_NF);
+                float q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v[r] -= mean; q += v[r] * v[r]; }
+                q += __shfl_xor(q, 32);
+                if (hi == 0) rq_[wave * 32 + l31] = q;
+                lds_barrier();
+                float var = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 12; ++w) var += rq_[w * 32 + l31];
+                const float inv = 1.0f / sqrtf(var * (1.0f / (float)S8_NF) + a.eps);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wave * 32 + 8 * g + 4 * hi;
+                    const f32x4q g4 = *reinterpret_cast<const f32x4q *>(c_g + nl), be4 = *reinterpret_cast<const f32x4q *>(c_be + nl);
+                    f32x4q ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ov[e] = v[4 * g + e] * inv * g4[e] + be4[e];
+                        if (valid) { const uint32_t kk = order_key(ov[e]); klo = min(klo, kk); khi = max(khi, kk); }
+                    }
+                    *reinterpret_cast<f32x4q *>(scr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = ov;
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+                    const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                    const int mt = t * S8_TR + blk * 32 + tl;
+                    if (mt < M) *reinterpret_cast<f32x4q *>(a.out_f + (size_t)mt * S8_NF + wave * 32 + ch * 4) = v4;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == S8_NBUF ? 0 : cur + 1;
+        t_prev = t;
+    }
+    if (EPI == SEPI_GELU_QUANT) { if (it > 0) store_out_tile(t_prev, (it - 1) & 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (EPI != SEPI_GELU_QUANT && a.mm_out) {
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
+        if (lane == 0) {
+            if (klo < __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMin(a.mm_out, klo);
+            if (khi > __atomic_load_n(a.mm_out + 1, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 1, khi);
+        }
+    }
+}
+
+// ---- tiled int8 GEMM over all 384 output features for K = 1536 (FFN down) + residual + LayerNorm ---------------------------------
+// 128 tokens x 384 features per workgroup, 8 waves = 2 token halves x 4 feature quarters (2 x 3 MFMA blocks each), K tiles of 128 bytes,
+// register-staged double-buffered LDS (rows of 128 B, 16-B chunks XOR-swizzled by row & 7). The weights are re-read per workgroup from
+// L2 (576 KiB); the kernel is bound by its three HBM streams (quantised activations, residual, output: 4.6 KB per token).
+constexpr int KT_TM = 128, KT_NF = 384, KT_KB = 128, KT_STAGE = (KT_TM + KT_NF) * KT_KB;      // 64 KiB per stage
+constexpr int KT_CONST = 2 * KT_STAGE, KT_LDS = KT_CONST + 6 * KT_NF * 4;
+__global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__restrict__ A /* [M][K] signed storage */, const int32_t *__restrict__ rsA, const uint32_t *__restrict__ mmA,
+                                                             const int8_t *__restrict__ W /* [384][K] row-major */, const float *__restrict__ wscale, const int32_t *__restrict__ rsz,
+                                                             const int32_t *__restrict__ zw, const float *__restrict__ bias, const float *resid, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps, float *out_f /* may alias resid */, uint32_t *__restrict__ mm_out, int M, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int m0 = blockIdx.x * KT_TM;
+    float *c_ws = reinterpret_cast<float *>(smem + KT_CONST);
+    int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + KT_NF);
+    float *c_b = reinterpret_cast<float *>(c_rz + KT_NF);
+    int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + KT_NF);
+    float *c_g = reinterpret_cast<float *>(c_zw + KT_NF), *c_be = c_g + KT_NF;
+    for (int i = tid; i < KT_NF; i += 512) { c_ws[i] = wscale[i]; c_rz[i] = rsz[i]; c_b[i] = bias[i]; c_zw[i] = zw ? zw[i] : 0; c_g[i] = gamma[i]; c_be[i] = beta[i]; }
+    const ActQ ap = act_params(mmA);
+    const float a_scale = ap.scale;
+    const int corr = 128 - ap.zp;
+    // staging: A tile 128 rows x 8 chunks = 1024 chunks (2 per thread), W tile 384 x 8 = 3072 (6 per thread)
+    u32x4qq pa[2], pw[6];
+    const int8_t *ga[2], *gw[6];
+    int la[2], lw[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sidx = i * 512 + tid, row = sidx >> 3, c = sidx & 7;
+        int ra = m0 + row; if (ra >= M) ra = M - 1;
+        ga[i] = A + (size_t)ra * K + c * 16;
+        la[i] = row * KT_KB + ((c ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int sidx = i * 512 + tid, row = sidx >> 3, c = sidx & 7;
+        gw[i] = W + (size_t)row * K + c * 16;
+        lw[i] = KT_TM * KT_KB + row * KT_KB + ((c ^ (row & 7)) << 4);
+    }
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pa[i] = *reinterpret_cast<const u32x4qq *>(ga[i] + kt * KT_KB);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pw[i] = *reinterpret_cast<const u32x4qq *>(gw[i] + kt * KT_KB);
+    };
+    auto stage = [&](int buf) {
+        unsigned char *base = smem + buf * KT_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4qq *>(base + la[i]) = pa[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4qq *>(base + lw[i]) = pw[i];
+    };
+    i32x16l acc[3][2];      // [feature block j][token block i]
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
+    int fo_a[2], fo_w[3];
+    const int sw = l31 & 7;          // every fragment row of this lane has row & 7 == l31 & 7 (block bases are multiples of 32)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fo_a[i] = (wr * 64 + i * 32 + l31) * KT_KB;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fo_w[j] = KT_TM * KT_KB + (wc * 96 + j * 32 + l31) * KT_KB;
+    const int nkt = K / KT_KB;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        const unsigned char *tb = smem + cur * KT_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            i32x4q fa[2], fw[3];
+            const int co = ((ks * 2 + hi) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const i32x4q *>(tb + fo_a[i] + co);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fw[j] = *reinterpret_cast<const i32x4q *>(tb + fo_w[j] + co);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stage(cur ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue (the stage buffers are free now: red = [2][4 quarters][128 tokens] f32 at 0, wave scratch 4 KiB each behind it)
+    float *red = reinterpret_cast<float *>(smem);
+    unsigned char *scr = smem + 4096 + wave * 4096;
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+    float v[2][3][16];
+    float mean[2], inv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wr * 64 + i * 32 + l31;
+        const int mc = m < M ? m : M - 1;
+        const int rsa = (rsA && zw) ? rsA[mc] : 0;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wc * 96 + j * 32 + 8 * g + 4 * hi;
+                const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+                const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+                const f32x4q r4 = *reinterpret_cast<const f32x4q *>(resid + (size_t)mc * KT_NF + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = (float)(acc[j][i][4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e] + r4[e];
+                    v[i][j][4 * g + e] = x; s += x;
+                }
+            }
+        s += __shfl_xor(s, 32);
+        if (hi == 0) red[wc * 128 + wr * 64 + i * 32 + l31] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tl = wr * 64 + i * 32 + l31;
+        mean[i] = (red[tl] + red[128 + tl] + red[256 + tl] + red[384 + tl]) * (1.0f / (float)KT_NF);
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[i][j][r] -= mean[i]; q += v[i][j][r] * v[i][j][r]; }
+        q += __shfl_xor(q, 32);
+        if (hi == 0) red[512 + wc * 128 + tl] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tl = wr * 64 + i * 32 + l31;
+        const float var = (red[512 + tl] + red[512 + 128 + tl] + red[512 + 256 + tl] + red[512 + 384 + tl]) * (1.0f / (float)KT_NF);
+        inv[i] = 1.0f / sqrtf(var + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool valid = m0 + wr * 64 + i * 32 + l31 < M;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wc * 96 + j * 32 + 8 * g + 4 * hi;
+                const f32x4q g4 = *reinterpret_cast<const f32x4q *>(c_g + nl), be4 = *reinterpret_cast<const f32x4q *>(c_be + nl);
+                f32x4q ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ov[e] = v[i][j][4 * g + e] * inv[i] * g4[e] + be4[e];
+                    if (valid) { const uint32_t kk = order_key(ov[e]); klo = min(klo, kk); khi = max(khi, kk); }
+                }
+                *reinterpret_cast<f32x4q *>(scr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = ov;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+                const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                const int mt = m0 + wr * 64 + i * 32 + tl;
+                if (mt < M) *reinterpret_cast<f32x4q *>(out_f + (size_t)mt * KT_NF + wc * 96 + j * 32 + ch * 4) = v4;
+            }
+        }
+    }
+    if (mm_out) {
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
+        if (lane == 0) {
+            if (klo < __atomic_load_n(mm_out, __ATOMIC_RELAXED)) atomicMin(mm_out, klo);
+            if (khi > __atomic_load_n(mm_out + 1, __ATOMIC_RELAXED)) atomicMax(mm_out + 1, khi);
+        }
+    }
+}
+
+// {scale, zp} of a tensor whose range keys are known (for the kernels that take the parameters instead of the keys)
+__global__ void params_from_range_kernel(const uint32_t *__restrict__ mm, float *__restrict__ params) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const ActQ p = act_params(mm); params[0] = p.scale; params[1] = (float)p.zp; }
+}
+
+}  // namespace shodh

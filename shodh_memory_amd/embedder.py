@@ -7,6 +7,7 @@ the reference tree (downloaded at first run, embeddings/downloader.rs:29-53), so
 them: a `tokenizers.Tokenizer` and either a weight blob or a synthetic seed.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -87,6 +88,42 @@ def finalize_pooled(pooled, apply_prenorm=False, dimension=None):
     return out[:m].copy()
 
 
+class WeightFile:
+    """Host-only view of a model file (shodh_weight_file_*): what shodh_embedder_load_file parses, without a device."""
+
+    def __init__(self, path, cfg=None):
+        self._cfg = cfg or embed_cfg()
+        self._h = C.c_void_p()
+        L.check(L.lib().shodh_weight_file_open(os.fsencode(path), C.byref(self._cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h and self._h.value:
+            L.lib().shodh_weight_file_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def blob(self):
+        n = param_count(self._cfg)
+        b = np.empty(n, np.float32)
+        L.check(L.lib().shodh_weight_file_blob(self._h, b.ctypes.data, n))
+        return b
+
+    def quantized(self, name, shape):
+        """-> None if the file stores `name` as floats, else (q int8 [N, K] signed storage, scale [n], zero_point int32 [n] in the same signed terms)"""
+        n = C.c_uint32()
+        L.check(L.lib().shodh_weight_file_quantized(self._h, name.encode(), None, 0, None, None, 0, C.byref(n)))
+        if n.value == 0:
+            return None
+        q = np.empty(shape, np.int8); sc = np.empty(n.value, np.float32); zp = np.empty(n.value, np.int32)
+        L.check(L.lib().shodh_weight_file_quantized(self._h, name.encode(), q.ctypes.data, q.size, sc.ctypes.data, zp.ctypes.data, n.value, C.byref(n)))
+        return q, sc, zp
+
+
 def estimate_tokens(text):
     """token_estimation.rs:36-88: content-aware estimate used by `count_tokens` when no tokenizer is loaded. A 512-byte
     sample decides the mode: CJK (more than 2.5 bytes per char) -> ceil(1.5 * chars); code (>= 8 % syntax punctuation in the
@@ -131,7 +168,7 @@ class Embedder:
 
 class MiniLMEmbedder(Embedder):
     def __init__(self, tokenizer=None, weights=None, synthetic_seed=None, dtype=L.DTYPE_BF16, device=0,
-                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384, compute_padded=None):
+                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384, compute_padded=None, weights_path=None, **cfg_kw):
         self._dim = dim
         self.simplified_mode = simplified
         self.query_prefix, self.doc_prefix = query_prefix, doc_prefix
@@ -146,8 +183,12 @@ class MiniLMEmbedder(Embedder):
             tokenizer.no_padding()
         if compute_padded is None:
             compute_padded = dtype == L.DTYPE_INT8      # the reference's INT8 tensor is padded to max_length (minilm.rs:588-593)
-        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim, compute_padded=int(bool(compute_padded)))
+        # weights_path: the model file itself, as EmbeddingConfig.model_path names it (minilm.rs:212-220): model.safetensors, model.onnx or the
+        # dynamic-quantisation export -- with dtype INT8 the export's own 8-bit tensors, scales and zero points are what the device multiplies
+        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim, compute_padded=int(bool(compute_padded)),
+                        weights_path=os.fsencode(weights_path) if weights_path is not None else None, **cfg_kw)      # cfg_kw: layers=, vocab=, ... (other BERT sizes)
         L.check(L.lib().shodh_embedder_create(C.byref(cfg), C.byref(self._h)))
+        cfg.weights_path = None
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).reshape(-1)
             L.check(L.lib().shodh_embedder_load_weights(self._h, w.ctypes.data, w.size))
@@ -173,6 +214,32 @@ class MiniLMEmbedder(Embedder):
 
     def dimension(self):
         return self._dim
+
+    # -- weights as files / tensors hand them over (shodh_embedder_load_file and friends) ---------
+    def load_file(self, path):
+        L.check(L.lib().shodh_embedder_load_file(self._h, os.fsencode(path)))
+
+    def load_tensor(self, name, data, transposed=False):
+        a = np.ascontiguousarray(data, np.float32)
+        L.check(L.lib().shodh_embedder_load_tensor(self._h, name.encode(), a.ctypes.data, a.size, int(bool(transposed))))
+
+    def load_quantized(self, name, q, scale, zero_point=None, transposed=False):
+        """q uint8 or int8, [N, K] (or [K, N] with transposed=True, as ONNX MatMul constants are stored); scale / zero_point scalars or [N]"""
+        q = np.ascontiguousarray(q)
+        assert q.dtype in (np.uint8, np.int8)
+        sc = np.ascontiguousarray(np.atleast_1d(scale), np.float32)
+        zp = None if zero_point is None else np.ascontiguousarray(np.atleast_1d(zero_point), q.dtype)
+        assert zp is None or zp.size == sc.size
+        L.check(L.lib().shodh_embedder_load_quantized(self._h, name.encode(), q.ctypes.data, int(q.dtype == np.int8), int(bool(transposed)), sc.ctypes.data,
+                                                      zp.ctypes.data if zp is not None else None, sc.size))
+
+    def finish_weights(self):
+        L.check(L.lib().shodh_embedder_finish_weights(self._h))
+
+    def weight_source(self, name):
+        out = C.c_uint32()
+        L.check(L.lib().shodh_embedder_weight_source(self._h, name.encode(), C.byref(out)))
+        return int(out.value)
 
     # -- device entry points -------------------------------------------------------------------
     def encode_ids(self, ids, mask):
