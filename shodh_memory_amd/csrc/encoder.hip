@@ -1041,8 +1041,10 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
 //   X f32 -> [quantise] XQ -> A: q|k|v + attention -> CTX f32 (+ range) -> [quantise] XQ -> B: attention output + residual + LayerNorm -> X
 //   -> [quantise] XQ -> C: FFN up + GELU -> HQ bytes (range pass, then quantising pass | f32 tensor, then a quantising pass over it)
 //   -> D: FFN down + residual + LayerNorm -> X
-__global__ void init_ranges_kernel(uint32_t *mm, int n_pairs) {
+__global__ void init_ranges_kernel(uint32_t *mm, int n_pairs, int layers) {
     for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+    uint32_t *stats = mm + 2 * n_pairs;           // per layer {max key (0 = none), min key (0xFFFFFFFF = none), max key, unused}
+    for (int i = threadIdx.x; i < layers; i += blockDim.x) { stats[4 * i] = 0u; stats[4 * i + 1] = 0xFFFFFFFFu; stats[4 * i + 2] = 0u; stats[4 * i + 3] = 0u; }
 }
 template <int EPI>
 static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
@@ -1050,8 +1052,13 @@ static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
     if (n_workers < 8) n_workers = 8;
     const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
     if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
-    SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI>, S8_LDS));
-    hipLaunchKernelGGL((i8_stream_kernel<EPI>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+    if (a.zw && a.rsA) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI, true>, S8_LDS));
+        hipLaunchKernelGGL((i8_stream_kernel<EPI, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+    } else {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI, false>, S8_LDS));
+        hipLaunchKernelGGL((i8_stream_kernel<EPI, false>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+    }
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
@@ -1073,14 +1080,14 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     const int ln_blocks = (ntok * 32 + 255) / 256;
     const bool shape_ok = H == S8_NF && I == 4 * S8_NF && heads * 32 == H;
     const int nkb_max = (max_keys + 31) / 32;
-    const size_t att_fused_lds = (size_t)nkb_max * 8192 + 4 * 4096;
+    const size_t att_fused_lds = (size_t)nkb_max * 8192 + 4 * 2048;
     const uint32_t stages = shape_ok ? e->int8_stages : 0u;
     const bool fA = (stages & 1u) && att_fused_lds <= 160 * 1024, fB = stages & 2u, fC = stages & 4u, fD = stages & 8u;
     if ((!fA && !QKV) || (!fC && !FF)) { set_error("INT8 encoder: this batch needs the round-2 kernels' buffers (keys per text %d); create the embedder with SHODH_INT8_STAGES=0", max_keys); return SHODH_ERR_UNSUPPORTED; }
     // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it, not from a pass of its own:
     // one pair of order keys per tensor of the forward, all initialised by one launch.
     const int n_pairs = 4 * (int)e->cfg.layers + 2;
-    hipLaunchKernelGGL(init_ranges_kernel, dim3(1), dim3(64), 0, st, e->mmr, n_pairs);
+    hipLaunchKernelGGL(init_ranges_kernel, dim3(1), dim3(64), 0, st, e->mmr, n_pairs, (int)e->cfg.layers);
     uint32_t *mmX = e->mmr;                               // range of the current layer input
     hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
                        w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
@@ -1122,8 +1129,10 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             S8Args a{};
             a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmX1; a.Wp = wu.qp; a.wscale = wu.scale; a.rsz = wu.rsz; a.zw = wu.zw; a.bias = w + l.ib;
             a.M = ntok; a.N = I; a.n_groups = I / S8_NF;
-            a.mm_out = mmF;
-            SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));                // pass 1: the range of gelu(up(x)), nothing stored
+            uint32_t *stats = e->mmr + 2 * n_pairs + 4 * li;                            // {nearest pre-activation left of gelu's argmin, right of it, largest}: see gelu_range_finalize_kernel
+            a.mm_out = stats;
+            SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));                // pass 1: the three pre-activations that decide the range of gelu(up(x)); nothing stored
+            hipLaunchKernelGGL(gelu_range_finalize_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)stats, mmF);
             a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw) ? e->rsH : nullptr;
             if (a.rs_out) SHODH_HIP_TRY(hipMemsetAsync(e->rsH, 0, (size_t)ntok * 4, st));
             SHODH_TRY(launch_i8_stream<SEPI_GELU_QUANT>(a, e->cus, st));                // pass 2: the same values again, quantised on the way out
@@ -1328,7 +1337,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
     if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess ||
-                                           hipMalloc((void **)&e->mmr, (size_t)(4 * cfg->layers + 2) * 8) != hipSuccess)) {
+                                           hipMalloc((void **)&e->mmr, (size_t)(4 * cfg->layers + 2) * 8 + (size_t)cfg->layers * 16) != hipSuccess)) {
         shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
     }
     SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));

@@ -50,6 +50,42 @@ __device__ __forceinline__ float gelu_i8(float x) {
     return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
 }
 
+// the same function on two values at once: the polynomial part runs on the packed-FP32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of
+// work per issue slot), v_rcp / v_exp per value. Bit-identical to gelu_i8 per element (same operations in the same order).
+typedef float f32x2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2q gelu_i8x2(f32x2q x) {
+    const f32x2q z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    const f32x2q d = __builtin_elementwise_fma(z, (f32x2q)0.3275911f, (f32x2q)1.0f);
+    f32x2q t; t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2q p = __builtin_elementwise_fma(t, (f32x2q)1.061405429f, (f32x2q)-1.453152027f);
+    p = __builtin_elementwise_fma(p, t, (f32x2q)1.421413741f);
+    p = __builtin_elementwise_fma(p, t, (f32x2q)-0.284496736f);
+    p = __builtin_elementwise_fma(p, t, (f32x2q)0.254829592f);
+    const f32x2q ea = -z * z * 1.44269504088896340736f;
+    f32x2q e; e.x = __builtin_amdgcn_exp2f(ea.x); e.y = __builtin_amdgcn_exp2f(ea.y);
+    const f32x2q erf_abs = 1.0f - p * t * e;
+    f32x2q sg; sg.x = __builtin_copysignf(erf_abs.x, x.x); sg.y = __builtin_copysignf(erf_abs.y, x.y);
+    return 0.5f * x * (1.0f + sg);
+}
+// GELU has ONE minimum, at x* = -0.75179...: decreasing on (-inf, x*], increasing on [x*, +inf). So the range of gelu over a set is
+// decided by three of its elements: the largest one (maximum, if positive) and the two nearest to x* from either side (minimum).
+// The range pass of the FFN tracks those three pre-activations (3 compares / selects per value instead of a GELU evaluation) and
+// gelu_range_finalize_kernel evaluates gelu_i8 on them: the values the quantising pass will produce for those very elements. Exact for
+// the function itself; for gelu_i8 (|error| <= 1.3e-7 |x|) the extremes found this way can differ from the extremes of the computed
+// tensor by that approximation error at most -- a relative 1e-7 on the scale, below the approximation's own effect on the bytes.
+constexpr float GELU_ARGMIN = -0.7517915964f;
+// stats[0] = key of max{x <= x*} (atomicMax, 0 = none), stats[1] = key of min{x >= x*} (atomicMin, 0xFFFFFFFF = none), stats[2] = key of max x
+__global__ void gelu_range_finalize_kernel(const uint32_t *__restrict__ stats, uint32_t *__restrict__ mm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lo = 0.0f, hi = 0.0f;           // DynamicQuantizeLinear widens the range to contain 0 anyway
+    bool any = false;
+    if (stats[0] != 0u) { const float g = gelu_i8(order_key_inv(stats[0])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
+    if (stats[1] != 0xFFFFFFFFu) { const float g = gelu_i8(order_key_inv(stats[1])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
+    if (stats[2] != 0u) { const float g = gelu_i8(order_key_inv(stats[2])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
+    (void)any;
+    mm[0] = order_key(lo); mm[1] = order_key(hi);
+}
+
 // W_q[N][K] signed bytes -> fragment-major [N/32][K/32][64 lanes][16]: lane = ((k % 32) / 16) * 32 + n % 32 holds bytes k % 16
 __global__ void pack_i8_frag_kernel(const int8_t *__restrict__ W, int8_t *__restrict__ out, int N, int K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +150,7 @@ __device__ __forceinline__ void f16_split8(const float *v, f16x8q &h, f16x8q &l)
 //                   order in which S^T's result hands the keys (and so P) to a lane: P never leaves its registers.
 // LDS: K / V fragments [key block][K | V][step 0..1][hi | lo part][64 lanes][16 B] = 8 KiB per 32 keys, then 4 KiB of output
 // scratch per wave.
-__global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__restrict__ XQ, const int32_t *__restrict__ rsA /* row sums of XQ, or null */,
+__global__ __launch_bounds__(256, 4) void qkv_attn_i8_kernel(const int8_t *__restrict__ XQ, const int32_t *__restrict__ rsA /* row sums of XQ, or null */,
                                                              const uint32_t *__restrict__ mmA /* range keys of the quantised tensor */,
                                                              const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const float *__restrict__ wscale,
                                                              const int32_t *__restrict__ rsz, const int32_t *__restrict__ zw /* or null */, const float *__restrict__ bias,
@@ -145,11 +181,14 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__res
         i32x16l acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-            const i32x4q xf = *reinterpret_cast<const i32x4q *>(xr + ks * 32);
-            const i32x4q w = wf[ks * 64];
-            acc = isv ? __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(w, xf, acc, 0, 0, 0);
+        // four k-steps (eight 16-byte loads) at a time: with four workgroups per CU the other waves cover the round trips, and the whole
+        // 24-load prologue of a full unroll would not fit 128 registers
+        if (isv) {
+#pragma unroll 4
+            for (int ks = 0; ks < 12; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(xr + ks * 32), wf[ks * 64], acc, 0, 0, 0);
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < 12; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks * 64], *reinterpret_cast<const i32x4q *>(xr + ks * 32), acc, 0, 0, 0);
         }
         float v[16];
         if (!isv) {                                       // lane = key `tok`, registers = features
@@ -188,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__res
 
     // ---- phase 2: per 32-query block: Q projection, online softmax over the key blocks, O^T, row-wise stores
     const float sc = 0.17677669529663688110f * 1.44269504088896340736f;      // 1/sqrt(32) * log2(e): softmax in base 2
-    unsigned char *scr = smem + kv_bytes + wave * 4096;
+    unsigned char *scr = smem + kv_bytes + wave * 2048;       // 16 tokens x 128 B: the 32-query block leaves in two halves
     for (int qb = wave; qb < nqb; qb += 4) {
         const int q = qb * 32 + l31;
         const int qc = q < P ? q : P - 1;
@@ -197,11 +236,8 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__res
         i32x16l acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-            const i32x4q xf = *reinterpret_cast<const i32x4q *>(xr + ks * 32);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks * 64], xf, acc, 0, 0, 0);
-        }
+#pragma unroll 4
+        for (int ks = 0; ks < 12; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks * 64], *reinterpret_cast<const i32x4q *>(xr + ks * 32), acc, 0, 0, 0);
         f16x8q bqh[2], bql[2];
         {
             float v[16];
@@ -266,23 +302,33 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_i8_kernel(const int8_t *__res
             }
         }
         // O^T: this lane = query q, register r = feature f(r, hi). Through the wave's scratch (16-byte chunks XOR-swizzled by
-        // token & 7) so that a token's 32 features leave as one 128-byte row.
+        // token & 7) so that a token's 32 features leave as one 128-byte row; two halves of 16 queries (2 KiB of scratch per wave
+        // keeps four workgroups on a CU).
         const float invl = 1.0f / l;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4q ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ov[e] = o[4 * g + e] * invl;
-                if (q < P) { const uint32_t kk = order_key(ov[e]); klo = min(klo, kk); khi = max(khi, kk); }
-            }
-            *reinterpret_cast<f32x4q *>(scr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = ov;
+        for (int r = 0; r < 16; ++r) {
+            o[r] *= invl;
+            if (q < P) { const uint32_t kk = order_key(o[r]); klo = min(klo, kk); khi = max(khi, kk); }
         }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int tl = h * 8 + (lane >> 3), ch = lane & 7;
-            const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
-            if (qb * 32 + tl < P) *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + qb * 32 + tl) * H + head * 32 + ch * 4) = v4;
+        for (int half = 0; half < 2; ++half) {
+            if ((l31 >> 4) == half) {
+                const int tl = l31 & 15;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4q ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = o[4 * g + e];
+                    *reinterpret_cast<f32x4q *>(scr + tl * 128 + (((2 * g + hi) ^ (tl & 7)) << 4)) = ov;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+                const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                const int qt = qb * 32 + half * 16 + tl;
+                if (qt < P) *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + qt) * H + head * 32 + ch * 4) = v4;
+            }
         }
     }
     if (mm_out) {
@@ -311,7 +357,8 @@ struct S8Args {
     int M, N, n_groups;
 };
 
-template <int EPI>
+// ZW: some weight zero point is non-zero (the row-sum term exists); without it the integer multiply per value is compiled out
+template <int EPI, bool ZW>
 __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     constexpr int KS = S8_KS, NS = 2 * KS, D = 5, RING = 6, PF = S8_NBUF - 1, NPC = S8_NPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -331,15 +378,17 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     float *c_b = reinterpret_cast<float *>(c_rz + S8_NF);
     int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + S8_NF);
     float *c_g = reinterpret_cast<float *>(c_zw + S8_NF), *c_be = c_g + S8_NF;
-    for (int i = tid; i < S8_NF; i += S8_NT) {
-        c_ws[i] = a.wscale[nbase + i]; c_rz[i] = a.rsz[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
-        if (EPI == SEPI_RESID_LN) { c_g[i] = a.gamma[i]; c_be[i] = a.beta[i]; }
-    }
     const ActQ ap = act_params(a.mmA);
     const float a_scale = ap.scale;
     const int corr = 128 - ap.zp;
-    float o_scale = 1.0f, o_zpf = 0.0f;
-    if (EPI == SEPI_GELU_QUANT) { const ActQ op = act_params(a.mmO); o_scale = op.scale; o_zpf = (float)op.zp; }
+    for (int i = tid; i < S8_NF; i += S8_NT) {      // per-feature constants with the tensor-wide ones folded in: s = a_scale * w_scale[n], crz = (128 - a_zp) * (rowsum_w[n] - K z[n])
+        c_ws[i] = a_scale * a.wscale[nbase + i]; c_rz[i] = corr * a.rsz[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
+        if (EPI == SEPI_RESID_LN) { c_g[i] = a.gamma[i]; c_be[i] = a.beta[i]; }
+    }
+    float o_inv = 1.0f, o_zpf = 0.0f;
+    if (EPI == SEPI_GELU_QUANT) { const ActQ op = act_params(a.mmO); o_inv = 1.0f / op.scale; o_zpf = (float)op.zp; }
+    const bool has_zw = ZW;
+    float xmax = -__builtin_inff(), xl = -__builtin_inff(), xr = __builtin_inff();      // SEPI_GELU_RANGE: largest pre-activation, nearest to gelu's argmin from the left / right
 
     uint32_t srcoff[NPC];
 #pragma unroll
@@ -434,8 +483,24 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
             const int m = t * S8_TR + blk * 32 + l31;
             const int mc = m < M ? m : M - 1;
             const bool valid = m < M;
-            const int rsa = (a.rsA && a.zw) ? a.rsA[mc] : 0;
-            if (EPI == SEPI_GELU_RANGE || EPI == SEPI_GELU_QUANT) {
+            const int rsa = has_zw ? a.rsA[mc] : 0;
+            if (EPI == SEPI_GELU_RANGE) {
+                if (valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wave * 32 + 8 * g + 4 * hi;
+                        const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+                        const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e];
+                            xmax = fmaxf(xmax, x);
+                            xl = fmaxf(xl, x <= GELU_ARGMIN ? x : -__builtin_inff());
+                            xr = fminf(xr, x >= GELU_ARGMIN ? x : __builtin_inff());
+                        }
+                    }
+                }
+            } else if (EPI == SEPI_GELU_QUANT) {
                 unsigned char *ot = smem + S8_SCR + (it & 1) * S8_TILE + (blk * 32 + l31) * S8_PITCH;
                 int ssum = 0;
 #pragma unroll
@@ -445,25 +510,23 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                     const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
                     uint32_t pk = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = (float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e];
-                        const float v = gelu_i8(x);
-                        if (EPI == SEPI_GELU_RANGE) {
-                            if (valid) { const uint32_t kk = order_key(v); klo = min(klo, kk); khi = max(khi, kk); }
-                        } else {
-                            float q = __builtin_rintf(v / o_scale) + o_zpf;
-                            q = fminf(fmaxf(q, 0.0f), 255.0f);
-                            const int qi = (int)q - 128;
-                            ssum += qi;
-                            pk |= (uint32_t)(qi & 0xFF) << (8 * e);
-                        }
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        f32x2q x2;
+                        x2.x = (float)(acc[4 * g + 2 * e2] + rz[2 * e2] - (ZW ? z4[2 * e2] * rsa : 0)) * ws[2 * e2] + b4[2 * e2];
+                        x2.y = (float)(acc[4 * g + 2 * e2 + 1] + rz[2 * e2 + 1] - (ZW ? z4[2 * e2 + 1] * rsa : 0)) * ws[2 * e2 + 1] + b4[2 * e2 + 1];
+                        const f32x2q v2 = gelu_i8x2(x2);
+                        // q = clip(rint(v / scale) + zp, 0, 255) with v / scale taken as v * (1 / scale): the two differ in the last place at most, which
+                        // moves a byte only when v / scale sits within 1e-7 of a rounding boundary -- the size of gelu_i8's own error
+                        float q0 = __builtin_rintf(v2.x * o_inv) + o_zpf, q1 = __builtin_rintf(v2.y * o_inv) + o_zpf;
+                        q0 = fminf(fmaxf(q0, 0.0f), 255.0f); q1 = fminf(fmaxf(q1, 0.0f), 255.0f);
+                        const int i0 = (int)q0 - 128, i1 = (int)q1 - 128;
+                        ssum += i0 + i1;
+                        pk |= ((uint32_t)(i0 & 0xFF) | ((uint32_t)(i1 & 0xFF) << 8)) << (16 * e2);
                     }
-                    if (EPI == SEPI_GELU_QUANT) {
-                        const int c = nl >> 4;
-                        *reinterpret_cast<uint32_t *>(ot + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;      // (32 + l31) & 7 == l31 & 7
-                    }
+                    const int c = nl >> 4;
+                    *reinterpret_cast<uint32_t *>(ot + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;      // (32 + l31) & 7 == l31 & 7
                 }
-                if (EPI == SEPI_GELU_QUANT && a.rs_out) {
+                if (a.rs_out) {
                     ssum += __shfl_xor(ssum, 32);
                     if (hi == 0 && valid) atomicAdd(a.rs_out + m, ssum);
                 }
@@ -479,7 +542,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                     const f32x4q r4 = *reinterpret_cast<const f32x4q *>(a.resid + (size_t)mc * S8_NF + nl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[4 * g + e] = (float)(acc[4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e] + r4[e];
+                        v[4 * g + e] = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e] + r4[e];
                         s += v[4 * g + e];
                     }
                 }
@@ -530,7 +593,15 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     }
     if (EPI == SEPI_GELU_QUANT) { if (it > 0) store_out_tile(t_prev, (it - 1) & 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (EPI != SEPI_GELU_QUANT && a.mm_out) {
+    if (EPI == SEPI_GELU_RANGE && a.mm_out) {       // mm_out = {key of max{x <= x*}, key of min{x >= x*}, key of max x}: gelu_range_finalize_kernel turns them into the range
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { xmax = fmaxf(xmax, __shfl_xor(xmax, ofs)); xl = fmaxf(xl, __shfl_xor(xl, ofs)); xr = fminf(xr, __shfl_xor(xr, ofs)); }
+        if (lane == 0) {
+            if (xl > -__builtin_inff()) { const uint32_t k = order_key(xl); if (k > __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMax(a.mm_out, k); }
+            if (xr < __builtin_inff()) { const uint32_t k = order_key(xr); if (k < __atomic_load_n(a.mm_out + 1, __ATOMIC_RELAXED)) atomicMin(a.mm_out + 1, k); }
+            if (xmax > -__builtin_inff()) { const uint32_t k = order_key(xmax); if (k > __atomic_load_n(a.mm_out + 2, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 2, k); }
+        }
+    }
+    if (EPI == SEPI_RESID_LN && a.mm_out) {
         for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
         if (lane == 0) {
             if (klo < __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMin(a.mm_out, klo);

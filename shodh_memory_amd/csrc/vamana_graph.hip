@@ -225,7 +225,14 @@ __device__ void vg_dist_master(const VgGraph &g, const VgLds &l, uint32_t m, int
 // 16 KiB; the group-sum area for the fourth wave). Scalar-4 order only (the 8-chain order would need 50 KiB of raw rows per wave).
 constexpr uint32_t VG_REQ_EXIT = 0xFFFFFFFFu, VG_REQ_BACKEDGE = 0xFFFFFFFEu;
 __host__ __device__ inline bool vg_parallel_backedges(uint32_t dim, uint32_t order, uint32_t R) {
-    return order != SHODH_ORDER_AVX2 && dim <= 512 && R + 1 <= 64 && (size_t)dim * 4 + (size_t)(R + 1) * (dim / 4 + 1) * 4 + 512 <= 16384;
+    // per wave: q[dim] + group sums [(R + 1)][dim / 4 + 1] + 64 ids + 64 distances. Waves 0-2 get 16 KiB slices of the frontier + visited set; wave 3
+    // gets the group-sum area of the walk, rows-per-batch x max(dim / 4 + 1, 8) floats, plus the walk's newid / newd behind it (2 x VG_MAXDEG
+    // words, free once the walk is over) -- what follows is `pr`, the neighbour list all four waves are reading. (Round 2 checked only the
+    // 16 KiB slices: max_degree 62 / 63 with dim 136 .. 232 put wave 3's distances on top of `pr`)
+    const size_t need = (size_t)dim + (size_t)(R + 1) * (dim / 4 + 1) + 128;
+    const size_t tcols = dim / 4 + 1 > 8 ? dim / 4 + 1 : 8;
+    const size_t wave3 = (size_t)vg_rows_per_batch(dim, order) * tcols + 2 * VG_MAXDEG;
+    return order != SHODH_ORDER_AVX2 && dim <= 512 && R + 1 <= 64 && need * 4 <= 16384 && need <= wave3;
 }
 __device__ void vg_backedge_task(const VgGraph &g, const VgLds &l, int wave, int lane) {
     const uint32_t id = l.req[2], take = l.req[3], R = l.req[4];
