@@ -400,11 +400,37 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             mg.build(rows_h)
             dtm = timed_steps(torch, lambda i: mg.search_batch(qh[i % 4], 10), 30, 5)
             ids_m, dist_m, _ = mg.search_batch(qh[0], 10)
+            outd = (torch.empty((256, 10), dtype=torch.int32, device=dev), torch.empty((256, 10), dtype=torch.float32, device=dev), torch.empty((256,), dtype=torch.int32, device=dev))
+            dtd = timed_steps(torch, lambda i: mg.search_batch_device(main_qpool[i % 4], 10, out=outd), 30, 5)      # shodh_sharded_index_search_device: no host round trip
+            mg.search_batch_device(main_qpool[0], 10, out=outd); torch.cuda.synchronize()
             e["layouts"].append({"layout": lname, "shards": len(devs), "uses_rccl": mg.uses_rccl(), "ms_per_step": round(dtm * 1e3, 4),
                                  "queries_per_s": round(256 / dtm, 1), "host_timings_us_last": {kk: round(v, 1) for kk, v in mg.host_timings_us().items()},
-                                 "identical_to_single_index": bool(np.array_equal(ids_m, ref_ids) and dist_m.tobytes() == ref_dist.tobytes())})
+                                 "device_pointer_ms_per_step": round(dtd * 1e3, 4), "device_pointer_queries_per_s": round(256 / dtd, 1),
+                                 "identical_to_single_index": bool(np.array_equal(ids_m, ref_ids) and dist_m.tobytes() == ref_dist.tobytes()
+                                                                   and np.array_equal(outd[0].cpu().numpy().view(np.uint32), ref_ids))})
             mg.close()
         del rows_h
+        done(e, t0)
+
+    # -- one configs[4] shard through the same C path: 10M rows behind shodh_sharded_index_* with RCCL (world = the visible GPUs; on a 1-GPU box
+    #    the all-gather runs with world size 1), device pointers. Its step time is what every GPU of the 8 x 10M layout does per batch before the exchange.
+    if want("sharded_c_abi_10M_b256") and not args.skip_10m:
+        t0 = time.perf_counter()
+        from shodh_memory_amd.distributed import MultiGpuIndex, rccl_info
+        ndev = torch.cuda.device_count()
+        n = 10_000_000 * ndev
+        e = {"name": "sharded_c_abi_10M_b256", "workload": "configs[4] shape, %d x 10M memories through shodh_sharded_index_search_device (RCCL all-gather of per-shard top-10 + device merge "
+             "inside the library), batch 256, top-10" % ndev, "rccl": rccl_info()[1], "visible_gpus": ndev}
+        mg = MultiGpuIndex(list(range(ndev)), dim=args.dim, exchange=L.EXCHANGE_RCCL, reserve_rows_per_shard=10_000_000 + 65536)
+        for part in range(n // 1_000_000):                    # grown in 1M-row pieces: appends are dealt to the shards in blocks of 65 536 ids
+            mg.add_vectors(synth_rows(torch, 1_000_000, args.dim, SEED + 70 + part, dev, adversarial_queries=main_qpool[0] if part == 0 else None).cpu().numpy())
+        outd = (torch.empty((256, 10), dtype=torch.int32, device=dev), torch.empty((256, 10), dtype=torch.float32, device=dev), torch.empty((256,), dtype=torch.int32, device=dev))
+        dtd = timed_steps(torch, lambda i: mg.search_batch_device(main_qpool[i % 4], 10, out=outd), 20, 3)
+        ids_d = outd[0].cpu().numpy().view(np.uint32)
+        e.update({"rows": n, "shards": ndev, "uses_rccl": mg.uses_rccl(), "ms_per_step": round(dtd * 1e3, 4), "queries_per_s": round(256 / dtd, 1),
+                  "step_hbm_frac_algorithmic_per_gpu": round(10_000_000 * args.dim * 4 / dtd / 1e9 / HBM_PEAK_GBS, 4),
+                  "self_is_top_hit": bool((outd[1][:, 0] <= -0.9999).float().mean().item() > 0.0), "ids_in_range": bool((ids_d < n).all())})
+        mg.close()
         done(e, t0)
 
     # -- configs[3]: 10M memories, IVF nlist = 4096, nprobe = 32, top-10, batch 1024 -------------------------------------------
@@ -507,6 +533,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             idx.search_batch(qemb.cpu().numpy(), 10)
             st = idx.scan_stats()
             e = {"name": "cfg3_pipeline", "workload": "configs[2]: %d synthetic texts -> MiniLM-L6 bf16 -> add_vectors -> recall top-10 of 256 query TEXTS" % n_texts,
+                 "parity": "timing only at this size; the chained parity test (HIP MiniLM -> add_vectors -> recall, bit-equal to the oracle on the device-produced embeddings) "
+                           "runs 50 000 texts: tests/test_round2_gpu.py::test_configs2_chained_encode_add_recall",
                  "ingest_texts_per_s": round(n_texts / t_ingest, 1), "ingest_s": round(t_ingest, 3), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
                  "tokens": tok, "recall_ms_per_step_incl_query_encode": round(dt * 1e3, 4), "recall_queries_per_s_incl_query_encode": round(256 / dt, 1),
                  "search_only_ms_per_step": round(dts * 1e3, 4), "survivors_emitted_per_query": round(st["emitted"] / 256, 1),
@@ -537,7 +565,7 @@ def main():
     ap.add_argument("--skip-10m", action="store_true")
     ap.add_argument("--skip-ivfpq", action="store_true")
     ap.add_argument("--skip-encoder", action="store_true")
-    ap.add_argument("--pipeline-texts", type=int, default=262_144)
+    ap.add_argument("--pipeline-texts", type=int, default=1_000_000, help="configs[2] at its stated size: 1M texts embedded, inserted and recalled")
     ap.add_argument("--sustained-s", type=float, default=2.0)
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed recall steps for this long BEFORE the contract's warm-up: the GPU idles at ~100 MHz while the corpus is "
@@ -787,6 +815,7 @@ def main():
                            "corpus": "SURVEY 8d: 50%% correlated + 50%% i.i.d. unit rows, 1%% exact duplicates, 0.1%% rows equal to a query, %.0f%% tombstoned; "
                                      "%d distinct query batches cycled" % (args.tombstones * 100, len(qpool)),
                            "layout": "row-sharded + RCCL all-gather of per-shard top-k" if world > 1 else "single device",
+                           "parallelism": ("row-shard x%d, one process per GPU, one all-gather of %d B per rank and step" % (world, args.nq * args.k * 8)) if world > 1 else "single device",
                            "value_counts": "answered queries per second over the whole corpus",
                            "weak_scaling_reference": ("per-GPU work is fixed at %d rows: the one-GPU point of this curve is the `flat_10M_b256` entry of the "
                                                       "N = 1 line's `configs`; ideal = the same queries/s while the corpus grows %d-fold" % (rows_local, world))

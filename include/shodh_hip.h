@@ -102,7 +102,9 @@ void shodh_index_cfg_default(shodh_index_cfg *cfg);                       /* Bac
 int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out);    /* VamanaIndex::new vamana.rs:170-172 */
 void shodh_index_destroy(shodh_index *idx);
 /* add_vector (vamana.rs:853-974): appends n rows, ids are dense and sequential; *first_id_out =
- * id of rows[0] (= len() before the call, + id_base). rows: host [n][dim] row-major f32. */
+ * id of rows[0] (= len() before the call, + id_base). rows: host [n][dim] row-major f32.
+ * SHODH_SCAN_GRAPH only: SHODH_ERR_UNSUPPORTED with "frontier overflowed" means the rows WERE added but a walk met thousands of
+ * equidistant rows and the graph may differ from the reference's -- do not retry the call. */
 int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out);
 int shodh_index_add_device(shodh_index *idx, const float *d_rows, uint64_t n, uint32_t *first_id_out);
 /* build (vamana.rs:200-284) / rebuild_from_vectors (:1363-1462): replaces the contents; ids 0..n-1;
@@ -211,7 +213,12 @@ uint64_t shodh_sharded_index_shard_len(const shodh_sharded_index *s, uint32_t sh
 int shodh_sharded_index_build(shodh_sharded_index *s, const float *rows, uint64_t n);                            /* vamana.rs:200-284 */
 int shodh_sharded_index_add(shodh_sharded_index *s, const float *rows, uint64_t n, uint32_t *first_id_out);      /* :853-974 */
 int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k,
-                               uint32_t *ids, float *dist, uint32_t *counts);                                    /* :764-808, :1167-1188; spann.rs:574-693 */
+                               uint32_t *ids, float *dist, uint32_t *counts);
+/* the same with device buffers ON THE FIRST DEVICE of the index (devices[0]): d_q [nq][dim], d_ids / d_dist [nq][k], d_counts [nq];
+ * asynchronous on `stream` (a hipStream_t of that device, NULL = its default stream): the queries reach the other shards by peer copies,
+ * the merged lists land in the caller's buffers, no host round trip. Queries are not screened for NaN / Inf (the host-pointer form is). */
+int shodh_sharded_index_search_device(shodh_sharded_index *s, const float *d_q, uint32_t nq, uint32_t k, uint32_t *d_ids, float *d_dist,
+                                      uint32_t *d_counts, void *stream);                                    /* :764-808, :1167-1188; spann.rs:574-693 */
 int shodh_sharded_index_mark_deleted(shodh_sharded_index *s, uint32_t id, int *was_valid);                        /* :813-820 */
 int shodh_sharded_index_mark_deleted_batch(shodh_sharded_index *s, const uint32_t *ids, uint64_t n, uint64_t *n_marked_out);
 int shodh_sharded_index_is_deleted(shodh_sharded_index *s, uint32_t id);

@@ -254,10 +254,13 @@ impl HipIndex {
                                      self.incremental_insert_count() as u64, deg.as_ptr(), nbr.as_ptr())
             });
         }
+        // no graph to write: empty adjacency lists, and `incremental_inserts` raised to the rebuild threshold so that a graph-walking reader
+        // (the reference without SHODH_VECTOR_EXACT) rebuilds before it walks -- the same rule as persist.py::save_vamana
+        let inserts = if n > 1 { self.incremental_insert_count().max(REBUILD_THRESHOLD) } else { self.incremental_insert_count() };
         check(unsafe {
             ffi::shodh_vama_save(p.as_ptr(), flat.as_ptr(), n as u64, self.dim as u32, self.max_degree as u32, 0, 0,
                                  if deleted.is_empty() { std::ptr::null() } else { deleted.as_ptr() }, deleted.len() as u32,
-                                 self.incremental_insert_count() as u64, std::ptr::null(), std::ptr::null())
+                                 inserts as u64, std::ptr::null(), std::ptr::null())
         })
     }
     /// `load_from_file` (vamana_persist.rs:290-391): vectors and tombstones of a persisted index, straight into HBM
@@ -271,7 +274,9 @@ impl HipIndex {
         let idx = Self::new(VamanaConfig { dimension: d, max_degree: info.max_degree as usize, ..Default::default() })?;
         if n > 0 { check(unsafe { ffi::shodh_index_build(idx.h, flat.as_ptr(), n as u64) })?; }
         for id in deleted { idx.mark_deleted(id); }
-        idx.incremental.store(info.incremental_inserts as usize, std::sync::atomic::Ordering::Release);
+        // an edge-less file's counter is the "rebuild me" sentinel for graph walkers (save_to_file): an exact index does not inherit it
+        let inherited = if info.graph_edges == 0 && n > 1 && info.incremental_inserts as usize >= REBUILD_THRESHOLD { 0 } else { info.incremental_inserts as usize };
+        idx.incremental.store(inherited, std::sync::atomic::Ordering::Release);
         Ok(idx)
     }
     /// `load_from_file` keeping the file's graph: the index answers by walking it, like the reference that wrote it

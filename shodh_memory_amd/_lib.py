@@ -134,6 +134,7 @@ SYMBOLS = {
     "shodh_sharded_index_build": (C.c_int, [_vp, _fp, C.c_uint64]),
     "shodh_sharded_index_add": (C.c_int, [_vp, _fp, C.c_uint64, C.POINTER(C.c_uint32)]),
     "shodh_sharded_index_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "shodh_sharded_index_search_device": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_sharded_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
     "shodh_sharded_index_mark_deleted_batch": (C.c_int, [_vp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "shodh_sharded_index_is_deleted": (C.c_int, [_vp, C.c_uint32]),

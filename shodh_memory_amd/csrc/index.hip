@@ -92,7 +92,8 @@ struct VgGraph { const float *rows; uint32_t dim; uint32_t *deg; uint32_t *nbr; 
 struct VgSearchArgs { VgGraph g; uint32_t n, medoid; const float *q; uint32_t nq, k, search_k; const uint32_t *deleted; uint32_t id_base;
                       uint32_t *visited; uint32_t vis_words; uint32_t *ids; float *dist; uint32_t *counts; uint32_t *overflow; };
 struct VgInsertArgs { VgGraph g; uint32_t first, count, R, medoid; uint32_t *visited; uint32_t *overflow; };
-struct VgBuildArgs { VgGraph g; uint32_t n, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; };
+struct VgBuildArgs { VgGraph g; uint32_t n, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; uint32_t first, count; uint32_t *updates; };
+constexpr uint32_t VG_BUILD_CHUNK = 512;
 struct VgRepairArgs { VgGraph g; uint32_t n, first, count, R, L, medoid; float alpha; uint32_t *visited; uint32_t *overflow; uint32_t *repaired; };
 int vg_launch_repair(const VgRepairArgs &a, hipStream_t st);
 int vg_launch_search(const VgSearchArgs &a, hipStream_t st);
@@ -224,7 +225,10 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
     if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
         uint32_t *gd = nullptr, *gn = nullptr, *gv = nullptr;
         if (hipMalloc((void **)&gd, nc * 4) != hipSuccess || hipMalloc((void **)&gn, nc * (size_t)idx->g_stride * 4) != hipSuccess ||
-            hipMalloc((void **)&gv, (nc / 32 + 1) * 4) != hipSuccess) { set_error("out of HBM (graph)"); return SHODH_ERR_OOM; }
+            hipMalloc((void **)&gv, (nc / 32 + 1) * 4) != hipSuccess) {
+            hipFree(gd); hipFree(gn); hipFree(gv); hipFree(nr); if (nh) hipFree(nh); hipFree(nd);      // nothing of the old slab was touched yet
+            set_error("out of HBM (graph)"); return SHODH_ERR_OOM;
+        }
         SHODH_HIP_TRY(hipMemset(gd, 0, nc * 4));
         if (idx->g_nodes) {
             SHODH_HIP_TRY(hipMemcpy(gd, idx->g_deg, idx->g_nodes * 4, hipMemcpyDeviceToDevice));
@@ -549,7 +553,12 @@ static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *f
     }
     SHODH_HIP_TRY(hipDeviceSynchronize());
     idx->n += n;
-    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !skip_graph) SHODH_TRY(check_graph_overflow(idx));
+    if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !skip_graph && check_graph_overflow(idx) != SHODH_OK) {
+        // the rows and their graph nodes ARE in the index at this point (a walk cannot be undone): say so, a caller that retried would add them twice
+        set_error("graph insert: a walk's frontier overflowed (thousands of equidistant rows), so the graph may differ from the reference's; the %llu rows WERE added (ids from %llu) -- do not retry",
+                  (unsigned long long)n, (unsigned long long)(idx->cfg.id_base + idx->n - n));
+        return SHODH_ERR_UNSUPPORTED;
+    }
     return SHODH_OK;
 }
 
@@ -969,10 +978,25 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
         SHODH_HIP_TRY(hipMemcpy(idx->g_deg, deg.data(), n * 4, hipMemcpyHostToDevice));
         SHODH_HIP_TRY(hipMemcpy(idx->g_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
         idx->g_medoid = medoid;
-        VgBuildArgs a{graph_of(idx), (uint32_t)n, R, idx->cfg.search_list_size, medoid, idx->cfg.alpha, idx->g_visited, idx->g_overflow};
-        SHODH_TRY(vg_launch_build(a, nullptr));
-        const hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) { set_error("graph build failed on device: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
+        // vamana.rs:246-283: pass after pass over all nodes, at most two, stopping when a pass changed nothing. Each launch takes
+        // VG_BUILD_CHUNK nodes (a node costs a few milliseconds: one launch stays in the range of seconds); the pass state lives here.
+        uint32_t *d_upd = nullptr;
+        SHODH_HIP_TRY(hipMalloc((void **)&d_upd, 4));
+        int rc = SHODH_OK;
+        for (int pass = 1; pass <= 2 && rc == SHODH_OK; ++pass) {
+            if (hipMemset(d_upd, 0, 4) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
+            for (uint64_t first = 0; first < n && rc == SHODH_OK; first += VG_BUILD_CHUNK) {
+                VgBuildArgs a{graph_of(idx), (uint32_t)n, R, idx->cfg.search_list_size, medoid, idx->cfg.alpha, idx->g_visited, idx->g_overflow,
+                              (uint32_t)first, (uint32_t)std::min<uint64_t>(VG_BUILD_CHUNK, n - first), d_upd};
+                rc = vg_launch_build(a, nullptr);
+                if (rc == SHODH_OK) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { set_error("graph build failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; } }
+            }
+            uint32_t upd = 0;
+            if (rc == SHODH_OK && hipMemcpy(&upd, d_upd, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SHODH_ERR_DEVICE;
+            if (upd == 0) break;
+        }
+        hipFree(d_upd);
+        if (rc != SHODH_OK) return rc;
         idx->g_nodes = n;
         SHODH_TRY(check_graph_overflow(idx));
     }

@@ -124,6 +124,7 @@ struct shodh_sharded_index {
     // merged result on the first device
     uint32_t *o_ids = nullptr; float *o_dist = nullptr; uint32_t *o_counts = nullptr; size_t o_elems = 0, o_nq = 0;
     float last_us[4] = {0, 0, 0, 0};   // search, exchange, merge, total (host wall clock of the last search)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;     // device-pointer searches: the caller's stream <-> the shard streams
 };
 
 namespace shodh {
@@ -226,6 +227,8 @@ int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devi
             for (uint32_t g = 0; g < n_devices; ++g) s->sh[g].comm = comms[g];
         }
     }
+    if (rc == SHODH_OK && (hipSetDevice(s->sh[0].device) != hipSuccess || hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess)) { set_error("event creation failed"); rc = SHODH_ERR_DEVICE; }
     if (rc != SHODH_OK) { shodh_sharded_index_destroy(s); return rc; }
     *out = s;
     return SHODH_OK;
@@ -245,6 +248,7 @@ void shodh_sharded_index_destroy(shodh_sharded_index *s) {
     }
     if (!s->sh.empty()) hipSetDevice(s->sh[0].device);
     if (s->o_ids) hipFree(s->o_ids); if (s->o_dist) hipFree(s->o_dist); if (s->o_counts) hipFree(s->o_counts);
+    if (s->ev_in) hipEventDestroy(s->ev_in); if (s->ev_out) hipEventDestroy(s->ev_out);
     delete s;
 }
 
@@ -391,23 +395,42 @@ int shodh_sharded_index_ivfpq_insert(shodh_sharded_index *s, uint32_t vector_id,
     return shodh_index_ivfpq_insert(s->sh[vector_id % s->sh.size()].idx, vector_id, row);
 }
 
-int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+// host_io: q / ids / dist / counts are host buffers and the call returns when they hold the answer. Otherwise they live on the FIRST device
+// of the index, the call is asynchronous on `user_st` (stream of that device) and touches the host only to enqueue: queries travel to the
+// other shards by peer copies, the merge writes straight into the caller's buffers, and `user_st` waits for it through an event.
+static int sharded_search_impl(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts, bool host_io, hipStream_t user_st) {
     if (!s || (nq && (!q || !counts)) || (nq && k && (!ids || !dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (nq == 0) return SHODH_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     const size_t G = s->sh.size();
-    if (k == 0) { for (uint32_t i = 0; i < nq; ++i) counts[i] = 0; return SHODH_OK; }
-    for (size_t i = 0; i < (size_t)nq * s->cfg.dim; ++i)
-        if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
+    Shard &h0 = s->sh[0];
+    if (k == 0) {
+        if (host_io) { for (uint32_t i = 0; i < nq; ++i) counts[i] = 0; return SHODH_OK; }
+        SHODH_HIP_TRY(hipSetDevice(h0.device));
+        SHODH_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nq * 4, user_st));
+        return SHODH_OK;
+    }
+    if (host_io)
+        for (size_t i = 0; i < (size_t)nq * s->cfg.dim; ++i)
+            if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
     SHODH_TRY(reserve_buffers(s, nq, k));
     Rccl *R = s->use_rccl ? rccl() : nullptr;
     const size_t words = 2ull * nq * k;
     const double t0 = now_us();
+    if (!host_io) {      // the shard streams start after whatever produced the queries on the caller's stream
+        SHODH_HIP_TRY(hipSetDevice(h0.device));
+        SHODH_HIP_TRY(hipEventRecord(s->ev_in, user_st));
+    }
     // 1. every shard: queries in, local top-k out (global ids), asynchronously on its own stream
     for (size_t g = 0; g < G; ++g) {
         Shard &h = s->sh[g];
         SHODH_HIP_TRY(hipSetDevice(h.device));
-        SHODH_HIP_TRY(hipMemcpyAsync(h.d_q, q, (size_t)nq * s->cfg.dim * 4, hipMemcpyHostToDevice, h.st));
+        if (host_io) SHODH_HIP_TRY(hipMemcpyAsync(h.d_q, q, (size_t)nq * s->cfg.dim * 4, hipMemcpyHostToDevice, h.st));
+        else {
+            SHODH_HIP_TRY(hipStreamWaitEvent(h.st, s->ev_in, 0));
+            if (h.device == h0.device) SHODH_HIP_TRY(hipMemcpyAsync(h.d_q, q, (size_t)nq * s->cfg.dim * 4, hipMemcpyDeviceToDevice, h.st));
+            else SHODH_HIP_TRY(hipMemcpyPeerAsync(h.d_q, h.device, q, h0.device, (size_t)nq * s->cfg.dim * 4, h.st));
+        }
         SHODH_TRY(shodh_index_search_device(h.idx, h.d_q, nq, k, h.pack, reinterpret_cast<float *>(h.pack + (size_t)nq * k), h.d_counts, h.st));
         if (s->cfg.kind == SHODH_INDEX_FLAT && G > 1) {
             const uint64_t cnt = (uint64_t)nq * k;
@@ -417,7 +440,6 @@ int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t 
     }
     const double t1 = now_us();
     // 2. exchange
-    Shard &h0 = s->sh[0];
     if (s->use_rccl) {
         SHODH_RCCL_TRY(R->GroupStart());
         for (size_t g = 0; g < G; ++g) {
@@ -439,8 +461,16 @@ int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t 
         }
     }
     const double t2 = now_us();
-    // 3. merge on the first device, results to the host
+    // 3. merge on the first device
     SHODH_HIP_TRY(hipSetDevice(h0.device));
+    if (!host_io) {
+        SHODH_TRY(launch_merge_lists(h0.all, reinterpret_cast<const float *>(h0.all + (size_t)nq * k), words, (uint32_t)G, nq, k, ids, dist, counts, h0.st));
+        SHODH_HIP_TRY(hipEventRecord(s->ev_out, h0.st));
+        SHODH_HIP_TRY(hipStreamWaitEvent(user_st, s->ev_out, 0));
+        const double t3 = now_us();
+        s->last_us[0] = (float)(t1 - t0); s->last_us[1] = (float)(t2 - t1); s->last_us[2] = (float)(t3 - t2); s->last_us[3] = (float)(t3 - t0);      // enqueue times only
+        return SHODH_OK;
+    }
     SHODH_TRY(launch_merge_lists(h0.all, reinterpret_cast<const float *>(h0.all + (size_t)nq * k), words, (uint32_t)G, nq, k, s->o_ids, s->o_dist, s->o_counts, h0.st));
     SHODH_HIP_TRY(hipMemcpyAsync(ids, s->o_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h0.st));
     SHODH_HIP_TRY(hipMemcpyAsync(dist, s->o_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h0.st));
@@ -453,6 +483,13 @@ int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t 
     const double t3 = now_us();
     s->last_us[0] = (float)(t1 - t0); s->last_us[1] = (float)(t2 - t1); s->last_us[2] = (float)(t3 - t2); s->last_us[3] = (float)(t3 - t0);
     return SHODH_OK;
+}
+
+int shodh_sharded_index_search(shodh_sharded_index *s, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+    return sharded_search_impl(s, q, nq, k, ids, dist, counts, true, nullptr);
+}
+int shodh_sharded_index_search_device(shodh_sharded_index *s, const float *d_q, uint32_t nq, uint32_t k, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream) {
+    return sharded_search_impl(s, d_q, nq, k, d_ids, d_dist, d_counts, false, (hipStream_t)stream);
 }
 
 int shodh_sharded_index_host_timings(const shodh_sharded_index *s, float *us4) {

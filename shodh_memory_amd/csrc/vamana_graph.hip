@@ -585,13 +585,19 @@ __device__ uint32_t vg_robust_prune(const VgGraph &g, const VgLds &l, uint32_t n
     return np;
 }
 
-// build (vamana.rs:200-284) over the graph already in deg / nbr (the initial random graph). One wave, node after node, two passes.
+// build (vamana.rs:200-284) over the graph already in deg / nbr (the initial random graph). One wave, node after node, at most two passes.
+// A launch covers the nodes [first, first + count) of ONE pass and adds the lists it changed to *updates: the host walks the node ranges
+// (VG_BUILD_CHUNK per launch) and decides about the second pass, so that no launch runs for minutes under the index's lock and a build can
+// be bounded / reported on (round 2 ran both passes over all nodes in one launch).
+constexpr uint32_t VG_BUILD_CHUNK = 512;
 struct VgBuildArgs {
     VgGraph g;
     uint32_t n, R, L, medoid;
     float alpha;
     uint32_t *visited;
     uint32_t *overflow;
+    uint32_t first, count;
+    uint32_t *updates;        // device counter (atomicAdd)
 };
 __global__ __launch_bounds__(256) void vg_build_kernel(VgBuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -601,9 +607,10 @@ __global__ __launch_bounds__(256) void vg_build_kernel(VgBuildArgs a) {
     const uint32_t dim = a.g.dim;
     uint32_t *pr = l.pr, *pr2 = l.pr2;
     float *dne = l.dne, *dne2 = l.dne2;
-    for (int iteration = 1;; ++iteration) {
+    {
         uint32_t updates = 0;
-        for (uint32_t node = 0; node < a.n; ++node) {
+        const uint32_t end = a.first + a.count < a.n ? a.first + a.count : a.n;
+        for (uint32_t node = a.first; node < end; ++node) {
             for (uint32_t i = lane; i < dim; i += 64) l.q[i] = a.g.rows[(size_t)node * dim + i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void vg_build_kernel(VgBuildArgs a) {
                 }
             }
         }
-        if (updates == 0 || iteration >= 2) break;
+        if (lane == 0 && updates) atomicAdd(a.updates, updates);
     }
     vg_walk_done(l, lane);
 }

@@ -171,6 +171,18 @@ class MultiGpuIndex:
         L.check(L.lib().shodh_sharded_index_search(self._h, q.ctypes.data, nq, k, ids.ctypes.data, dist.ctypes.data, counts.ctypes.data))
         return ids[:, :k], dist[:, :k], counts
 
+    def search_batch_device(self, queries, k, out=None, stream=None):
+        """queries: float32 CUDA tensor on the index's FIRST device; results stay there (ids int32 view of u32, dist, counts). Asynchronous on the
+        current stream of that device: no host round trip (shodh_sharded_index_search_device)."""
+        import torch
+        nq = queries.shape[0]
+        if out is None:
+            out = (torch.empty((nq, max(k, 1)), dtype=torch.int32, device=queries.device), torch.empty((nq, max(k, 1)), dtype=torch.float32, device=queries.device),
+                   torch.empty((nq,), dtype=torch.int32, device=queries.device))
+        st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
+        L.check(L.lib().shodh_sharded_index_search_device(self._h, queries.data_ptr(), nq, k, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), C.c_void_p(st)))
+        return out
+
     def search(self, query, k):
         ids, dist, counts = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
         return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(counts[0]))]

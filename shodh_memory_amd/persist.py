@@ -75,7 +75,12 @@ def load_vamana(path, device=0, scan_mode=L.SCAN_AUTO):
             idx.build(f["vectors"])
     for i in f["deleted"]:
         idx.mark_deleted(int(i))
-    idx._incremental = int(info["incremental_inserts"])
+    # A file WITHOUT edges carries `incremental_inserts >= REBUILD_THRESHOLD` as a message to a graph-walking reader ("rebuild me", see
+    # save_vamana); an exact-scan index has no graph to rebuild, so it must not inherit that sentinel -- it would make needs_rebuild()
+    # true forever and the next auto_rebuild_if_needed() would renumber ids under the caller.
+    from .index import REBUILD_THRESHOLD
+    sentinel = int(info["graph_edges"]) == 0 and int(info["num_vectors"]) > 1 and int(info["incremental_inserts"]) >= REBUILD_THRESHOLD
+    idx._incremental = 0 if (sentinel and scan_mode != L.SCAN_GRAPH) else int(info["incremental_inserts"])
     idx._graph = dict(n=int(info["num_vectors"]), medoid=int(info["medoid"]), degree=f["degree"], neighbors=f["neighbors"])
     return idx
 

@@ -104,6 +104,10 @@ def test_reference_built_graph_survives_a_round_trip(S, tmp_path):
     idx.save_to_file(out)
     f = P.read_vamana(out, with_graph=True)
     assert f["info"]["graph_edges"] == 0 and f["info"]["incremental_inserts"] >= REBUILD_THRESHOLD and f["info"]["num_vectors"] == 301
+    # ... which is a message to graph-walking readers: this library's own exact index must not inherit it (needs_rebuild() would be true
+    # forever and the next auto_rebuild_if_needed() would renumber ids under the caller)
+    back = P.load_vamana(out)
+    assert back.incremental_insert_count() == 0 and not back.needs_rebuild() and back.len() == 301
 
 
 def test_shard_with_id_base_keeps_its_tombstones(S, tmp_path):

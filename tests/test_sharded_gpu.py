@@ -127,3 +127,27 @@ def test_sharded_one_million_rows_two_shards_on_one_gpu(D):
     assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes() and (counts == 10).all()
     assert (np.diff(dist, axis=1) >= 0).all()
     idx.close()
+
+
+def test_sharded_search_on_device_pointers(D, oracle):
+    """shodh_sharded_index_search_device: queries and results on the first device, asynchronous on the caller's stream, same bits as the host form"""
+    rows = synth.corpus(9000)
+    q = synth.queries(33)
+    dq = torch.from_numpy(q).cuda()
+    for name, devs, exch in layouts():
+        idx = D.MultiGpuIndex(devs, block_log2=8, exchange=exch)
+        idx.build(rows)
+        idx.mark_deleted_many(np.arange(0, 9000, 7, dtype=np.uint32))
+        h_ids, h_dist, h_counts = idx.search_batch(q, 10)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            dq2 = dq * 1.0                                                  # produced on the caller's stream: the shard streams must wait for it
+            ids, dist, counts = idx.search_batch_device(dq2, 10)
+            ids2, dist2, counts2 = idx.search_batch_device(dq2[:5], 120)   # back to back on the same buffers
+        side.synchronize()
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), h_ids) and dist.cpu().numpy().tobytes() == h_dist.tobytes(), name
+        assert np.array_equal(counts.cpu().numpy().view(np.uint32), h_counts)
+        e_ids, e_dist, _ = idx.search_batch(q[:5], 120)
+        assert np.array_equal(ids2.cpu().numpy().view(np.uint32), e_ids) and dist2.cpu().numpy().tobytes() == e_dist.tobytes(), name
+        assert idx.search_batch_device(dq[:2], 0)[2].cpu().tolist() == [0, 0]
+        idx.close()

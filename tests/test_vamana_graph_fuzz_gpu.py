@@ -58,3 +58,20 @@ def test_random_graph_workloads(S, oracle):
             assert_graph_equal(idx, g)
             assert_search_equal(idx, g, q[:6], 5, deleted=deleted)
         idx.close()
+
+
+@pytest.mark.parametrize("dim,R", [(192, 63), (136, 62), (232, 63), (200, 48)])
+def test_backedge_rerank_with_wide_lists(S, oracle, dim, R):
+    """with max_degree 62 / 63 and 136 <= dim <= 232 (scalar-4 order) the fourth wave's private buffers of the parallel back-edge
+    re-rank reached into the neighbour list all four waves were reading. Dense clusters make back-edge lists overflow R early."""
+    n = 700
+    rows = unit_rows(n, dim, 77, clusters=2)
+    idx = gpu_index(S, dim, R, 75, 0)
+    g = oracle.VamanaGraph(dim, R=R, L=75, order=0, capacity=n)
+    for at in range(0, n, 100):
+        assert idx.add_vectors(rows[at:at + 100]) == at
+        for r in rows[at:at + 100]:
+            g.add_vector(r)
+    assert_graph_equal(idx, g)
+    assert_search_equal(idx, g, rows[:8], 10)
+    idx.close()
