@@ -110,7 +110,7 @@ def save_vamana(index, path):
         flat = nb[np.arange(nb.shape[1])[None, :] < deg[:, None]]
         write_vamana(path, vec, max_degree=index.config.max_degree, medoid=medoid, metric=0, deleted=deleted,
                      incremental_inserts=index.incremental_insert_count(), degree=deg.astype(np.uint16), neighbors=np.ascontiguousarray(flat, np.uint32))
-    elif g is not None and g["n"] == vec.shape[0]:
+    elif g is not None and g["n"] == vec.shape[0] and (len(g["neighbors"]) > 0 or vec.shape[0] <= 1):      # a loaded file WITH edges round-trips with them
         write_vamana(path, vec, max_degree=index.config.max_degree, medoid=g["medoid"], metric=0, deleted=deleted,
                      incremental_inserts=index.incremental_insert_count(), degree=g["degree"], neighbors=g["neighbors"])
     else:
