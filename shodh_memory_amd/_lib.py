@@ -17,7 +17,7 @@ except ImportError:          # standalone use from C/C++/Rust or a torch-free py
     _torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libshodh_hip.so")
+LIB_PATH = os.environ.get("SHODH_HIP_LIB") or os.path.join(HERE, "libshodh_hip.so")      # SHODH_HIP_LIB: a diagnostic build of the same library (tools/)
 
 OK = 0
 ERR_INVALID, ERR_DIM, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_IO, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8

@@ -18,6 +18,7 @@ from shodh_memory_amd import embedder as E          # noqa: E402  (host-only hel
 from tests import bert_ref                            # noqa: E402
 
 SEED = 1234
+HARSH_SEED = 4242
 
 
 def hf_model(blob):
@@ -32,20 +33,30 @@ def hf_model(blob):
     return m
 
 
-def main():
-    blob = E.synthetic_weights(SEED)
-    m = hf_model(blob)
-    cases = {"b1": [3], "b4": [3, 17, 128, 64], "edge": [1, 2, 128, 0, 50]}
+def run_cases(m, cases, seeds):
     out = {}
     with torch.no_grad():
         for name, lens in cases.items():
-            ids, mask = bert_ref.synth_batch(len(lens), 256, seed={"b1": 11, "b4": 12, "edge": 13}[name], lengths=lens)
+            ids, mask = bert_ref.synth_batch(len(lens), 256, seed=seeds[name], lengths=lens)
             hidden = m(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids)).last_hidden_state
             out[name + "_ids"] = ids.numpy().astype(np.int32)
             out[name + "_mask"] = mask.numpy().astype(np.uint8)
             out[name + "_emb"] = bert_ref.pool(hidden, mask).numpy().astype(np.float32)
+    return out
+
+
+def main():
+    blob = E.synthetic_weights(SEED)
+    out = run_cases(hf_model(blob), {"b1": [3], "b4": [3, 17, 128, 64], "edge": [1, 2, 128, 0, 50]}, {"b1": 11, "b4": 12, "edge": 13})
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz"), seed=np.int64(SEED), **out)
     print({k: v.shape for k, v in out.items()})
+    # the HARSH weight set (tests/synth_weights.py: outlier channels, LayerNorm gains over two decades, heavy-tailed word table): the closest
+    # thing to a trained checkpoint the offline image allows. Same architecture oracle (transformers.BertModel, fp32, CPU).
+    from tests import synth_weights as SW
+    hb = SW.harsh_blob(E, HARSH_SEED)
+    hout = run_cases(hf_model(hb), {"h8": [5, 9, 23, 40, 64, 97, 128, 128]}, {"h8": 21})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "encoder_harsh_golden.npz"), seed=np.int64(HARSH_SEED), **hout)
+    print({k: v.shape for k, v in hout.items()}, "harsh fixture; hidden-state scale check:", float(np.abs(hb).max()))
 
 
 if __name__ == "__main__":

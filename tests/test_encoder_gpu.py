@@ -15,6 +15,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FP32_TOL = 1e-4
 BF16_COS = 0.999
+# harsh weight set (tests/synth_weights.py), gates just below what MI355X measured (round 3, gpurun_out/r3_harsh.txt):
+#   fp32 max |diff| 2.9e-5, cosine 1.0000000 vs transformers.BertModel        -> FP32_TOL holds unchanged
+#   bf16 per-text cosines 0.9839 .. 0.99997 (min 0.98390)                       -> the operand rounding of the x25 outlier channels; the round-1
+#        path with f32 pre-norm sums (SHODH_ENC_UNFUSED=1) measures 0.98161: keeping the residual stream in f32 does NOT buy it back
+#   INT8 vs the fp32 fixture 0.9238 .. 0.9936; the numpy restatement of the same graph scores 0.9235 .. 0.9939 against that fixture:
+#        the loss is the per-tensor 8-bit quantisation of outlier-laden tensors, not this implementation
+#   INT8 vs its restatement min 0.98692: two faithful evaluations of the quantised graph differ by that much here, because f32
+#        reassociation flips bytes at rounding boundaries and the outliers make one byte step large (the reference's own figure for
+#        pad-128 vs pad-256 of the real export is 0.9859, minilm.rs:591)
+HARSH_BF16_COS = 0.975
+HARSH_INT8_VS_RESTATEMENT_COS = 0.98
+HARSH_INT8_VS_FP32_COS = 0.90
 
 
 @pytest.fixture(scope="module")
@@ -238,3 +250,34 @@ def test_big_batches_run_as_sub_batches_with_identical_results(S):
     parts = np.concatenate([enc.encode_ids(ids[:8192], mask[:8192]), enc.encode_ids(ids[8192:], mask[8192:])])
     assert whole.shape == (b, 384) and whole.tobytes() == parts.tobytes()
     assert np.allclose(np.linalg.norm(whole, axis=1), 1.0, atol=1e-3)
+
+
+def test_harsh_weight_set_fp32_bf16_int8(S):
+    """a second weight set with outlier channels (x25), LayerNorm gains over [0.1, 10] and a heavy-tailed word table
+    (tests/synth_weights.py), golden vectors from transformers.BertModel in fp32 (tests/golden/encoder_harsh_golden.npz). The cosines are
+    MEASURED and printed; the gates sit just below what was measured on MI355X (stated in DESIGN.md), not at an assumed 0.999."""
+    from oracle import int8_ref as R
+    from shodh_memory_amd import _lib as L
+    from shodh_memory_amd import embedder as E
+    from tests import synth_weights as SW
+    g = np.load(os.path.join(ROOT, "tests", "golden", "encoder_harsh_golden.npz"))
+    blob = SW.harsh_blob(E, int(g["seed"]))
+    ids, mask, exp = g["h8_ids"], g["h8_mask"], g["h8_emb"]
+    e32 = S.MiniLMEmbedder(weights=blob, dtype=L.DTYPE_FP32)
+    a32 = e32.encode_ids(ids, mask)
+    d32 = float(np.abs(a32 - exp).max())
+    c32 = cos(a32, exp)
+    e16 = S.MiniLMEmbedder(weights=blob, dtype=L.DTYPE_BF16)
+    c16 = cos(e16.encode_ids(ids, mask), exp)
+    e8 = S.MiniLMEmbedder(weights=blob, dtype=L.DTYPE_INT8)
+    a8 = e8.encode_ids(ids, mask)
+    c8 = cos(a8, exp)
+    r8 = R.encode(E.blob_to_state_dict(blob), ids, mask)               # the restated INT8 graph on the same weights (self-quantised: per tensor, symmetric)
+    c8r = cos(a8, r8)
+    print("harsh weights: fp32 max|diff| %.3g min cos %.7f | bf16 min cos %.5f | int8 vs fp32 fixture min cos %.5f | int8 vs its restatement min cos %.6f"
+          % (d32, c32.min(), c16.min(), c8.min(), c8r.min()))
+    print("harsh per-text cosines bf16", np.round(c16, 5), "int8", np.round(c8, 5), "restated int8 vs fp32 fixture", np.round(cos(r8, exp), 5))
+    assert d32 < 2e-4 and c32.min() > 0.999999, (d32, c32)
+    assert c16.min() > HARSH_BF16_COS, c16
+    assert c8r.min() > HARSH_INT8_VS_RESTATEMENT_COS, c8r
+    assert c8.min() > HARSH_INT8_VS_FP32_COS, c8
