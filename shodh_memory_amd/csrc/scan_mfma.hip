@@ -859,30 +859,36 @@ __device__ __forceinline__ float exact_dot_row(const float *__restrict__ q_lds, 
 }
 
 constexpr int FS_CH = 16;     // AVX2 order: rows of the re-score window staged raw in LDS at a time
-constexpr int FS_TC = 64;     // scalar-4 order: rows whose per-group partial sums are staged at a time
-constexpr int FS_RW = 16;      // scalar-4 order: rows in flight per wave (FS_TC / 4 waves)
+constexpr int FS_RW = 16;      // scalar-4 order: rows in flight per wave; a re-score chunk is (waves x FS_RW) = NT / 4 rows whose per-group partial sums are staged
 constexpr int FS_STAGE = 2048; // candidate keys staged in LDS (the rest, if any, is re-read from global)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim, uint32_t order, uint32_t ch_rows) {
-    const size_t a = (size_t)FS_TC * (dim / 4 + 1) * 4;
+// nt = threads of the workgroup (256 or 512): the scalar-4 re-score stages nt / 4 rows at a time (FS_RW rows in flight per wave)
+__host__ __device__ inline size_t final_stage_region_bytes(uint32_t dim, uint32_t order, uint32_t ch_rows, uint32_t nt) {
+    const size_t a = (size_t)(nt / 4) * (dim / 4 + 1) * 4;
     const size_t b = (size_t)ch_rows * (dim + 8) * 4 + (size_t)ch_rows * 8 * 4;
     return ((order == SHODH_ORDER_SCALAR4 ? a : b) + 15) & ~(size_t)15;
 }
 
-template <int ORDER>
-__global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
+// NT = 256: several workgroups share a CU (thousands of queries: k-means assignment, IVF encoding). NT = 512 (up to a few hundred queries,
+// one workgroup per CU anyway): twice the rows of the re-score in flight, twice the lanes in the selections -- at recall's index-level
+// k = 120 the 256-thread form spent 47 % of its 67 us in five sequential 64-row re-score chunks and 32 % ranking 280 keys on 256 lanes.
+template <int ORDER, int NT>
+__global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
+    constexpr int SJ = 1024 / NT;          // staged loads per thread (1024 slots / up to 1024 query floats)
+    constexpr int NW = NT / 64;            // waves
+    constexpr int TC = NT / 4;             // scalar-4 order: rows per re-score chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);                          // [dim]
     uint64_t *keys = reinterpret_cast<uint64_t *>(qs + a.dim);            // [cap]
-    uint64_t *mins = keys + a.cap;                                        // [512]
-    uint64_t *ekeys = mins + 512;                                         // [fcap] exact keys of the window
+    uint64_t *mins = keys + a.cap;                                        // [2 * NT]
+    uint64_t *ekeys = mins + 2 * NT;                                         // [fcap] exact keys of the window
     uint64_t *thr = ekeys + a.fcap;
     uint32_t *flist = reinterpret_cast<uint32_t *>(thr + 1);              // [fcap] rows of the window
     uint32_t *cnt = flist + a.fcap;
     uint32_t *fcnt = cnt + 1;
     float *region = reinterpret_cast<float *>(fcnt + 1);                  // 16-B aligned: thr sits at a 16-B boundary
-    uint32_t *sel32 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(region) + final_stage_region_bytes(a.dim, ORDER, a.ch_rows));   // [KTH_SCRATCH_U32]
+    uint32_t *sel32 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(region) + final_stage_region_bytes(a.dim, ORDER, a.ch_rows, NT));   // [KTH_SCRATCH_U32]
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (q >= a.nq) return;
@@ -891,12 +897,12 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     // runtime condition makes hipcc wait for each one separately -- measured as 4 + 2 + 2 dependent round trips here).
     const uint32_t n_main = a.nb * MF_SLOTS;
     uint64_t *slots_q = a.slots + (size_t)q * n_main;
-    uint64_t kv[4];
+    uint64_t kv[SJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; kv[j] = slots_q[i < n_main ? i : 0]; }
-    float qv[4];
+    for (int j = 0; j < SJ; ++j) { const uint32_t i = j * NT + tid; kv[j] = slots_q[i < n_main ? i : 0]; }
+    float qv[SJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 1024 on this path
+    for (int j = 0; j < SJ; ++j) { const uint32_t i = j * NT + tid; qv[j] = a.q[(size_t)q * a.dim + (i < a.dim ? i : 0)]; }   // dim <= 1024 on this path
     const uint32_t n_ovf = a.cand_cnt[q];
     if (a.cnt_reset) {                  // block-uniform; every thread has read the counter before it is handed back
         __syncthreads();
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
     PROF_DECL
     if (!bad) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; if (i < a.dim) qs[i] = qv[j]; }
+        for (int j = 0; j < SJ; ++j) { const uint32_t i = j * NT + tid; if (i < a.dim) qs[i] = qv[j]; }
         if (tid == 0) { *fcnt = 0; *ecnt = 0; }
         TopKBuf buf{keys, cnt, thr, a.cap, a.k};
         uint64_t *list = a.cand + (size_t)q * a.cand_cap;
@@ -919,15 +925,15 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
         const uint32_t n_st = n < a.stage_cap ? n : a.stage_cap;
         const uint32_t st_main = n_main < n_st ? n_main : n_st;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = j * 256 + tid; if (i < st_main) { skey[i] = (uint32_t)(kv[j] >> 32); srow[i] = (uint32_t)kv[j]; } }
+        for (int j = 0; j < SJ; ++j) { const uint32_t i = j * NT + tid; if (i < st_main) { skey[i] = (uint32_t)(kv[j] >> 32); srow[i] = (uint32_t)kv[j]; } }
         for (uint32_t i0 = 1024; i0 < st_main; i0 += 1024) {      // more than 256 workgroups in the pre-scan
-            uint64_t kw[4];
+            uint64_t kw[SJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * 256 + tid; kw[j] = slots_q[i < st_main ? i : 0]; }
+            for (int j = 0; j < SJ; ++j) { const uint32_t i = i0 + j * NT + tid; kw[j] = slots_q[i < st_main ? i : 0]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * 256 + tid; if (i < st_main) { skey[i] = (uint32_t)(kw[j] >> 32); srow[i] = (uint32_t)kw[j]; } }
+            for (int j = 0; j < SJ; ++j) { const uint32_t i = i0 + j * NT + tid; if (i < st_main) { skey[i] = (uint32_t)(kw[j] >> 32); srow[i] = (uint32_t)kw[j]; } }
         }
-        for (uint32_t i = n_main + tid; i < n_st; i += 256) { const uint64_t key = list[i - n_main]; skey[i] = (uint32_t)(key >> 32); srow[i] = (uint32_t)key; }
+        for (uint32_t i = n_main + tid; i < n_st; i += NT) { const uint64_t key = list[i - n_main]; skey[i] = (uint32_t)(key >> 32); srow[i] = (uint32_t)key; }
         __syncthreads();
         auto key_at = [&](uint32_t i) -> uint64_t { return i < n_st ? (((uint64_t)skey[i] << 32) | srow[i]) : key_glb(i); };
         // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
@@ -938,14 +944,14 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             if (a.k > 0 && a.k <= 128) {
                 auto key32 = [&](uint32_t i) -> uint32_t { return i < n_st ? skey[i] : (uint32_t)(key_glb(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
                 bool ovf = false;
-                const uint32_t kk = block_kth_u32<256>(key32, n, a.k, sel32, &ovf);
+                const uint32_t kk = block_kth_u32<NT>(key32, n, a.k, sel32, &ovf);
                 if (kk != 0xFFFFFFFFu) {
                     const float kth = -order_key_inv(kk);
                     lo_ = kth - (2.001f * eps_q + 1e-7f * __builtin_fabsf(kth));
                 }
             } else if (a.k > 0) {
                 auto key_a = [&](uint64_t i) -> uint64_t { return key_at((uint32_t)i); };
-                const uint32_t ma = block_select_topk<256>(key_a, n, buf, mins);
+                const uint32_t ma = block_select_topk<NT>(key_a, n, buf, mins);
                 if (ma == a.k && buf.keys[a.k - 1] != KEY_NONE) {
                     const float kth = -order_key_inv((uint32_t)(buf.keys[a.k - 1] >> 32));
                     lo_ = kth - (2.001f * eps_q + 1e-7f * __builtin_fabsf(kth));
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             if (tid == 0) *fcnt = 0;
             __syncthreads();
             uint32_t real = 0;
-            for (uint32_t i = tid; i < n; i += 256) {
+            for (uint32_t i = tid; i < n; i += NT) {
                 const uint64_t key = key_at(i);
                 if (key == KEY_NONE) continue;
                 ++real;
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             const f32x4 qc = ln + 128 < d4 ? qs4[ln + 128] : z4, qd = ln + 192 < d4 ? qs4[ln + 192] : z4;
             const uint32_t gc = ln + 128 < d4 ? ln + 128 : 0u, gd = ln + 192 < d4 ? ln + 192 : 0u;
             const uint32_t n_groups = (n + 63) >> 6;
-            for (uint32_t g = wv; g < n_groups; g += 4) {
+            for (uint32_t g = wv; g < n_groups; g += NW) {
                 const uint32_t i = g * 64 + ln;
                 const uint64_t key = i < n ? key_at(i) : KEY_NONE;
                 const bool in = key != KEY_NONE && -order_key_inv((uint32_t)(key >> 32)) >= lo;
@@ -1076,18 +1082,18 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                 float *tbuf = region;
                 const uint32_t tp = d4 + 1;
                 const uint32_t wv = tid >> 6, ln = tid & 63;
-                for (uint32_t c0 = 0; c0 < nf; c0 += FS_TC) {
-                    const uint32_t nc = (nf - c0) < (uint32_t)FS_TC ? (nf - c0) : (uint32_t)FS_TC;
+                for (uint32_t c0 = 0; c0 < nf; c0 += TC) {
+                    const uint32_t nc = (nf - c0) < (uint32_t)TC ? (nf - c0) : (uint32_t)TC;
                     // wave w takes rows w, w+4, ...; its lanes take float4 groups ln, ln+64, ... (one row = one
                     // coalesced d4*16-byte read); FS_RW rows' loads are in flight per wave before any is reduced (the rows are
                     // cold in HBM: every round trip is ~2 us)
-                    for (uint32_t cb = wv; cb < nc; cb += 4 * FS_RW) {
+                    for (uint32_t cb = wv; cb < nc; cb += NW * FS_RW) {
                         for (uint32_t g0 = 0; g0 < d4; g0 += 128) {
                             f32x4 r[FS_RW][2];
 #pragma unroll
                             for (int u = 0; u < FS_RW; ++u) {
                                 // unconditional loads on clamped indices (see the staging loop above): all FS_RW x 2 in flight
-                                const uint32_t c = cb + 4 * u < nc ? cb + 4 * u : nc - 1;
+                                const uint32_t c = cb + NW * u < nc ? cb + NW * u : nc - 1;
                                 const float *rp_ = a.rows + (size_t)flist[c0 + c] * dim;
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                             }
 #pragma unroll
                             for (int u = 0; u < FS_RW; ++u) {
-                                const uint32_t c = cb + 4 * u;
+                                const uint32_t c = cb + NW * u;
                                 if (c < nc) {
 #pragma unroll
                                     for (int h = 0; h < 2; ++h) {
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
                 float *tbuf = rowbuf + (size_t)ch * rp;
                 for (uint32_t c0 = 0; c0 < nf; c0 += ch) {
                     const uint32_t nc = (nf - c0) < ch ? (nf - c0) : ch;
-                    for (uint32_t e = tid; e < nc * d4; e += 256) {
+                    for (uint32_t e = tid; e < nc * d4; e += NT) {
                         const uint32_t c = e / d4, j = e % d4;
                         rowbuf4[c * (rp >> 2) + j] = *reinterpret_cast<const f32x4 *>(a.rows + (size_t)flist[c0 + c] * dim + j * 4);
                     }
@@ -1181,12 +1187,12 @@ __global__ __launch_bounds__(256) void final_stage_kernel(FinalArgs a) {
             }
             PROF_T(3)
             auto key_b = [&](uint64_t i) -> uint64_t { return ekeys[i]; };
-            const uint32_t m = block_select_topk<256>(key_b, nf, buf, mins);
+            const uint32_t m = block_select_topk<NT>(key_b, nf, buf, mins);
             PROF_T(4)
 #ifdef SHODH_PROF
             if (tid == 0 && (q % 37) == 0) printf("final q %u n %u nf %u | load-q %lld selectA %lld window %lld rescore %lld selectB %lld\n", q, n, nf, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4]);
 #endif
-            for (uint32_t i = tid; i < a.k; i += 256) {
+            for (uint32_t i = tid; i < a.k; i += NT) {
                 if (i < m) {
                     const uint64_t key = buf.keys[i];
                     a.ids[(size_t)q * a.k + i] = (uint32_t)key;
@@ -1354,21 +1360,29 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
         ch_rows = next_pow2(k ? k : 1);
         ch_rows = ch_rows < 4u ? 4u : (ch_rows > (uint32_t)FS_CH ? (uint32_t)FS_CH : ch_rows);
     }
-    FinalArgs f{rows, dim, d_q, nq, k, p.topk_cap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
+    static const int nt_env = getenv("SHODH_FINAL_NT") ? atoi(getenv("SHODH_FINAL_NT")) : 0;
+    const uint32_t nt = (nt_env == 256 || nt_env == 512) ? (uint32_t)nt_env : (nq >= 1024 ? 256u : 512u);
+    // the selection buffer takes up to 2 * nt pushes between two compaction checks on top of the k keys it keeps (topk.h: a push past the capacity is dropped)
+    uint32_t tcap = k + 2 * nt;
+    if (tcap < 2 * k) tcap = 2 * k;
+    if (tcap < 1024) tcap = 1024;
+    tcap = next_pow2(tcap);
+    FinalArgs f{rows, dim, d_q, nq, k, tcap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset};
     // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
-    const size_t flds = (size_t)dim * 4 + (size_t)p.topk_cap * 8 + 512 * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
-                        final_stage_region_bytes(dim, order, ch_rows) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
-    if (order == SHODH_ORDER_SEQ_1M) {
-        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_SEQ_1M>, flds));
-        hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SEQ_1M>), dim3(nq), dim3(256), flds, st, f);
-    } else if (order == SHODH_ORDER_AVX2) {
-        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_AVX2>, flds));
-        hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_AVX2>), dim3(nq), dim3(256), flds, st, f);
-    } else {
-        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<SHODH_ORDER_SCALAR4>, flds));
-        hipLaunchKernelGGL((final_stage_kernel<SHODH_ORDER_SCALAR4>), dim3(nq), dim3(256), flds, st, f);
-    }
+    // up to a few hundred queries every workgroup has a CU to itself: 512 threads (twice the re-score rows in flight and twice the lanes in the
+    // selections); thousands of queries keep 256 so that several workgroups share a CU. SHODH_FINAL_NT=256 forces the small form (speed only).
+    const size_t flds = (size_t)dim * 4 + (size_t)tcap * 8 + (size_t)2 * nt * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
+                        final_stage_region_bytes(dim, order, ch_rows, nt) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
+#define SHODH_LAUNCH_FINAL(ORD, NTV)                                                                         \
+    do {                                                                                                     \
+        SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<ORD, NTV>, flds));                     \
+        hipLaunchKernelGGL((final_stage_kernel<ORD, NTV>), dim3(nq), dim3(NTV), flds, st, f);                \
+    } while (0)
+    if (order == SHODH_ORDER_SEQ_1M) { if (nt == 512) SHODH_LAUNCH_FINAL(SHODH_ORDER_SEQ_1M, 512); else SHODH_LAUNCH_FINAL(SHODH_ORDER_SEQ_1M, 256); }
+    else if (order == SHODH_ORDER_AVX2) { if (nt == 512) SHODH_LAUNCH_FINAL(SHODH_ORDER_AVX2, 512); else SHODH_LAUNCH_FINAL(SHODH_ORDER_AVX2, 256); }
+    else { if (nt == 512) SHODH_LAUNCH_FINAL(SHODH_ORDER_SCALAR4, 512); else SHODH_LAUNCH_FINAL(SHODH_ORDER_SCALAR4, 256); }
+#undef SHODH_LAUNCH_FINAL
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
