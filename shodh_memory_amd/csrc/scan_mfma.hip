@@ -1360,20 +1360,27 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
         ch_rows = next_pow2(k ? k : 1);
         ch_rows = ch_rows < 4u ? 4u : (ch_rows > (uint32_t)FS_CH ? (uint32_t)FS_CH : ch_rows);
     }
+    // Up to a few hundred queries every workgroup has a CU to itself: 512 threads (twice the re-score rows in flight and twice the lanes in the
+    // selections) where its LDS fits; thousands of queries keep 256 so that several workgroups share a CU, and so do shapes whose 512-thread
+    // layout would not fit 160 KiB (768 / 1024 dimensions). SHODH_FINAL_NT=256 forces the small form (speed only).
     static const int nt_env = getenv("SHODH_FINAL_NT") ? atoi(getenv("SHODH_FINAL_NT")) : 0;
-    const uint32_t nt = (nt_env == 256 || nt_env == 512) ? (uint32_t)nt_env : (nq >= 1024 ? 256u : 512u);
-    // the selection buffer takes up to 2 * nt pushes between two compaction checks on top of the k keys it keeps (topk.h: a push past the capacity is dropped)
-    uint32_t tcap = k + 2 * nt;
-    if (tcap < 2 * k) tcap = 2 * k;
-    if (tcap < 1024) tcap = 1024;
-    tcap = next_pow2(tcap);
+    uint32_t nt = (nt_env == 256 || nt_env == 512) ? (uint32_t)nt_env : (nq >= 1024 ? 256u : 512u);
+    uint32_t tcap = 0;
+    size_t flds = 0;
+    for (;;) {
+        // the selection buffer takes up to 2 * nt pushes between two compaction checks on top of the k keys it keeps (topk.h: a push past the capacity is dropped)
+        tcap = k + 2 * nt;
+        if (tcap < 2 * k) tcap = 2 * k;
+        if (tcap < 1024) tcap = 1024;
+        tcap = next_pow2(tcap);
+        // qs[dim] | keys[tcap] | mins[2 nt] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
+        flds = (size_t)dim * 4 + (size_t)tcap * 8 + (size_t)2 * nt * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
+               final_stage_region_bytes(dim, order, ch_rows, nt) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
+        if (nt == 512 && flds > 160 * 1024) { nt = 256; continue; }
+        break;
+    }
     FinalArgs f{rows, dim, d_q, nq, k, tcap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
                 w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset};
-    // qs[dim] | keys[cap] | mins[512] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
-    // up to a few hundred queries every workgroup has a CU to itself: 512 threads (twice the re-score rows in flight and twice the lanes in the
-    // selections); thousands of queries keep 256 so that several workgroups share a CU. SHODH_FINAL_NT=256 forces the small form (speed only).
-    const size_t flds = (size_t)dim * 4 + (size_t)tcap * 8 + (size_t)2 * nt * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
-                        final_stage_region_bytes(dim, order, ch_rows, nt) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
 #define SHODH_LAUNCH_FINAL(ORD, NTV)                                                                         \
     do {                                                                                                     \
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<ORD, NTV>, flds));                     \
