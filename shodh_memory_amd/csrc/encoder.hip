@@ -505,46 +505,63 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     int id = ids[(size_t)sq * max_len + p];
     if (id < 0) id = 0;
     if (id >= vocab) id = vocab - 1;
-    if constexpr (!std::is_same<T, float>::value) {
-        // bf16 mode: 16-byte loads and 8-byte stores (a lane takes float4 groups lane and lane + 64 of the row). The f32 / INT8 modes keep
-        // the scalar form below: their tests pin quantities that depend on the exact order of the LayerNorm sums.
-        if (!word_q && (H & 3) == 0 && H <= 512) {
-            const int h4 = H >> 2;
-            f32x4e xv[2];
-            float s = 0.0f;
+    // bf16 and INT8 modes: 16-byte loads (a lane takes float4 groups lane and lane + 64 of the row; the 8-bit word table arrives four bytes at a
+    // time), 8 / 16-byte stores. The plain f32 mode keeps the scalar form below: its tests pin quantities that depend on the exact order of the
+    // LayerNorm sums against a torch reference.
+    if ((!std::is_same<T, float>::value || word_q) && (H & 3) == 0 && H <= 512) {
+        const int h4 = H >> 2;
+        f32x4e xv[2];
+        float s = 0.0f;
+        const float wsc = word_q ? word_scale[0] : 0.0f;
+        const int wzp = word_q ? (int)word_scale[1] : 0;          // zero point in signed-storage terms
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int g = lane + 64 * j;
-                if (g < h4) {
-                    const f32x4e w4 = *reinterpret_cast<const f32x4e *>(word + (size_t)id * H + g * 4), p4 = *reinterpret_cast<const f32x4e *>(pos + (size_t)p * H + g * 4),
-                                 t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
+        for (int j = 0; j < 2; ++j) {
+            const int g = lane + 64 * j;
+            if (g < h4) {
+                f32x4e w4;
+                if (word_q) {                                     // Gather + DequantizeLinear: (q - zp) * scale
+                    const uint32_t pk = *reinterpret_cast<const uint32_t *>(word_q + (size_t)id * H + g * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { xv[j][e] = w4[e] + p4[e] + t4[e]; s += xv[j][e]; }
-                }
+                    for (int e = 0; e < 4; ++e) w4[e] = (float)((int)(int8_t)(pk >> (8 * e)) - wzp) * wsc;
+                } else w4 = *reinterpret_cast<const f32x4e *>(word + (size_t)id * H + g * 4);
+                const f32x4e p4 = *reinterpret_cast<const f32x4e *>(pos + (size_t)p * H + g * 4), t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[j][e] = w4[e] + p4[e] + t4[e]; s += xv[j][e]; }
             }
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)H;
-            float v = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
-            }
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            const float inv = 1.0f / sqrtf(v / (float)H + eps);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int g = lane + 64 * j;
-                if (g < h4) {
-                    const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
-                    bf16x4e o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (__bf16)((xv[j][e] - mean) * inv * g4[e] + b4[e]);
-                    *reinterpret_cast<bf16x4e *>(out + (size_t)tok * H + g * 4) = o4;
-                }
-            }
-            return;
         }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)H;
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
+        }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float inv = 1.0f / sqrtf(v / (float)H + eps);
+        uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = lane + 64 * j;
+            if (g < h4) {
+                const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
+                f32x4e o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o4[e] = (xv[j][e] - mean) * inv * g4[e] + b4[e];
+                    if (mm) { const uint32_t kk = order_key(o4[e]); klo = min(klo, kk); khi = max(khi, kk); }
+                }
+                if constexpr (std::is_same<T, float>::value) *reinterpret_cast<f32x4e *>(out + (size_t)tok * H + g * 4) = o4;
+                else {
+                    bf16x4e ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob[e] = (__bf16)o4[e];
+                    *reinterpret_cast<bf16x4e *>(out + (size_t)tok * H + g * 4) = ob;
+                }
+            }
+        }
+        if (mm) minmax_commit(klo, khi, mm);
+        return;
     }
     float x[16];
     int cnt = 0;

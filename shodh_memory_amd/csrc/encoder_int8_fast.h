@@ -35,43 +35,49 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7 (+ ~1e-7 from v_rcp / v_exp), so
-// |gelu error| <= 1.3e-7 |x| -- against a quantisation step of (max - min) / 255 of the tensor it feeds. Exact erff costs ~40 VALU
-// operations per value, this ~16; the INT8 FFN evaluates 1.6e9 of them per layer and pass.
-__device__ __forceinline__ float gelu_i8(float x) {
-    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = 1.0f - p * t * e;
-    return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
-}
-
-// the same function on two values at once: the polynomial part runs on the packed-FP32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of
-// work per issue slot), v_rcp / v_exp per value. Bit-identical to gelu_i8 per element (same operations in the same order).
+// GELU(x) = x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with erfc(z) = 2^P(z) on z in [0, 4.4]: P = the degree-8 weighted least-squares fit of
+// log2 erfc (Chebyshev nodes, weight erfc: what counts is the absolute error of erfc); beyond 4.4 (|x| > 6.2) z is clamped, erfc(4.4) = 5e-10.
+// Measured in f32 Horner arithmetic over x in [-8, 8] against the exact function: |erfc error| <= 8.1e-8, |gelu error| <= 3.0e-7 absolute and
+// <= 9.5e-8 |x| (+ one ulp of v_exp_f32) -- tighter than Abramowitz-Stegun 7.1.26 (1.5e-7 on erf), which this replaces: 7.1.26 needs v_rcp AND v_exp
+// (quarter-rate instructions, 8 issue slots per value) plus 8 more slots; this needs one v_exp and eight fused multiply-adds on the packed-FP32 pipe
+// (v_pk_fma_f32: two values per slot): ~12 slots per value against ~16. Exact erff costs ~40. The INT8 FFN evaluates it on 1.6e9 values per layer.
 typedef float f32x2q __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2q gelu_i8x2(f32x2q x) {
-    const f32x2q z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
-    const f32x2q d = __builtin_elementwise_fma(z, (f32x2q)0.3275911f, (f32x2q)1.0f);
-    f32x2q t; t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
-    f32x2q p = __builtin_elementwise_fma(t, (f32x2q)1.061405429f, (f32x2q)-1.453152027f);
-    p = __builtin_elementwise_fma(p, t, (f32x2q)1.421413741f);
-    p = __builtin_elementwise_fma(p, t, (f32x2q)-0.284496736f);
-    p = __builtin_elementwise_fma(p, t, (f32x2q)0.254829592f);
-    const f32x2q ea = -z * z * 1.44269504088896340736f;
-    f32x2q e; e.x = __builtin_amdgcn_exp2f(ea.x); e.y = __builtin_amdgcn_exp2f(ea.y);
-    const f32x2q erf_abs = 1.0f - p * t * e;
-    f32x2q sg; sg.x = __builtin_copysignf(erf_abs.x, x.x); sg.y = __builtin_copysignf(erf_abs.y, x.y);
-    return 0.5f * x * (1.0f + sg);
+    const f32x2q ax = __builtin_elementwise_abs(x);
+    f32x2q z = ax * 0.70710678118654752440f;
+    z.x = fminf(z.x, 4.4f); z.y = fminf(z.y, 4.4f);
+    f32x2q p = __builtin_elementwise_fma(z, (f32x2q)-2.753492845e-05f, (f32x2q)3.102343180e-04f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)-1.085499767e-03f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)-1.382132061e-03f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)2.874283120e-02f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)-1.486884505e-01f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)-9.183745980e-01f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)-1.627911806e+00f);
+    p = __builtin_elementwise_fma(p, z, (f32x2q)4.870492631e-08f);
+    f32x2q e; e.x = __builtin_amdgcn_exp2f(p.x); e.y = __builtin_amdgcn_exp2f(p.y);      // erfc(z)
+    const f32x2q m = ax * 0.5f;
+    f32x2q r; r.x = fmaxf(x.x, 0.0f); r.y = fmaxf(x.y, 0.0f);
+    return __builtin_elementwise_fma(-m, e, r);
+}
+__device__ __forceinline__ float gelu_i8(float x) { f32x2q v; v.x = x; v.y = x; return gelu_i8x2(v).x; }      // the same bits as the packed form
+// f32 -> uint8 the way DynamicQuantizeLinear writes it, q = saturate(round_half_even(t) + zp), four values into one dword: v_rndne + add + ONE
+// v_cvt_pk_u8_f32 per value (round-half-even and saturation to [0, 255] measured on gfx950, tools/ubench/cvt_probe.hip; `rq` is already integral,
+// so the instruction's own rounding is idle). The stored byte is q - 128 = q ^ 0x80: one XOR per dword.
+__device__ __forceinline__ uint32_t pack_u8(uint32_t acc, float rq, int byte) {
+    uint32_t r;
+    switch (byte) {
+        case 0: asm("v_cvt_pk_u8_f32 %0, %1, 0, %2" : "=v"(r) : "v"(rq), "v"(acc)); break;
+        case 1: asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(r) : "v"(rq), "v"(acc)); break;
+        case 2: asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(r) : "v"(rq), "v"(acc)); break;
+        default: asm("v_cvt_pk_u8_f32 %0, %1, 3, %2" : "=v"(r) : "v"(rq), "v"(acc)); break;
+    }
+    return r;
 }
 // GELU has ONE minimum, at x* = -0.75179...: decreasing on (-inf, x*], increasing on [x*, +inf). So the range of gelu over a set is
 // decided by three of its elements: the largest one (maximum, if positive) and the two nearest to x* from either side (minimum).
 // The range pass of the FFN tracks those three pre-activations (3 compares / selects per value instead of a GELU evaluation) and
 // gelu_range_finalize_kernel evaluates gelu_i8 on them: the values the quantising pass will produce for those very elements. Exact for
-// the function itself; for gelu_i8 (|error| <= 1.3e-7 |x|) the extremes found this way can differ from the extremes of the computed
+// the function itself; for gelu_i8 (|error| <= 1e-7 |x|) the extremes found this way can differ from the extremes of the computed
 // tensor by that approximation error at most -- a relative 1e-7 on the scale, below the approximation's own effect on the bytes.
 constexpr float GELU_ARGMIN = -0.7517915964f;
 // stats[0] = key of max{x <= x*} (atomicMax, 0 = none), stats[1] = key of min{x >= x*} (atomicMin, 0xFFFFFFFF = none), stats[2] = key of max x
@@ -515,14 +521,14 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                         x2.x = (float)(acc[4 * g + 2 * e2] + rz[2 * e2] - (ZW ? z4[2 * e2] * rsa : 0)) * ws[2 * e2] + b4[2 * e2];
                         x2.y = (float)(acc[4 * g + 2 * e2 + 1] + rz[2 * e2 + 1] - (ZW ? z4[2 * e2 + 1] * rsa : 0)) * ws[2 * e2 + 1] + b4[2 * e2 + 1];
                         const f32x2q v2 = gelu_i8x2(x2);
-                        // q = clip(rint(v / scale) + zp, 0, 255) with v / scale taken as v * (1 / scale): the two differ in the last place at most, which
+                        // q = saturate(rint(v / scale) + zp) with v / scale taken as v * (1 / scale): the two differ in the last place at most, which
                         // moves a byte only when v / scale sits within 1e-7 of a rounding boundary -- the size of gelu_i8's own error
-                        float q0 = __builtin_rintf(v2.x * o_inv) + o_zpf, q1 = __builtin_rintf(v2.y * o_inv) + o_zpf;
-                        q0 = fminf(fmaxf(q0, 0.0f), 255.0f); q1 = fminf(fmaxf(q1, 0.0f), 255.0f);
-                        const int i0 = (int)q0 - 128, i1 = (int)q1 - 128;
-                        ssum += i0 + i1;
-                        pk |= ((uint32_t)(i0 & 0xFF) | ((uint32_t)(i1 & 0xFF) << 8)) << (16 * e2);
+                        const float q0 = __builtin_rintf(v2.x * o_inv) + o_zpf, q1 = __builtin_rintf(v2.y * o_inv) + o_zpf;
+                        pk = pack_u8(pk, q0, 2 * e2);
+                        pk = pack_u8(pk, q1, 2 * e2 + 1);
+                        if (ZW) ssum += (int)fminf(fmaxf(q0, 0.0f), 255.0f) + (int)fminf(fmaxf(q1, 0.0f), 255.0f) - 256;      // row sums of the stored bytes: only with weight zero points
                     }
+                    pk ^= 0x80808080u;
                     const int c = nl >> 4;
                     *reinterpret_cast<uint32_t *>(ot + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;      // (32 + l31) & 7 == l31 & 7
                 }
