@@ -828,9 +828,10 @@ struct shodh_embedder {
     int8_t *HQ = nullptr;                // quantised GELU output [tok_cap][I] (fast INT8 path: the f32 intermediate never exists)
     int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
     bool need_rs = false;
-    uint32_t int8_stages = 0xF;          // bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
+    uint32_t int8_stages = 0x2F;         // bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
     uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][2]
+    uint32_t *qkv_hc = nullptr;          // [layers][heads][4][128] per-head constants of the fused q|k|v matrices (pack_head_consts_kernel)
     float *act_params = nullptr;         // {scale, zp} of the current activation tensor
     uint32_t *qscratch = nullptr;        // min/max keys, absmax
     int32_t *d_klen = nullptr, *d_orow = nullptr;   // padded mode: real tokens per computed sequence, output row of each computed sequence
@@ -1100,6 +1101,8 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     const size_t att_fused_lds = (size_t)nkb_max * 8192 + 4 * 2048;
     const uint32_t stages = shape_ok ? e->int8_stages : 0u;
     const bool fA = (stages & 1u) && att_fused_lds <= 160 * 1024, fB = stages & 2u, fC = stages & 4u, fD = stages & 8u;
+    // bit 5: q | k | v + attention per SEQUENCE (qkv_attn_seq_kernel: reads the f32 layer input and quantises it itself); needs the tokenizer's window
+    const bool fS = fA && (stages & 32u) && max_keys <= 128 && (int)e->cfg.max_len <= 256;
     if ((!fA && !QKV) || (!fC && !FF)) { set_error("INT8 encoder: this batch needs the round-2 kernels' buffers (keys per text %d); create the embedder with SHODH_INT8_STAGES=0", max_keys); return SHODH_ERR_UNSUPPORTED; }
     // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it, not from a pass of its own:
     // one pair of order keys per tensor of the forward, all initialised by one launch.
@@ -1118,12 +1121,23 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         uint32_t *mmC = e->mmr + 2 * (4 * li + 1), *mmX1 = e->mmr + 2 * (4 * li + 2), *mmF = e->mmr + 2 * (4 * li + 3), *mmXn = e->mmr + 2 * (4 * li + 4);
         const QWeight &wq = e->q_qkv[li], &wo = e->q_o[li], &wu = e->q_up[li], &wd = e->q_dn[li];
         // ---- A: q | k | v projections + attention
-        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));              // one quantisation feeds q, k and v (same tensor)
-        if (fA) {
+        if (fS) {
+            if (wq.zw) {
+                SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<true>, QS_LDS));
+                hipLaunchKernelGGL((qkv_attn_seq_kernel<true>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads);
+            } else {
+                SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<false>, QS_LDS));
+                hipLaunchKernelGGL((qkv_attn_seq_kernel<false>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads);
+            }
+        } else if (fA) {
+            SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));          // one quantisation feeds q, k and v (same tensor)
             const int blocks = ((nseq + 7) / 8) * 8 * heads;
             hipLaunchKernelGGL(qkv_attn_i8_kernel, dim3(blocks), dim3(256), att_fused_lds, st, (const int8_t *)e->XQ, (const int32_t *)e->rsX, (const uint32_t *)mmX, (const int8_t *)wq.qp,
                                (const float *)wq.scale, (const int32_t *)wq.rsz, (const int32_t *)wq.zw, bqkv, (const int32_t *)e->d_cu, klen, CTX, mmC, nseq, heads, H, nkb_max * 8192);
         } else {
+            SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));
             SHODH_TRY(gemm_i8<EPI8_BIAS>(e->XQ, wq, 0, 3 * H, e->act_params, bqkv, nullptr, QKV, nullptr, ntok, st, nullptr, e->rsX));
             hipLaunchKernelGGL((attention_kernel<float>), dim3(nseq * heads), dim3(128), att_lds, st, QKV, e->d_cu, CTX, H, heads, klen, mmC);
         }
@@ -1264,6 +1278,17 @@ static int finish_weights_int8(shodh_embedder *e) {
         SHODH_TRY(install_qweight_rows(e->q_dn[li], 0, H, exported(s0 + 12), e->w32 + l.dw, e->qscratch + 2));
         for (QWeight *q : {&e->q_qkv[li], &e->q_o[li], &e->q_up[li], &e->q_dn[li]}) { SHODH_TRY(finish_qweight(*q)); e->need_rs |= q->zw != nullptr; }
     }
+    {   // per-head constant blocks of the fused q|k|v matrices (the fused attention kernel fetches them with the head's weights)
+        const uint32_t heads = e->cfg.heads;
+        if (!e->qkv_hc) SHODH_HIP_TRY(hipMalloc((void **)&e->qkv_hc, (size_t)e->cfg.layers * heads * 512 * 4));
+        for (uint32_t li = 0; li < e->cfg.layers; ++li) {
+            const QWeight &q = e->q_qkv[li];
+            hipLaunchKernelGGL(pack_head_consts_kernel, dim3((uint32_t)ceil_div((size_t)heads * 512, 256)), dim3(256), 0, nullptr, (const float *)q.scale, (const int32_t *)q.rsz,
+                               (const float *)(e->bqkv + (size_t)li * 3 * H), (const int32_t *)q.zw, e->qkv_hc + (size_t)li * heads * 512, (int)heads, H);
+        }
+        SHODH_HIP_TRY(hipGetLastError());
+        SHODH_HIP_TRY(hipDeviceSynchronize());
+    }
     return SHODH_OK;
 }
 
@@ -1341,8 +1366,8 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     e->cfg = *cfg;
     if (cfg->weights_path) e->weights_path = cfg->weights_path;
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
-    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0xFu;       // speed only: which stages run the fused kernels
-    e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && e->int8_stages == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
+    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x3Fu;       // speed only: which stages run the fused kernels
+    e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);
     if (hipMalloc((void **)&e->w32, e->n_params * 4) != hipSuccess || hipMalloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
@@ -1376,7 +1401,7 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     hipFree(e->d_ids); hipFree(e->d_tok_seq); hipFree(e->d_tok_pos); hipFree(e->d_cu); hipFree(e->d_out);
     for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) for (auto &q : *v) free_qweight(q);
     hipFree(e->word_q); hipFree(e->word_scale); hipFree(e->XQ); hipFree(e->act_params); hipFree(e->qscratch); hipFree(e->d_klen); hipFree(e->d_orow);
-    hipFree(e->HQ); hipFree(e->rsX); hipFree(e->rsH); hipFree(e->mmr);
+    hipFree(e->HQ); hipFree(e->rsX); hipFree(e->rsH); hipFree(e->mmr); hipFree(e->qkv_hc);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);

@@ -346,6 +346,301 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_i8_kernel(const int8_t *__res
     }
 }
 
+// ---- q | k | v + attention, one workgroup per SEQUENCE (all heads) ---------------------------------------------------------------------
+// qkv_attn_i8_kernel above runs one workgroup per (sequence, head): every head fetches the sequence's quantised rows again (32 bytes per row and load
+// instruction: 32 cache lines per kilobyte) and its own weight fragments once per task; measured 1.8 ms per layer at 4096 padded texts, of which
+// ~0.7 ms is the load path. Here a workgroup of EIGHT waves keeps the sequence: wave w holds token block w as twelve int8 MFMA fragments in
+// registers for all heads -- quantised on the way in from the f32 layer input (DynamicQuantizeLinear with the tensor's range keys: the separate
+// quantising pass over X and its 0.4 GB of bytes are gone) -- and the head's three weight blocks (36 KiB, fragment-major) arrive in LDS by LDS-DMA,
+// double-buffered, shared by the eight waves. Per head: every wave projects Q for its block; waves 0-3 project K for key block w, waves 4-7 project
+// V^T for key block w - 4 (they keep that block's fragments too), both only for real keys; ONE barrier; then the attention of qkv_attn_i8_kernel
+// (same operand layouts, f16 hi/lo split products, f32 softmax). K / V fragments are double-buffered, so a head needs no second barrier.
+// Needs: hidden 384, 32-wide heads, <= 256 positions and <= 128 keys per sequence (the tokenizer's window, minilm.rs:112-117); other shapes take
+// the per-head kernel.
+constexpr int QS_WB = 36 * 1024;                          // one head's q | k | v weight fragments
+constexpr int QS_KV = 4 * 8192;                           // K / V fragments of up to 4 key blocks
+constexpr int QS_OFF_KV = 2 * QS_WB, QS_OFF_SCR = QS_OFF_KV + 2 * QS_KV, QS_OFF_C = QS_OFF_SCR + 8 * 2048, QS_CB = 4 * 128 * 4, QS_LDS = QS_OFF_C + 2 * QS_CB;
+// per-head constants of the fused q|k|v matrix as ONE 2 KiB block [scale | rowsum_w - K z | bias | z][128] (96 used: q, k, v features of the head), so that
+// they travel with the weights by LDS-DMA
+__global__ void pack_head_consts_kernel(const float *__restrict__ wscale, const int32_t *__restrict__ rsz, const float *__restrict__ bias, const int32_t *__restrict__ zw,
+                                        uint32_t *__restrict__ out, int heads, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * 512) return;
+    const int h = i >> 9, arr = (i >> 7) & 3, j = i & 127;
+    uint32_t v = 0;
+    if (j < 96) {
+        const int n = (j >> 5) * H + h * 32 + (j & 31);
+        if (arr == 0) v = __float_as_uint(wscale[n]); else if (arr == 1) v = (uint32_t)rsz[n]; else if (arr == 2) v = __float_as_uint(bias[n]); else v = zw ? (uint32_t)zw[n] : 0u;
+    }
+    out[i] = v;
+}
+template <bool ZW>
+__global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__restrict__ X /* f32 layer input [M][384] */, const uint32_t *__restrict__ mmA /* its range keys */,
+                                                              const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const uint32_t *__restrict__ hconsts /* pack_head_consts_kernel: [heads][4][128] */,
+                                                              const int32_t *__restrict__ cu, const int32_t *__restrict__ klen /* or null */, float *__restrict__ ctx,
+                                                              uint32_t *__restrict__ mm_out, int heads) {
+    constexpr int H = 384, KS = 12;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int seq = blockIdx.x;
+    const int t0 = cu[seq], P = cu[seq + 1] - t0;
+    const int S = klen ? klen[seq] : P;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkb = (S + 31) >> 5, nqb = (P + 31) >> 5;               // nkb <= 4, nqb <= 8 (launcher)
+    const ActQ ap = act_params(mmA);
+    const float a_scale = ap.scale, zpf = (float)ap.zp;
+    const int corr = 128 - ap.zp;
+    float omin = __builtin_inff(), omax = -__builtin_inff();      // range of this wave's outputs (order keys only at the very end)
+
+    // ---- the sequence's rows as int8 MFMA fragments: lane (token l31 of the block, half hi), step ks: bytes 32 ks + 16 hi .. + 16 of the row
+    auto load_block = [&](int blk, i32x4q (&xf)[KS], int &rowsum) {
+        int tok = blk * 32 + l31; if (tok >= P) tok = P - 1; if (tok < 0) tok = 0;
+        const f32x4q *xr = reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + tok) * H) + hi * 4;
+        int ssum = 0;
+        // round_half_even(x / scale) without a division per element, and still the operator's value: t = x * (1 / scale) is within 2 ulp of the
+        // quotient, so rint(t) can differ from rint(x / scale) only when t lies within 2 ulp of a half-integer -- tested per value (|(t + 1/2) -
+        // rint(t + 1/2)| <= 2^-21 |t|), and a 16-value group in which any lane of the wave sees such a value is redone with the division
+        // (about one group in a hundred). The division sequence costs ~14 issue slots per value, this 8; 192-384 values per lane and sequence.
+        const float r_scale = 1.0f / a_scale;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f32x4q v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = xr[ks * 8 + c];
+            float rq[16];
+            bool amb = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[c][e] * r_scale;
+                    const float u = t + 0.5f;
+                    amb = amb || __builtin_fabsf(u - __builtin_rintf(u)) <= 4.76837158e-07f * __builtin_fabsf(t);
+                    rq[4 * c + e] = __builtin_rintf(t) + zpf;
+                }
+            if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rq[4 * c + e] = __builtin_rintf(v[c][e] / a_scale) + zpf;
+            }
+            i32x4q fr;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pk = pack_u8(pk, rq[4 * c + e], e);
+                    if (ZW) ssum += (int)fminf(fmaxf(rq[4 * c + e], 0.0f), 255.0f) - 128;
+                }
+                fr[c] = (int)(pk ^ 0x80808080u);
+            }
+            xf[ks] = fr;
+        }
+        if (ZW) { ssum += __shfl_xor(ssum, 32); rowsum = ssum; }
+    };
+    i32x4q xf_own[KS], xf_aux[KS];
+    int rs_own = 0, rs_aux = 0;
+    load_block(wave, xf_own, rs_own);
+    const bool does_k = wave < 4 && wave < nkb, does_v = wave >= 4 && wave - 4 < nkb;      // wave-uniform
+    if (wave >= 4) load_block(wave - 4, xf_aux, rs_aux);
+
+    // ---- per-head constants and weights into LDS (double-buffered); head 0 now
+    const unsigned char *wg = reinterpret_cast<const unsigned char *>(Wp);
+    const unsigned char *cg = reinterpret_cast<const unsigned char *>(hconsts);
+    auto issue_head = [&](int h, int buf) {                // 38 pieces of 1 KiB: 36 weight fragments (piece i = which * 12 + ks) + the head's 2 KiB of constants; wave w issues pieces w, w + 8, ...
+#pragma unroll
+        for (int i0 = 0; i0 < 5; ++i0) {
+            const int i = i0 * 8 + wave;
+            if (i < 36) {
+                const int which = i / 12, ks = i % 12;
+                const unsigned char *src = uniform_ptr(wg + ((size_t)(which * 12 + h) * KS + ks) * 1024);
+                glds16(src, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (uint32_t)buf * QS_WB + (uint32_t)i * 1024u)));
+            } else if (i < 38) {
+                const unsigned char *src = uniform_ptr(cg + (size_t)h * QS_CB + (size_t)(i - 36) * 1024);
+                glds16(src, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (uint32_t)QS_OFF_C + (uint32_t)buf * QS_CB + (uint32_t)(i - 36) * 1024u)));
+            }
+        }
+    };
+    // Two buffers, two heads ahead: the weights of head h are needed by its projections only, so their buffer is free as soon as every wave has
+    // passed the head's barrier -- head h + 2 is requested right there and has a whole head (attention of h, projections of h + 1) to arrive.
+    // (Requested at the top of head h + 1 instead, it had only that head's projections, and every head stalled on it: 1.71 ms per layer.)
+    issue_head(0, 0);
+    if (heads > 1) issue_head(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float sc = 0.17677669529663688110f * 1.44269504088896340736f;      // 1/sqrt(32) * log2(e): softmax in base 2
+    unsigned char *scr = smem + QS_OFF_SCR + wave * 2048;
+    for (int h = 0; h < heads; ++h) {
+        const unsigned char *wb = smem + (h & 1) * QS_WB;
+        const float *cs = reinterpret_cast<const float *>(smem + QS_OFF_C + (h & 1) * QS_CB);
+        const int32_t *ci = reinterpret_cast<const int32_t *>(cs);
+        unsigned char *kv = smem + QS_OFF_KV + (h & 1) * QS_KV;
+        // ---- Q for this wave's token block: lane = query, registers = features f(r, hi)
+        f16x8q bqh[2], bql[2];
+        if (wave < nqb) {
+            i32x16l acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(wb + ks * 1024 + lane * 16), xf_own[ks], acc, 0, 0, 0);
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * hi;
+                const f32x4q ws = *reinterpret_cast<const f32x4q *>(cs + nl), b4 = *reinterpret_cast<const f32x4q *>(cs + 256 + nl);
+                const i32x4q rz = *reinterpret_cast<const i32x4q *>(ci + 128 + nl), z4 = *reinterpret_cast<const i32x4q *>(ci + 384 + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = ((float)(acc[4 * g + e] + __mul24(corr, rz[e]) - (ZW ? z4[e] * rs_own : 0)) * (a_scale * ws[e]) + b4[e]) * sc;
+            }
+            f16_split8(v, bqh[0], bql[0]);
+            f16_split8(v + 8, bqh[1], bql[1]);
+        }
+        // ---- K (waves 0-3: key block w) / V^T (waves 4-7: key block w - 4): fragments -> LDS
+        if (does_k) {
+            i32x16l acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(wb + (12 + ks) * 1024 + lane * 16), xf_own[ks], acc, 0, 0, 0);
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 32 + 8 * g + 4 * hi;
+                const f32x4q ws = *reinterpret_cast<const f32x4q *>(cs + nl), b4 = *reinterpret_cast<const f32x4q *>(cs + 256 + nl);
+                const i32x4q rz = *reinterpret_cast<const i32x4q *>(ci + 128 + nl), z4 = *reinterpret_cast<const i32x4q *>(ci + 384 + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = (float)(acc[4 * g + e] + __mul24(corr, rz[e]) - (ZW ? z4[e] * rs_own : 0)) * (a_scale * ws[e]) + b4[e];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8q fh, fl;
+                f16_split8(v + 8 * s2, fh, fl);
+                unsigned char *dst = kv + (size_t)((wave * 2 + 0) * 2 + s2) * 2048 + lane * 16;
+                *reinterpret_cast<f16x8q *>(dst) = fh;
+                *reinterpret_cast<f16x8q *>(dst + 1024) = fl;
+            }
+        }
+        if (does_v) {                                     // operands swapped: lane = feature d, registers = keys f(r, hi) of the block
+            const int kb = wave - 4;
+            i32x16l acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf_aux[ks], *reinterpret_cast<const i32x4q *>(wb + (24 + ks) * 1024 + lane * 16), acc, 0, 0, 0);
+            const float ws1 = a_scale * cs[64 + l31], b1 = cs[256 + 64 + l31];
+            const int rz1 = __mul24(corr, ci[128 + 64 + l31]), z1 = ci[384 + 64 + l31];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;           // token of the block whose value register r holds
+                const int rsa = ZW ? __shfl(rs_aux, tl) : 0;               // (lane tl of this wave holds that token's row sum)
+                v[r] = (float)(acc[r] + rz1 - (ZW ? z1 * rsa : 0)) * ws1 + b1;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8q fh, fl;
+                f16_split8(v + 8 * s2, fh, fl);
+                unsigned char *dst = kv + (size_t)((kb * 2 + 1) * 2 + s2) * 2048 + lane * 16;
+                *reinterpret_cast<f16x8q *>(dst) = fh;
+                *reinterpret_cast<f16x8q *>(dst + 1024) = fl;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next head (requested a head ago) and its stores
+        __syncthreads();
+        if (h + 2 < heads) issue_head(h + 2, h & 1);
+        // ---- attention of this wave's query block over the real keys
+        if (wave < nqb) {
+            const int q = wave * 32 + l31;
+            f32x16q o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+            float mx = -3.0e38f, l = 0.0f;
+            for (int kb = 0; kb < nkb; ++kb) {
+                f32x16q st;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+                const unsigned char *kf = kv + (size_t)(kb * 2) * 4096 + lane * 16;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f16x8q kh = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048), kl = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048 + 1024);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bqh[s2], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bql[s2], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, bqh[s2], st, 0, 0, 0);
+                }
+                float bm = -3.0e38f;
+                if (kb == nkb - 1) {                         // only the last key block can hold masked keys
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        st[r] = key < S ? st[r] : -3.0e38f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bm = fmaxf(bm, st[r]);
+                bm = fmaxf(bm, __shfl_xor(bm, 32));
+                const float mn = fmaxf(mx, bm);
+                const float cf = __builtin_amdgcn_exp2f(mx - mn);
+                float ps = 0.0f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(st[r] - mn); ps += pv[r]; }
+                ps += __shfl_xor(ps, 32);
+                l = l * cf + ps;
+                mx = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] *= cf;
+                const unsigned char *vf = kv + (size_t)(kb * 2 + 1) * 4096 + lane * 16;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f16x8q ph, pl;
+                    f16_split8(pv + 8 * s2, ph, pl);
+                    const f16x8q vh = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048), vl = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048 + 1024);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+                }
+            }
+            const float invl = 1.0f / l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[r] *= invl;
+                if (q < P) { omin = fminf(omin, o[r]); omax = fmaxf(omax, o[r]); }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((l31 >> 4) == half) {
+                    const int tl = l31 & 15;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4q ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = o[4 * g + e];
+                        *reinterpret_cast<f32x4q *>(scr + tl * 128 + (((2 * g + hi) ^ (tl & 7)) << 4)) = ov;
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int tl = hh * 8 + (lane >> 3), ch = lane & 7;
+                    const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                    const int qt = wave * 32 + half * 16 + tl;
+                    if (qt < P) *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + qt) * H + h * 32 + ch * 4) = v4;
+                }
+            }
+        }
+    }
+    if (mm_out) {
+        uint32_t klo = omin <= omax ? order_key(omin) : 0xFFFFFFFFu, khi = omin <= omax ? order_key(omax) : 0u;
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
+        if (lane == 0) {
+            if (klo < __atomic_load_n(mm_out, __ATOMIC_RELAXED)) atomicMin(mm_out, klo);
+            if (khi > __atomic_load_n(mm_out + 1, __ATOMIC_RELAXED)) atomicMax(mm_out + 1, khi);
+        }
+    }
+}
+
 // ---- weight-stationary int8 GEMM, K = 384, 384 output features per workgroup ---------------------------------------------------
 constexpr int S8_TR = 64, S8_PITCH = 384, S8_TILE = S8_TR * S8_PITCH, S8_NBUF = 3, S8_KS = 12, S8_NT = 768, S8_NPC = 6, S8_NF = 384;
 constexpr int S8_CONST = S8_NBUF * S8_TILE;               // wscale | rsz | bias | zw | gamma | beta: 6 x 384 x 4 B

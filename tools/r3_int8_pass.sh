@@ -5,7 +5,7 @@ cd $ROOT
 timeout 900 python -m pytest tests/test_encoder_int8_gpu.py -x -q -s 2>&1 | tail -60 > $OUT/r3_int8_tests.txt
 tail -25 $OUT/r3_int8_tests.txt
 cd /tmp && export TMPDIR=/tmp
-for ST in 15 0; do
+for ST in 47 15 0; do
   SHODH_INT8_STAGES=$ST timeout 300 python $ROOT/tools/enc_bench.py int8 > $OUT/r3_encoder_int8_line_st$ST.json 2>$OUT/r3_enc_st$ST.err; cat $OUT/r3_encoder_int8_line_st$ST.json
 done
 rm -rf /tmp/pe8; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe8 -- python $ROOT/tools/enc_bench.py int8 > $OUT/r3_encoder_int8_line.json 2>/dev/null
