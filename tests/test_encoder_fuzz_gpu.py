@@ -48,3 +48,45 @@ def test_random_encoder_batches(S):
             cos = (a[~empty] * r[~empty]).sum(1)
             assert cos.min() >= 0.999, (rnd, float(cos.min()), int(np.argmin(cos)))
             assert np.allclose(np.linalg.norm(a[~empty], axis=1), 1.0, atol=2e-3)
+
+
+def test_random_int8_batches_fused_layer_vs_round2_kernels(S, monkeypatch):
+    """The fused INT8 layer (per-sequence q|k|v + attention with in-kernel quantisation, streaming GEMMs with LayerNorm / GELU epilogues, K-tiled FFN
+    down) against the round-2 kernels (SHODH_INT8_STAGES=0) on random batches: batch sizes around the tile sizes, lengths incl. empty / one token /
+    the full window (exactly 4 key blocks), padded and unpadded tensors. Same function, so cosine >= 0.9999 per text (the difference is f32
+    reassociation inside a stage and the f16-split attention products), zero vectors for empty texts, bit-identical repeats."""
+    from shodh_memory_amd import _lib as L
+    rounds = int(os.environ.get("SHODH_FUZZ_ROUNDS", "6"))
+    rng = np.random.default_rng(int(os.environ.get("SHODH_FUZZ_SEED", "424242")))
+    ML = 256
+    for rnd in range(rounds):
+        padded = bool(rng.integers(0, 2))
+        monkeypatch.delenv("SHODH_INT8_STAGES", raising=False)
+        fused = S.MiniLMEmbedder(synthetic_seed=7 + rnd, dtype=L.DTYPE_INT8, compute_padded=padded)
+        monkeypatch.setenv("SHODH_INT8_STAGES", "0")
+        old = S.MiniLMEmbedder(synthetic_seed=7 + rnd, dtype=L.DTYPE_INT8, compute_padded=padded)
+        b = int(rng.choice([1, 2, 3, 7, 31, 64, 65, 200]))
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            lens = rng.integers(0, 129, b)
+        elif mode == 1:
+            lens = np.full(b, int(rng.choice([1, 2, 31, 32, 33, 96, 97, 127, 128])))
+        elif mode == 2:
+            lens = rng.choice([0, 1, 128], b)
+        else:
+            lens = rng.integers(1, 20, b)
+        print("int8 fuzz round %d: batch %d mode %d padded %s tokens %d" % (rnd, b, mode, padded, int(lens.sum())), flush=True)
+        ids = np.zeros((b, ML), np.int32); mask = np.zeros((b, ML), np.uint8)
+        for i, n in enumerate(lens):
+            ids[i, :n] = rng.integers(1000, 30522, n); mask[i, :n] = 1
+        a = fused.encode_ids(ids, mask)
+        a2 = fused.encode_ids(ids, mask)
+        r = old.encode_ids(ids, mask)
+        fused.close(); old.close()
+        assert a.tobytes() == a2.tobytes() and np.isfinite(a).all()
+        empty = lens == 0
+        assert (a[empty] == 0).all() and (r[empty] == 0).all()
+        if (~empty).any():
+            cos = (a[~empty] * r[~empty]).sum(1)
+            assert cos.min() >= 0.9999, (rnd, float(cos.min()), int(np.argmin(cos)))
+            assert np.allclose(np.linalg.norm(a[~empty], axis=1), 1.0, atol=2e-3)
