@@ -16,6 +16,7 @@
 // Weight zero points are general (per tensor or per output channel, any value): with a' = a - 128, w' the signed storage and
 // z[n] its zero point, sum_k (a - a_zp)(w' - z[n]) = sum a'w' + c * (rowsum_w[n] - K z[n]) - z[n] * rowsum_a[m],  c = 128 - a_zp.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "glds.h"
 #include "encoder_int8.h"
@@ -139,9 +140,43 @@ __global__ __launch_bounds__(256) void act_quant_rows_kernel(const float *__rest
 
 // x = hi + lo with hi = f16(x), lo = f16(x - hi): |x - (hi + lo)| <= 2^-22 |x| (+ 2^-25 absolute where lo is subnormal), so
 // a.b ~ ah.bh + ah.bl + al.bh drops only al.bl: relative error <= 2^-21 per product, f32 accumulation in the MFMA as for any f32 dot.
+// Three instructions per pair of values: v_cvt_pk_f16_f32 for the hi parts, then v_fma_mixlo_f16 / v_fma_mixhi_f16 compute x * 1.0 - hi with the hi
+// part read as the f16 it is and write the f16 result: x - hi is exact in f32 (hi is x rounded to 11 bits), so the one rounding is the f16 one --
+// the same values as (f16)(x - (float)hi), which costs six (two conversions back, two subtractions, one more pack). tools/ubench/mix_split_probe.hip
+// compares the two forms bit for bit. ONE asm block per eight values, closed by a wait state: v_fma_mixhi_f16 writes half a register, and on this
+// chip a VALU / MFMA instruction that reads such a register in the very next slot gets the old half (the compiler pads this hazard for its own
+// instructions, it cannot see into an asm block -- found as one wrong text in the fixture test when the split sat right in front of an MFMA).
+__device__ __forceinline__ void f16_split_asm(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, f16x8q &h, f16x8q &l) {
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s hh, ll;
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
+        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
+        "v_fma_mixlo_f16 %4, %8, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %5, %10, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %6, %12, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %14, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %4, %9, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %5, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %13, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %15, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+    hh[0] = h0; hh[1] = h1; hh[2] = h2; hh[3] = h3; ll[0] = l0; ll[1] = l1; ll[2] = l2; ll[3] = l3;
+    h = __builtin_bit_cast(f16x8q, hh);
+    l = __builtin_bit_cast(f16x8q, ll);
+}
+// (the per-head kernel, at 128 registers, keeps the plain form)
 __device__ __forceinline__ void f16_split8(const float *v, f16x8q &h, f16x8q &l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const _Float16 a = (_Float16)v[j]; h[j] = a; l[j] = (_Float16)(v[j] - (float)a); }
+}
+// the same for four PAIRS of values (the callers keep their arithmetic on the packed-FP32 pipe: a pair is a 64-bit register pair)
+__device__ __forceinline__ void f16_split8p(const f32x2q *v2, f16x8q &h, f16x8q &l) {
+    f16_split_asm(v2[0][0], v2[0][1], v2[1][0], v2[1][1], v2[2][0], v2[2][1], v2[3][0], v2[3][1], h, l);
 }
 
 // ---- fused Q/K/V projection + attention --------------------------------------------------------------------------------------
@@ -374,6 +409,15 @@ __global__ void pack_head_consts_kernel(const float *__restrict__ wscale, const 
     }
     out[i] = v;
 }
+#ifdef SHODH_PROF
+#define QPROF_DECL long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64(); const long long t00_ = tq_, w00_ = wall_clock64();
+#define QPROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
+#define QPROF_END if (lane == 0 && (blockIdx.x == 7 || blockIdx.x == 2049) ) printf("seqprof blk %d wave %d P %d S %d wall100MHz %lld total %lld : load %lld aux %lld w0 %lld | Q %lld KV %lld vmwait %lld bar %lld issue %lld att %lld out %lld\n", (int)blockIdx.x, wave, P, S, wall_clock64() - w00_, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], pt_[6], pt_[7], pt_[8], pt_[9]);
+#else
+#define QPROF_DECL
+#define QPROF_T(i)
+#define QPROF_END
+#endif
 template <bool ZW>
 __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__restrict__ X /* f32 layer input [M][384] */, const uint32_t *__restrict__ mmA /* its range keys */,
                                                               const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const uint32_t *__restrict__ hconsts /* pack_head_consts_kernel: [heads][4][128] */,
@@ -392,61 +436,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
     const float a_scale = ap.scale, zpf = (float)ap.zp;
     const int corr = 128 - ap.zp;
     float omin = __builtin_inff(), omax = -__builtin_inff();      // range of this wave's outputs (order keys only at the very end)
+    QPROF_DECL
 
-    // ---- the sequence's rows as int8 MFMA fragments: lane (token l31 of the block, half hi), step ks: bytes 32 ks + 16 hi .. + 16 of the row
-    auto load_block = [&](int blk, i32x4q (&xf)[KS], int &rowsum) {
-        int tok = blk * 32 + l31; if (tok >= P) tok = P - 1; if (tok < 0) tok = 0;
-        const f32x4q *xr = reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + tok) * H) + hi * 4;
-        int ssum = 0;
-        // round_half_even(x / scale) without a division per element, and still the operator's value: t = x * (1 / scale) is within 2 ulp of the
-        // quotient, so rint(t) can differ from rint(x / scale) only when t lies within 2 ulp of a half-integer -- tested per value (|(t + 1/2) -
-        // rint(t + 1/2)| <= 2^-21 |t|), and a 16-value group in which any lane of the wave sees such a value is redone with the division
-        // (about one group in a hundred). The division sequence costs ~14 issue slots per value, this 8; 192-384 values per lane and sequence.
-        const float r_scale = 1.0f / a_scale;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            f32x4q v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = xr[ks * 8 + c];
-            float rq[16];
-            bool amb = false;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = v[c][e] * r_scale;
-                    const float u = t + 0.5f;
-                    amb = amb || __builtin_fabsf(u - __builtin_rintf(u)) <= 4.76837158e-07f * __builtin_fabsf(t);
-                    rq[4 * c + e] = __builtin_rintf(t) + zpf;
-                }
-            if (__builtin_amdgcn_ballot_w64(amb) != 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rq[4 * c + e] = __builtin_rintf(v[c][e] / a_scale) + zpf;
-            }
-            i32x4q fr;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint32_t pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pk = pack_u8(pk, rq[4 * c + e], e);
-                    if (ZW) ssum += (int)fminf(fmaxf(rq[4 * c + e], 0.0f), 255.0f) - 128;
-                }
-                fr[c] = (int)(pk ^ 0x80808080u);
-            }
-            xf[ks] = fr;
-        }
-        if (ZW) { ssum += __shfl_xor(ssum, 32); rowsum = ssum; }
-    };
-    i32x4q xf_own[KS], xf_aux[KS];
-    int rs_own = 0, rs_aux = 0;
-    load_block(wave, xf_own, rs_own);
-    const bool does_k = wave < 4 && wave < nkb, does_v = wave >= 4 && wave - 4 < nkb;      // wave-uniform
-    if (wave >= 4) load_block(wave - 4, xf_aux, rs_aux);
-
-    // ---- per-head constants and weights into LDS (double-buffered); head 0 now
+    // ---- per-head constants and weights into LDS (double-buffered); heads 0 and 1 are requested before the rows are fetched
     const unsigned char *wg = reinterpret_cast<const unsigned char *>(Wp);
     const unsigned char *cg = reinterpret_cast<const unsigned char *>(hconsts);
     auto issue_head = [&](int h, int buf) {                // 38 pieces of 1 KiB: 36 weight fragments (piece i = which * 12 + ks) + the head's 2 KiB of constants; wave w issues pieces w, w + 8, ...
@@ -468,11 +460,144 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
     // (Requested at the top of head h + 1 instead, it had only that head's projections, and every head stalled on it: 1.71 ms per layer.)
     issue_head(0, 0);
     if (heads > 1) issue_head(1, 1);
+
+    // ---- this wave's token block as int8 MFMA fragments: lane (token l31 of the block, half hi), step ks: bytes 32 ks + 16 hi .. + 16 of the row.
+    // A workgroup is alone on its CU (LDS) and its eight waves are all it has to cover the latency of HBM, so the block is fetched the way memory likes
+    // it and reshaped on chip: a half block (16 rows = 24 KiB of f32, contiguous) arrives as 24 fully coalesced 1-KiB requests per wave, all 48 of a
+    // block in flight at once; every lane quantises the 16-byte pieces it happens to hold (DynamicQuantizeLinear is elementwise) and drops the four
+    // bytes into a row-major staging block in LDS (16-byte chunks XOR-swizzled by row & 7: the fragment reads below are conflict-free), from which
+    // the lanes take their fragments. (s_memtime, per sequence of 180 000 cycles: fetching with lane = row -- 64 separate 16-byte requests per
+    // instruction -- took 31 000 cycles for one block and as much again for the second block waves 4-7 then needed; 33 000 with the requests
+    // batched; this form ...) Waves 0-3 keep their staged block: it is where the V^T tasks below find another wave's rows.
+    i32x4q xf_own[KS], xf_aux[KS];
+    int rs_own = 0, rs_aux = 0;
+    unsigned char *xch = smem + QS_OFF_KV + QS_KV;                               // staged blocks 0-3, 12 KiB each: the second K / V buffer and the scratch behind it (free until the first head's barrier)
+    if (wave < nqb) {
+        // round_half_even(x / scale) without a division per element, and still the operator's value: t = x * fl(1 / scale) and fl(x / scale) both lie
+        // within 1.5 * 2^-23 |t| of each other (two roundings against one), so rint(t) can differ from rint(fl(x / scale)) only when t lies that close
+        // to a half-integer. |t| <= 255 for every value of the tensor whose range defines the scale, so the test is |t - rint(t)| >= 1/2 - 2^-14
+        // (2^-22 * 256: a third more than needed) on the largest residual of a lane's sixteen values (v_max3 with |.| modifiers: half an issue slot
+        // per value), and a 16-value group in which any lane of the wave sees such a value is redone with the division (about one group in nine).
+        // The division sequence costs ~14 issue slots per value, this ~4; 192 values per lane and sequence.
+        const float r_scale = 1.0f / a_scale;
+        unsigned char *stg = wave < 4 ? xch + wave * 12288 : smem + QS_OFF_KV + (wave - 4) * 6144;      // waves 4-7: 6 KiB of the first K / V buffer, used for both halves
+        const int half_step = wave < 4 ? 6144 : 0;
+        f32x4q va[24], vb[24];
+        auto fetch = [&](f32x4q (&v)[24], int hf) {
+            const int row0 = wave * 32 + hf * 16;
+            if (row0 + 16 <= P) {                              // wave-uniform: the half block is one contiguous span
+                const f32x4q *bp = reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + row0) * H) + lane;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) v[i] = bp[i * 64];
+            } else {                                           // rows past the sequence's end repeat its last row (their results are never used)
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;
+                    if (pc >= 96) { pc -= 96; row += 1; }
+                    int tok = row0 + row; if (tok >= P) tok = P - 1; if (tok < 0) tok = 0;
+                    v[i] = *(reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + tok) * H) + pc);
+                }
+            }
+        };
+        auto stage = [&](const f32x4q (&v)[24], int hf) {
+            unsigned char *dst = stg + hf * half_step;
+#pragma unroll
+            for (int i4 = 0; i4 < 6; ++i4) {
+                float rq[16];
+                float dm = 0.0f;                                // largest |t - rint(t)| of the lane's sixteen values
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {            // two values at a time: the multiply, the residual and the zero-point add run on the packed-FP32 pipe
+                        f32x2q x2; x2[0] = v[4 * i4 + c][2 * e2]; x2[1] = v[4 * i4 + c][2 * e2 + 1];
+                        const f32x2q t2 = x2 * r_scale;
+                        f32x2q q2; q2[0] = __builtin_rintf(t2[0]); q2[1] = __builtin_rintf(t2[1]);
+                        const f32x2q d2 = t2 - q2;
+                        dm = __builtin_fmaxf(__builtin_fmaxf(dm, __builtin_fabsf(d2[0])), __builtin_fabsf(d2[1]));
+                        const f32x2q r2 = q2 + zpf;
+                        rq[4 * c + 2 * e2] = r2[0]; rq[4 * c + 2 * e2 + 1] = r2[1];
+                    }
+                const bool amb = dm >= 0.5f - 6.103515625e-05f;    // within 2^-22 * 256 >= 2^-22 |t| of a half-integer
+                if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rq[4 * c + e] = __builtin_rintf(v[4 * i4 + c][e] / a_scale) + zpf;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = 4 * i4 + c;
+                    int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;          // piece pc (4 values -> 4 bytes) of row `row` of the half
+                    if (pc >= 96) { pc -= 96; row += 1; }
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk = pack_u8(pk, rq[4 * c + e], e);           // saturating: the operator's clamp to [0, 255]
+                    *reinterpret_cast<uint32_t *>(dst + row * 384 + (((pc >> 2) ^ (row & 7)) << 4) + ((pc & 3) << 2)) = pk ^ 0x80808080u;
+                }
+            }
+            if ((l31 >> 4) == hf) {                            // the lanes whose token lies in this half take their fragments
+                const unsigned char *src = dst + (l31 & 15) * 384;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xf_own[ks] = *reinterpret_cast<const i32x4q *>(src + (((2 * ks + hi) ^ (l31 & 7)) << 4));
+            }
+        };
+        fetch(va, 0);
+        fetch(vb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(va, 0);
+        stage(vb, 1);
+        if (ZW) {                                              // row sums of the stored bytes a - 128
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rs_own = __builtin_amdgcn_sdot4(xf_own[ks][c], 0x01010101, rs_own, false);
+            rs_own += __shfl_xor(rs_own, 32);
+        }
+    }
+    QPROF_T(0)
+    // K / V^T tasks of a head: task t < nkb = K of key block t, task nkb + kb = V^T of key block kb; wave t takes task t, so that up to four tasks
+    // land on four different SIMDs (waves w and w + 4 share one). K of block w uses the wave's own fragments; V^T of block w - nkb reads that
+    // block's staged rows.
+    const bool does_k = wave < nkb, does_v = wave >= nkb && wave < 2 * nkb;      // wave-uniform
+    const int vkb = wave - nkb;
+    QPROF_T(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (does_v) {
+        const unsigned char *src = xch + (size_t)vkb * 12288 + l31 * 384;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xf_aux[ks] = *reinterpret_cast<const i32x4q *>(src + (((2 * ks + hi) ^ (l31 & 7)) << 4));
+            if (ZW) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rs_aux = __builtin_amdgcn_sdot4(xf_aux[ks][c], 0x01010101, rs_aux, false);
+            }
+        }
+        if (ZW) rs_aux += __shfl_xor(rs_aux, 32);
+    }
+    QPROF_T(2)
 
     const float sc = 0.17677669529663688110f * 1.44269504088896340736f;      // 1/sqrt(32) * log2(e): softmax in base 2
-    unsigned char *scr = smem + QS_OFF_SCR + wave * 2048;
+    // float(acc + (128 - a_zp) (rowsum_w - K z) - z rowsum_a) * (a_scale * w_scale) + bias for the sixteen features f(r, hi) of a 32-feature block starting at
+    // constant slot nb0, two at a time on the packed-FP32 pipe (the operations and their order are those of the scalar form)
+    auto dequant_rows = [&](const i32x16l &acc, int nb0, const float *cs, const int32_t *ci, f32x2q (&v2)[8]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = nb0 + 8 * g + 4 * hi;
+            const f32x4q ws = *reinterpret_cast<const f32x4q *>(cs + nl), b4 = *reinterpret_cast<const f32x4q *>(cs + 256 + nl);
+            const i32x4q rz = *reinterpret_cast<const i32x4q *>(ci + 128 + nl), z4 = *reinterpret_cast<const i32x4q *>(ci + 384 + nl);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                f32x2q f, w, b;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    f[e] = (float)(acc[4 * g + 2 * e2 + e] + __mul24(corr, rz[2 * e2 + e]) - (ZW ? z4[2 * e2 + e] * rs_own : 0));
+                    w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e];
+                }
+                v2[2 * g + e2] = f * (w * a_scale) + b;
+            }
+        }
+    };
     for (int h = 0; h < heads; ++h) {
         const unsigned char *wb = smem + (h & 1) * QS_WB;
         const float *cs = reinterpret_cast<const float *>(smem + QS_OFF_C + (h & 1) * QS_CB);
@@ -486,45 +611,34 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
             for (int r = 0; r < 16; ++r) acc[r] = 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(wb + ks * 1024 + lane * 16), xf_own[ks], acc, 0, 0, 0);
-            float v[16];
+            f32x2q v2[8];
+            dequant_rows(acc, 0, cs, ci, v2);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = 8 * g + 4 * hi;
-                const f32x4q ws = *reinterpret_cast<const f32x4q *>(cs + nl), b4 = *reinterpret_cast<const f32x4q *>(cs + 256 + nl);
-                const i32x4q rz = *reinterpret_cast<const i32x4q *>(ci + 128 + nl), z4 = *reinterpret_cast<const i32x4q *>(ci + 384 + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = ((float)(acc[4 * g + e] + __mul24(corr, rz[e]) - (ZW ? z4[e] * rs_own : 0)) * (a_scale * ws[e]) + b4[e]) * sc;
-            }
-            f16_split8(v, bqh[0], bql[0]);
-            f16_split8(v + 8, bqh[1], bql[1]);
+            for (int j = 0; j < 8; ++j) v2[j] = v2[j] * sc;
+            f16_split8p(v2, bqh[0], bql[0]);
+            f16_split8p(v2 + 4, bqh[1], bql[1]);
         }
-        // ---- K (waves 0-3: key block w) / V^T (waves 4-7: key block w - 4): fragments -> LDS
+        QPROF_T(3)
+        // ---- K (task waves 0 .. nkb-1: key block w) / V^T (task waves nkb .. 2 nkb-1: key block w - nkb): fragments -> LDS
         if (does_k) {
             i32x16l acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(wb + (12 + ks) * 1024 + lane * 16), xf_own[ks], acc, 0, 0, 0);
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = 32 + 8 * g + 4 * hi;
-                const f32x4q ws = *reinterpret_cast<const f32x4q *>(cs + nl), b4 = *reinterpret_cast<const f32x4q *>(cs + 256 + nl);
-                const i32x4q rz = *reinterpret_cast<const i32x4q *>(ci + 128 + nl), z4 = *reinterpret_cast<const i32x4q *>(ci + 384 + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = (float)(acc[4 * g + e] + __mul24(corr, rz[e]) - (ZW ? z4[e] * rs_own : 0)) * (a_scale * ws[e]) + b4[e];
-            }
+            f32x2q v2[8];
+            dequant_rows(acc, 32, cs, ci, v2);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 f16x8q fh, fl;
-                f16_split8(v + 8 * s2, fh, fl);
+                f16_split8p(v2 + 4 * s2, fh, fl);
                 unsigned char *dst = kv + (size_t)((wave * 2 + 0) * 2 + s2) * 2048 + lane * 16;
                 *reinterpret_cast<f16x8q *>(dst) = fh;
                 *reinterpret_cast<f16x8q *>(dst + 1024) = fl;
             }
         }
         if (does_v) {                                     // operands swapped: lane = feature d, registers = keys f(r, hi) of the block
-            const int kb = wave - 4;
+            const int kb = vkb;
             i32x16l acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0;
@@ -532,105 +646,143 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf_aux[ks], *reinterpret_cast<const i32x4q *>(wb + (24 + ks) * 1024 + lane * 16), acc, 0, 0, 0);
             const float ws1 = a_scale * cs[64 + l31], b1 = cs[256 + 64 + l31];
             const int rz1 = __mul24(corr, ci[128 + 64 + l31]), z1 = ci[384 + 64 + l31];
-            float v[16];
+            f32x2q v2[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;           // token of the block whose value register r holds
-                const int rsa = ZW ? __shfl(rs_aux, tl) : 0;               // (lane tl of this wave holds that token's row sum)
-                v[r] = (float)(acc[r] + rz1 - (ZW ? z1 * rsa : 0)) * ws1 + b1;
+            for (int j = 0; j < 8; ++j) {
+                f32x2q f;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * j + e;
+                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;       // token of the block whose value register r holds
+                    const int rsa = ZW ? __shfl(rs_aux, tl) : 0;           // (lane tl of this wave holds that token's row sum)
+                    f[e] = (float)(acc[r] + rz1 - (ZW ? z1 * rsa : 0));
+                }
+                v2[j] = f * ws1 + b1;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 f16x8q fh, fl;
-                f16_split8(v + 8 * s2, fh, fl);
+                f16_split8p(v2 + 4 * s2, fh, fl);
                 unsigned char *dst = kv + (size_t)((kb * 2 + 1) * 2 + s2) * 2048 + lane * 16;
                 *reinterpret_cast<f16x8q *>(dst) = fh;
                 *reinterpret_cast<f16x8q *>(dst + 1024) = fl;
             }
         }
+        QPROF_T(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next head (requested a head ago) and its stores
+        QPROF_T(5)
         __syncthreads();
+        QPROF_T(6)
         if (h + 2 < heads) issue_head(h + 2, h & 1);
-        // ---- attention of this wave's query block over the real keys
+        QPROF_T(7)
+        // ---- attention of this wave's query block over the real keys. A sequence has at most four key blocks, so the softmax is taken in one piece:
+        // all score blocks first (independent accumulators, their MFMAs interleaved so that no product waits for the previous one), one maximum, one
+        // pass of exponentials, then P V on two accumulators. (Block after block with a running maximum, every product chain was dependent and every
+        // block paid a rescale of the output: 1 700 cycles per key block against ~1 200 here.)
         if (wave < nqb) {
             const int q = wave * 32 + l31;
-            f32x16q o;
+            f32x16q o, o2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-            float mx = -3.0e38f, l = 0.0f;
-            for (int kb = 0; kb < nkb; ++kb) {
-                f32x16q st;
+            for (int r = 0; r < 16; ++r) { o[r] = 0.0f; o2[r] = 0.0f; }
+            float l = 0.0f;
+            auto attend = [&](auto nk_c) {
+                constexpr int NK = decltype(nk_c)::value;
+                f32x16q st[NK];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[r] = 0.0f;
-                const unsigned char *kf = kv + (size_t)(kb * 2) * 4096 + lane * 16;
+                for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kb][r] = 0.0f;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const f16x8q kh = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048), kl = *reinterpret_cast<const f16x8q *>(kf + s2 * 2048 + 1024);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bqh[s2], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bql[s2], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, bqh[s2], st, 0, 0, 0);
-                }
-                float bm = -3.0e38f;
-                if (kb == nkb - 1) {                         // only the last key block can hold masked keys
+                    f16x8q kh[NK], kl[NK];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        st[r] = key < S ? st[r] : -3.0e38f;
+                    for (int kb = 0; kb < NK; ++kb) {
+                        const unsigned char *kf = kv + (size_t)(kb * 2) * 4096 + lane * 16 + s2 * 2048;
+                        kh[kb] = *reinterpret_cast<const f16x8q *>(kf); kl[kb] = *reinterpret_cast<const f16x8q *>(kf + 1024);
                     }
+#pragma unroll
+                    for (int kb = 0; kb < NK; ++kb) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kb], bqh[s2], st[kb], 0, 0, 0);
+#pragma unroll
+                    for (int kb = 0; kb < NK; ++kb) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kb], bql[s2], st[kb], 0, 0, 0);
+#pragma unroll
+                    for (int kb = 0; kb < NK; ++kb) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[kb], bqh[s2], st[kb], 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bm = fmaxf(bm, st[r]);
-                bm = fmaxf(bm, __shfl_xor(bm, 32));
-                const float mn = fmaxf(mx, bm);
-                const float cf = __builtin_amdgcn_exp2f(mx - mn);
-                float ps = 0.0f;
-                float pv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(st[r] - mn); ps += pv[r]; }
-                ps += __shfl_xor(ps, 32);
-                l = l * cf + ps;
-                mx = mn;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] *= cf;
-                const unsigned char *vf = kv + (size_t)(kb * 2 + 1) * 4096 + lane * 16;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    f16x8q ph, pl;
-                    f16_split8(pv + 8 * s2, ph, pl);
-                    const f16x8q vh = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048), vl = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048 + 1024);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {                  // only the last key block can hold masked keys
+                    const int key = (NK - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    st[NK - 1][r] = key < S ? st[NK - 1][r] : -3.0e38f;
                 }
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                f32x2q ps2 = 0.0f;                             // (subtraction and row sum two values at a time; v_exp_f32 has no packed form)
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        f32x2q d2; d2[0] = st[kb][2 * j]; d2[1] = st[kb][2 * j + 1];
+                        d2 = d2 - mx;
+                        f32x2q e2; e2[0] = __builtin_amdgcn_exp2f(d2[0]); e2[1] = __builtin_amdgcn_exp2f(d2[1]);
+                        ps2 = ps2 + e2;
+                        st[kb][2 * j] = e2[0]; st[kb][2 * j + 1] = e2[1];
+                    }
+                const float ps = ps2[0] + ps2[1];
+                l = ps + __shfl_xor(ps, 32);
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) {
+                    const unsigned char *vf = kv + (size_t)(kb * 2 + 1) * 4096 + lane * 16;
+                    f32x2q p2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { p2[j][0] = st[kb][2 * j]; p2[j][1] = st[kb][2 * j + 1]; }
+                    f16x8q ph[2], pl[2], vh[2], vl[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        f16_split8p(p2 + 4 * s2, ph[s2], pl[s2]);
+                        vh[s2] = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048); vl[s2] = *reinterpret_cast<const f16x8q *>(vf + s2 * 2048 + 1024);
+                    }
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[0], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[1], o2, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], pl[0], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], pl[1], o2, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[0], ph[0], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[1], ph[1], o2, 0, 0, 0);
+                }
+            };
+            switch (nkb) {                                    // wave-uniform
+                case 1: attend(std::integral_constant<int, 1>{}); break;
+                case 2: attend(std::integral_constant<int, 2>{}); break;
+                case 3: attend(std::integral_constant<int, 3>{}); break;
+                case 4: attend(std::integral_constant<int, 4>{}); break;
+                default: break;                               // no keys: l = 0, the row below becomes 0 * inf as before
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] += o2[r];
+            QPROF_T(8)
             const float invl = 1.0f / l;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 o[r] *= invl;
                 if (q < P) { omin = fminf(omin, o[r]); omax = fmaxf(omax, o[r]); }
             }
+            // O^T: this lane = query q, register r = feature f(r, hi): four runs of four consecutive features, stored as they are -- the four stores
+            // of a wave complete every row's 128-byte line of this head. (Through a wave-private LDS transposition, so that each store instruction
+            // wrote whole lines, the epilogue took 1 450 cycles per head instead of 600.)
+            if (q < P) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if ((l31 >> 4) == half) {
-                    const int tl = l31 & 15;
+                for (int g = 0; g < 4; ++g) {
+                    f32x4q ov;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4q ov;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = o[4 * g + e];
-                        *reinterpret_cast<f32x4q *>(scr + tl * 128 + (((2 * g + hi) ^ (tl & 7)) << 4)) = ov;
-                    }
-                }
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int tl = hh * 8 + (lane >> 3), ch = lane & 7;
-                    const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
-                    const int qt = wave * 32 + half * 16 + tl;
-                    if (qt < P) *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + qt) * H + h * 32 + ch * 4) = v4;
+                    for (int e = 0; e < 4; ++e) ov[e] = o[4 * g + e];
+                    *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + q) * H + h * 32 + 8 * g + 4 * hi) = ov;
                 }
             }
         }
+        QPROF_T(9)
     }
+    QPROF_END
     if (mm_out) {
         uint32_t klo = omin <= omax ? order_key(omin) : 0xFFFFFFFFu, khi = omin <= omax ? order_key(omax) : 0u;
         for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
