@@ -828,7 +828,7 @@ struct shodh_embedder {
     int8_t *HQ = nullptr;                // quantised GELU output [tok_cap][I] (fast INT8 path: the f32 intermediate never exists)
     int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
     bool need_rs = false;
-    uint32_t int8_stages = 0x2F;         // bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
+    uint32_t int8_stages = 0x6F;         // bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
     uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][2]
     uint32_t *qkv_hc = nullptr;          // [layers][heads][4][128] per-head constants of the fused q|k|v matrices (pack_head_consts_kernel)
@@ -1080,6 +1080,23 @@ static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
+template <bool QUANT>
+static int launch_i8_stream_gelu(const S8Args &a, int cus, hipStream_t st) {
+    int n_workers = (cus / a.n_groups) & ~7;
+    if (n_workers < 8) n_workers = 8;
+    const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
+    if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
+    const size_t lds = QUANT ? S8G_LDS_QUANT : S8G_LDS_RANGE;
+    if (a.zw && a.rsA) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true>, lds));
+        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+    } else {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false>, lds));
+        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+    }
+    SHODH_HIP_TRY(hipGetLastError());
+    return SHODH_OK;
+}
 static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t *xq, const uint32_t *mm, int32_t *rs, hipStream_t st) {
     if (e->need_rs) {
         const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div((size_t)M * 32, 256), 1), 4096);
@@ -1162,11 +1179,14 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             a.M = ntok; a.N = I; a.n_groups = I / S8_NF;
             uint32_t *stats = e->mmr + 2 * n_pairs + 4 * li;                            // {nearest pre-activation left of gelu's argmin, right of it, largest}: see gelu_range_finalize_kernel
             a.mm_out = stats;
-            SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));                // pass 1: the three pre-activations that decide the range of gelu(up(x)); nothing stored
+            const bool piped = stages & 64u;
+            if (piped) SHODH_TRY(launch_i8_stream_gelu<false>(a, e->cus, st));          // pass 1: the three pre-activations that decide the range of gelu(up(x)); nothing stored
+            else SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));
             hipLaunchKernelGGL(gelu_range_finalize_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)stats, mmF);
             a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw) ? e->rsH : nullptr;
             if (a.rs_out) SHODH_HIP_TRY(hipMemsetAsync(e->rsH, 0, (size_t)ntok * 4, st));
-            SHODH_TRY(launch_i8_stream<SEPI_GELU_QUANT>(a, e->cus, st));                // pass 2: the same values again, quantised on the way out
+            if (piped) SHODH_TRY(launch_i8_stream_gelu<true>(a, e->cus, st));           // pass 2: the same values again, quantised on the way out
+            else SHODH_TRY(launch_i8_stream<SEPI_GELU_QUANT>(a, e->cus, st));
         } else {
             SHODH_TRY(gemm_i8<EPI8_BIAS_GELU>(e->XQ, wu, 0, I, e->act_params, w + l.ib, nullptr, FF, nullptr, ntok, st, mmF, e->rsX));
             SHODH_TRY(quantize_act(e, FF, ntok, I, e->HQ, mmF, e->rsH, st));
@@ -1366,7 +1386,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     e->cfg = *cfg;
     if (cfg->weights_path) e->weights_path = cfg->weights_path;
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
-    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x3Fu;       // speed only: which stages run the fused kernels
+    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x7Fu;       // speed only: which stages run the fused kernels
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);

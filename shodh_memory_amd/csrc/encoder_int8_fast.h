@@ -37,16 +37,18 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // GELU(x) = x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with erfc(z) = 2^P(z) on z in [0, 4.4]: P = the degree-8 weighted least-squares fit of
-// log2 erfc (Chebyshev nodes, weight erfc: what counts is the absolute error of erfc); beyond 4.4 (|x| > 6.2) z is clamped, erfc(4.4) = 5e-10.
+// log2 erfc (Chebyshev nodes, weight erfc: what counts is the absolute error of erfc), fitted on [0, 4.4] (|x| <= 6.2; erfc(4.4) = 5e-10).
 // Measured in f32 Horner arithmetic over x in [-8, 8] against the exact function: |erfc error| <= 8.1e-8, |gelu error| <= 3.0e-7 absolute and
 // <= 9.5e-8 |x| (+ one ulp of v_exp_f32) -- tighter than Abramowitz-Stegun 7.1.26 (1.5e-7 on erf), which this replaces: 7.1.26 needs v_rcp AND v_exp
 // (quarter-rate instructions, 8 issue slots per value) plus 8 more slots; this needs one v_exp and eight fused multiply-adds on the packed-FP32 pipe
 // (v_pk_fma_f32: two values per slot): ~12 slots per value against ~16. Exact erff costs ~40. The INT8 FFN evaluates it on 1.6e9 values per layer.
 typedef float f32x2q __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2q gelu_i8x2(f32x2q x) {
-    const f32x2q ax = __builtin_elementwise_abs(x);
-    f32x2q z = ax * 0.70710678118654752440f;
-    z.x = fminf(z.x, 4.4f); z.y = fminf(z.y, 4.4f);
+    // gelu(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), erfc(z) = 2^P(z). No clamp on z: past the fitted interval (z > 4.4, |x| > 6.2) P keeps
+    // falling faster than log2 erfc does (P(5) = -39.5, P(8) = -171, P(20) = -3.8e5, -inf from 1e10 on: tests/test_gelu_poly_cpu.py), so the
+    // correction term only shrinks below its 5e-10 |x| there. |x| itself is never formed: z and |x| / 2 come from multiplies with the |.| operand
+    // modifier.
+    f32x2q z; z.x = __builtin_fabsf(x.x) * 0.70710678118654752440f; z.y = __builtin_fabsf(x.y) * 0.70710678118654752440f;
     f32x2q p = __builtin_elementwise_fma(z, (f32x2q)-2.753492845e-05f, (f32x2q)3.102343180e-04f);
     p = __builtin_elementwise_fma(p, z, (f32x2q)-1.085499767e-03f);
     p = __builtin_elementwise_fma(p, z, (f32x2q)-1.382132061e-03f);
@@ -56,7 +58,7 @@ __device__ __forceinline__ f32x2q gelu_i8x2(f32x2q x) {
     p = __builtin_elementwise_fma(p, z, (f32x2q)-1.627911806e+00f);
     p = __builtin_elementwise_fma(p, z, (f32x2q)4.870492631e-08f);
     f32x2q e; e.x = __builtin_amdgcn_exp2f(p.x); e.y = __builtin_amdgcn_exp2f(p.y);      // erfc(z)
-    const f32x2q m = ax * 0.5f;
+    f32x2q m; m.x = __builtin_fabsf(x.x) * 0.5f; m.y = __builtin_fabsf(x.y) * 0.5f;
     f32x2q r; r.x = fmaxf(x.x, 0.0f); r.y = fmaxf(x.y, 0.0f);
     return __builtin_elementwise_fma(-m, e, r);
 }
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     for (int i = 0; i < NPC; ++i) {
         const int p = i * 256 + (tid & 255);
         const int row = p / 24, slot = p % 24;
-        const int c = (slot & ~7) | ((slot & 7) ^ (row & 7));
+        const int c = (slot & ~7) | ((slot & 7) ^ ((row >> 1) & 7));      // key (row >> 1) & 7: conflict-free for the lane groups of ds_read_b128 at a 384-byte pitch (see i8_stream_gelu_kernel)
         srcoff[i] = (uint32_t)(row * S8_PITCH + c * 16);
     }
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(a.XQ);
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     }
     int aoff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aoff[j] = l31 * S8_PITCH + (((2 * j + hi) ^ (l31 & 7)) << 4);
+    for (int j = 0; j < 4; ++j) aoff[j] = l31 * S8_PITCH + (((2 * j + hi) ^ ((l31 >> 1) & 7)) << 4);
 
     uint32_t klo = 0xFFFFFFFFu, khi = 0u;
     float *red = reinterpret_cast<float *>(smem + S8_RED);
@@ -1059,6 +1061,271 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
         if (lane == 0) {
             if (klo < __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMin(a.mm_out, klo);
             if (khi > __atomic_load_n(a.mm_out + 1, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 1, khi);
+        }
+    }
+}
+
+// ---- the two FFN-up passes (range, then quantised bytes) with the epilogue of one token block running under the MFMAs of the next ---------------
+// i8_stream_kernel<SEPI_GELU_*> computes a tile (24 dependent MFMAs per wave) and then post-processes it (GELU and quantisation: ~450 VALU
+// instructions per wave and tile); its twelve waves meet at a barrier per tile, so all of them are in the matrix phase together and in the VALU phase
+// together: measured 1.38 ms (bytes) / 0.84 ms (range) per layer where the matrix work is 0.28 ms and the VALU work 0.66 / 0.33 ms. Here the two
+// accumulators alternate roles half a tile apart -- while block 0 of tile t accumulates, block 1 of tile t - 1 is post-processed from the other
+// accumulator, then block 1 of tile t under the epilogue of its block 0 -- so every wave always has three MFMAs and a few dozen independent VALU
+// instructions in the same scheduling region. Same tiles, same DMA ring, same barrier per tile; the output bytes of a tile are complete one
+// iteration later, so the byte pass rotates three output tiles in LDS instead of two.
+constexpr int S8G_LDS_RANGE = S8_RED, S8G_LDS_QUANT = S8_RED + 3 * S8_TILE;
+template <bool QUANT, bool ZW>
+__global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) {
+    constexpr int KS = S8_KS, NS = 2 * KS, D = 3, RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.M;
+    const int n_workers = gridDim.x / a.n_groups;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int grp = rr % a.n_groups, worker = (rr / a.n_groups) * 8 + xcd;
+    const int nbase = grp * S8_NF;
+    const int nblk = grp * 12 + wave;
+
+    float *c_ws = reinterpret_cast<float *>(smem + S8_CONST);
+    int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + S8_NF);
+    float *c_b = reinterpret_cast<float *>(c_rz + S8_NF);
+    int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + S8_NF);
+    const ActQ ap = act_params(a.mmA);
+    const float a_scale = ap.scale;
+    const int corr = 128 - ap.zp;
+    // Without weight zero points the integer term (128 - a_zp) * rowsum_w[n] is added as a FLOAT after the conversion: |acc| <= 384 * 128 * 127 and
+    // |term| <= 128 * 384 * 128 are integers below 2^23, so is their sum -- the float addition is exact and equals float(acc + term) (one conversion and
+    // half a packed add per value instead of an integer add and a conversion). With zero points the terms outgrow that and stay integer.
+    for (int i = tid; i < S8_NF; i += S8_NT) {
+        c_ws[i] = a_scale * a.wscale[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
+        if (ZW) c_rz[i] = corr * a.rsz[nbase + i]; else reinterpret_cast<float *>(c_rz)[i] = (float)(corr * a.rsz[nbase + i]);
+    }
+    float o_inv = 1.0f, o_zpf = 0.0f;
+    if (QUANT) { const ActQ op = act_params(a.mmO); o_inv = 1.0f / op.scale; o_zpf = (float)op.zp; }
+    // range pass: the wave's running {distance below x* of the nearest value left of it, distance above of the nearest NEGATIVE value right of it} as
+    // differences of IEEE bit patterns (see epi_chunk), and the largest value
+    constexpr uint32_t XSB = 0xBF40756Au;                            // bits of GELU_ARGMIN = -0.7517915964f
+    static_assert(__builtin_bit_cast(uint32_t, GELU_ARGMIN) == XSB, "XSB holds the bit pattern of GELU_ARGMIN");
+    uint32_t w_dl = 0xFFFFFFFFu, w_dr = 0xFFFFFFFFu;
+    float xmax = -__builtin_inff();
+
+    // the tile DMA is shared by all twelve waves (two 1-KiB pieces each; i8_stream_kernel lets waves 0-3 issue six each behind a branch, which would
+    // cut the scheduling regions below in two)
+    uint32_t srcoff[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int p = i * S8_NT + tid;
+        const int row = p / 24, slot = p % 24;
+        const int c = (slot & ~7) | ((slot & 7) ^ ((row >> 1) & 7));      // key (row >> 1) & 7: see aoff
+        srcoff[i] = (uint32_t)(row * S8_PITCH + c * 16);
+    }
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(a.XQ);
+    const uint32_t wave_lds = smem_lds + (uint32_t)wave * 1024u;
+    const int n_tiles = (M + S8_TR - 1) / S8_TR;
+    int t = worker;
+#pragma unroll
+    for (int b = 0; b < PF; ++b) {
+        const int tt = t + b * n_workers < n_tiles ? t + b * n_workers : (t < n_tiles ? t : 0);
+        const unsigned char *src = uniform_ptr(xb + (size_t)tt * S8_TILE);
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * S8_TILE + i * 12288);
+    }
+    i32x4q bw[KS];
+    {
+        const i32x4q *wp = reinterpret_cast<const i32x4q *>(a.Wp) + (size_t)nblk * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[ks] = wp[ks * 64];
+    }
+    // A-fragment reads: ds_read_b128 is served in four groups of sixteen lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over
+    // 64 banks (256 B). Rows are 384 B apart, so a row's 128-byte segment starts at bank 0 or 32 by the row's parity, and within each group the eight
+    // even and the eight odd rows must take eight different 16-byte slots: the XOR key is (row >> 1) & 7. (With row & 7, i8_stream_kernel's key, rows
+    // 12 and 20 -- same group, same parity, same key -- collide: SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE.)
+    int aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[j] = l31 * S8_PITCH + (((2 * j + hi) ^ ((l31 >> 1) & 7)) << 4);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    lds_barrier();
+    const i32x16l zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    i32x16l acc0 = zero16, acc1 = zero16;
+    uint32_t cur = 0;
+    int it = 0, t_p1 = 0, t_p2 = 0;                                 // the tiles of the previous two iterations
+    auto store_out_tile = [&](int tile, int buf) {
+        const unsigned char *ot = smem + OUT0 + buf * S8_TILE;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int p = pass * S8_NT + tid;
+            const int row = p / 24, c = p % 24;
+            const u32x4qq v4 = *reinterpret_cast<const u32x4qq *>(ot + row * S8_PITCH + (((c & ~7) | ((c & 7) ^ (row & 7))) << 4));
+            const int m = tile * S8_TR + row;
+            if (m < M) *reinterpret_cast<u32x4qq *>(a.out_q + (size_t)m * a.N + nbase + c * 16) = v4;
+        }
+    };
+    // four values (features 32 wave + 8 g + 4 hi ..) of token (tile, blk, l31) from accumulator registers 4 g .. 4 g + 3
+    struct BlockAcc { uint32_t dl, dr; float mx; int ssum; };       // per token block: range trackers / row sum of the bytes
+    auto epi_chunk = [&](const i32x16l &acc, int g, int rsa, unsigned char *orow, BlockAcc &ba) {
+        const int nl = wave * 32 + 8 * g + 4 * hi;
+        const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+        f32x2q x2[2];
+        if (ZW) {
+            const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                f32x2q f, w, b;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { f[e] = (float)(acc[4 * g + 2 * e2 + e] + rz[2 * e2 + e] - z4[2 * e2 + e] * rsa); w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                x2[e2] = f * w + b;
+            }
+        } else {
+            const f32x4q rzf = *reinterpret_cast<const f32x4q *>(reinterpret_cast<const float *>(c_rz) + nl);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                f32x2q f, r, w, b;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { f[e] = (float)acc[4 * g + 2 * e2 + e]; r[e] = rzf[2 * e2 + e]; w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                x2[e2] = (f + r) * w + b;
+            }
+        }
+        if (!QUANT) {
+            // nearest to x* = GELU_ARGMIN (negative) from the left: x <= x* <=> bits(x) >= bits(x*) as unsigned (negative floats grow in magnitude with
+            // their bits, everything non-negative lies below 0x80000000), and the nearest has the smallest bits: min of bits(x) - bits(x*), which wraps
+            // to something huge for every other x. From the right only NEGATIVE values matter (gelu >= 0 from 0 on, and the range contains 0 anyway):
+            // min of bits(x*) - bits(x); a non-negative x gives at least bits(x*) - 0x7F800000, more than any x in [x*, -0]. Two subtractions and
+            // 1.5 three-operand min / max per value, exact -- the values come back as x = bits(x*) +- difference.
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const uint32_t u0 = __float_as_uint(x2[e2][0]), u1 = __float_as_uint(x2[e2][1]);
+                ba.dl = min(min(ba.dl, u0 - XSB), u1 - XSB);
+                ba.dr = min(min(ba.dr, XSB - u0), XSB - u1);
+                ba.mx = fmaxf(fmaxf(ba.mx, x2[e2][0]), x2[e2][1]);
+            }
+        } else {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const f32x2q v2 = gelu_i8x2(x2[e2]);
+                // q = saturate(round_half_even(v / scale + zp)): v / scale is taken as v * (1 / scale) and the zero point joins in the same fused
+                // multiply-add; v_cvt_pk_u8_f32 rounds half to even and saturates. Against rint(v / scale) + zp this moves a byte only when
+                // v / scale sits within ~1e-5 of a rounding boundary -- the size of gelu_i8's own error (1e-7 |x| / scale) -- and saves the
+                // separate multiply, rint and add (five of the eight slots of a pair).
+                const f32x2q t2 = __builtin_elementwise_fma(v2, (f32x2q)o_inv, (f32x2q)o_zpf);
+                pk = pack_u8(pk, t2[0], 2 * e2);
+                pk = pack_u8(pk, t2[1], 2 * e2 + 1);
+            }
+            pk ^= 0x80808080u;
+            if (ZW) ba.ssum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, ba.ssum, false);      // row sums of the stored bytes: only with weight zero points
+            const int c = nl >> 4;
+            *reinterpret_cast<uint32_t *>(orow + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;
+        }
+    };
+    auto finish_block = [&](int m, bool valid, const BlockAcc &ba) {  // a finished token block: its trackers join the wave's (padding rows of the last tile do not), its row sums go out
+        if (!QUANT) {
+            w_dl = min(w_dl, valid ? ba.dl : 0xFFFFFFFFu);
+            w_dr = min(w_dr, valid ? ba.dr : 0xFFFFFFFFu);
+            xmax = fmaxf(xmax, valid ? ba.mx : -__builtin_inff());
+        } else if (ZW && a.rs_out) {
+            int ssum = ba.ssum;
+            ssum += __shfl_xor(ssum, 32);
+            if (hi == 0 && valid) atomicAdd(a.rs_out + m, ssum);
+        }
+    };
+    const BlockAcc ba_init = {0xFFFFFFFFu, 0xFFFFFFFFu, -__builtin_inff(), 0};
+    for (; t < n_tiles; t += n_workers, ++it) {
+        if (QUANT) { if (it > 1) store_out_tile(t_p2, (it - 2) % 3); }
+        const unsigned char *buf = smem + cur * S8_TILE;
+        const uint32_t pfb = cur + PF >= S8_NBUF ? cur + PF - S8_NBUF : cur + PF;
+        const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
+        const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * S8_TILE);
+        const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * S8_TILE));
+        i32x4q ring[RING];
+        auto rd = [&](int st) {
+            const int rb = st / KS, ks = st % KS;
+            ring[st % RING] = *reinterpret_cast<const i32x4q *>(buf + rb * 32 * S8_PITCH + aoff[ks & 3] + (ks >> 2) * 128);
+        };
+        auto mfma_step = [&](int st) {
+            if (st + D < NS) rd(st + D);
+            if (st < KS) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bw[st], ring[st % RING], st == 0 ? zero16 : acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bw[st - KS], ring[st % RING], st == KS ? zero16 : acc1, 0, 0, 0);
+            if (st == 2) glds16(psrc, srcoff[0], pdst);
+            if (st == KS + 2) glds16(psrc, srcoff[1], pdst + 12288);
+        };
+#pragma unroll
+        for (int st = 0; st < D; ++st) rd(st);
+        // ---- phase 1: block 0 of this tile accumulates; block 1 of the previous tile is post-processed from acc1
+        if (it == 0) {
+#pragma unroll
+            for (int st = 0; st < KS; ++st) { mfma_step(st); __builtin_amdgcn_sched_barrier(0); }
+        } else {
+            const int m = t_p1 * S8_TR + 32 + l31;
+            const bool valid = m < M;
+            const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+            unsigned char *orow = smem + OUT0 + ((it - 1) % 3) * S8_TILE + (32 + l31) * S8_PITCH;
+            BlockAcc ba = ba_init;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mfma_step(3 * g); mfma_step(3 * g + 1); mfma_step(3 * g + 2);
+                epi_chunk(acc1, g, rsa, orow, ba);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            finish_block(m, valid, ba);
+        }
+        // ---- phase 2: block 1 accumulates; block 0 of this tile is post-processed from acc0
+        {
+            const int m = t * S8_TR + l31;
+            const bool valid = m < M;
+            const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+            unsigned char *orow = smem + OUT0 + (it % 3) * S8_TILE + l31 * S8_PITCH;
+            BlockAcc ba = ba_init;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mfma_step(KS + 3 * g); mfma_step(KS + 3 * g + 1); mfma_step(KS + 3 * g + 2);
+                epi_chunk(acc0, g, rsa, orow, ba);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            finish_block(m, valid, ba);
+        }
+        // the next tile must have landed before the barrier (counted wait: everything younger than that tile's DMA is this tile's NPC pieces)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == S8_NBUF ? 0 : cur + 1;
+        t_p2 = t_p1; t_p1 = t;
+    }
+    // ---- drain: the last tile's block 1, then the output tiles still in LDS
+    if (it > 0) {
+        if (QUANT) { if (it > 1) store_out_tile(t_p2, (it - 2) % 3); }
+        const int m = t_p1 * S8_TR + 32 + l31;
+        const bool valid = m < M;
+        const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+        unsigned char *orow = smem + OUT0 + ((it - 1) % 3) * S8_TILE + (32 + l31) * S8_PITCH;
+        BlockAcc ba = ba_init;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) epi_chunk(acc1, g, rsa, orow, ba);
+        finish_block(m, valid, ba);
+        if (QUANT) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            store_out_tile(t_p1, (it - 1) % 3);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!QUANT && a.mm_out) {       // mm_out = {key of max{x <= x*}, key of min{x >= x*}, key of max x}: gelu_range_finalize_kernel turns them into the range
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            xmax = fmaxf(xmax, __shfl_xor(xmax, ofs));
+            w_dl = min(w_dl, (uint32_t)__shfl_xor((int)w_dl, ofs)); w_dr = min(w_dr, (uint32_t)__shfl_xor((int)w_dr, ofs));
+        }
+        if (lane == 0) {
+            if (w_dl <= 0xFF800000u - XSB) { const uint32_t k = order_key(__uint_as_float(XSB + w_dl)); if (k > __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMax(a.mm_out, k); }            // a finite x (or -inf) at or left of x*
+            if (w_dr <= XSB - 0x80000000u) { const uint32_t k = order_key(__uint_as_float(XSB - w_dr)); if (k < __atomic_load_n(a.mm_out + 1, __ATOMIC_RELAXED)) atomicMin(a.mm_out + 1, k); }      // a negative x in [x*, -0]
+            if (xmax > -__builtin_inff()) { const uint32_t k = order_key(xmax); if (k > __atomic_load_n(a.mm_out + 2, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 2, k); }
         }
     }
 }
