@@ -8,6 +8,10 @@
 //                          operand layouts of the attention (K and V^T fragments through LDS, Q and P in registers), softmax in f32,
 //                          both attention products as three f16 MFMAs on (hi, lo) splits of the f32 operands (error <= 2^-21 relative,
 //                          see f16_split). K and V are projected for the real keys only -- masked keys are never read.
+//   qkv_attn_seq_kernel    the same per SEQUENCE (the default): the f32 layer input is fetched once, quantised in the kernel and kept as
+//                          fragments for all twelve heads; head weights through LDS by LDS-DMA; softmax in one piece over <= 4 key blocks.
+//   i8_stream_gelu_kernel  the two FFN-up passes (range, then bytes) of i8_stream_kernel with the epilogue of one token block running
+//                          under the MFMAs of the next (the default for those two passes).
 //   i8_stream_kernel       weight-stationary int8 GEMM for K = 384 (attention output, FFN up): 12 waves hold 384 output features as
 //                          resident fragments, the quantised activations stream through LDS by LDS-DMA (gemm_k384_stream_kernel's
 //                          structure). Epilogues: + residual + LayerNorm (whole rows in the workgroup) | GELU -> range only |
