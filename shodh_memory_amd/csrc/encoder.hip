@@ -878,8 +878,8 @@ static int reserve(shodh_embedder *e, size_t ntok, size_t nseq) {
         if (int8) {
             SHODH_HIP_TRY(hipMalloc((void **)&e->XQ, cap * std::max(H, I)));
             SHODH_HIP_TRY(hipMalloc((void **)&e->HQ, cap * I));
-            SHODH_HIP_TRY(hipMalloc((void **)&e->rsX, cap * 4));
-            SHODH_HIP_TRY(hipMalloc((void **)&e->rsH, cap * 4));
+            SHODH_HIP_TRY(hipMalloc((void **)&e->rsX, (cap + 256) * 4));     // (+ 256: the streaming kernels fetch the row sums of a tile as one 1-KiB DMA piece)
+            SHODH_HIP_TRY(hipMalloc((void **)&e->rsH, (cap + 256) * 4));
         }
         // the fast INT8 layer keeps neither the q|k|v tensor nor the f32 GELU output (encoder_int8_fast.h); they exist only for the stages
         // switched back to the round-2 kernels (SHODH_INT8_STAGES) or for shapes the fused kernels do not take
@@ -1183,7 +1183,7 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             if (piped) SHODH_TRY(launch_i8_stream_gelu<false>(a, e->cus, st));          // pass 1: the three pre-activations that decide the range of gelu(up(x)); nothing stored
             else SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));
             hipLaunchKernelGGL(gelu_range_finalize_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)stats, mmF);
-            a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw) ? e->rsH : nullptr;
+            a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw && !fD) ? e->rsH : nullptr;      // (the fused FFN-down kernel forms the row sums of these bytes itself)
             if (a.rs_out) SHODH_HIP_TRY(hipMemsetAsync(e->rsH, 0, (size_t)ntok * 4, st));
             if (piped) SHODH_TRY(launch_i8_stream_gelu<true>(a, e->cus, st));           // pass 2: the same values again, quantised on the way out
             else SHODH_TRY(launch_i8_stream<SEPI_GELU_QUANT>(a, e->cus, st));
@@ -1193,9 +1193,15 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         }
         // ---- D: FFN down + residual + LayerNorm
         if (fD) {
-            SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel, KT_LDS));
-            hipLaunchKernelGGL(i8_ktile_ln_kernel, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)e->rsH, (const uint32_t *)mmF,
-                               (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+            if (wd.zw) {
+                SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel<true>, KT_LDS));
+                hipLaunchKernelGGL(i8_ktile_ln_kernel<true>, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)nullptr, (const uint32_t *)mmF,
+                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+            } else {
+                SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel<false>, KT_LDS));
+                hipLaunchKernelGGL(i8_ktile_ln_kernel<false>, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)nullptr, (const uint32_t *)mmF,
+                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+            }
             SHODH_HIP_TRY(hipGetLastError());
         } else {
             hipLaunchKernelGGL(params_from_range_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)mmF, e->act_params);

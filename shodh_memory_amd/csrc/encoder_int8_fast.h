@@ -804,7 +804,8 @@ constexpr int S8_TR = 64, S8_PITCH = 384, S8_TILE = S8_TR * S8_PITCH, S8_NBUF = 
 constexpr int S8_CONST = S8_NBUF * S8_TILE;               // wscale | rsz | bias | zw | gamma | beta: 6 x 384 x 4 B
 constexpr int S8_RED = S8_CONST + 6 * S8_NF * 4;          // [2][12 waves][64 tokens] f32
 constexpr int S8_SCR = S8_RED + 2 * 12 * 64 * 4;          // 12 x 4 KiB wave scratch (LayerNorm epilogue) / 2 x 24 KiB output tiles (quantising epilogue)
-constexpr int S8_LDS = S8_SCR + 12 * 4096;
+constexpr int S8_RS = S8_SCR + 12 * 4096;               // row sums of the three tiles in flight (weight zero points only): [S8_NBUF][256] int32, 64 used
+constexpr int S8_LDS = S8_RS + S8_NBUF * 1024;
 enum { SEPI_RESID_LN = 0, SEPI_GELU_RANGE = 1, SEPI_GELU_QUANT = 2 };
 
 struct S8Args {
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     for (int b = 0; b < PF; ++b) {
         const int tt = t + b * n_workers < n_tiles ? t + b * n_workers : (t < n_tiles ? t : 0);
         const unsigned char *src = uniform_ptr(xb + (size_t)tt * S8_TILE);
+        if (ZW && wave == 0) glds16(uniform_ptr(reinterpret_cast<const unsigned char *>(a.rsA + (size_t)tt * S8_TR)), (uint32_t)lane * 16u, smem_lds + (uint32_t)S8_RS + (uint32_t)b * 1024u);      // the tile's row sums travel with it (see i8_stream_gelu_kernel)
         if (wave < 4) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * S8_TILE + i * 4096);
@@ -910,6 +912,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
         const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
         const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * S8_TILE);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * S8_TILE));
+        if (ZW && wave == 0) glds16(uniform_ptr(reinterpret_cast<const unsigned char *>(a.rsA + (size_t)pt * S8_TR)), (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (uint32_t)S8_RS + pfb * 1024u)));      // (older than this iteration's tile pieces: the counted wait below covers it)
         i32x4q ring[RING];
         auto rd = [&](int st) {
             const int rb = st / KS, ks = st % KS;
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
             const int m = t * S8_TR + blk * 32 + l31;
             const int mc = m < M ? m : M - 1;
             const bool valid = m < M;
-            const int rsa = has_zw ? a.rsA[mc] : 0;
+            const int rsa = has_zw ? reinterpret_cast<const int32_t *>(smem + S8_RS)[cur * 256 + blk * 32 + l31] : 0;
             if (EPI == SEPI_GELU_RANGE) {
                 if (valid) {
 #pragma unroll
@@ -1096,6 +1099,13 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + S8_NF);
     float *c_b = reinterpret_cast<float *>(c_rz + S8_NF);
     int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + S8_NF);
+    // With weight zero points every token needs the row sum of its quantised bytes. A global load for it inside the pipelined regions would be waited
+    // for with the compiler's own vmcnt, which knows nothing of the tile DMA issued just before it and so waits for THAT (an HBM round trip per token
+    // block: the zero-point variants ran 1.61 / 0.84 ms against 1.17 / 0.66). The 64 sums of a tile travel with the tile instead: one more DMA
+    // piece from wave 0 (a whole 1-KiB piece, of which the first 256 bytes matter: no divergent branch around the asm) into a slot behind the
+    // constants (the LayerNorm gains' place in i8_stream_kernel), read back with ds_read_b32.
+    int32_t *c_rs = c_zw + S8_NF;                                    // [S8_NBUF][256], 64 used
+    const uint32_t rs_lds = smem_lds + (uint32_t)S8_CONST + 4u * S8_NF * 4u;
     const ActQ ap = act_params(a.mmA);
     const float a_scale = ap.scale;
     const int corr = 128 - ap.zp;
@@ -1135,6 +1145,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         const unsigned char *src = uniform_ptr(xb + (size_t)tt * S8_TILE);
 #pragma unroll
         for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * S8_TILE + i * 12288);
+        if (ZW && wave == 0) glds16(uniform_ptr(reinterpret_cast<const unsigned char *>(a.rsA + (size_t)tt * S8_TR)), (uint32_t)lane * 16u, rs_lds + (uint32_t)b * 1024u);
     }
     i32x4q bw[KS];
     {
@@ -1157,6 +1168,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     i32x16l acc0 = zero16, acc1 = zero16;
     uint32_t cur = 0;
     int it = 0, t_p1 = 0, t_p2 = 0;                                 // the tiles of the previous two iterations
+    int rsa_b1 = 0;
     auto store_out_tile = [&](int tile, int buf) {
         const unsigned char *ot = smem + OUT0 + buf * S8_TILE;
 #pragma unroll
@@ -1244,6 +1256,9 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
         const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * S8_TILE);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * S8_TILE));
+        const int rsa_p1 = rsa_b1;                                  // row sums of the previous tile's block 1 (its slot is the one being refilled now: taken while it was this tile)
+        rsa_b1 = ZW ? c_rs[cur * 256 + 32 + l31] : 0;
+        if (ZW && wave == 0) glds16(uniform_ptr(reinterpret_cast<const unsigned char *>(a.rsA + (size_t)pt * S8_TR)), (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rs_lds + pfb * 1024u)));
         i32x4q ring[RING];
         auto rd = [&](int st) {
             const int rb = st / KS, ks = st % KS;
@@ -1265,7 +1280,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         } else {
             const int m = t_p1 * S8_TR + 32 + l31;
             const bool valid = m < M;
-            const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+            const int rsa = rsa_p1;
             unsigned char *orow = smem + OUT0 + ((it - 1) % 3) * S8_TILE + (32 + l31) * S8_PITCH;
             BlockAcc ba = ba_init;
 #pragma unroll
@@ -1282,7 +1297,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         {
             const int m = t * S8_TR + l31;
             const bool valid = m < M;
-            const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+            const int rsa = ZW ? c_rs[cur * 256 + l31] : 0;
             unsigned char *orow = smem + OUT0 + (it % 3) * S8_TILE + l31 * S8_PITCH;
             BlockAcc ba = ba_init;
 #pragma unroll
@@ -1296,7 +1311,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             finish_block(m, valid, ba);
         }
         // the next tile must have landed before the barrier (counted wait: everything younger than that tile's DMA is this tile's NPC pieces)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");      // (wave 0's row-sum piece of this iteration was requested BEFORE the two tile pieces: it is older than the NPC allowed to stay out and simply lands an iteration early; a wave-dependent count behind a branch here made the register allocator spill the weight fragments)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1308,7 +1323,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         if (QUANT) { if (it > 1) store_out_tile(t_p2, (it - 2) % 3); }
         const int m = t_p1 * S8_TR + 32 + l31;
         const bool valid = m < M;
-        const int rsa = ZW ? a.rsA[valid ? m : M - 1] : 0;
+        const int rsa = rsa_b1;
         unsigned char *orow = smem + OUT0 + ((it - 1) % 3) * S8_TILE + (32 + l31) * S8_PITCH;
         BlockAcc ba = ba_init;
 #pragma unroll
@@ -1340,7 +1355,10 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
 // L2 (576 KiB); the kernel is bound by its three HBM streams (quantised activations, residual, output: 4.6 KB per token).
 constexpr int KT_TM = 128, KT_NF = 384, KT_KB = 128, KT_STAGE = (KT_TM + KT_NF) * KT_KB;      // 64 KiB per stage
 constexpr int KT_CONST = 2 * KT_STAGE, KT_LDS = KT_CONST + 6 * KT_NF * 4;
-__global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__restrict__ A /* [M][K] signed storage */, const int32_t *__restrict__ rsA, const uint32_t *__restrict__ mmA,
+// ZWK: the weight has zero points; the row sums of the activation bytes that term needs are formed here from the fragments the wave reads anyway
+// (v_dot4 with ones: 32 per K tile and wave next to 24 MFMAs) -- the producer does not have to emit them (it did, with 48 atomic adds per token).
+template <bool ZWK>
+__global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__restrict__ A /* [M][K] signed storage */, const int32_t *__restrict__ rsA /* unused */, const uint32_t *__restrict__ mmA,
                                                              const int8_t *__restrict__ W /* [384][K] row-major */, const float *__restrict__ wscale, const int32_t *__restrict__ rsz,
                                                              const int32_t *__restrict__ zw, const float *__restrict__ bias, const float *resid, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, float eps, float *out_f /* may alias resid */, uint32_t *__restrict__ mm_out, int M, int K) {
@@ -1396,6 +1414,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
     int fo_a[2], fo_w[3];
+    int rs_acc[2] = {0, 0};                    // ZWK: this lane's half of its tokens' row sums
     const int sw = l31 & 7;          // every fragment row of this lane has row & 7 == l31 & 7 (block bases are multiples of 32)
 #pragma unroll
     for (int i = 0; i < 2; ++i) fo_a[i] = (wr * 64 + i * 32 + l31) * KT_KB;
@@ -1414,7 +1433,13 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
             i32x4q fa[2], fw[3];
             const int co = ((ks * 2 + hi) ^ sw) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const i32x4q *>(tb + fo_a[i] + co);
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const i32x4q *>(tb + fo_a[i] + co);
+                if (ZWK) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rs_acc[i] = __builtin_amdgcn_sdot4(fa[i][c], 0x01010101, rs_acc[i], false);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) fw[j] = *reinterpret_cast<const i32x4q *>(tb + fo_w[j] + co);
 #pragma unroll
@@ -1435,7 +1460,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wr * 64 + i * 32 + l31;
         const int mc = m < M ? m : M - 1;
-        const int rsa = (rsA && zw) ? rsA[mc] : 0;
+        const int rsa = ZWK ? rs_acc[i] + __shfl_xor(rs_acc[i], 32) : 0;
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -1447,7 +1472,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
                 const f32x4q r4 = *reinterpret_cast<const f32x4q *>(resid + (size_t)mc * KT_NF + nl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = (float)(acc[j][i][4 * g + e] + corr * rz[e] - z4[e] * rsa) * (a_scale * ws[e]) + b4[e] + r4[e];
+                    const float x = (float)(acc[j][i][4 * g + e] + corr * rz[e] - (ZWK ? z4[e] * rsa : 0)) * (a_scale * ws[e]) + b4[e] + r4[e];
                     v[i][j][4 * g + e] = x; s += x;
                 }
             }
