@@ -482,21 +482,40 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
     if want("encoder", "cfg3_pipeline") and not args.skip_encoder:
         g = torch.Generator(device=dev).manual_seed(SEED + 50)
         ML = 256
-        for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS),) + ((("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS),) if hasattr(L, "DTYPE_INT8") else ()):
+        for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS),) + ((("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS), ("int8_export", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS)) if hasattr(L, "DTYPE_INT8") else ()):
             t0 = time.perf_counter()
             b = 8192 if dname == "bf16" else 4096
-            enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+            if dname == "int8_export":
+                # the tensors of a dynamic-quantisation export handed over one by one (shodh_embedder_load_quantized): uint8 weights with their own
+                # scale and a non-zero zero point per tensor, as onnxruntime's quantize_dynamic stores them -- the kernels' zero-point variants
+                from shodh_memory_amd import embedder as E
+                cfg = E.embed_cfg()
+                sd = E.blob_to_state_dict(E.synthetic_weights(1234, cfg), cfg)
+                enc = S.MiniLMEmbedder(dtype=dtype)
+                for name, a in sd.items():
+                    if a.ndim == 2 and (name.endswith("dense.weight") or name.endswith("query.weight") or name.endswith("key.weight") or name.endswith("value.weight") or name.endswith("word_embeddings.weight")):
+                        a = a + np.float32(0.004)                                  # an asymmetric range
+                        lo, hi = min(float(a.min()), 0.0), max(float(a.max()), 0.0)
+                        sc = np.float32((hi - lo) / 255.0)
+                        zp = np.uint8(np.clip(np.rint(-lo / sc), 0, 255))
+                        q = np.clip(np.rint(a / sc) + np.float32(zp), 0, 255).astype(np.uint8)
+                        enc.load_quantized(name, q, sc, zp)
+                    else:
+                        enc.load_tensor(name, a)
+                enc.finish_weights()
+            else:
+                enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
             ids, mask, lens = synth_tokens(torch, b, ML, g, dev)
             emb = torch.empty((b, args.dim), dtype=torch.float32, device=dev)
             dt = timed_steps(torch, lambda i: enc.encode_ids_device(ids, mask, out=emb), 10, 3)
             tokens = int(lens.sum())
             H, F, LAYERS = 384, 1536, 6
             # INT8 computes the reference's PADDED tensor (every position of every text is a query; keys are the real tokens)
-            tok_c = b * ML if dname == "int8" else tokens
-            att = float((lens.double() * ML).sum()) if dname == "int8" else float((lens.double() ** 2).sum())
+            tok_c = b * ML if dname != "bf16" else tokens
+            att = float((lens.double() * ML).sum()) if dname != "bf16" else float((lens.double() ** 2).sum())
             flop = float(tok_c * 2 * (4 * H * H + 2 * H * F) * LAYERS + att * 4 * H * LAYERS)
             e = {"name": "encoder_%s_b%d" % (dname, b), "workload": "MiniLM-L6 (6 x 384, 12 heads, FFN 1536) forward + mean-pool, %d texts, lengths U[8,128], %s"
-                 % (b, "the padded [B, 256] tensor of the reference's quantised export (dynamic uint8 activations x 8-bit weights, int32 MFMA)" if dname == "int8" else "real tokens only"),
+                 % (b, ("the padded [B, 256] tensor of the reference's quantised export (dynamic uint8 activations x 8-bit weights, int32 MFMA)" + ("; weights as an export stores them: uint8 with a zero point per tensor" if dname == "int8_export" else "; symmetric fallback weights")) if dname != "bf16" else "real tokens only"),
                  "ms_per_step": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1), "tokens": tokens, "positions_computed": tok_c,
                  "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / 1e12 / peak, 4), "mfma_peak_used": peak,
                  "flop_per_step": flop}
