@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
 
 // ---- tiled int8 GEMM over all 384 output features for K = 1536 (FFN down) + residual + LayerNorm ---------------------------------
 // 128 tokens x 384 features per workgroup, 8 waves = 2 token halves x 4 feature quarters (2 x 3 MFMA blocks each), K tiles of 128 bytes,
-// register-staged double-buffered LDS (rows of 128 B, 16-B chunks XOR-swizzled by row & 7). The weights are re-read per workgroup from
+// register-staged double-buffered LDS (rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7). The weights are re-read per workgroup from
 // L2 (576 KiB); the kernel is bound by its three HBM streams (quantised activations, residual, output: 4.6 KB per token).
 constexpr int KT_TM = 128, KT_NF = 384, KT_KB = 128, KT_STAGE = (KT_TM + KT_NF) * KT_KB;      // 64 KiB per stage
 constexpr int KT_CONST = 2 * KT_STAGE, KT_LDS = KT_CONST + 6 * KT_NF * 4;
@@ -1385,13 +1385,13 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
         const int sidx = i * 512 + tid, row = sidx >> 3, c = sidx & 7;
         int ra = m0 + row; if (ra >= M) ra = M - 1;
         ga[i] = A + (size_t)ra * K + c * 16;
-        la[i] = row * KT_KB + ((c ^ (row & 7)) << 4);
+        la[i] = row * KT_KB + ((c ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int sidx = i * 512 + tid, row = sidx >> 3, c = sidx & 7;
         gw[i] = W + (size_t)row * K + c * 16;
-        lw[i] = KT_TM * KT_KB + row * KT_KB + ((c ^ (row & 7)) << 4);
+        lw[i] = KT_TM * KT_KB + row * KT_KB + ((c ^ ((row >> 1) & 7)) << 4);
     }
     auto gload = [&](int kt) {
 #pragma unroll
@@ -1415,7 +1415,9 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
     int fo_a[2], fo_w[3];
     int rs_acc[2] = {0, 0};                    // ZWK: this lane's half of its tokens' row sums
-    const int sw = l31 & 7;          // every fragment row of this lane has row & 7 == l31 & 7 (block bases are multiples of 32)
+    // key (row >> 1) & 7: rows of 128 B start at bank 0 or 32 by their parity, and the sixteen lanes of a ds_read_b128 group ({0-3, 12-15, 20-27}, ...) hold
+    // eight even and eight odd rows whose (row >> 1) & 7 are all different (with row & 7, rows 12 and 20 collided: a quarter of the LDS cycles were conflicts)
+    const int sw = (l31 >> 1) & 7;   // every fragment row of this lane has the same key (block bases are multiples of 32)
 #pragma unroll
     for (int i = 0; i < 2; ++i) fo_a[i] = (wr * 64 + i * 32 + l31) * KT_KB;
 #pragma unroll
