@@ -75,12 +75,12 @@ bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const Mfm
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
                          uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext);
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext, uint32_t *stats_mirror);
 int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
                          uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext);
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext, uint32_t *stats_mirror);
 int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
 int launch_count_nonfinite(const float *x, uint64_t n, uint32_t *counter, hipStream_t st);
 int launch_shadow_set_row(const float *rows, _Float16 *rows_h, uint64_t row, uint32_t dim, int zero, hipStream_t st);
@@ -120,6 +120,7 @@ struct Workspace {
     uint32_t *solo_cnt = nullptr;        // single-query scan: its overflow counter, zero between calls (scan_mfma.hip, launch_solo_pipeline)
     // host-pointer calls: queries in, and ONE output block [ids | dist | counts] with a pinned host mirror, so that the results come back in
     // a single copy (three small copies plus their API calls were a visible part of a single query's latency)
+    float *h_q = nullptr;                // one-query host calls: the query in pinned, device-visible host memory (the kernels read it from there: no H2D copy command)
     float *d_q = nullptr; uint32_t *d_out = nullptr, *h_out = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr, *d_stats = nullptr;
     size_t q_floats = 0, out_words = 0;
     // ring of (start, end) events around the dominant scan kernel of each search, for
@@ -136,6 +137,7 @@ struct Workspace {
         for (auto &r : ring) { SHODH_HIP_TRY(hipEventCreate(&r[0])); SHODH_HIP_TRY(hipEventCreate(&r[1])); }
         SHODH_HIP_TRY(hipMalloc((void **)&solo_cnt, 256));
         SHODH_HIP_TRY(hipMemset(solo_cnt, 0, 256));
+        SHODH_HIP_TRY(hipHostMalloc((void **)&h_q, 4096));
         return SHODH_OK;
     }
     int reserve(size_t need) {
@@ -160,7 +162,7 @@ struct Workspace {
     void destroy() {
         if (buf) hipFree(buf);
         if (solo_cnt) hipFree(solo_cnt);
-        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out);
+        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); if (h_q) hipHostFree(h_q);
         for (auto &e : ev) if (e) hipEventDestroy(e);
         if (last_use) hipEventDestroy(last_use);
         for (auto &r : ring) { if (r[0]) hipEventDestroy(r[0]); if (r[1]) hipEventDestroy(r[1]); }
@@ -346,7 +348,7 @@ static int enqueue_flat_fallback(shodh_index *idx, Workspace *w, const FlatCall 
 // `stats_ext` (four words in its output block) afterwards, so the stage events are recorded and a single query's exact fallback can wait
 // for that look at the statistics instead of costing two empty launches on every call.
 static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32_t nq, uint32_t k,
-                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, FlatCall *fc, bool host_call, uint32_t *stats_ext) {
+                        uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st, FlatCall *fc, bool host_call, uint32_t *stats_ext, uint32_t *stats_mirror = nullptr) {
     // events: the per-stage ones only for host-pointer calls (their timings are read back after the call's own
     // synchronisation); the pair around the scan kernel unless SHODH_KERNEL_EVENTS=0. Each record is a packet in the
     // stream between two kernels.
@@ -374,11 +376,11 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
         if (fc->solo) {     // one query: a single pass over the shadow copy with workgroup-local thresholds
             SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, p, w->buf, fc->offs,
                                            w->solo_cnt, idx->cus, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
-                                           stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
+                                            stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext, stats_mirror));
         } else {
             SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
                                            idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
-                                           stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext));
+                                            stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext, stats_mirror));
         }
         // exact scan of whatever the pre-scan could not settle (device-side list; normally empty). A host-pointer call looks at the
         // statistics after its synchronisation and enqueues it only then, if at all.
@@ -632,10 +634,24 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         }
         const float *d_q = q;
         uint32_t *d_ids = ids; float *d_dist = dist; uint32_t *d_counts = counts;
+        // One query through host pointers (what `recall` does): the query is placed in pinned host memory the kernels read directly and the result
+        // block (<= 1 KiB) is written by the last kernel straight into the pinned mirror -- no H2D and no D2H copy command around ~160 us of kernels.
+        // The four statistics words stay in device memory (they are updated with atomics) and the one final-stage workgroup mirrors them at its end.
+        static const bool zc_off = getenv("SHODH_ZERO_COPY") && atoi(getenv("SHODH_ZERO_COPY")) == 0;
+        const bool zero_copy = sync_host && !zc_off && nq == 1 && (size_t)dim * 4 <= 4096 && idx->cfg.kind == SHODH_INDEX_FLAT && (idx->cfg.scan_mode != SHODH_SCAN_GRAPH || force_exact);
+        uint32_t *stats_mirror = nullptr;
         if (sync_host) {
             if ((rc = w->reserve_io((size_t)nq * dim, (size_t)nq * k, nq)) != SHODH_OK) break;
-            if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
-            d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
+            if (zero_copy) {
+                memcpy(w->h_q, q, (size_t)dim * 4);
+                const size_t oe = (size_t)k;
+                d_q = w->h_q; d_ids = w->h_out; d_dist = reinterpret_cast<float *>(w->h_out + oe); d_counts = w->h_out + 2 * oe;
+                stats_mirror = w->h_out + 2 * oe + nq;
+                stats_mirror[0] = stats_mirror[1] = stats_mirror[2] = stats_mirror[3] = 0;       // (paths without a final stage leave them alone)
+            } else {
+                if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
+                d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
+            }
         }
         if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !force_exact) {
             // VamanaIndex::search without SHODH_VECTOR_EXACT (vamana.rs:764-808)
@@ -650,7 +666,7 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
                            (uint32_t)idx->cfg.id_base, (uint32_t *)w->buf, vis_words, d_ids, d_dist, d_counts, idx->g_overflow};
             rc = vg_launch_search(a, st);
             if (sync_host) { hipEventRecord(w->ev[1], st); hipEventRecord(w->ev[2], st); hipEventRecord(w->ev[3], st); }
-        } else if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &fc, sync_host, sync_host ? w->d_stats : nullptr);
+        } else if (idx->cfg.kind == SHODH_INDEX_FLAT) rc = enqueue_flat(idx, w, d_q, nq, k, d_ids, d_dist, d_counts, st, &fc, sync_host, sync_host ? w->d_stats : nullptr, stats_mirror);
         else {
             if ((rc = w->reserve(ivfpq_scratch_bytes(idx->ivfpq, idx->cfg, nq, k) + 256)) != SHODH_OK) break;
             if (sync_host) hipEventRecord(w->ev[0], st);
@@ -661,13 +677,13 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         if (sync_host) {
             const size_t oe = (size_t)nq * k;
             const size_t out_bytes = (2 * oe + nq + 4) * 4;
-            if (hipMemcpyAsync(w->h_out, w->d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+            if (!zero_copy && hipMemcpyAsync(w->h_out, w->d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             if (fc.deferred && w->h_out[2 * oe + nq + 2] != 0) {
                 // some query could not be settled by the pre-scan (unquantisable values, thousands of near-duplicates, an unusable threshold): exact scan now
                 if ((rc = enqueue_flat_fallback(idx, w, fc, d_q, nq, k, d_ids, d_dist, d_counts, st)) != SHODH_OK) break;
-                if (hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+                if (!zero_copy && hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
                 e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             }

@@ -822,6 +822,7 @@ struct FinalArgs {
     uint32_t *counts;
     uint32_t *stats;          // [0] emitted, [1] rescored, [2] overflowed queries, [3] queries that went through level 2
     uint32_t *cnt_reset;      // single-query path: its overflow counter lives across calls and is handed back zeroed (nullptr otherwise)
+    uint32_t *stats_mirror;   // one-query host calls: the four statistics words are copied here (host-mapped memory) by the one workgroup, after its own updates
 };
 
 template <int ORDER>
@@ -1215,6 +1216,10 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
         a.fb_list[s] = q;
         atomicAdd(a.stats + 2, 1u);
     }
+    if (a.stats_mirror && tid == 0 && gridDim.x == 1) {         // (thread 0 made every update of this workgroup itself)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.stats_mirror[i] = __atomic_load_n(a.stats + i, __ATOMIC_RELAXED);
+    }
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -1277,6 +1282,7 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
 struct MfmaWorkspace {
     _Float16 *q_h; float *qnorm; float *thr; float *eps; uint32_t *cand_cnt; uint32_t *fallback; uint32_t *fb_list;
     uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand; uint64_t *slots; float *eps2;
+    uint32_t *stats_mirror = nullptr;
 };
 
 size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[MFMA_WS_PARTS = 16]*/) {
@@ -1380,7 +1386,7 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
         break;
     }
     FinalArgs f{rows, dim, d_q, nq, k, tcap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
-                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset};
+                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset, w.stats_mirror};
 #define SHODH_LAUNCH_FINAL(ORD, NTV)                                                                         \
     do {                                                                                                     \
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<ORD, NTV>, flds));                     \
@@ -1684,10 +1690,11 @@ bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const Mfm
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
                          uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext) {
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext, uint32_t *stats_mirror) {
     MfmaWorkspace w;
     unpack_workspace(w, ws_base, offs);
     if (stats_ext) w.stats = stats_ext;
+    w.stats_mirror = stats_mirror;
     static const uint32_t max_k_local = getenv("SHODH_SOLO_MAX_K") ? (uint32_t)atoi(getenv("SHODH_SOLO_MAX_K")) : SOLO_MAX_K;
     const bool global_thr = k > max_k_local;
     uint64_t nb = solo_workgroups(n_rows, cus);
@@ -1742,10 +1749,11 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
                          uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
-                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext) {
+                         hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext, uint32_t *stats_mirror) {
     MfmaWorkspace w;
     unpack_workspace(w, ws_base, offs);
     if (stats_ext) w.stats = stats_ext;      // host-pointer calls: the statistics words of the caller's output block
+    w.stats_mirror = nq == 1 ? stats_mirror : nullptr;
 
     QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
