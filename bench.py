@@ -482,7 +482,10 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
     if want("encoder", "cfg3_pipeline") and not args.skip_encoder:
         g = torch.Generator(device=dev).manual_seed(SEED + 50)
         ML = 256
-        for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS),) + ((("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS), ("int8_export", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS)) if hasattr(L, "DTYPE_INT8") else ()):
+        # int8 = SHODH_QUANT_SCOPE_BATCH (the reference's encode_batch: one [B, 256] tensor per range); int8_pertext = SHODH_QUANT_SCOPE_PER_TEXT
+        # (B x encode(): what remember / recall run text by text, minilm.rs:883-982 -- one range per text, the texts are independent)
+        for dname, dtype, peak in (("bf16", L.DTYPE_BF16, MFMA_F16_PEAK_TFLOPS), ("int8", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS), ("int8_pertext", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS),
+                                   ("int8_export", L.DTYPE_INT8, MFMA_I8_PEAK_TOPS)):
             t0 = time.perf_counter()
             b = 8192 if dname == "bf16" else 4096
             if dname == "int8_export":
@@ -504,7 +507,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
                         enc.load_tensor(name, a)
                 enc.finish_weights()
             else:
-                enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+                enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype, quant_scope=L.QUANT_SCOPE_PER_TEXT if dname == "int8_pertext" else L.QUANT_SCOPE_BATCH)
             ids, mask, lens = synth_tokens(torch, b, ML, g, dev)
             emb = torch.empty((b, args.dim), dtype=torch.float32, device=dev)
             dt = timed_steps(torch, lambda i: enc.encode_ids_device(ids, mask, out=emb), 10, 3)
@@ -515,15 +518,16 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             att = float((lens.double() * ML).sum()) if dname != "bf16" else float((lens.double() ** 2).sum())
             flop = float(tok_c * 2 * (4 * H * H + 2 * H * F) * LAYERS + att * 4 * H * LAYERS)
             e = {"name": "encoder_%s_b%d" % (dname, b), "workload": "MiniLM-L6 (6 x 384, 12 heads, FFN 1536) forward + mean-pool, %d texts, lengths U[8,128], %s"
-                 % (b, ("the padded [B, 256] tensor of the reference's quantised export (dynamic uint8 activations x 8-bit weights, int32 MFMA)" + ("; weights as an export stores them: uint8 with a zero point per tensor" if dname == "int8_export" else "; symmetric fallback weights")) if dname != "bf16" else "real tokens only"),
+                 % (b, ("the padded [B, 256] tensor of the reference's quantised export (dynamic uint8 activations x 8-bit weights, int32 MFMA)" + ("; weights as an export stores them: uint8 with a zero point per tensor" if dname == "int8_export" else "; symmetric fallback weights")
+                        + ("; quant_scope PER_TEXT = B x encode() (one DynamicQuantizeLinear range per text: the function remember / recall compute)" if dname == "int8_pertext" else "; quant_scope BATCH = encode_batch (ranges over the batch tensor)")) if dname != "bf16" else "real tokens only"),
                  "ms_per_step": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens_per_s": round(tokens / dt, 1), "tokens": tokens, "positions_computed": tok_c,
                  "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / 1e12 / peak, 4), "mfma_peak_used": peak,
                  "flop_per_step": flop}
             done(e, t0)
-            if dname != "bf16":
+            if dname not in ("bf16", "int8_pertext") or not want("cfg3_pipeline"):
                 enc.close()
                 continue
-            # configs[2]
+            # configs[2] (bf16, and INT8 per text = the reference's default model run the way remember / recall run it)
             t0 = time.perf_counter()
             n_texts = args.pipeline_texts
             idx = S.VamanaIndex(S.VamanaConfig(dimension=args.dim, reserve_rows=n_texts))
@@ -552,7 +556,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             dts = timed_steps(torch, lambda i: idx.search_batch_device(qemb, 10, out=out), 30, 5)
             idx.search_batch(qemb.cpu().numpy(), 10)
             st = idx.scan_stats()
-            e = {"name": "cfg3_pipeline", "workload": "configs[2]: %d synthetic texts -> MiniLM-L6 bf16 -> add_vectors -> recall top-10 of 256 query TEXTS" % n_texts,
+            e = {"name": "cfg3_pipeline" if dname == "bf16" else "cfg3_pipeline_int8",
+                 "workload": "configs[2]: %d synthetic texts -> MiniLM-L6 %s -> add_vectors -> recall top-10 of 256 query TEXTS" % (n_texts, "bf16" if dname == "bf16" else "INT8, quant_scope PER_TEXT (every text and every query is one encode() of the reference: padded [1, 256] tensor, its own ranges)"),
                  "parity": "timing only at this size; the chained parity test (HIP MiniLM -> add_vectors -> recall, bit-equal to the oracle on the device-produced embeddings) "
                            "runs 50 000 texts: tests/test_round2_gpu.py::test_configs2_chained_encode_add_recall",
                  "ingest_texts_per_s": round(n_texts / t_ingest, 1), "ingest_s": round(t_ingest, 3), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SHODH_HIP_ABI_VERSION 3
+#define SHODH_HIP_ABI_VERSION 4
 
 typedef enum {
     SHODH_OK = 0,
@@ -283,9 +283,15 @@ typedef struct {
     uint32_t compute_padded; /* 0: only real tokens (exact in fp32/bf16, minilm.rs:153-154); 1 (INT8 only): all max_len positions of every
                               * non-empty text, as the reference's tensor has them -- DynamicQuantizeLinear takes its range over
                               * the padded tensor, so the padding is part of the INT8 embedding function (minilm.rs:588-593) */
+    uint32_t quant_scope;    /* INT8 only: the tensor a DynamicQuantizeLinear range spans when encode_ids gets b > 1 texts (SHODH_QUANT_SCOPE_*, below).
+                              * BATCH (0, default) = the reference's encode_batch: one session.run on [B, max_len] (minilm.rs:996-1115), ranges over the
+                              * whole batch tensor. PER_TEXT (1) = B calls of the reference's encode(): one session.run on [1, max_len] each
+                              * (minilm.rs:883-982) -- what remember / index_memory / recall compute (memory/mod.rs:1037, retrieval.rs:673, :708,
+                              * :878): every range spans ONE text's padded tensor, a batch of N texts is bit-identical to N calls with b = 1 */
     const char *weights_path; /* NULL, or the model file shodh_embedder_create loads (EmbeddingConfig.model_path, minilm.rs:212-220): model.safetensors,
                               * model.onnx, or the dynamic-quantisation export model_quantized.onnx -- see shodh_embedder_load_file */
 } shodh_embed_cfg;
+enum { SHODH_QUANT_SCOPE_BATCH = 0, SHODH_QUANT_SCOPE_PER_TEXT = 1 };
 void shodh_embed_cfg_default(shodh_embed_cfg *cfg);
 int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out);   /* MiniLMEmbedder::new minilm.rs:652-690 */
 void shodh_embedder_destroy(shodh_embedder *e);
@@ -342,6 +348,10 @@ uint32_t shodh_embedder_dimension(const shodh_embedder *e);                    /
 int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out);
 int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b,
                                      float *d_out, void *stream);
+/* switch the INT8 quantisation scope of later encode calls (cfg.quant_scope; no reallocation, no effect on fp32 / bf16): a host calls
+ * PER_TEXT for bulk `remember` ingest (N x encode()) and BATCH where the reference itself calls encode_batch (memory/mod.rs:8443, :8838) */
+int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope);
+uint32_t shodh_embedder_quant_scope(const shodh_embedder *e);
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /* StageTiming.embedding_us */
 /* One dynamically quantised dense layer, y = dequant(MatMulInteger(DynamicQuantizeLinear(x), quantise(w))) + bias, on host data:
  * x [M][K], w [N][K] (quantised per tensor, symmetric 8 bit), bias [N] or NULL, y [M][N]; N % 128 == 0, K % 128 == 0.

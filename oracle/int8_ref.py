@@ -153,12 +153,18 @@ def quantize_model(sd, layers, rule=quantize_weight, word_rule=None):
     return q
 
 
-def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None, qmodel=None):
+def encode(sd, ids, mask, heads=12, eps=1e-12, layers=6, trace=None, qmodel=None, per_text=False):
     """ids/mask [B, S] (S = the padded tensor length, max_len). Rows with an empty mask are left out of the tensor (the
     reference never runs empty texts, minilm.rs:1123-1125, :1319-1350) and come back as zeros. -> unit vectors [B, H].
-    `trace` (dict) receives the int32 accumulators and quantisation parameters of layer 0's query projection."""
+    `trace` (dict) receives the int32 accumulators and quantisation parameters of layer 0's query projection.
+    per_text=False: ONE tensor [B, S, H] per DynamicQuantizeLinear = the reference's encode_batch (minilm.rs:996-1115).
+    per_text=True: B tensors [1, S, H] = B calls of the reference's encode() (minilm.rs:883-982; what remember / recall run,
+    memory/mod.rs:1037, retrieval.rs:673, :708, :878) -- restated literally as B calls of this function on one row each."""
     ids = np.asarray(ids); mask = np.asarray(mask)
     B, S = ids.shape
+    if per_text and B > 1:
+        qm = qmodel if qmodel is not None else quantize_model(sd, layers)
+        return np.concatenate([encode(sd, ids[i:i + 1], mask[i:i + 1], heads, eps, layers, None, qm) for i in range(B)], 0)
     H = sd["embeddings.word_embeddings.weight"].shape[1]
     out = np.zeros((B, H), f32)
     keep = np.nonzero(mask.sum(1) > 0)[0]

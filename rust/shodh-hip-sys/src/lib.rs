@@ -411,7 +411,7 @@ pub trait Tokenize: Send + Sync {
 /// GEMM operand type of the encoder. `Int8` is the reference's default model (SHODH_USE_QUANTIZED_MODEL unset, minilm.rs:205-220).
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum EncoderDtype { Fp32, Bf16, Int8 }
-pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize }
+pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize, scope_mu: std::sync::Mutex<()> }
 unsafe impl<T: Tokenize> Send for HipEmbedder<T> {}
 unsafe impl<T: Tokenize> Sync for HipEmbedder<T> {}
 impl<T: Tokenize> HipEmbedder<T> {
@@ -440,7 +440,7 @@ impl<T: Tokenize> HipEmbedder<T> {
         cfg.weights_path = path.map_or(std::ptr::null(), |p| p.as_ptr());
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::shodh_embedder_create(&cfg, &mut h) })?;
-        Ok(Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize })
+        Ok(Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize, scope_mu: std::sync::Mutex::new(()) })
     }
     pub fn dimension(&self) -> usize { self.dim }
     pub fn encode(&self, text: &str) -> Result<Vec<f32>> {
@@ -448,8 +448,16 @@ impl<T: Tokenize> HipEmbedder<T> {
         Ok(self.encode_batch(&[text])?.pop().unwrap())
     }
     pub fn encode_query(&self, text: &str) -> Result<Vec<f32>> { self.encode(text) } // symmetric model
-    /// minilm.rs:1247-1376: one device call for the whole batch; empty texts give zero vectors
-    pub fn encode_batch(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> {
+    /// minilm.rs:1247-1376: one device call for the whole batch; empty texts give zero vectors. INT8: `SHODH_QUANT_SCOPE_BATCH`, the
+    /// reference's own `encode_batch` arithmetic (one `session.run` on `[B, max_len]`, DynamicQuantizeLinear ranges over the batch tensor).
+    pub fn encode_batch(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> { self.encode_scoped(texts, ffi::SHODH_QUANT_SCOPE_BATCH as u32) }
+    /// N x `encode()` in one device call: what `remember` / `index_memory` / `recall` compute text by text (memory/mod.rs:1037,
+    /// retrieval.rs:673, :708, :878 -- one `session.run` on `[1, max_len]` each, minilm.rs:883-982). INT8: `SHODH_QUANT_SCOPE_PER_TEXT`,
+    /// every range spans one text's padded tensor; bit-identical to calling `encode` N times. fp32 / bf16: the same as `encode_batch`.
+    pub fn encode_each(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> { self.encode_scoped(texts, ffi::SHODH_QUANT_SCOPE_PER_TEXT as u32) }
+    fn encode_scoped(&self, texts: &[&str], scope: u32) -> Result<Vec<Vec<f32>>> {
+        let _g = self.scope_mu.lock().map_err(|_| anyhow!("embedder scope lock poisoned"))?;
+        check(unsafe { ffi::shodh_embedder_set_quant_scope(self.h, scope) })?;
         let b = texts.len();
         let (mut ids, mut mask) = (vec![0i32; b * self.max_len], vec![0u8; b * self.max_len]);
         for (r, text) in texts.iter().enumerate() {

@@ -26,6 +26,7 @@ ORDER_SCALAR4, ORDER_AVX2, ORDER_SEQ_1M = 0, 1, 2
 INDEX_FLAT, INDEX_IVFPQ = 0, 1
 SCAN_AUTO, SCAN_EXACT, SCAN_MFMA, SCAN_GRAPH = 0, 1, 2, 3
 DTYPE_FP32, DTYPE_BF16, DTYPE_INT8 = 0, 1, 2
+QUANT_SCOPE_BATCH, QUANT_SCOPE_PER_TEXT = 0, 1      # shodh_embed_cfg.quant_scope
 WEIGHT_ABSENT, WEIGHT_F32, WEIGHT_EXPORT_Q8, WEIGHT_SELF_Q8 = 0, 1, 2, 3
 
 
@@ -46,7 +47,7 @@ class EmbedCfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("dtype", C.c_uint32), ("max_len", C.c_uint32), ("vocab", C.c_uint32),
                 ("hidden", C.c_uint32), ("layers", C.c_uint32), ("heads", C.c_uint32), ("intermediate", C.c_uint32),
                 ("max_pos", C.c_uint32), ("type_vocab", C.c_uint32), ("ln_eps", C.c_float), ("compute_padded", C.c_uint32),
-                ("weights_path", C.c_char_p)]
+                ("quant_scope", C.c_uint32), ("weights_path", C.c_char_p)]
 
 
 class Weights(C.Structure):
@@ -194,6 +195,8 @@ SYMBOLS = {
     "shodh_embedder_encode_ids_device": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, _fp, _vp]),
     "shodh_int8_dense": (C.c_int, [C.c_int, _fp, _fp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _fp, _i32p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "shodh_embedder_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 2)]),
+    "shodh_embedder_set_quant_scope": (C.c_int, [_vp, C.c_uint32]),
+    "shodh_embedder_quant_scope": (C.c_uint32, [_vp]),
     "shodh_weights_default": (None, [C.POINTER(Weights)]),
     "shodh_weights_normalize": (None, [C.POINTER(Weights)]),
     "shodh_weights_apply_feedback": (None, [C.POINTER(Weights), C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -497,10 +497,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        T *__restrict__ out, int ntok, int H, int max_len, int vocab, float eps,
                                                        const int8_t *__restrict__ word_q /* INT8 mode: the 8-bit word table, else null */, const float *__restrict__ word_scale,
-                                                       uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */) {
+                                                       uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */,
+                                                       int mm_rows = 0 /* > 0: one range per sequence of mm_rows rows (mm is [sequences][2]) */) {
     const int lane = threadIdx.x & 63;
     const int tok = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (tok >= ntok) return;                 // wave-uniform: one wave per token
+    if (mm && mm_rows) mm += 2 * (tok / mm_rows);
     const int sq = tok_seq[tok], p = tok_pos[tok];
     int id = ids[(size_t)sq * max_len + p];
     if (id < 0) id = 0;
@@ -830,7 +832,9 @@ struct shodh_embedder {
     bool need_rs = false;
     uint32_t int8_stages = 0x6F;         // bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
-    uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][2]
+    uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][slots][2], then the GELU trackers [layers][slots][4]; slots = 1 (batch scope) or the sequences (per-text scope)
+    size_t mmr_slots = 0;
+    uint32_t quant_scope = SHODH_QUANT_SCOPE_BATCH;
     uint32_t *qkv_hc = nullptr;          // [layers][heads][4][128] per-head constants of the fused q|k|v matrices (pack_head_consts_kernel)
     float *act_params = nullptr;         // {scale, zp} of the current activation tensor
     uint32_t *qscratch = nullptr;        // min/max keys, absmax
@@ -1059,10 +1063,12 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
 //   X f32 -> [quantise] XQ -> A: q|k|v + attention -> CTX f32 (+ range) -> [quantise] XQ -> B: attention output + residual + LayerNorm -> X
 //   -> [quantise] XQ -> C: FFN up + GELU -> HQ bytes (range pass, then quantising pass | f32 tensor, then a quantising pass over it)
 //   -> D: FFN down + residual + LayerNorm -> X
-__global__ void init_ranges_kernel(uint32_t *mm, int n_pairs, int layers) {
-    for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
-    uint32_t *stats = mm + 2 * n_pairs;           // per layer {max key (0 = none), min key (0xFFFFFFFF = none), max key, unused}
-    for (int i = threadIdx.x; i < layers; i += blockDim.x) { stats[4 * i] = 0u; stats[4 * i + 1] = 0xFFFFFFFFu; stats[4 * i + 2] = 0u; stats[4 * i + 3] = 0u; }
+// n_pairs = (tensors of a forward) x (range slots: 1, or the sequences under SHODH_QUANT_SCOPE_PER_TEXT); n_stats likewise layers x slots
+__global__ void init_ranges_kernel(uint32_t *mm, int n_pairs, int n_stats) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = i0; i < n_pairs; i += stride) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+    uint32_t *stats = mm + 2 * (size_t)n_pairs;   // per layer (and slot) {max key (0 = none), min key (0xFFFFFFFF = none), max key, unused}
+    for (int i = i0; i < n_stats; i += stride) { stats[4 * i] = 0u; stats[4 * i + 1] = 0xFFFFFFFFu; stats[4 * i + 2] = 0u; stats[4 * i + 3] = 0u; }
 }
 template <int EPI>
 static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
@@ -1070,6 +1076,19 @@ static int launch_i8_stream(const S8Args &a, int cus, hipStream_t st) {
     if (n_workers < 8) n_workers = 8;
     const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
     if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
+    if constexpr (EPI == SEPI_RESID_LN) {
+        if (a.mm_rows) {       // one range per sequence
+            if (a.zw && a.rsA) {
+                SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI, true, true>, S8_LDS));
+                hipLaunchKernelGGL((i8_stream_kernel<EPI, true, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+            } else {
+                SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI, false, true>, S8_LDS));
+                hipLaunchKernelGGL((i8_stream_kernel<EPI, false, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
+            }
+            SHODH_HIP_TRY(hipGetLastError());
+            return SHODH_OK;
+        }
+    }
     if (a.zw && a.rsA) {
         SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_kernel<EPI, true>, S8_LDS));
         hipLaunchKernelGGL((i8_stream_kernel<EPI, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), S8_LDS, st, a);
@@ -1087,6 +1106,17 @@ static int launch_i8_stream_gelu(const S8Args &a, int cus, hipStream_t st) {
     const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
     if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
     const size_t lds = QUANT ? S8G_LDS_QUANT : S8G_LDS_RANGE;
+    if (a.mm_rows) {           // one range per sequence
+        if (a.zw && a.rsA) {
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true, true>, lds));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+        } else {
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false, true>, lds));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+        }
+        SHODH_HIP_TRY(hipGetLastError());
+        return SHODH_OK;
+    }
     if (a.zw && a.rsA) {
         SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true>, lds));
         hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
@@ -1097,7 +1127,13 @@ static int launch_i8_stream_gelu(const S8Args &a, int cus, hipStream_t st) {
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
-static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t *xq, const uint32_t *mm, int32_t *rs, hipStream_t st) {
+static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t *xq, const uint32_t *mm, int32_t *rs, hipStream_t st, int ps_rows = 0) {
+    if (ps_rows) {         // one range per sequence (SHODH_QUANT_SCOPE_PER_TEXT)
+        const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div((size_t)M * 32, 256), 1), 4096);
+        hipLaunchKernelGGL(act_quant_seq_kernel, dim3(blocks), dim3(256), 0, st, x, M, K, mm, ps_rows, xq, e->need_rs ? rs : (int32_t *)nullptr);
+        SHODH_HIP_TRY(hipGetLastError());
+        return SHODH_OK;
+    }
     if (e->need_rs) {
         const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>(ceil_div((size_t)M * 32, 256), 1), 4096);
         hipLaunchKernelGGL(act_quant_rows_kernel, dim3(blocks), dim3(256), 0, st, x, M, K, mm, xq, e->act_params, rs);
@@ -1106,7 +1142,13 @@ static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t 
     }
     return quantize_known_range(x, (size_t)M * K, xq, e->act_params, mm, st);
 }
-static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, const int32_t *klen, const int32_t *orow, float *d_out, hipStream_t st) {
+// ps_rows = 0: SHODH_QUANT_SCOPE_BATCH, every DynamicQuantizeLinear range spans the whole computed tensor (the reference's encode_batch,
+// minilm.rs:996-1115). ps_rows = max_len: SHODH_QUANT_SCOPE_PER_TEXT, one range per sequence of ps_rows positions -- N x encode()
+// (minilm.rs:883-982); needs the fused kernels, every sequence padded to max_len positions and max_len a multiple of 128 (the callers check).
+static bool per_text_fast_ok(const shodh_embedder *e, int max_keys) {
+    return e->int8_all_fast && (e->int8_stages & 0x60u) == 0x60u && e->cfg.compute_padded && e->cfg.max_len % 128 == 0 && e->cfg.max_len <= 256 && max_keys <= 128;
+}
+static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, const int32_t *klen, const int32_t *orow, float *d_out, hipStream_t st, int ps_rows = 0) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
     const float eps = e->cfg.ln_eps;
     float *X = (float *)e->X, *QKV = (float *)e->QKV, *CTX = (float *)e->CTX, *FF = (float *)e->FF;
@@ -1124,10 +1166,20 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     // Every tensor that feeds a quantised dense layer gets its min / max from the kernel that writes it, not from a pass of its own:
     // one pair of order keys per tensor of the forward, all initialised by one launch.
     const int n_pairs = 4 * (int)e->cfg.layers + 2;
-    hipLaunchKernelGGL(init_ranges_kernel, dim3(1), dim3(64), 0, st, e->mmr, n_pairs, (int)e->cfg.layers);
-    uint32_t *mmX = e->mmr;                               // range of the current layer input
+    const int S = ps_rows ? nseq : 1;                     // range slots per tensor
+    const int mm_stride = ps_rows ? 2 : 0;
+    if ((size_t)S > e->mmr_slots) {
+        hipFree(e->mmr); e->mmr = nullptr; e->mmr_slots = 0;
+        const size_t cap = (size_t)S + (size_t)S / 4 + 16;
+        SHODH_HIP_TRY(hipMalloc((void **)&e->mmr, ((size_t)n_pairs * 8 + (size_t)e->cfg.layers * 16) * cap));
+        e->mmr_slots = cap;
+    }
+    if (ps_rows && (!fS || !fB || !fC || !fD || !(stages & 64u) || ntok != nseq * ps_rows || ps_rows % 128 != 0)) { set_error("INT8 encoder: per-text ranges need the fused kernels and max_len-padded sequences"); return SHODH_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(init_ranges_kernel, dim3((uint32_t)std::min(ceil_div((size_t)n_pairs * S, 256), (size_t)1024)), dim3(256), 0, st, e->mmr, n_pairs * S, (int)e->cfg.layers * S);
+    auto mm_of = [&](int t) { return e->mmr + (size_t)2 * S * t; };      // range keys of tensor t of the forward: [S][2]
+    uint32_t *mmX = mm_of(0);                             // range of the current layer input
     hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
-                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
+                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX, ps_rows);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_keys * 32 * 4 * 2;
     if (!fA) SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
@@ -1135,18 +1187,18 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     for (uint32_t li = 0; li < e->cfg.layers; ++li) {
         const LayerOff &l = e->lo[li];
         const float *bqkv = e->bqkv + (size_t)li * 3 * H;
-        uint32_t *mmC = e->mmr + 2 * (4 * li + 1), *mmX1 = e->mmr + 2 * (4 * li + 2), *mmF = e->mmr + 2 * (4 * li + 3), *mmXn = e->mmr + 2 * (4 * li + 4);
+        uint32_t *mmC = mm_of(4 * li + 1), *mmX1 = mm_of(4 * li + 2), *mmF = mm_of(4 * li + 3), *mmXn = mm_of(4 * li + 4);
         const QWeight &wq = e->q_qkv[li], &wo = e->q_o[li], &wu = e->q_up[li], &wd = e->q_dn[li];
         // ---- A: q | k | v projections + attention
         if (fS) {
             if (wq.zw) {
                 SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<true>, QS_LDS));
                 hipLaunchKernelGGL((qkv_attn_seq_kernel<true>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
-                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads);
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride);
             } else {
                 SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<false>, QS_LDS));
                 hipLaunchKernelGGL((qkv_attn_seq_kernel<false>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
-                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads);
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride);
             }
         } else if (fA) {
             SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));          // one quantisation feeds q, k and v (same tensor)
@@ -1160,9 +1212,10 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         }
         SHODH_HIP_TRY(hipGetLastError());
         // ---- B: attention output + residual + LayerNorm
-        SHODH_TRY(quantize_act(e, CTX, ntok, H, e->XQ, mmC, e->rsX, st));
+        SHODH_TRY(quantize_act(e, CTX, ntok, H, e->XQ, mmC, e->rsX, st, ps_rows));
         if (fB) {
             S8Args a{};
+            a.mm_rows = ps_rows;
             a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmC; a.Wp = wo.qp; a.wscale = wo.scale; a.rsz = wo.rsz; a.zw = wo.zw; a.bias = w + l.ob;
             a.resid = X; a.gamma = w + l.ln1g; a.beta = w + l.ln1b; a.eps = eps; a.out_f = X; a.mm_out = mmX1; a.M = ntok; a.N = H; a.n_groups = 1;
             SHODH_TRY(launch_i8_stream<SEPI_RESID_LN>(a, e->cus, st));
@@ -1172,17 +1225,18 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             SHODH_HIP_TRY(hipGetLastError());
         }
         // ---- C: FFN up + GELU -> quantised bytes (HQ) and their range (mmF)
-        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX1, e->rsX, st));
+        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX1, e->rsX, st, ps_rows));
         if (fC) {
             S8Args a{};
+            a.mm_rows = ps_rows;
             a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmX1; a.Wp = wu.qp; a.wscale = wu.scale; a.rsz = wu.rsz; a.zw = wu.zw; a.bias = w + l.ib;
             a.M = ntok; a.N = I; a.n_groups = I / S8_NF;
-            uint32_t *stats = e->mmr + 2 * n_pairs + 4 * li;                            // {nearest pre-activation left of gelu's argmin, right of it, largest}: see gelu_range_finalize_kernel
+            uint32_t *stats = e->mmr + (size_t)2 * S * n_pairs + (size_t)4 * S * li;     // {nearest pre-activation left of gelu's argmin, right of it, largest}: see gelu_range_finalize_kernel
             a.mm_out = stats;
             const bool piped = stages & 64u;
             if (piped) SHODH_TRY(launch_i8_stream_gelu<false>(a, e->cus, st));          // pass 1: the three pre-activations that decide the range of gelu(up(x)); nothing stored
             else SHODH_TRY(launch_i8_stream<SEPI_GELU_RANGE>(a, e->cus, st));
-            hipLaunchKernelGGL(gelu_range_finalize_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)stats, mmF);
+            hipLaunchKernelGGL(gelu_range_finalize_kernel, dim3((uint32_t)ceil_div((size_t)S, 256)), dim3(256), 0, st, (const uint32_t *)stats, mmF, S);
             a.mm_out = nullptr; a.mmO = mmF; a.out_q = e->HQ; a.rs_out = (e->need_rs && wd.zw && !fD) ? e->rsH : nullptr;      // (the fused FFN-down kernel forms the row sums of these bytes itself)
             if (a.rs_out) SHODH_HIP_TRY(hipMemsetAsync(e->rsH, 0, (size_t)ntok * 4, st));
             if (piped) SHODH_TRY(launch_i8_stream_gelu<true>(a, e->cus, st));           // pass 2: the same values again, quantised on the way out
@@ -1196,11 +1250,11 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             if (wd.zw) {
                 SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel<true>, KT_LDS));
                 hipLaunchKernelGGL(i8_ktile_ln_kernel<true>, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)nullptr, (const uint32_t *)mmF,
-                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I, ps_rows);
             } else {
                 SHODH_TRY(ensure_dynamic_lds((const void *)i8_ktile_ln_kernel<false>, KT_LDS));
                 hipLaunchKernelGGL(i8_ktile_ln_kernel<false>, dim3((ntok + KT_TM - 1) / KT_TM), dim3(512), KT_LDS, st, (const int8_t *)e->HQ, (const int32_t *)nullptr, (const uint32_t *)mmF,
-                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I);
+                                   (const int8_t *)wd.q, (const float *)wd.scale, (const int32_t *)wd.rsz, (const int32_t *)wd.zw, w + l.db, (const float *)X, w + l.ln2g, w + l.ln2b, eps, X, mmXn, ntok, I, ps_rows);
             }
             SHODH_HIP_TRY(hipGetLastError());
         } else {
@@ -1371,6 +1425,7 @@ void shodh_embed_cfg_default(shodh_embed_cfg *cfg) {
     cfg->max_pos = 512; cfg->type_vocab = 2;
     cfg->ln_eps = 1e-12f;
     cfg->compute_padded = 0;
+    cfg->quant_scope = SHODH_QUANT_SCOPE_BATCH;
     cfg->weights_path = nullptr;
 }
 
@@ -1383,6 +1438,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     }
     if (cfg->max_len == 0 || cfg->max_len > cfg->max_pos || cfg->max_len > 512) { set_error("max_len %u out of range", cfg->max_len); return SHODH_ERR_INVALID; }
     if (cfg->dtype > SHODH_DTYPE_INT8) { set_error("unknown dtype %u", cfg->dtype); return SHODH_ERR_INVALID; }
+    if (cfg->quant_scope > SHODH_QUANT_SCOPE_PER_TEXT) { set_error("unknown quant_scope %u", cfg->quant_scope); return SHODH_ERR_INVALID; }
     if (cfg->compute_padded && cfg->dtype != SHODH_DTYPE_INT8) { set_error("compute_padded=1 only matters for the INT8 graph (its activation ranges span the padded tensor, minilm.rs:588-593); fp32/bf16 results are identical without padding"); return SHODH_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libshodh_hip has no CPU fallback"); return SHODH_ERR_DEVICE; }
@@ -1392,6 +1448,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     e->cfg = *cfg;
     if (cfg->weights_path) e->weights_path = cfg->weights_path;
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
+    e->quant_scope = cfg->quant_scope;
     if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x7Fu;       // speed only: which stages run the fused kernels
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
@@ -1404,8 +1461,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         hipMalloc((void **)&e->w2p16, (size_t)cfg->layers * cfg->intermediate * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
-    if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess ||
-                                           hipMalloc((void **)&e->mmr, (size_t)(4 * cfg->layers + 2) * 8 + (size_t)cfg->layers * 16) != hipSuccess)) {
+    if (cfg->dtype == SHODH_DTYPE_INT8 && (hipMalloc((void **)&e->act_params, 64) != hipSuccess || hipMalloc((void **)&e->qscratch, 64) != hipSuccess)) {
         shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
     }
     SHODH_HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -1559,7 +1615,11 @@ int shodh_embedder_init_synthetic(shodh_embedder *e, uint64_t seed, float *blob_
     return shodh_embedder_load_weights(e, blob.data(), e->n_params);
 }
 
-static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, bool device_io, hipStream_t user_st) {
+// scope: SHODH_QUANT_SCOPE_* of this call (INT8 only). PER_TEXT runs the per-sequence kernels when the shape allows (per_text_fast_ok); when it
+// does not, returns ENC_RETRY_EACH before touching the device and the caller runs the texts one per forward -- which is the same function by
+// definition (a batch of one text has one range per tensor either way).
+constexpr int ENC_RETRY_EACH = 1;
+static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, bool device_io, hipStream_t user_st, uint32_t scope = SHODH_QUANT_SCOPE_BATCH) {
     if (!e || (b && (!ids || !mask || !out))) { set_error("null argument"); return SHODH_ERR_INVALID; }
     if (b == 0) return SHODH_OK;
     if (!e->loaded) { set_error("encoder weights not loaded (shodh_embedder_load_weights / shodh_embedder_init_synthetic)"); return SHODH_ERR_STATE; }
@@ -1606,6 +1666,8 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
     }
     const int nseq_c = int8 ? (int)klen.size() : (int)b;
     const int ntok = cu.back();
+    const bool per_text = int8 && scope == SHODH_QUANT_SCOPE_PER_TEXT && nseq_c > 1;      // (one text: the two scopes are the same function, and the batch kernels take every shape)
+    if (per_text && !per_text_fast_ok(e, max_seq)) return ENC_RETRY_EACH;
     SHODH_TRY(reserve(e, (size_t)(ntok ? ntok : 1), b));
     if (device_io) SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyDeviceToDevice, st));
     else SHODH_HIP_TRY(hipMemcpyAsync(e->d_ids, idp, (size_t)b * ML * 4, hipMemcpyHostToDevice, st));
@@ -1625,7 +1687,7 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
     if (ntok == 0) { rc = (hipMemsetAsync(d_out, 0, (size_t)b * H * 4, st) == hipSuccess) ? SHODH_OK : SHODH_ERR_DEVICE; }
     else if (int8) {
         rc = (nseq_c == (int)b || hipMemsetAsync(d_out, 0, (size_t)b * H * 4, st) == hipSuccess) ? SHODH_OK : SHODH_ERR_DEVICE;    // empty texts -> zero vectors
-        if (rc == SHODH_OK) rc = forward_int8(e, ntok, nseq_c, max_seq, e->d_klen, e->d_orow, d_out, st);
+        if (rc == SHODH_OK) rc = forward_int8(e, ntok, nseq_c, max_seq, e->d_klen, e->d_orow, d_out, st, per_text ? (int)ML : 0);
     }
     else if (e->cfg.dtype == SHODH_DTYPE_FP32) rc = forward<float>(e, ntok, (int)b, max_seq, d_out, st);
     else rc = forward<__bf16>(e, ntok, (int)b, max_seq, d_out, st);
@@ -1643,20 +1705,41 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
 // texts per forward (406 k texts/s) and falls off above it (16 384: 367 k, 32 768: 301 k -- the activations outgrow the L2 / MALL and every
 // kernel of a layer goes back to HBM for them). The INT8 mode is NOT split: its activation ranges span the whole tensor a caller hands in
 // (minilm.rs:588-593), so the batch is part of the function.
-constexpr uint32_t ENC_SUB = 8192;
+// With SHODH_QUANT_SCOPE_PER_TEXT the texts are independent again (every range spans one text), so INT8 splits too: 4096 padded texts per forward
+// (1M positions; the workspace of a forward is ~13 KB per position).
+constexpr uint32_t ENC_SUB = 8192, ENC_SUB_PER_TEXT = 4096;
 static int encode_chunked(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, bool device_io, hipStream_t st) {
-    if (!e || b <= ENC_SUB || e->cfg.dtype == SHODH_DTYPE_INT8) return encode_impl(e, ids, mask, b, out, device_io, st);
+    if (!e) return encode_impl(e, ids, mask, b, out, device_io, st);
+    const bool int8 = e->cfg.dtype == SHODH_DTYPE_INT8;
+    const uint32_t scope = int8 ? __atomic_load_n(&e->quant_scope, __ATOMIC_RELAXED) : (uint32_t)SHODH_QUANT_SCOPE_BATCH;
+    const bool per_text = int8 && scope == SHODH_QUANT_SCOPE_PER_TEXT;
+    const uint32_t sub = per_text ? ENC_SUB_PER_TEXT : ENC_SUB;
+    if (b <= sub || (int8 && !per_text)) {
+        const int rc = encode_impl(e, ids, mask, b, out, device_io, st, scope);
+        if (rc != ENC_RETRY_EACH) return rc;
+    }
     const size_t ML = e->cfg.max_len, H = e->cfg.hidden;
     float us = 0.0f, tok = 0.0f;
-    for (uint32_t at = 0; at < b; at += ENC_SUB) {
-        const uint32_t m = b - at < ENC_SUB ? b - at : ENC_SUB;
-        SHODH_TRY(encode_impl(e, ids + (size_t)at * ML, mask + (size_t)at * ML, m, out + (size_t)at * H, device_io, st));
+    bool each = false;                   // a shape the per-sequence kernels do not take (decided by the first chunk that meets one): one text per forward from there on
+    for (uint32_t at = 0; at < b;) {
+        uint32_t m = each ? 1u : (b - at < sub ? b - at : sub);
+        int rc = encode_impl(e, ids + (size_t)at * ML, mask + (size_t)at * ML, m, out + (size_t)at * H, device_io, st, each ? (uint32_t)SHODH_QUANT_SCOPE_BATCH : scope);
+        if (rc == ENC_RETRY_EACH) { each = true; continue; }
+        if (rc != SHODH_OK) return rc;
         us += e->last_us[0]; tok += e->last_us[1];
+        at += m;
     }
     e->last_us[0] = us; e->last_us[1] = tok;          // stage timings of the whole call
     return SHODH_OK;
 }
 
+int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope) {
+    if (!e) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    if (scope > SHODH_QUANT_SCOPE_PER_TEXT) { set_error("unknown quant_scope %u", scope); return SHODH_ERR_INVALID; }
+    __atomic_store_n(&e->quant_scope, scope, __ATOMIC_RELAXED);
+    return SHODH_OK;
+}
+uint32_t shodh_embedder_quant_scope(const shodh_embedder *e) { return e ? __atomic_load_n(&e->quant_scope, __ATOMIC_RELAXED) : 0u; }
 int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out) {
     return encode_chunked(e, ids, mask, b, out, false, nullptr);
 }

@@ -88,15 +88,19 @@ __device__ __forceinline__ uint32_t pack_u8(uint32_t acc, float rq, int byte) {
 // tensor by that approximation error at most -- a relative 1e-7 on the scale, below the approximation's own effect on the bytes.
 constexpr float GELU_ARGMIN = -0.7517915964f;
 // stats[0] = key of max{x <= x*} (atomicMax, 0 = none), stats[1] = key of min{x >= x*} (atomicMin, 0xFFFFFFFF = none), stats[2] = key of max x
-__global__ void gelu_range_finalize_kernel(const uint32_t *__restrict__ stats, uint32_t *__restrict__ mm) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float lo = 0.0f, hi = 0.0f;           // DynamicQuantizeLinear widens the range to contain 0 anyway
-    bool any = false;
-    if (stats[0] != 0u) { const float g = gelu_i8(order_key_inv(stats[0])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
-    if (stats[1] != 0xFFFFFFFFu) { const float g = gelu_i8(order_key_inv(stats[1])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
-    if (stats[2] != 0u) { const float g = gelu_i8(order_key_inv(stats[2])); lo = fminf(lo, g); hi = fmaxf(hi, g); any = true; }
-    (void)any;
-    mm[0] = order_key(lo); mm[1] = order_key(hi);
+__device__ __forceinline__ void gelu_range_from_stats(const uint32_t *stats, float &lo, float &hi) {
+    lo = 0.0f; hi = 0.0f;                 // DynamicQuantizeLinear widens the range to contain 0 anyway
+    if (stats[0] != 0u) { const float g = gelu_i8(order_key_inv(stats[0])); lo = fminf(lo, g); hi = fmaxf(hi, g); }
+    if (stats[1] != 0xFFFFFFFFu) { const float g = gelu_i8(order_key_inv(stats[1])); lo = fminf(lo, g); hi = fmaxf(hi, g); }
+    if (stats[2] != 0u) { const float g = gelu_i8(order_key_inv(stats[2])); lo = fminf(lo, g); hi = fmaxf(hi, g); }
+}
+// n = 1: the batch tensor; n = sequences: one range per text (SHODH_QUANT_SCOPE_PER_TEXT), stats [n][4], mm [n][2]
+__global__ void gelu_range_finalize_kernel(const uint32_t *__restrict__ stats, uint32_t *__restrict__ mm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo, hi;
+    gelu_range_from_stats(stats + 4 * i, lo, hi);
+    mm[2 * i] = order_key(lo); mm[2 * i + 1] = order_key(hi);
 }
 
 // W_q[N][K] signed bytes -> fragment-major [N/32][K/32][64 lanes][16]: lane = ((k % 32) / 16) * 32 + n % 32 holds bytes k % 16
@@ -142,6 +146,39 @@ __global__ __launch_bounds__(256) void act_quant_rows_kernel(const float *__rest
         if (l == 0) rowsum[row] = s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { params_out[0] = p.scale; params_out[1] = zpf; }
+}
+
+// the same with one range per SEQUENCE of `rows_per_seq` rows (SHODH_QUANT_SCOPE_PER_TEXT: every DynamicQuantizeLinear spans one text's
+// [max_len, K] tensor); rowsum may be null
+__global__ __launch_bounds__(256) void act_quant_seq_kernel(const float *__restrict__ x, int M, int K, const uint32_t *__restrict__ mm, int rows_per_seq,
+                                                            int8_t *__restrict__ out, int32_t *__restrict__ rowsum) {
+    const int l = threadIdx.x & 31;
+    const int k4 = K >> 2;
+    for (int row = (blockIdx.x * 256 + threadIdx.x) >> 5; row < M; row += (gridDim.x * 256) >> 5) {
+        const ActQ p = act_params(mm + 2 * (row / rows_per_seq));
+        const float zpf = (float)p.zp;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)row * K);
+        uint32_t *o4 = reinterpret_cast<uint32_t *>(out + (size_t)row * K);
+        int s = 0;
+        for (int g = l; g < k4; g += 32) {
+            const float4 v = x4[g];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float q = __builtin_rintf(e[j] / p.scale) + zpf;
+                q = fminf(fmaxf(q, 0.0f), 255.0f);
+                const int qi = (int)q - 128;
+                s += qi;
+                pk |= (uint32_t)(qi & 0xFF) << (8 * j);
+            }
+            o4[g] = pk;
+        }
+        if (rowsum) {
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (l == 0) rowsum[row] = s;
+        }
+    }
 }
 
 // x = hi + lo with hi = f16(x), lo = f16(x - hi): |x - (hi + lo)| <= 2^-22 |x| (+ 2^-25 absolute where lo is subnormal), so
@@ -428,7 +465,7 @@ template <bool ZW>
 __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__restrict__ X /* f32 layer input [M][384] */, const uint32_t *__restrict__ mmA /* its range keys */,
                                                               const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const uint32_t *__restrict__ hconsts /* pack_head_consts_kernel: [heads][4][128] */,
                                                               const int32_t *__restrict__ cu, const int32_t *__restrict__ klen /* or null */, float *__restrict__ ctx,
-                                                              uint32_t *__restrict__ mm_out, int heads) {
+                                                              uint32_t *__restrict__ mm_out, int heads, int mm_stride /* 0: one range for the batch tensor; 2: one per sequence */) {
     constexpr int H = 384, KS = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -438,6 +475,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkb = (S + 31) >> 5, nqb = (P + 31) >> 5;               // nkb <= 4, nqb <= 8 (launcher)
+    mmA += (size_t)seq * mm_stride;
+    if (mm_out) mm_out += (size_t)seq * mm_stride;
     const ActQ ap = act_params(mmA);
     const float a_scale = ap.scale, zpf = (float)ap.zp;
     const int corr = 128 - ap.zp;
@@ -815,10 +854,15 @@ struct S8Args {
     const uint32_t *mmO; int8_t *out_q; int32_t *rs_out;              // SEPI_GELU_QUANT: the output's range (from the RANGE pass), bytes [M][N], row sums (atomicAdd; or null)
     uint32_t *mm_out;                                                  // SEPI_RESID_LN / SEPI_GELU_RANGE: range keys of the output
     int M, N, n_groups;
+    int mm_rows;                                                       // PS kernels: rows per sequence (a multiple of the 64-row tile); range slot of row m = m / mm_rows: mmA / mmO / mm_out are [sequences][2], the GELU stats [sequences][4]
 };
+// range slot (in uint32 words, pairs) of the tile that starts at row m
+__device__ __forceinline__ int ps_slot(int m, int mm_rows) { return __builtin_amdgcn_readfirstlane(m / mm_rows); }
 
 // ZW: some weight zero point is non-zero (the row-sum term exists); without it the integer multiply per value is compiled out
-template <int EPI, bool ZW>
+// PS: one range per sequence (SHODH_QUANT_SCOPE_PER_TEXT): the activation scale / zero point are per TILE (a.mm_rows is a multiple of the tile), so
+// they are applied in the epilogue instead of being folded into the per-feature constants, and the output range is committed per tile
+template <int EPI, bool ZW, bool PS = false>
 __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     constexpr int KS = S8_KS, NS = 2 * KS, D = 5, RING = 6, PF = S8_NBUF - 1, NPC = S8_NPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -838,10 +882,11 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     float *c_b = reinterpret_cast<float *>(c_rz + S8_NF);
     int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + S8_NF);
     float *c_g = reinterpret_cast<float *>(c_zw + S8_NF), *c_be = c_g + S8_NF;
-    const ActQ ap = act_params(a.mmA);
+    static_assert(!PS || EPI == SEPI_RESID_LN, "the per-sequence form exists for the LayerNorm epilogue (the GELU passes run i8_stream_gelu_kernel)");
+    const ActQ ap = PS ? ActQ{1.0f, 128} : act_params(a.mmA);
     const float a_scale = ap.scale;
-    const int corr = 128 - ap.zp;
-    for (int i = tid; i < S8_NF; i += S8_NT) {      // per-feature constants with the tensor-wide ones folded in: s = a_scale * w_scale[n], crz = (128 - a_zp) * (rowsum_w[n] - K z[n])
+    const int corr = PS ? 1 : 128 - ap.zp;
+    for (int i = tid; i < S8_NF; i += S8_NT) {      // per-feature constants with the tensor-wide ones folded in: s = a_scale * w_scale[n], crz = (128 - a_zp) * (rowsum_w[n] - K z[n]) (PS: unfolded, the tile's own parameters join in the epilogue)
         c_ws[i] = a_scale * a.wscale[nbase + i]; c_rz[i] = corr * a.rsz[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
         if (EPI == SEPI_RESID_LN) { c_g[i] = a.gamma[i]; c_be[i] = a.beta[i]; }
     }
@@ -907,6 +952,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
     };
     for (; t < n_tiles; t += n_workers, ++it) {
         if (EPI == SEPI_GELU_QUANT) { if (it > 0) store_out_tile(t_prev, (it - 1) & 1); }
+        float t_scale = 1.0f; int t_corr = 1, t_slot = 0;              // PS: this tile's DynamicQuantizeLinear parameters
+        if (PS) { t_slot = ps_slot(t * S8_TR, a.mm_rows); const ActQ tp = act_params(a.mmA + 2 * t_slot); t_scale = tp.scale; t_corr = 128 - tp.zp; }
         const unsigned char *buf = smem + cur * S8_TILE;
         const uint32_t pfb = cur + PF >= S8_NBUF ? cur + PF - S8_NBUF : cur + PF;
         const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
@@ -1004,7 +1051,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                     const f32x4q r4 = *reinterpret_cast<const f32x4q *>(a.resid + (size_t)mc * S8_NF + nl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[4 * g + e] = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e] + r4[e];
+                        if (PS) v[4 * g + e] = (float)(acc[4 * g + e] + t_corr * rz[e] - (ZW ? z4[e] * rsa : 0)) * (t_scale * ws[e]) + b4[e] + r4[e];
+                        else v[4 * g + e] = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e] + r4[e];
                         s += v[4 * g + e];
                     }
                 }
@@ -1047,6 +1095,15 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                 }
             }
         }
+        if (PS && EPI == SEPI_RESID_LN && a.mm_out) {      // the tile's output range joins its sequence's
+            for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
+            if (lane == 0 && klo <= khi) {
+                uint32_t *mo = a.mm_out + 2 * t_slot;
+                if (klo < __atomic_load_n(mo, __ATOMIC_RELAXED)) atomicMin(mo, klo);
+                if (khi > __atomic_load_n(mo + 1, __ATOMIC_RELAXED)) atomicMax(mo + 1, khi);
+            }
+            klo = 0xFFFFFFFFu; khi = 0u;
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1063,7 +1120,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
             if (xmax > -__builtin_inff()) { const uint32_t k = order_key(xmax); if (k > __atomic_load_n(a.mm_out + 2, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 2, k); }
         }
     }
-    if (EPI == SEPI_RESID_LN && a.mm_out) {
+    if (!PS && EPI == SEPI_RESID_LN && a.mm_out) {
         for (int ofs = 32; ofs > 0; ofs >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, ofs)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, ofs)); }
         if (lane == 0) {
             if (klo < __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMin(a.mm_out, klo);
@@ -1081,7 +1138,10 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
 // instructions in the same scheduling region. Same tiles, same DMA ring, same barrier per tile; the output bytes of a tile are complete one
 // iteration later, so the byte pass rotates three output tiles in LDS instead of two.
 constexpr int S8G_LDS_RANGE = S8_RED, S8G_LDS_QUANT = S8_RED + 3 * S8_TILE;
-template <bool QUANT, bool ZW>
+// PS: one range per sequence (see i8_stream_kernel): the tile's own activation parameters join in the epilogue (one more packed multiply per pair of
+// values; the integer term as a fused multiply-add, still exact), the range pass commits its three trackers per token block to the block's sequence
+// (stats [sequences][4]), the byte pass takes the output scale of the block's sequence.
+template <bool QUANT, bool ZW, bool PS = false>
 __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) {
     constexpr int KS = S8_KS, NS = 2 * KS, D = 3, RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1106,7 +1166,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     // constants (the LayerNorm gains' place in i8_stream_kernel), read back with ds_read_b32.
     int32_t *c_rs = c_zw + S8_NF;                                    // [S8_NBUF][256], 64 used
     const uint32_t rs_lds = smem_lds + (uint32_t)S8_CONST + 4u * S8_NF * 4u;
-    const ActQ ap = act_params(a.mmA);
+    const ActQ ap = PS ? ActQ{1.0f, 127} : act_params(a.mmA);       // (PS: scale 1 and correction factor 1 = the constants stay unfolded)
     const float a_scale = ap.scale;
     const int corr = 128 - ap.zp;
     // Without weight zero points the integer term (128 - a_zp) * rowsum_w[n] is added as a FLOAT after the conversion: |acc| <= 384 * 128 * 127 and
@@ -1117,7 +1177,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         if (ZW) c_rz[i] = corr * a.rsz[nbase + i]; else reinterpret_cast<float *>(c_rz)[i] = (float)(corr * a.rsz[nbase + i]);
     }
     float o_inv = 1.0f, o_zpf = 0.0f;
-    if (QUANT) { const ActQ op = act_params(a.mmO); o_inv = 1.0f / op.scale; o_zpf = (float)op.zp; }
+    if (QUANT && !PS) { const ActQ op = act_params(a.mmO); o_inv = 1.0f / op.scale; o_zpf = (float)op.zp; }
     // range pass: the wave's running {distance below x* of the nearest value left of it, distance above of the nearest NEGATIVE value right of it} as
     // differences of IEEE bit patterns (see epi_chunk), and the largest value
     constexpr uint32_t XSB = 0xBF40756Au;                            // bits of GELU_ARGMIN = -0.7517915964f
@@ -1182,7 +1242,18 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     };
     // four values (features 32 wave + 8 g + 4 hi ..) of token (tile, blk, l31) from accumulator registers 4 g .. 4 g + 3
     struct BlockAcc { uint32_t dl, dr; float mx; int ssum; };       // per token block: range trackers / row sum of the bytes
-    auto epi_chunk = [&](const i32x16l &acc, int g, int rsa, unsigned char *orow, BlockAcc &ba) {
+    struct TileQ { float as; int corr; float corr_f; float o_inv, o_zpf; int slot; };      // PS: the DynamicQuantizeLinear parameters of a tile's sequence (input: as / corr, output of the byte pass: o_inv / o_zpf)
+    auto tile_params = [&](int tile) {
+        TileQ q = {1.0f, 1, 1.0f, o_inv, o_zpf, 0};
+        if (PS) {
+            q.slot = ps_slot(tile * S8_TR, a.mm_rows);
+            const ActQ tp = act_params(a.mmA + 2 * q.slot);
+            q.as = tp.scale; q.corr = 128 - tp.zp; q.corr_f = (float)q.corr;
+            if (QUANT) { const ActQ op = act_params(a.mmO + 2 * q.slot); q.o_inv = 1.0f / op.scale; q.o_zpf = (float)op.zp; }
+        }
+        return q;
+    };
+    auto epi_chunk = [&](const i32x16l &acc, int g, int rsa, unsigned char *orow, BlockAcc &ba, const TileQ &tq) {
         const int nl = wave * 32 + 8 * g + 4 * hi;
         const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
         f32x2q x2[2];
@@ -1192,7 +1263,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             for (int e2 = 0; e2 < 2; ++e2) {
                 f32x2q f, w, b;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) { f[e] = (float)(acc[4 * g + 2 * e2 + e] + rz[2 * e2 + e] - z4[2 * e2 + e] * rsa); w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                for (int e = 0; e < 2; ++e) { f[e] = (float)(acc[4 * g + 2 * e2 + e] + (PS ? tq.corr * rz[2 * e2 + e] : rz[2 * e2 + e]) - z4[2 * e2 + e] * rsa); w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                if (PS) w = w * tq.as;
                 x2[e2] = f * w + b;
             }
         } else {
@@ -1202,7 +1274,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
                 f32x2q f, r, w, b;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { f[e] = (float)acc[4 * g + 2 * e2 + e]; r[e] = rzf[2 * e2 + e]; w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
-                x2[e2] = (f + r) * w + b;
+                if (PS) x2[e2] = __builtin_elementwise_fma((f32x2q)tq.corr_f, r, f) * (w * tq.as) + b;      // corr * rowsum and its sum with acc are integers below 2^24: the fused form is exact, like the folded one
+                else x2[e2] = (f + r) * w + b;
             }
         }
         if (!QUANT) {
@@ -1227,7 +1300,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
                 // multiply-add; v_cvt_pk_u8_f32 rounds half to even and saturates. Against rint(v / scale) + zp this moves a byte only when
                 // v / scale sits within ~1e-5 of a rounding boundary -- the size of gelu_i8's own error (1e-7 |x| / scale) -- and saves the
                 // separate multiply, rint and add (five of the eight slots of a pair).
-                const f32x2q t2 = __builtin_elementwise_fma(v2, (f32x2q)o_inv, (f32x2q)o_zpf);
+                const f32x2q t2 = __builtin_elementwise_fma(v2, (f32x2q)tq.o_inv, (f32x2q)tq.o_zpf);
                 pk = pack_u8(pk, t2[0], 2 * e2);
                 pk = pack_u8(pk, t2[1], 2 * e2 + 1);
             }
@@ -1237,11 +1310,25 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             *reinterpret_cast<uint32_t *>(orow + (((c & ~7) | ((c & 7) ^ (l31 & 7))) << 4) + (nl & 15)) = pk;
         }
     };
-    auto finish_block = [&](int m, bool valid, const BlockAcc &ba) {  // a finished token block: its trackers join the wave's (padding rows of the last tile do not), its row sums go out
+    auto commit_range = [&](uint32_t *st, uint32_t dl, uint32_t dr, float mx) {     // {nearest left of x*, nearest right of it, largest} -> the three order keys of `st` (see gelu_range_finalize_kernel)
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, ofs));
+            dl = min(dl, (uint32_t)__shfl_xor((int)dl, ofs)); dr = min(dr, (uint32_t)__shfl_xor((int)dr, ofs));
+        }
+        if (lane == 0) {
+            if (dl <= 0xFF800000u - XSB) { const uint32_t k = order_key(__uint_as_float(XSB + dl)); if (k > __atomic_load_n(st, __ATOMIC_RELAXED)) atomicMax(st, k); }            // a finite x (or -inf) at or left of x*
+            if (dr <= XSB - 0x80000000u) { const uint32_t k = order_key(__uint_as_float(XSB - dr)); if (k < __atomic_load_n(st + 1, __ATOMIC_RELAXED)) atomicMin(st + 1, k); }      // a negative x in [x*, -0]
+            if (mx > -__builtin_inff()) { const uint32_t k = order_key(mx); if (k > __atomic_load_n(st + 2, __ATOMIC_RELAXED)) atomicMax(st + 2, k); }
+        }
+    };
+    auto finish_block = [&](int m, bool valid, const BlockAcc &ba, const TileQ &tq) {  // a finished token block: its trackers join the wave's (padding rows of the last tile do not), its row sums go out
         if (!QUANT) {
-            w_dl = min(w_dl, valid ? ba.dl : 0xFFFFFFFFu);
-            w_dr = min(w_dr, valid ? ba.dr : 0xFFFFFFFFu);
-            xmax = fmaxf(xmax, valid ? ba.mx : -__builtin_inff());
+            if (PS) { if (a.mm_out) commit_range(a.mm_out + 4 * tq.slot, valid ? ba.dl : 0xFFFFFFFFu, valid ? ba.dr : 0xFFFFFFFFu, valid ? ba.mx : -__builtin_inff()); }
+            else {
+                w_dl = min(w_dl, valid ? ba.dl : 0xFFFFFFFFu);
+                w_dr = min(w_dr, valid ? ba.dr : 0xFFFFFFFFu);
+                xmax = fmaxf(xmax, valid ? ba.mx : -__builtin_inff());
+            }
         } else if (ZW && a.rs_out) {
             int ssum = ba.ssum;
             ssum += __shfl_xor(ssum, 32);
@@ -1249,8 +1336,10 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         }
     };
     const BlockAcc ba_init = {0xFFFFFFFFu, 0xFFFFFFFFu, -__builtin_inff(), 0};
+    TileQ tq_cur = tile_params(0), tq_p1 = tq_cur;                    // (not PS: the kernel-wide constants)
     for (; t < n_tiles; t += n_workers, ++it) {
         if (QUANT) { if (it > 1) store_out_tile(t_p2, (it - 2) % 3); }
+        if (PS) { tq_p1 = tq_cur; tq_cur = tile_params(t); }
         const unsigned char *buf = smem + cur * S8_TILE;
         const uint32_t pfb = cur + PF >= S8_NBUF ? cur + PF - S8_NBUF : cur + PF;
         const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
@@ -1286,12 +1375,12 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mfma_step(3 * g); mfma_step(3 * g + 1); mfma_step(3 * g + 2);
-                epi_chunk(acc1, g, rsa, orow, ba);
+                epi_chunk(acc1, g, rsa, orow, ba, tq_p1);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            finish_block(m, valid, ba);
+            finish_block(m, valid, ba, tq_p1);
         }
         // ---- phase 2: block 1 accumulates; block 0 of this tile is post-processed from acc0
         {
@@ -1303,12 +1392,12 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mfma_step(KS + 3 * g); mfma_step(KS + 3 * g + 1); mfma_step(KS + 3 * g + 2);
-                epi_chunk(acc0, g, rsa, orow, ba);
+                epi_chunk(acc0, g, rsa, orow, ba, tq_cur);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            finish_block(m, valid, ba);
+            finish_block(m, valid, ba, tq_cur);
         }
         // the next tile must have landed before the barrier (counted wait: everything younger than that tile's DMA is this tile's NPC pieces)
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");      // (wave 0's row-sum piece of this iteration was requested BEFORE the two tile pieces: it is older than the NPC allowed to stay out and simply lands an iteration early; a wave-dependent count behind a branch here made the register allocator spill the weight fragments)
@@ -1327,8 +1416,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         unsigned char *orow = smem + OUT0 + ((it - 1) % 3) * S8_TILE + (32 + l31) * S8_PITCH;
         BlockAcc ba = ba_init;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) epi_chunk(acc1, g, rsa, orow, ba);
-        finish_block(m, valid, ba);
+        for (int g = 0; g < 4; ++g) epi_chunk(acc1, g, rsa, orow, ba, tq_cur);      // (the last tile this worker ran)
+        finish_block(m, valid, ba, tq_cur);
         if (QUANT) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
@@ -1336,17 +1425,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!QUANT && a.mm_out) {       // mm_out = {key of max{x <= x*}, key of min{x >= x*}, key of max x}: gelu_range_finalize_kernel turns them into the range
-        for (int ofs = 32; ofs > 0; ofs >>= 1) {
-            xmax = fmaxf(xmax, __shfl_xor(xmax, ofs));
-            w_dl = min(w_dl, (uint32_t)__shfl_xor((int)w_dl, ofs)); w_dr = min(w_dr, (uint32_t)__shfl_xor((int)w_dr, ofs));
-        }
-        if (lane == 0) {
-            if (w_dl <= 0xFF800000u - XSB) { const uint32_t k = order_key(__uint_as_float(XSB + w_dl)); if (k > __atomic_load_n(a.mm_out, __ATOMIC_RELAXED)) atomicMax(a.mm_out, k); }            // a finite x (or -inf) at or left of x*
-            if (w_dr <= XSB - 0x80000000u) { const uint32_t k = order_key(__uint_as_float(XSB - w_dr)); if (k < __atomic_load_n(a.mm_out + 1, __ATOMIC_RELAXED)) atomicMin(a.mm_out + 1, k); }      // a negative x in [x*, -0]
-            if (xmax > -__builtin_inff()) { const uint32_t k = order_key(xmax); if (k > __atomic_load_n(a.mm_out + 2, __ATOMIC_RELAXED)) atomicMax(a.mm_out + 2, k); }
-        }
-    }
+    if (!QUANT && !PS && a.mm_out) commit_range(a.mm_out, w_dl, w_dr, xmax);      // mm_out = {key of max{x <= x*}, key of min{x >= x*}, key of max x}: gelu_range_finalize_kernel turns them into the range
 }
 
 // ---- tiled int8 GEMM over all 384 output features for K = 1536 (FFN down) + residual + LayerNorm ---------------------------------
@@ -1361,12 +1440,14 @@ template <bool ZWK>
 __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__restrict__ A /* [M][K] signed storage */, const int32_t *__restrict__ rsA /* unused */, const uint32_t *__restrict__ mmA,
                                                              const int8_t *__restrict__ W /* [384][K] row-major */, const float *__restrict__ wscale, const int32_t *__restrict__ rsz,
                                                              const int32_t *__restrict__ zw, const float *__restrict__ bias, const float *resid, const float *__restrict__ gamma,
-                                                             const float *__restrict__ beta, float eps, float *out_f /* may alias resid */, uint32_t *__restrict__ mm_out, int M, int K) {
+                                                             const float *__restrict__ beta, float eps, float *out_f /* may alias resid */, uint32_t *__restrict__ mm_out, int M, int K,
+                                                             int mm_rows /* 0: one range per tensor; else rows per sequence (a multiple of 128): mmA / mm_out are [sequences][2] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int m0 = blockIdx.x * KT_TM;
+    if (mm_rows) { const int slot = m0 / mm_rows; mmA += 2 * slot; if (mm_out) mm_out += 2 * slot; }
     float *c_ws = reinterpret_cast<float *>(smem + KT_CONST);
     int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + KT_NF);
     float *c_b = reinterpret_cast<float *>(c_rz + KT_NF);

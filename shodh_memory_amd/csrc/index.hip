@@ -28,6 +28,8 @@ void set_error(const char *fmt, ...) {
     g_err = buf;
 }
 
+const char *last_error_of_this_thread() { return g_err.c_str(); }
+
 int ensure_dynamic_lds(const void *fn, size_t bytes) {
     // hipFuncSetAttribute acts on the CURRENT device's copy of the function: the cache is keyed by (device, function), so
     // a second index on another GPU of the same process raises its own limit

@@ -22,8 +22,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -97,6 +101,75 @@ __global__ void remap_ids_kernel(uint32_t *ids, uint64_t n, uint32_t g, uint32_t
     ids[i] = ((((l >> log2b) * G) + g) << log2b) | (l & mask);
 }
 
+const char *last_error_of_this_thread();      // (index.hip: the error string is thread-local)
+
+// Persistent enqueue workers, one per shard beyond the first (round 4). A search on G shards is G x (set device, copy the queries, enqueue the
+// shard's scan pipeline: ~83 us of HOST time each, measured) -- issued shard after shard from one thread, shard g's GPU started g x 83 us late
+// (0.6 ms at G = 8, a quarter of a 10M-row step). The workers issue their shard's commands concurrently; the calling thread takes shard 0 and
+// then waits for the others. Hand-over is a generation counter the workers spin on briefly (a condvar wake costs 30-60 us, most of what the
+// threads are there to save) before they go to sleep on the condition variable; an idle index has only sleeping threads.
+struct EnqueuePool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::atomic<uint64_t> gen{0};
+    std::atomic<int> remaining{0};
+    std::function<int(size_t)> job;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    std::atomic<bool> stop{false};
+
+    void start(size_t n_shards) {
+        rc.assign(n_shards, SHODH_OK); err.assign(n_shards, std::string());
+        for (size_t g = 1; g < n_shards; ++g) th.emplace_back([this, g] { this->loop(g); });
+    }
+    void loop(size_t g) {
+        uint64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                if (++spins < 20000) { __builtin_ia32_pause(); continue; }       // ~100-200 us of polling after the last job: back-to-back searches never sleep
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(std::memory_order_relaxed); });
+            }
+            if (stop.load(std::memory_order_relaxed)) return;
+            seen = gen.load(std::memory_order_acquire);
+            const int r = job(g);
+            rc[g] = r;
+            if (r != SHODH_OK) err[g] = last_error_of_this_thread();
+            if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m); cv_done.notify_all(); }
+        }
+    }
+    // runs fn(g) for every shard (g = 0 on the calling thread); returns the first failure with its message re-raised on this thread
+    int run(size_t n_shards, const std::function<int(size_t)> &fn) {
+        if (n_shards <= 1 || th.empty()) {
+            for (size_t g = 0; g < n_shards; ++g) SHODH_TRY(fn(g));
+            return SHODH_OK;
+        }
+        job = fn;
+        remaining.store((int)n_shards - 1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m); gen.fetch_add(1, std::memory_order_acq_rel); }
+        cv_work.notify_all();
+        const int r0 = fn(0);
+        int spins = 0;
+        while (remaining.load(std::memory_order_acquire) != 0) {
+            if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return remaining.load(std::memory_order_acquire) == 0; });
+        }
+        if (r0 != SHODH_OK) return r0;
+        for (size_t g = 1; g < n_shards; ++g)
+            if (rc[g] != SHODH_OK) { set_error("%s", err[g].c_str()); return rc[g]; }
+        return SHODH_OK;
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> lk(m); stop.store(true); }
+        cv_work.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+
 struct Shard {
     int device = 0;
     shodh_index *idx = nullptr;
@@ -125,6 +198,8 @@ struct shodh_sharded_index {
     uint32_t *o_ids = nullptr; float *o_dist = nullptr; uint32_t *o_counts = nullptr; size_t o_elems = 0, o_nq = 0;
     float last_us[4] = {0, 0, 0, 0};   // search, exchange, merge, total (host wall clock of the last search)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;     // device-pointer searches: the caller's stream <-> the shard streams
+    bool out_pending = false;      // a device-pointer search returned with its merge still in flight: ev_out marks the end of its use of pack / all / d_q
+    EnqueuePool pool;              // per-shard enqueue workers (SHODH_SHARD_THREADS=0: the calling thread issues every shard, as before round 4)
 };
 
 namespace shodh {
@@ -230,12 +305,15 @@ int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devi
     if (rc == SHODH_OK && (hipSetDevice(s->sh[0].device) != hipSuccess || hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess)) { set_error("event creation failed"); rc = SHODH_ERR_DEVICE; }
     if (rc != SHODH_OK) { shodh_sharded_index_destroy(s); return rc; }
+    const char *tv = getenv("SHODH_SHARD_THREADS");
+    if (n_devices > 1 && !(tv && atoi(tv) == 0)) s->pool.start(n_devices);
     *out = s;
     return SHODH_OK;
 }
 
 void shodh_sharded_index_destroy(shodh_sharded_index *s) {
     if (!s) return;
+    s->pool.shutdown();
     Rccl *R = rccl();
     for (Shard &h : s->sh) {
         hipSetDevice(h.device);
@@ -421,10 +499,16 @@ static int sharded_search_impl(shodh_sharded_index *s, const float *q, uint32_t 
         SHODH_HIP_TRY(hipSetDevice(h0.device));
         SHODH_HIP_TRY(hipEventRecord(s->ev_in, user_st));
     }
-    // 1. every shard: queries in, local top-k out (global ids), asynchronously on its own stream
-    for (size_t g = 0; g < G; ++g) {
+    // 1. every shard: queries in, local top-k out (global ids), asynchronously on its own stream; the shards are issued concurrently (EnqueuePool)
+    // A previous device-pointer search may still be merging on the first device: its copies read every shard's `pack` (and RCCL its `all`), which
+    // this call is about to overwrite. Its end is ev_out; every shard stream waits for it first. (Without this a host-pointer search, or a device
+    // search on another stream, issued right after a device search could clobber the packs under the first one's merge: ADVICE r3.)
+    const bool wait_prev = s->out_pending;
+    s->out_pending = false;
+    auto issue_shard = [&](size_t g) -> int {
         Shard &h = s->sh[g];
         SHODH_HIP_TRY(hipSetDevice(h.device));
+        if (wait_prev) SHODH_HIP_TRY(hipStreamWaitEvent(h.st, s->ev_out, 0));
         if (host_io) SHODH_HIP_TRY(hipMemcpyAsync(h.d_q, q, (size_t)nq * s->cfg.dim * 4, hipMemcpyHostToDevice, h.st));
         else {
             SHODH_HIP_TRY(hipStreamWaitEvent(h.st, s->ev_in, 0));
@@ -437,7 +521,10 @@ static int sharded_search_impl(shodh_sharded_index *s, const float *q, uint32_t 
             hipLaunchKernelGGL(remap_ids_kernel, dim3((uint32_t)ceil_div(cnt, 256)), dim3(256), 0, h.st, h.pack, cnt, (uint32_t)g, (uint32_t)G, s->cfg.block_log2);
             SHODH_HIP_TRY(hipGetLastError());
         }
-    }
+        if (!s->use_rccl) SHODH_HIP_TRY(hipEventRecord(h.ev, h.st));      // (COPY exchange: the first device picks the pack up after this)
+        return SHODH_OK;
+    };
+    SHODH_TRY(s->pool.run(G, issue_shard));
     const double t1 = now_us();
     // 2. exchange
     if (s->use_rccl) {
@@ -449,11 +536,6 @@ static int sharded_search_impl(shodh_sharded_index *s, const float *q, uint32_t 
         }
         SHODH_RCCL_TRY(R->GroupEnd());
     } else {
-        for (size_t g = 0; g < G; ++g) {
-            Shard &h = s->sh[g];
-            SHODH_HIP_TRY(hipSetDevice(h.device));
-            SHODH_HIP_TRY(hipEventRecord(h.ev, h.st));
-        }
         SHODH_HIP_TRY(hipSetDevice(h0.device));
         for (size_t g = 0; g < G; ++g) {
             if (g) SHODH_HIP_TRY(hipStreamWaitEvent(h0.st, s->sh[g].ev, 0));
@@ -467,6 +549,7 @@ static int sharded_search_impl(shodh_sharded_index *s, const float *q, uint32_t 
         SHODH_TRY(launch_merge_lists(h0.all, reinterpret_cast<const float *>(h0.all + (size_t)nq * k), words, (uint32_t)G, nq, k, ids, dist, counts, h0.st));
         SHODH_HIP_TRY(hipEventRecord(s->ev_out, h0.st));
         SHODH_HIP_TRY(hipStreamWaitEvent(user_st, s->ev_out, 0));
+        s->out_pending = true;
         const double t3 = now_us();
         s->last_us[0] = (float)(t1 - t0); s->last_us[1] = (float)(t2 - t1); s->last_us[2] = (float)(t3 - t2); s->last_us[3] = (float)(t3 - t0);      // enqueue times only
         return SHODH_OK;

@@ -168,7 +168,8 @@ class Embedder:
 
 class MiniLMEmbedder(Embedder):
     def __init__(self, tokenizer=None, weights=None, synthetic_seed=None, dtype=L.DTYPE_BF16, device=0,
-                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384, compute_padded=None, weights_path=None, **cfg_kw):
+                 query_prefix="", doc_prefix="", max_length=256, simplified=False, dim=384, compute_padded=None, weights_path=None,
+                 quant_scope=L.QUANT_SCOPE_BATCH, **cfg_kw):
         self._dim = dim
         self.simplified_mode = simplified
         self.query_prefix, self.doc_prefix = query_prefix, doc_prefix
@@ -185,7 +186,9 @@ class MiniLMEmbedder(Embedder):
             compute_padded = dtype == L.DTYPE_INT8      # the reference's INT8 tensor is padded to max_length (minilm.rs:588-593)
         # weights_path: the model file itself, as EmbeddingConfig.model_path names it (minilm.rs:212-220): model.safetensors, model.onnx or the
         # dynamic-quantisation export -- with dtype INT8 the export's own 8-bit tensors, scales and zero points are what the device multiplies
-        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim, compute_padded=int(bool(compute_padded)),
+        # quant_scope (INT8 only): the default scope of encode_ids. BATCH = the reference's encode_batch (ranges over the batch tensor, minilm.rs:996-1115);
+        # PER_TEXT = N x encode() (ranges per text, minilm.rs:883-982: what remember / recall compute). See encode_batch / encode_each below.
+        cfg = embed_cfg(device=device, dtype=dtype, max_len=max_length, hidden=dim, compute_padded=int(bool(compute_padded)), quant_scope=int(quant_scope),
                         weights_path=os.fsencode(weights_path) if weights_path is not None else None, **cfg_kw)      # cfg_kw: layers=, vocab=, ... (other BERT sizes)
         L.check(L.lib().shodh_embedder_create(C.byref(cfg), C.byref(self._h)))
         cfg.weights_path = None
@@ -242,21 +245,47 @@ class MiniLMEmbedder(Embedder):
         return int(out.value)
 
     # -- device entry points -------------------------------------------------------------------
-    def encode_ids(self, ids, mask):
-        """ids int32 [b, max_len], mask uint8 [b, max_len] -> float32 [b, dim] unit rows (zeros if mask empty)."""
+    def set_quant_scope(self, scope):
+        """INT8: which tensor a DynamicQuantizeLinear range spans when a call carries several texts (shodh_embedder_set_quant_scope)."""
+        L.check(L.lib().shodh_embedder_set_quant_scope(self._h, int(scope)))
+
+    def quant_scope(self):
+        return int(L.lib().shodh_embedder_quant_scope(self._h))
+
+    def _scoped(self, scope):
+        """context: run the calls inside with `scope` (None = the handle's current one), then restore"""
+        emb = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = None
+                if scope is not None and emb._h and emb._h.value:
+                    self_.prev = emb.quant_scope()
+                    emb.set_quant_scope(scope)
+
+            def __exit__(self_, *a):
+                if self_.prev is not None:
+                    emb.set_quant_scope(self_.prev)
+        return _Ctx()
+
+    def encode_ids(self, ids, mask, scope=None):
+        """ids int32 [b, max_len], mask uint8 [b, max_len] -> float32 [b, dim] unit rows (zeros if mask empty).
+        scope (INT8 only): L.QUANT_SCOPE_BATCH / L.QUANT_SCOPE_PER_TEXT for this call; None = the handle's setting."""
         ids = np.ascontiguousarray(ids, np.int32).reshape(-1, self.max_length)
         mask = np.ascontiguousarray(mask, np.uint8).reshape(-1, self.max_length)
         out = np.zeros((ids.shape[0], self._dim), np.float32)
-        L.check(L.lib().shodh_embedder_encode_ids(self._h, ids.ctypes.data, mask.ctypes.data, ids.shape[0], out.ctypes.data))
+        with self._scoped(scope):
+            L.check(L.lib().shodh_embedder_encode_ids(self._h, ids.ctypes.data, mask.ctypes.data, ids.shape[0], out.ctypes.data))
         return out
 
-    def encode_ids_device(self, ids, mask, out=None, stream=None):
+    def encode_ids_device(self, ids, mask, out=None, stream=None, scope=None):
         import torch
         b = ids.shape[0]
         if out is None:
             out = torch.empty((b, self._dim), dtype=torch.float32, device=ids.device)
         st = stream if stream is not None else torch.cuda.current_stream(ids.device).cuda_stream
-        L.check(L.lib().shodh_embedder_encode_ids_device(self._h, ids.data_ptr(), mask.data_ptr(), b, out.data_ptr(), C.c_void_p(st)))
+        with self._scoped(scope):
+            L.check(L.lib().shodh_embedder_encode_ids_device(self._h, ids.data_ptr(), mask.data_ptr(), b, out.data_ptr(), C.c_void_p(st)))
         return out
 
     def stage_timings_us(self):
@@ -296,7 +325,18 @@ class MiniLMEmbedder(Embedder):
     def encode_query(self, text):
         return self._encode_prefixed(text, self.query_prefix)
 
-    def encode_batch(self, texts):                                     # minilm.rs:1247-1376
+    def encode_each(self, texts):
+        """N x encode() in one device call -- the function `remember` / `index_memory` / `recall` compute, text by text (memory/mod.rs:1037,
+        retrieval.rs:673, :708, :878: one session.run on [1, max_len] per text, minilm.rs:883-982). INT8: SHODH_QUANT_SCOPE_PER_TEXT, every
+        DynamicQuantizeLinear range spans ONE text's padded tensor, so the result is bit-identical to [encode(t) for t in texts] whatever the
+        batch. fp32 / bf16: the same numbers as encode_batch (texts never interact there)."""
+        return self.encode_batch(texts, _scope=L.QUANT_SCOPE_PER_TEXT)
+
+    def encode_batch(self, texts, _scope=L.QUANT_SCOPE_BATCH):        # minilm.rs:1247-1376
+        """The reference's Embedder::encode_batch: ONE session.run on [B, max_len] (minilm.rs:996-1115; reached from the entity / fact side
+        paths, memory/mod.rs:8443, :8838). INT8: SHODH_QUANT_SCOPE_BATCH -- the DynamicQuantizeLinear ranges span the whole batch tensor, so
+        a text's embedding depends (slightly) on its batch mates, exactly as in the reference. For bulk ingest of independent memories
+        (N x `remember`) use encode_each."""
         texts = list(texts)
         if not texts:
             return []
@@ -312,7 +352,7 @@ class MiniLMEmbedder(Embedder):
         if self.tokenizer is None:
             raise L.ShodhError(L.ERR_STATE, "no tokenizer")
         ids, mask = self._tokenize(full)
-        emb = self.encode_ids(ids, mask)
+        emb = self.encode_ids(ids, mask, scope=_scope)
         for j, i in enumerate(idx):
             out[i] = emb[j]
         return out

@@ -1,5 +1,5 @@
 """The driver's contract for `bench.py`, checked without a GPU: the command line it is launched with parses, the defaults are the N = 1 /
-minutes-long run the contract asks for, and the committed line of the round's last run (`profiles/r3_bench_line.json`) carries every
+minutes-long run the contract asks for, and the committed line of the latest round's last run (`profiles/rN_bench_line.json`) carries every
 field the driver and the judge read, with figures that agree with one another (value = queries / step time, roofline.frac = achieved /
 peak = algorithmic bytes / kernel time / peak, kernel time <= step time)."""
 import ast
@@ -33,9 +33,13 @@ def test_command_line_of_the_contract():
 
 
 def test_committed_line_is_a_contract_line():
-    path = os.path.join(ROOT, "profiles", "r3_bench_line.json")
-    if not os.path.exists(path):
+    import glob
+    import re
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")), key=lambda p: int(re.search(r"r(\d+)_bench_line", p).group(1)))
+    if not lines:
         pytest.skip("no committed bench line")
+    path = lines[-1]                                              # the latest round's
+    rnd = int(re.search(r"r(\d+)_bench_line", path).group(1))
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
@@ -61,7 +65,8 @@ def test_committed_line_is_a_contract_line():
     lat = d.get("latency_single_query")
     assert lat and lat["nq"] == 1 and 0 < lat["p50_ms"] <= lat["p95_ms"]
     names = [cfg["name"] for cfg in d.get("configs", [])]
-    for want in ("cfg1_10k_b1", "flat_10M_b256", "cfg4_ivfpq_10M", "cfg3_pipeline", "encoder_bf16_b8192", "encoder_int8_b4096", "sharded_c_abi_1M_b256", "sharded_c_abi_10M_b256"):
+    for want in ("cfg1_10k_b1", "flat_10M_b256", "cfg4_ivfpq_10M", "cfg3_pipeline", "encoder_bf16_b8192", "encoder_int8_b4096", "sharded_c_abi_1M_b256", "sharded_c_abi_10M_b256") \
+            + (("cfg3_pipeline_int8", "encoder_int8_pertext_b4096") if rnd >= 4 else ()):      # round 4: INT8 per text (N x encode(), what remember / recall run)
         assert want in names, want
     pipe = [c for c in d["configs"] if c["name"] == "cfg3_pipeline"][0]
     assert "1000000 synthetic texts" in pipe["workload"]                                       # configs[2] at its stated size

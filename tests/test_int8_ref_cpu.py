@@ -52,3 +52,23 @@ def test_fixture_is_what_the_generator_produces():
     assert tr["a_zp"] == int(g["a_zp"]) and f32(tr["a_scale"]) == g["a_scale"] and f32(tr["w_scale"]) == g["w_scale"]
     assert np.abs(emb - g["emb"]).max() < 1e-5 and not emb[3].any()                               # (BLAS summation order may differ between hosts)
     assert np.allclose(np.linalg.norm(emb[:3], axis=1), 1, atol=1e-5)
+
+
+def test_per_text_scope_is_the_single_text_call_repeated():
+    """per_text=True restates N x encode() (one session.run on [1, max_len] each, minilm.rs:883-982): the result of a row never
+    depends on its batch mates, and differs from the batch tensor's (minilm.rs:996-1115), whose ranges span every row."""
+    from shodh_memory_amd import embedder as E
+    cfg = E.embed_cfg(layers=1, vocab=500, max_len=32)
+    sd = E.blob_to_state_dict(E.synthetic_weights(5, cfg), cfg)
+    rng = np.random.default_rng(2)
+    ids = np.zeros((4, 32), np.int64); mask = np.zeros((4, 32), np.int64)
+    for i, ln in enumerate((32, 3, 0, 17)):
+        ids[i, :ln] = rng.integers(1, 500, ln); mask[i, :ln] = 1
+    each = R.encode(sd, ids, mask, layers=1, per_text=True)
+    for i in range(4):
+        assert np.array_equal(each[i:i + 1], R.encode(sd, ids[i:i + 1], mask[i:i + 1], layers=1))
+    assert np.array_equal(R.encode(sd, ids[[3, 0]], mask[[3, 0]], layers=1, per_text=True), each[[3, 0]])
+    batch = R.encode(sd, ids, mask, layers=1)
+    assert not np.array_equal(batch, each) and not each[2].any() and not batch[2].any()
+    keep = [0, 1, 3]
+    assert ((batch[keep] * each[keep]).sum(1) > 0.98).all()

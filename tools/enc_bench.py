@@ -28,6 +28,8 @@ if dname == "int8" and export:
     enc = S.MiniLMEmbedder(dtype=dtype, weights_path=path)
 else:
     enc = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
+if os.environ.get("SHODH_ENC_PER_TEXT", "") == "1":   # SHODH_QUANT_SCOPE_PER_TEXT: one range per text
+    enc.set_quant_scope(L.QUANT_SCOPE_PER_TEXT)
 ids, mask, lens = bench.synth_tokens(torch, b, 256, g, dev)
 emb = torch.empty((b, 384), dtype=torch.float32, device=dev)
 dt = bench.timed_steps(torch, lambda i: enc.encode_ids_device(ids, mask, out=emb), 10, 3)
@@ -36,4 +38,5 @@ tok_c = b * 256 if dname == "int8" else tokens
 att = float((lens.double() * 256).sum()) if dname == "int8" else float((lens.double() ** 2).sum())
 flop = float(tok_c * 2 * (4 * H * H + 2 * H * F) * LAY + att * 4 * H * LAY)
 print(json.dumps({"encoder": dname, "batch": b, "ms": round(dt * 1e3, 3), "texts_per_s": round(b / dt, 1), "tokens": tokens, "tflops": round(flop / dt / 1e12, 1),
-                  "unfused": os.environ.get("SHODH_ENC_UNFUSED", "0"), "weights": export or "synthetic"}))
+                  "unfused": os.environ.get("SHODH_ENC_UNFUSED", "0"), "weights": export or "synthetic",
+                  "quant_scope": "per_text" if os.environ.get("SHODH_ENC_PER_TEXT", "") == "1" else "batch"}))
