@@ -591,6 +591,76 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
     if (mm) minmax_commit(klo, khi, mm);
 }
 
+// ---- the same for SHODH_QUANT_SCOPE_PER_TEXT: one workgroup per SEQUENCE of `rows` positions, so that the sequence's output range is reduced on chip
+// and written once (with one pair of global atomics per token, as embed_ln_kernel commits the batch tensor's range, a forward of 4096 texts spent
+// 9 ms here: 2M atomics on 4096 slots, eight of them per cache line). f32 out, (H & 3) == 0, H <= 512; the arithmetic is embed_ln_kernel's vector path.
+__global__ __launch_bounds__(256) void embed_ln_seq_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ tok_seq, const int32_t *__restrict__ tok_pos,
+                                                           const float *__restrict__ word, const float *__restrict__ pos, const float *__restrict__ type0,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ out, int rows, int H, int max_len, int vocab,
+                                                           float eps, const int8_t *__restrict__ word_q, const float *__restrict__ word_scale, uint32_t *__restrict__ mm /* [sequences][2] */) {
+    __shared__ uint32_t red[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h4 = H >> 2;
+    const float wsc = word_q ? word_scale[0] : 0.0f;
+    const int wzp = word_q ? (int)word_scale[1] : 0;              // zero point in signed-storage terms
+    uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+    for (int r = wv; r < rows; r += 4) {
+        const int tok = blockIdx.x * rows + r;
+        const int sq = tok_seq[tok], p = tok_pos[tok];
+        int id = ids[(size_t)sq * max_len + p];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        f32x4e xv[2];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = lane + 64 * j;
+            if (g < h4) {
+                f32x4e w4;
+                if (word_q) {                                     // Gather + DequantizeLinear: (q - zp) * scale
+                    const uint32_t pk = *reinterpret_cast<const uint32_t *>(word_q + (size_t)id * H + g * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = (float)((int)(int8_t)(pk >> (8 * e)) - wzp) * wsc;
+                } else w4 = *reinterpret_cast<const f32x4e *>(word + (size_t)id * H + g * 4);
+                const f32x4e p4 = *reinterpret_cast<const f32x4e *>(pos + (size_t)p * H + g * 4), t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[j][e] = w4[e] + p4[e] + t4[e]; s += xv[j][e]; }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)H;
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
+        }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float inv = 1.0f / sqrtf(v / (float)H + eps);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = lane + 64 * j;
+            if (g < h4) {
+                const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
+                f32x4e o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o4[e] = (xv[j][e] - mean) * inv * g4[e] + b4[e];
+                    const uint32_t kk = order_key(o4[e]); klo = min(klo, kk); khi = max(khi, kk);
+                }
+                *reinterpret_cast<f32x4e *>(out + (size_t)tok * H + g * 4) = o4;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { klo = min(klo, (uint32_t)__shfl_xor((int)klo, o)); khi = max(khi, (uint32_t)__shfl_xor((int)khi, o)); }
+    if (lane == 0) { red[2 * wv] = klo; red[2 * wv + 1] = khi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[2 * blockIdx.x] = min(min(red[0], red[2]), min(red[4], red[6]));
+        mm[2 * blockIdx.x + 1] = max(max(red[1], red[3]), max(red[5], red[7]));
+    }
+}
+
 // ---- attention: one workgroup per (sequence, head); d_head = 32; online softmax per query row ---------------
 // klen (may be null): keys attended per sequence (the padded INT8 tensor computes every position as a QUERY but only real tokens
 // are KEYS: HF BERT adds finfo.min to masked keys, which is the restriction to the real ones)
@@ -830,7 +900,7 @@ struct shodh_embedder {
     int8_t *HQ = nullptr;                // quantised GELU output [tok_cap][I] (fast INT8 path: the f32 intermediate never exists)
     int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
     bool need_rs = false;
-    uint32_t int8_stages = 0x6F;         // bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
+    uint32_t int8_stages = 0xEF;         // bit 7 (per-text scope only): attention output + LayerNorm + both quantising passes inside the per-sequence kernel (qkv_attn_seq_kernel<., TAIL>); bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
     uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][slots][2], then the GELU trackers [layers][slots][4]; slots = 1 (batch scope) or the sequences (per-text scope)
     size_t mmr_slots = 0;
@@ -1146,7 +1216,7 @@ static int quantize_act(shodh_embedder *e, const float *x, int M, int K, int8_t 
 // minilm.rs:996-1115). ps_rows = max_len: SHODH_QUANT_SCOPE_PER_TEXT, one range per sequence of ps_rows positions -- N x encode()
 // (minilm.rs:883-982); needs the fused kernels, every sequence padded to max_len positions and max_len a multiple of 128 (the callers check).
 static bool per_text_fast_ok(const shodh_embedder *e, int max_keys) {
-    return e->int8_all_fast && (e->int8_stages & 0x60u) == 0x60u && e->cfg.compute_padded && e->cfg.max_len % 128 == 0 && e->cfg.max_len <= 256 && max_keys <= 128;
+    return e->int8_all_fast && (e->int8_stages & 0x60u) == 0x60u && e->cfg.compute_padded && (e->cfg.max_len == 128 || e->cfg.max_len == 256) && max_keys <= 128;
 }
 static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, const int32_t *klen, const int32_t *orow, float *d_out, hipStream_t st, int ps_rows = 0) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
@@ -1178,8 +1248,10 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     hipLaunchKernelGGL(init_ranges_kernel, dim3((uint32_t)std::min(ceil_div((size_t)n_pairs * S, 256), (size_t)1024)), dim3(256), 0, st, e->mmr, n_pairs * S, (int)e->cfg.layers * S);
     auto mm_of = [&](int t) { return e->mmr + (size_t)2 * S * t; };      // range keys of tensor t of the forward: [S][2]
     uint32_t *mmX = mm_of(0);                             // range of the current layer input
-    hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
-                       w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX, ps_rows);
+    if (ps_rows) hipLaunchKernelGGL(embed_ln_seq_kernel, dim3(nseq), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
+                                    w + e->o_type, w + e->o_eg, w + e->o_eb, X, ps_rows, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
+    else hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
+                            w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX, 0);
     SHODH_HIP_TRY(hipGetLastError());
     const size_t att_lds = (size_t)max_keys * 32 * 4 * 2;
     if (!fA) SHODH_TRY(ensure_dynamic_lds((const void *)attention_kernel<float>, att_lds));
@@ -1190,6 +1262,7 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         uint32_t *mmC = mm_of(4 * li + 1), *mmX1 = mm_of(4 * li + 2), *mmF = mm_of(4 * li + 3), *mmXn = mm_of(4 * li + 4);
         const QWeight &wq = e->q_qkv[li], &wo = e->q_o[li], &wu = e->q_up[li], &wd = e->q_dn[li];
         // ---- A: q | k | v projections + attention
+        const bool fT = ps_rows && (stages & 128u);       // per-text scope: B and both quantising passes as one kernel per sequence (attn_out_ln_quant_seq_kernel)
         if (fS) {
             if (wq.zw) {
                 SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<true>, QS_LDS));
@@ -1212,8 +1285,20 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         }
         SHODH_HIP_TRY(hipGetLastError());
         // ---- B: attention output + residual + LayerNorm
-        SHODH_TRY(quantize_act(e, CTX, ntok, H, e->XQ, mmC, e->rsX, st, ps_rows));
-        if (fB) {
+        if (!fT) SHODH_TRY(quantize_act(e, CTX, ntok, H, e->XQ, mmC, e->rsX, st, ps_rows));
+        if (fT) {
+            AttnOutArgs t{};
+            t.ctx = CTX; t.mm_ctx = mmC; t.Wp = wo.qp; t.wscale = wo.scale; t.rsz = wo.rsz; t.zw = wo.zw; t.bias = w + l.ob; t.gamma = w + l.ln1g; t.beta = w + l.ln1b; t.eps = eps;
+            t.X = X; t.XQ = e->XQ; t.rsq = e->need_rs ? e->rsX : nullptr; t.mm_x1 = mmX1; t.rows = ps_rows;
+            if (ps_rows == 256) {
+                SHODH_TRY(ensure_dynamic_lds((const void *)attn_out_ln_quant_seq_kernel<2>, OT_LDS));
+                hipLaunchKernelGGL((attn_out_ln_quant_seq_kernel<2>), dim3(nseq), dim3(512), OT_LDS, st, t);
+            } else {
+                SHODH_TRY(ensure_dynamic_lds((const void *)attn_out_ln_quant_seq_kernel<1>, OT_LDS));
+                hipLaunchKernelGGL((attn_out_ln_quant_seq_kernel<1>), dim3(nseq), dim3(512), OT_LDS, st, t);
+            }
+            SHODH_HIP_TRY(hipGetLastError());
+        } else if (fB) {
             S8Args a{};
             a.mm_rows = ps_rows;
             a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmC; a.Wp = wo.qp; a.wscale = wo.scale; a.rsz = wo.rsz; a.zw = wo.zw; a.bias = w + l.ob;
@@ -1225,7 +1310,7 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             SHODH_HIP_TRY(hipGetLastError());
         }
         // ---- C: FFN up + GELU -> quantised bytes (HQ) and their range (mmF)
-        SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX1, e->rsX, st, ps_rows));
+        if (!fT) SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX1, e->rsX, st, ps_rows));
         if (fC) {
             S8Args a{};
             a.mm_rows = ps_rows;
@@ -1449,7 +1534,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     if (cfg->weights_path) e->weights_path = cfg->weights_path;
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
     e->quant_scope = cfg->quant_scope;
-    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x7Fu;       // speed only: which stages run the fused kernels
+    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0xFFu;       // speed only: which stages run the fused kernels
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);

@@ -33,6 +33,9 @@ typedef float f32x4q __attribute__((ext_vector_type(4)));
 typedef int i32x4q __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4qq __attribute__((ext_vector_type(4)));
 typedef int i32x16l __attribute__((ext_vector_type(16)));
+#include <utility>
+// f(integral_constant<int, 0>), f(integral_constant<int, 1>), ...: a loop whose index is a constant expression in the body (immediate operands of s_waitcnt)
+template <int... I, class F> __device__ __forceinline__ void static_for_i(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
 // LDS hand-over between the waves of a workgroup WITHOUT touching vmcnt: __syncthreads() would also wait for the LDS-DMA in flight
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -424,6 +427,59 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_i8_kernel(const int8_t *__res
     }
 }
 
+// half a token block (16 rows = 24 KiB of f32, contiguous at `rows`) as 24 fully coalesced 1-KiB requests per wave: lane i of request j holds
+// the 16-byte piece 64 j + i of the span (row (64 j + i) / 96, piece (64 j + i) % 96 of it)
+__device__ __forceinline__ void fetch_rows16(const float *rows, int lane, f32x4q (&v)[24]) {
+    const f32x4q *bp = reinterpret_cast<const f32x4q *>(rows) + lane;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = bp[i * 64];
+}
+// DynamicQuantizeLinear of a fetched half block with the parameters (q_scale, q_zpf) -> row-major bytes at dst (16 rows x 384 B, 16-byte chunks
+// XOR-swizzled by row & 7).
+// round_half_even(x / scale) without a division per element, and still the operator's value: t = x * fl(1 / scale) and fl(x / scale) both lie
+// within 1.5 * 2^-23 |t| of each other (two roundings against one), so rint(t) can differ from rint(fl(x / scale)) only when t lies that close
+// to a half-integer. |t| <= 255 for every value of the tensor whose range defines the scale, so the test is |t - rint(t)| >= 1/2 - 2^-14
+// (2^-22 * 256: a third more than needed) on the largest residual of a lane's sixteen values (v_max3 with |.| modifiers: half an issue slot
+// per value), and a 16-value group in which any lane of the wave sees such a value is redone with the division (about one group in nine).
+// The division sequence costs ~14 issue slots per value, this ~4; 192 values per lane and sequence.
+__device__ __forceinline__ void quant_half16(const f32x4q (&v)[24], unsigned char *dst, float q_scale, float q_zpf, int lane) {
+    const float r_scale = 1.0f / q_scale;
+#pragma unroll
+    for (int i4 = 0; i4 < 6; ++i4) {
+        float rq[16];
+        float dm = 0.0f;                                // largest |t - rint(t)| of the lane's sixteen values
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {            // two values at a time: the multiply, the residual and the zero-point add run on the packed-FP32 pipe
+                f32x2q x2; x2[0] = v[4 * i4 + c][2 * e2]; x2[1] = v[4 * i4 + c][2 * e2 + 1];
+                const f32x2q t2 = x2 * r_scale;
+                f32x2q q2; q2[0] = __builtin_rintf(t2[0]); q2[1] = __builtin_rintf(t2[1]);
+                const f32x2q d2 = t2 - q2;
+                dm = __builtin_fmaxf(__builtin_fmaxf(dm, __builtin_fabsf(d2[0])), __builtin_fabsf(d2[1]));
+                const f32x2q r2 = q2 + q_zpf;
+                rq[4 * c + 2 * e2] = r2[0]; rq[4 * c + 2 * e2 + 1] = r2[1];
+            }
+        const bool amb = dm >= 0.5f - 6.103515625e-05f;    // within 2^-22 * 256 >= 2^-22 |t| of a half-integer
+        if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rq[4 * c + e] = __builtin_rintf(v[4 * i4 + c][e] / q_scale) + q_zpf;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 4 * i4 + c;
+            int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;          // piece pc (4 values -> 4 bytes) of row `row` of the half
+            if (pc >= 96) { pc -= 96; row += 1; }
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk = pack_u8(pk, rq[4 * c + e], e);           // saturating: the operator's clamp to [0, 255]
+            *reinterpret_cast<uint32_t *>(dst + row * 384 + (((pc >> 2) ^ (row & 7)) << 4) + ((pc & 3) << 2)) = pk ^ 0x80808080u;
+        }
+    }
+}
+
 // ---- q | k | v + attention, one workgroup per SEQUENCE (all heads) ---------------------------------------------------------------------
 // qkv_attn_i8_kernel above runs one workgroup per (sequence, head): every head fetches the sequence's quantised rows again (32 bytes per row and load
 // instruction: 32 cache lines per kilobyte) and its own weight fragments once per task; measured 1.8 ms per layer at 4096 padded texts, of which
@@ -506,88 +562,45 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
     issue_head(0, 0);
     if (heads > 1) issue_head(1, 1);
 
-    // ---- this wave's token block as int8 MFMA fragments: lane (token l31 of the block, half hi), step ks: bytes 32 ks + 16 hi .. + 16 of the row.
-    // A workgroup is alone on its CU (LDS) and its eight waves are all it has to cover the latency of HBM, so the block is fetched the way memory likes
-    // it and reshaped on chip: a half block (16 rows = 24 KiB of f32, contiguous) arrives as 24 fully coalesced 1-KiB requests per wave, all 48 of a
-    // block in flight at once; every lane quantises the 16-byte pieces it happens to hold (DynamicQuantizeLinear is elementwise) and drops the four
-    // bytes into a row-major staging block in LDS (16-byte chunks XOR-swizzled by row & 7: the fragment reads below are conflict-free), from which
-    // the lanes take their fragments. (s_memtime, per sequence of 180 000 cycles: fetching with lane = row -- 64 separate 16-byte requests per
-    // instruction -- took 31 000 cycles for one block and as much again for the second block waves 4-7 then needed; 33 000 with the requests
-    // batched; this form ...) Waves 0-3 keep their staged block: it is where the V^T tasks below find another wave's rows.
     i32x4q xf_own[KS], xf_aux[KS];
     int rs_own = 0, rs_aux = 0;
     unsigned char *xch = smem + QS_OFF_KV + QS_KV;                               // staged blocks 0-3, 12 KiB each: the second K / V buffer and the scratch behind it (free until the first head's barrier)
+    // half a token block (16 rows = 24 KiB of f32, contiguous) of `src` (row pitch 384 floats) as 24 fully coalesced 1-KiB requests per wave
+    auto fetch = [&](const float *src, f32x4q (&v)[24], int hf) {
+        const int row0 = wave * 32 + hf * 16;
+        if (row0 + 16 <= P) fetch_rows16(src + (size_t)(t0 + row0) * H, lane, v);      // wave-uniform: the half block is one contiguous span
+        else {                                           // rows past the sequence's end repeat its last row (their results are never used)
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;
+                if (pc >= 96) { pc -= 96; row += 1; }
+                int tok = row0 + row; if (tok >= P) tok = P - 1; if (tok < 0) tok = 0;
+                v[i] = *(reinterpret_cast<const f32x4q *>(src + (size_t)(t0 + tok) * H) + pc);
+            }
+        }
+    };
+    // ---- this wave's token block as int8 MFMA fragments: lane (token l31 of the block, half hi), step ks: bytes 32 ks + 16 hi .. + 16 of the row.
+    // A workgroup is alone on its CU (LDS) and its eight waves are all it has to cover the latency of HBM, so the block is fetched the way memory likes
+    // it and reshaped on chip: a half block arrives fully coalesced, all 48 requests of a block in flight at once; every lane quantises the 16-byte
+    // pieces it happens to hold (DynamicQuantizeLinear is elementwise) and drops the four bytes into a row-major staging block in LDS, from which
+    // the lanes take their fragments (conflict-free with the swizzle). (s_memtime, per sequence of 180 000 cycles: fetching with lane = row -- 64
+    // separate 16-byte requests per instruction -- took 31 000 cycles for one block and as much again for the second block waves 4-7 then needed;
+    // 33 000 with the requests batched; this form ...) Waves 0-3 keep their staged block: it is where the V^T tasks below find another wave's rows.
     if (wave < nqb) {
-        // round_half_even(x / scale) without a division per element, and still the operator's value: t = x * fl(1 / scale) and fl(x / scale) both lie
-        // within 1.5 * 2^-23 |t| of each other (two roundings against one), so rint(t) can differ from rint(fl(x / scale)) only when t lies that close
-        // to a half-integer. |t| <= 255 for every value of the tensor whose range defines the scale, so the test is |t - rint(t)| >= 1/2 - 2^-14
-        // (2^-22 * 256: a third more than needed) on the largest residual of a lane's sixteen values (v_max3 with |.| modifiers: half an issue slot
-        // per value), and a 16-value group in which any lane of the wave sees such a value is redone with the division (about one group in nine).
-        // The division sequence costs ~14 issue slots per value, this ~4; 192 values per lane and sequence.
-        const float r_scale = 1.0f / a_scale;
         unsigned char *stg = wave < 4 ? xch + wave * 12288 : smem + QS_OFF_KV + (wave - 4) * 6144;      // waves 4-7: 6 KiB of the first K / V buffer, used for both halves
         const int half_step = wave < 4 ? 6144 : 0;
         f32x4q va[24], vb[24];
-        auto fetch = [&](f32x4q (&v)[24], int hf) {
-            const int row0 = wave * 32 + hf * 16;
-            if (row0 + 16 <= P) {                              // wave-uniform: the half block is one contiguous span
-                const f32x4q *bp = reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + row0) * H) + lane;
-#pragma unroll
-                for (int i = 0; i < 24; ++i) v[i] = bp[i * 64];
-            } else {                                           // rows past the sequence's end repeat its last row (their results are never used)
-#pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;
-                    if (pc >= 96) { pc -= 96; row += 1; }
-                    int tok = row0 + row; if (tok >= P) tok = P - 1; if (tok < 0) tok = 0;
-                    v[i] = *(reinterpret_cast<const f32x4q *>(X + (size_t)(t0 + tok) * H) + pc);
-                }
-            }
-        };
         auto stage = [&](const f32x4q (&v)[24], int hf) {
             unsigned char *dst = stg + hf * half_step;
-#pragma unroll
-            for (int i4 = 0; i4 < 6; ++i4) {
-                float rq[16];
-                float dm = 0.0f;                                // largest |t - rint(t)| of the lane's sixteen values
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {            // two values at a time: the multiply, the residual and the zero-point add run on the packed-FP32 pipe
-                        f32x2q x2; x2[0] = v[4 * i4 + c][2 * e2]; x2[1] = v[4 * i4 + c][2 * e2 + 1];
-                        const f32x2q t2 = x2 * r_scale;
-                        f32x2q q2; q2[0] = __builtin_rintf(t2[0]); q2[1] = __builtin_rintf(t2[1]);
-                        const f32x2q d2 = t2 - q2;
-                        dm = __builtin_fmaxf(__builtin_fmaxf(dm, __builtin_fabsf(d2[0])), __builtin_fabsf(d2[1]));
-                        const f32x2q r2 = q2 + zpf;
-                        rq[4 * c + 2 * e2] = r2[0]; rq[4 * c + 2 * e2 + 1] = r2[1];
-                    }
-                const bool amb = dm >= 0.5f - 6.103515625e-05f;    // within 2^-22 * 256 >= 2^-22 |t| of a half-integer
-                if (__builtin_amdgcn_ballot_w64(amb) != 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) rq[4 * c + e] = __builtin_rintf(v[4 * i4 + c][e] / a_scale) + zpf;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int i = 4 * i4 + c;
-                    int row = (i * 64) / 96, pc = (i * 64) % 96 + lane;          // piece pc (4 values -> 4 bytes) of row `row` of the half
-                    if (pc >= 96) { pc -= 96; row += 1; }
-                    uint32_t pk = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk = pack_u8(pk, rq[4 * c + e], e);           // saturating: the operator's clamp to [0, 255]
-                    *reinterpret_cast<uint32_t *>(dst + row * 384 + (((pc >> 2) ^ (row & 7)) << 4) + ((pc & 3) << 2)) = pk ^ 0x80808080u;
-                }
-            }
+            quant_half16(v, dst, a_scale, zpf, lane);
             if ((l31 >> 4) == hf) {                            // the lanes whose token lies in this half take their fragments
                 const unsigned char *src = dst + (l31 & 15) * 384;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xf_own[ks] = *reinterpret_cast<const i32x4q *>(src + (((2 * ks + hi) ^ (l31 & 7)) << 4));
             }
         };
-        fetch(va, 0);
-        fetch(vb, 1);
+        fetch(X, va, 0);
+        fetch(X, vb, 1);
         __builtin_amdgcn_sched_barrier(0);
         stage(va, 0);
         stage(vb, 1);
@@ -836,6 +849,292 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
             if (khi > __atomic_load_n(mm_out + 1, __ATOMIC_RELAXED)) atomicMax(mm_out + 1, khi);
         }
     }
+}
+
+// ---- attention output projection + residual + LayerNorm + DynamicQuantizeLinear of the result, one workgroup per SEQUENCE (round 4) -----------------
+// SHODH_QUANT_SCOPE_PER_TEXT only: every range of the layer's first half is local to one sequence, so what the batch scope runs as four launches
+// (act_quant over CTX, i8_stream_kernel<RESID_LN>, act_quant over the LayerNorm output, and the range atomics that tie them together: 0.43 + 0.78 +
+// 0.43 ms per layer at 4096 texts, 7.5 GB of traffic) is one kernel without a global atomic:
+//   the sequence's ctx range (left by qkv_attn_seq_kernel) -> the eight waves fetch the sequence's ctx rows the way the layer input is fetched
+//   (fetch_rows16 / quant_half16: coalesced 1-KiB requests, quantised in the lane that holds them, row-major swizzled staging blocks in LDS)
+//   -> out^T = W_o . ctx^T with k OUTERMOST. A PAIR of waves (sharing a SIMD pair) owns a 32-token block: wave fh of the pair keeps the 6 x 16
+//   accumulators of feature blocks 6 fh .. 6 fh + 5 (96 registers), per k-step one token fragment from the block's staging bytes and six weight
+//   fragments from a 4-slot ring of 12-KiB k-slices that LDS-DMA keeps three slices ahead (W_o, 144 KiB, cannot sit in LDS next to 96 KiB of ctx bytes)
+//   -> dequantise + bias + residual (all 24 residual loads of the wave's half rows in flight at once) -> LayerNorm: a token's row lies in the two
+//   lane pairs of the wave pair; the block sums are chained in block order THROUGH the pair (first half, hand-over in LDS, second half: i8_stream_kernel's
+//   order of additions, the same bits) -> f32 rows out through a 4-KiB LDS tile per wave (whole 128-byte segments per store, in place over X)
+//   -> the sequence's output range over the eight waves (LDS) -> the waves fetch the rows back (their L2 holds them) through fetch_rows16 / quant_half16
+//   with the new range -> whole rows of XQ, row sums, and the range keys for the FFN kernels.
+// Tried first: four waves with a whole row per lane pair (192 accumulators, a lone wave's 512 registers): the compiler kept the accumulators in AGPRs,
+// copied them out for the LayerNorm and spilled around them, and every spill reload is a vmcnt(0) in front of the residual loads: 245 000 cycles per
+// sequence (2.0 ms per layer -- no faster than the four launches it replaces). And inside qkv_attn_seq_kernel (256 registers) the same code spilled 2.3 KB per lane: 4.8 ms.
+#ifdef SHODH_PROF
+#define OPROF_DECL long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64(); const long long t00_ = tq_;
+#define OPROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
+#define OPROF_END if (lane0 == 0 && (blockIdx.x == 7 || blockIdx.x == 2049)) printf("outprof blk %d wave %d total %lld : ctx stage %lld | wait+bar %lld gemm %lld dequant+resid %lld mean chain %lld var chain %lld norm+store %lld | range bar %lld refetch+quant+out %lld\n", (int)blockIdx.x, wave, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], pt_[6], pt_[7], pt_[8]);
+#else
+#define OPROF_DECL
+#define OPROF_T(i)
+#define OPROF_END
+#endif
+struct AttnOutArgs {
+    const float *ctx; const uint32_t *mm_ctx;     // attention output [M][384], its range keys [sequences][2]
+    const int8_t *Wp;                             // W_o fragment-major [12][12][64][16] (pack_i8_frag_kernel)
+    const float *wscale; const int32_t *rsz; const int32_t *zw /* or null */; const float *bias, *gamma, *beta; float eps;
+    float *X;                                     // residual in, LayerNorm output out (in place)
+    int8_t *XQ; int32_t *rsq /* or null */;       // DynamicQuantizeLinear(LayerNorm output) [M][384] (signed storage), its row sums
+    uint32_t *mm_x1;                              // [sequences][2] range keys of the LayerNorm output
+    int rows;                                     // positions per sequence: 128 or 256
+};
+constexpr int OT_SLOT = 12 * 1024, OT_NSLOT = 4, OT_STG = OT_NSLOT * OT_SLOT, OT_CONST = OT_STG + 8 * 12288, OT_RED = OT_CONST + 6 * 1536, OT_LDS = OT_RED + 64 + 2 * 4 * 32 * 4;      // 154 KiB
+template <int BPW /* token blocks per wave pair: 2 (256 positions) or 1 (128) */>
+__global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const AttnOutArgs a) {
+    constexpr int H = 384, KS = 12, NBW = 6, NBLK = 4 * BPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int seq = blockIdx.x;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr = wave >> 1, fh = wave & 1;                             // wave pair, feature half
+    const int s0 = seq * a.rows;                                         // the sequence's first row
+    // The lane id is re-read through an empty asm at the top of every stage: otherwise the compiler computes every swizzled LDS address of the kernel
+    // (hundreds of loop-invariant values) up front and parks them in scratch next to the accumulators
+    int lane = lane0, hi = lane0 >> 5, l31 = lane0 & 31;
+#define OT_FRESH_LANE() { lane = lane0; asm volatile("" : "+v"(lane)); hi = lane >> 5; l31 = lane & 31; }
+    float *t_red = reinterpret_cast<float *>(smem + OT_RED);            // [8 waves][min, max]
+    float *ex_a = t_red + 16, *ex_m = ex_a + 4 * 32;                      // [4 pairs][32 tokens]: the chain's hand-over, the finished statistic
+    float *c_ws = reinterpret_cast<float *>(smem + OT_CONST);
+    int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + H);
+    float *c_b = reinterpret_cast<float *>(c_rz + H);
+    int32_t *c_zw = reinterpret_cast<int32_t *>(c_b + H);
+    float *c_g = reinterpret_cast<float *>(c_zw + H), *c_be = c_g + H;
+    const bool zwo = a.zw != nullptr;
+    // k-slice ks of W_o (twelve 1-KiB fragment blocks, one per 32 output features) -> ring slot ks & 3: waves 0-3 request blocks w and w + 8, waves 4-7 block w
+    auto issue_wslice = [&](int ks) {
+        const unsigned char *wo = reinterpret_cast<const unsigned char *>(a.Wp);
+        const uint32_t slot = smem_lds + (uint32_t)((ks & (OT_NSLOT - 1)) * OT_SLOT);
+        glds16(uniform_ptr(wo + ((size_t)wave * KS + ks) * 1024), (uint32_t)lane0 * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot + (uint32_t)wave * 1024u)));
+        if (wave < 4) glds16(uniform_ptr(wo + ((size_t)(wave + 8) * KS + ks) * 1024), (uint32_t)lane0 * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot + (uint32_t)(wave + 8) * 1024u)));
+    };
+    OPROF_DECL
+    issue_wslice(0); issue_wslice(1); issue_wslice(2);
+    const ActQ cp = act_params(a.mm_ctx + 2 * seq);
+    const float c_scale = cp.scale;
+    const int c_corr = 128 - cp.zp;
+    for (int i = tid; i < H; i += 512) {      // per-feature constants with the sequence's activation parameters folded in, as i8_stream_kernel folds the tensor's
+        c_ws[i] = c_scale * a.wscale[i]; c_rz[i] = c_corr * a.rsz[i]; c_b[i] = a.bias[i]; c_zw[i] = zwo ? a.zw[i] : 0; c_g[i] = a.gamma[i]; c_be[i] = a.beta[i];
+    }
+    // ---- the sequence's ctx rows -> bytes in the staging blocks: 2 NBLK half blocks over eight waves
+#pragma unroll 1
+    for (int u = wave; u < 2 * NBLK; u += 8) {
+        OT_FRESH_LANE();
+        f32x4q v[24];
+        fetch_rows16(a.ctx + (size_t)(s0 + u * 16) * H, lane, v);
+        quant_half16(v, smem + OT_STG + (u >> 1) * 12288 + (u & 1) * 6144, c_scale, (float)cp.zp, lane);
+    }
+    OPROF_T(0)
+    float xmin = __builtin_inff(), xmax = -__builtin_inff();
+#pragma unroll 1
+    for (int b = 0; b < BPW; ++b) {
+        const int tb = pr * BPW + b;                                     // this pair's token block
+        // reg[j]: the 32 x 32 block (features 32 (6 fh + j) .., the block's tokens): lane = token, registers = features f(r, hi); int32 accumulators first,
+        // the f32 results of the later stages in the same registers
+        f32x16q reg[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) reg[j][r] = 0.0f;               // (+0.0f == int 0)
+        int rs_t = 0;
+        unsigned char *sblk = smem + OT_STG + tb * 12288;
+        const bool more = b + 1 < BPW;                                   // uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // slices 0-2 of this pass (and everything older) have landed
+        __syncthreads();
+        OPROF_T(1)
+        static_for_i(std::make_integer_sequence<int, KS>{}, [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            if (ks > 0) {
+                // slice ks must have landed for every wave, and slot (ks - 1) & 3 must be drained before it is refilled: this wave's pieces of the slices after
+                // ks (at most two of them: ks + 1, ks + 2; two pieces each for waves 0-3, one for waves 4-7) may stay in flight
+                constexpr int after = KS - 1 - ks < 2 ? KS - 1 - ks : 2;
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * after) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(after) : "memory");
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks + 3 < KS) issue_wslice(ks + 3);
+            if (ks == KS - 1 && more) { issue_wslice(0); issue_wslice(1); issue_wslice(2); }      // slots 0-2 were last read at steps 8-10: every wave is past them (this step's barrier)
+            OT_FRESH_LANE();
+            const i32x4q xf = *reinterpret_cast<const i32x4q *>(sblk + l31 * 384 + (((2 * ks + hi) ^ (l31 & 7)) << 4));
+            if (zwo) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rs_t = __builtin_amdgcn_sdot4(xf[c], 0x01010101, rs_t, false);
+            }
+            const unsigned char *ring = smem + (ks & (OT_NSLOT - 1)) * OT_SLOT + fh * (NBW * 1024) + lane * 16;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                reg[j] = __builtin_bit_cast(f32x16q, __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(ring + j * 1024), xf, __builtin_bit_cast(i32x16l, reg[j]), 0, 0, 0));
+        });
+        OPROF_T(2)
+        // ---- + bias + residual; block sums
+        OT_FRESH_LANE();
+        const int rsa = zwo ? rs_t + __shfl_xor(rs_t, 32) : 0;
+        float sb[NBW];
+        {
+            const float *xrow = a.X + (size_t)(s0 + tb * 32 + l31) * H + fh * (NBW * 32);
+            f32x4q rr[NBW][4];                                           // the wave's half of the residual rows: all 24 requests at once
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rr[j][g] = *reinterpret_cast<const f32x4q *>(xrow + j * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const i32x16l acc = __builtin_bit_cast(i32x16l, reg[j]);
+                float s1 = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = (fh * NBW + j) * 32 + 8 * g + 4 * hi;
+                    const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
+                    const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = (float)(acc[4 * g + e] + rz[e] - (zwo ? z4[e] * rsa : 0)) * ws[e] + b4[e] + rr[j][g][e];
+                        reg[j][4 * g + e] = v; s1 += v;
+                    }
+                }
+                s1 += __shfl_xor(s1, 32);
+                sb[j] = s1;
+            }
+        }
+        OPROF_T(3)
+        // ---- mean: 0 + s_0 + s_1 + ... + s_11 in block order, first half in wave 0 of the pair, handed over through LDS, second half in wave 1
+        float mean;
+        {
+            float ch = 0.0f;
+            if (fh == 0) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) ch += sb[j];
+                if (hi == 0) ex_a[pr * 32 + l31] = ch;
+            }
+            __syncthreads();
+            if (fh == 1) {
+                ch = ex_a[pr * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) ch += sb[j];
+                ch *= (1.0f / (float)H);
+                if (hi == 0) ex_m[pr * 32 + l31] = ch;
+            }
+            __syncthreads();
+            mean = ex_m[pr * 32 + l31];
+        }
+        OPROF_T(4)
+        float inv;
+        {
+            float qb[NBW];
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                float q1 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { reg[j][r] -= mean; q1 += reg[j][r] * reg[j][r]; }
+                q1 += __shfl_xor(q1, 32);
+                qb[j] = q1;
+            }
+            float ch = 0.0f;
+            __syncthreads();                                             // (every wave has read the mean: ex_a / ex_m are free again)
+            if (fh == 0) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) ch += qb[j];
+                if (hi == 0) ex_a[pr * 32 + l31] = ch;
+            }
+            __syncthreads();
+            if (fh == 1) {
+                ch = ex_a[pr * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) ch += qb[j];
+                if (hi == 0) ex_m[pr * 32 + l31] = ch;
+            }
+            __syncthreads();
+            const float var = ex_m[pr * 32 + l31];
+            inv = 1.0f / sqrtf(var * (1.0f / (float)H) + a.eps);
+        }
+        OPROF_T(5)
+        // The rows leave through LDS: in the accumulator layout a store instruction writes 16-byte pieces scattered over 32 rows, which the write path digests
+        // at ~4 B/clk per CU. The block's staging bytes are dead after the k loop (the chain's barriers lie in between): each wave of the pair turns its
+        // feature blocks through a 4-KiB tile there (32 rows x 128 B, 16-byte chunks XOR-swizzled by row & 7) and every store instruction writes eight whole
+        // 128-byte row segments.
+        {
+            unsigned char *tile = sblk + fh * 6144;
+            float *xblk = a.X + (size_t)(s0 + tb * 32) * H + fh * (NBW * 32);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = (fh * NBW + j) * 32 + 8 * g + 4 * hi;
+                    const f32x4q g4 = *reinterpret_cast<const f32x4q *>(c_g + nl), be4 = *reinterpret_cast<const f32x4q *>(c_be + nl);
+                    f32x4q ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ov[e] = reg[j][4 * g + e] * inv * g4[e] + be4[e];
+                        xmin = fminf(xmin, ov[e]); xmax = fmaxf(xmax, ov[e]);
+                    }
+                    *reinterpret_cast<f32x4q *>(tile + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = ov;
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int tl = h * 8 + (lane >> 3), ch = lane & 7;
+                    const f32x4q v4 = *reinterpret_cast<const f32x4q *>(tile + tl * 128 + ((ch ^ (tl & 7)) << 4));
+                    *reinterpret_cast<f32x4q *>(xblk + (size_t)tl * H + j * 32 + ch * 4) = v4;
+                }
+            }
+        }
+        OPROF_T(6)
+    }
+    // ---- the sequence's range of the LayerNorm output over the eight waves; then the waves fetch the rows back (L2 holds them) and quantise them on the way
+    // through the staging blocks, as the ctx rows were: whole rows of XQ leave as 16-byte pieces
+    for (int ofs = 32; ofs > 0; ofs >>= 1) { xmin = fminf(xmin, __shfl_xor(xmin, ofs)); xmax = fmaxf(xmax, __shfl_xor(xmax, ofs)); }
+    if (lane0 == 0) { t_red[2 * wave] = xmin; t_red[2 * wave + 1] = xmax; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's rows are written
+    __syncthreads();
+    OPROF_T(7)
+    float ymin = __builtin_inff(), ymax = -__builtin_inff();
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { ymin = fminf(ymin, t_red[2 * w]); ymax = fmaxf(ymax, t_red[2 * w + 1]); }
+    uint32_t ykeys[2] = {order_key(ymin), order_key(ymax)};
+    if (tid == 0) { a.mm_x1[2 * seq] = ykeys[0]; a.mm_x1[2 * seq + 1] = ykeys[1]; }
+    const ActQ yp = act_params(ykeys);
+#pragma unroll 1
+    for (int u = wave; u < 2 * NBLK; u += 8) {
+        OT_FRESH_LANE();
+        unsigned char *dst = smem + OT_STG + (u >> 1) * 12288 + (u & 1) * 6144;
+        {
+            f32x4q v[24];
+            fetch_rows16(a.X + (size_t)(s0 + u * 16) * H, lane, v);
+            quant_half16(v, dst, yp.scale, (float)yp.zp, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (a.rsq) {                                                     // row sums of the stored bytes: lane = (row lane & 15, quarter lane >> 4 of its 24 chunks)
+            const int r = lane & 15, qd = lane >> 4;
+            int rsum = 0;
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) {
+                const i32x4q x4 = *reinterpret_cast<const i32x4q *>(dst + r * 384 + (((qd * 6 + c6) ^ (r & 7)) << 4));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rsum = __builtin_amdgcn_sdot4(x4[c], 0x01010101, rsum, false);
+            }
+            rsum += __shfl_xor(rsum, 16);
+            rsum += __shfl_xor(rsum, 32);
+            if (lane < 16) a.rsq[s0 + u * 16 + r] = rsum;
+        }
+        unsigned char *xq = reinterpret_cast<unsigned char *>(a.XQ) + (size_t)(s0 + u * 16) * H;      // the half block's 16 rows are 6 KiB contiguous
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) {
+            const int B = pc * 1024 + lane * 16, row = B / 384, ch = (B % 384) >> 4;
+            *reinterpret_cast<u32x4qq *>(xq + B) = *reinterpret_cast<const u32x4qq *>(dst + row * 384 + ((ch ^ (row & 7)) << 4));
+        }
+    }
+    OPROF_T(8)
+    OPROF_END
+#undef OT_FRESH_LANE
 }
 
 // ---- weight-stationary int8 GEMM, K = 384, 384 output features per workgroup ---------------------------------------------------
