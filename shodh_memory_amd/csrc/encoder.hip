@@ -1176,13 +1176,19 @@ static int launch_i8_stream_gelu(const S8Args &a, int cus, hipStream_t st) {
     const int n_tiles = (a.M + S8_TR - 1) / S8_TR;
     if (n_workers > ((n_tiles + 7) & ~7)) n_workers = (n_tiles + 7) & ~7;
     const size_t lds = QUANT ? S8G_LDS_QUANT : S8G_LDS_RANGE;
-    if (a.mm_rows) {           // one range per sequence
+    if (a.mm_rows) {           // one range per sequence: workers take whole sequences, whose parameters sit in an LDS table of S8G_PS_TAB entries
+        const int nseq = a.M / a.mm_rows;
+        n_workers = (cus / a.n_groups) & ~7;
+        if (n_workers < 8) n_workers = 8;
+        if (n_workers > ((nseq + 7) & ~7)) n_workers = (nseq + 7) & ~7;
+        if ((size_t)nseq > (size_t)S8G_PS_TAB * n_workers) { set_error("INT8 per-text forward: %d sequences exceed %d per worker", nseq, S8G_PS_TAB); return SHODH_ERR_UNSUPPORTED; }
+        const size_t ldp = lds + S8G_PS_EXTRA;
         if (a.zw && a.rsA) {
-            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true, true>, lds));
-            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true, true>, ldp));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
         } else {
-            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false, true>, lds));
-            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false, true>, ldp));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
         }
         SHODH_HIP_TRY(hipGetLastError());
         return SHODH_OK;

@@ -1437,9 +1437,16 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
 // instructions in the same scheduling region. Same tiles, same DMA ring, same barrier per tile; the output bytes of a tile are complete one
 // iteration later, so the byte pass rotates three output tiles in LDS instead of two.
 constexpr int S8G_LDS_RANGE = S8_RED, S8G_LDS_QUANT = S8_RED + 3 * S8_TILE;
-// PS: one range per sequence (see i8_stream_kernel): the tile's own activation parameters join in the epilogue (one more packed multiply per pair of
-// values; the integer term as a fused multiply-add, still exact), the range pass commits its three trackers per token block to the block's sequence
-// (stats [sequences][4]), the byte pass takes the output scale of the block's sequence.
+// PS: one range per sequence (SHODH_QUANT_SCOPE_PER_TEXT; a.mm_rows = 128 or 256 rows per sequence, whole tiles). A worker takes whole SEQUENCES (its
+// tiles one after the other, then the sequence n_workers further on), so that
+//  * the DynamicQuantizeLinear parameters of its sequences -- input scale / correction, and for the byte pass the output scale / zero point -- are
+//    computed once, at kernel start, into an LDS table (one entry per sequence of the worker; a global load of the range keys inside the pipelined loop
+//    is waited for with a vmcnt that also covers the tile DMA in flight: the first form of this kernel, with such a load per tile and a load + atomics
+//    per token block for the range, took 2.2 ms per layer against the batch scope's 0.65);
+//  * the tile's parameters join in the epilogue (one more packed multiply per pair of values; the integer term as a fused multiply-add, still exact);
+//  * the range pass keeps its three trackers in the wave across the tiles of a sequence and hands them over at the sequence's LAST token block: twelve
+//    waves -> LDS -> wave 0 -> three unconditional atomics per sequence and feature group (stats [sequences][4]).
+constexpr int S8G_PS_TAB = 128, S8G_PS_EXTRA = S8G_PS_TAB * 16 + 12 * 16;      // LDS behind the kernel's own: the table, then [12 waves][4] words of range hand-over
 template <bool QUANT, bool ZW, bool PS = false>
 __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) {
     constexpr int KS = S8_KS, NS = 2 * KS, D = 3, RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles)
@@ -1466,6 +1473,22 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     int32_t *c_rs = c_zw + S8_NF;                                    // [S8_NBUF][256], 64 used
     const uint32_t rs_lds = smem_lds + (uint32_t)S8_CONST + 4u * S8_NF * 4u;
     const ActQ ap = PS ? ActQ{1.0f, 127} : act_params(a.mmA);       // (PS: scale 1 and correction factor 1 = the constants stay unfolded)
+    // PS: sequence-major tile order and the parameter table
+    const int tps_log2 = PS ? (a.mm_rows == 256 ? 2 : 1) : 0;       // tiles per sequence: 4 or 2
+    const int nseq_all = PS ? M / a.mm_rows : 0;
+    f32x4q *ps_tab = reinterpret_cast<f32x4q *>(smem + (QUANT ? S8G_LDS_QUANT : S8G_LDS_RANGE));
+    uint32_t *ps_red = reinterpret_cast<uint32_t *>(ps_tab + S8G_PS_TAB);
+    if (PS) {
+        for (int q = tid; q < S8G_PS_TAB; q += S8_NT) {
+            const int sq = worker + q * n_workers;
+            if (sq < nseq_all) {
+                const ActQ tp = act_params(a.mmA + 2 * sq);
+                f32x4q ent; ent[0] = tp.scale; ent[1] = (float)(128 - tp.zp); ent[2] = 1.0f; ent[3] = 0.0f;
+                if (QUANT) { const ActQ op = act_params(a.mmO + 2 * sq); ent[2] = 1.0f / op.scale; ent[3] = (float)op.zp; }
+                ps_tab[q] = ent;
+            }
+        }
+    }
     const float a_scale = ap.scale;
     const int corr = 128 - ap.zp;
     // Without weight zero points the integer term (128 - a_zp) * rowsum_w[n] is added as a FLOAT after the conversion: |acc| <= 384 * 128 * 127 and
@@ -1497,10 +1520,17 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(a.XQ);
     const uint32_t wave_lds = smem_lds + (uint32_t)wave * 1024u;
     const int n_tiles = (M + S8_TR - 1) / S8_TR;
-    int t = worker;
+    // the tile of iteration i of this worker (n_tiles and beyond: none). Batch scope: tiles worker, worker + n_workers, ...; PS: the tiles of sequence
+    // worker, then of sequence worker + n_workers, ...
+    auto tile_at = [&](int i) -> int {
+        if (!PS) return worker + i * n_workers;
+        const int sq = worker + (i >> tps_log2) * n_workers;
+        return sq < nseq_all ? (sq << tps_log2) + (i & ((1 << tps_log2) - 1)) : n_tiles;
+    };
+    int t = tile_at(0);
 #pragma unroll
     for (int b = 0; b < PF; ++b) {
-        const int tt = t + b * n_workers < n_tiles ? t + b * n_workers : (t < n_tiles ? t : 0);
+        const int tt = tile_at(b) < n_tiles ? tile_at(b) : (t < n_tiles ? t : 0);
         const unsigned char *src = uniform_ptr(xb + (size_t)tt * S8_TILE);
 #pragma unroll
         for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * S8_TILE + i * 12288);
@@ -1542,13 +1572,13 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     // four values (features 32 wave + 8 g + 4 hi ..) of token (tile, blk, l31) from accumulator registers 4 g .. 4 g + 3
     struct BlockAcc { uint32_t dl, dr; float mx; int ssum; };       // per token block: range trackers / row sum of the bytes
     struct TileQ { float as; int corr; float corr_f; float o_inv, o_zpf; int slot; };      // PS: the DynamicQuantizeLinear parameters of a tile's sequence (input: as / corr, output of the byte pass: o_inv / o_zpf)
-    auto tile_params = [&](int tile) {
+    auto tile_params = [&](int i) {                                   // of iteration i's tile
         TileQ q = {1.0f, 1, 1.0f, o_inv, o_zpf, 0};
         if (PS) {
-            q.slot = ps_slot(tile * S8_TR, a.mm_rows);
-            const ActQ tp = act_params(a.mmA + 2 * q.slot);
-            q.as = tp.scale; q.corr = 128 - tp.zp; q.corr_f = (float)q.corr;
-            if (QUANT) { const ActQ op = act_params(a.mmO + 2 * q.slot); q.o_inv = 1.0f / op.scale; q.o_zpf = (float)op.zp; }
+            const int ql = (i >> tps_log2) & (S8G_PS_TAB - 1);
+            const f32x4q ent = ps_tab[ql];
+            q.slot = worker + (i >> tps_log2) * n_workers;
+            q.as = ent[0]; q.corr_f = ent[1]; q.corr = (int)ent[1]; q.o_inv = ent[2]; q.o_zpf = ent[3];
         }
         return q;
     };
@@ -1620,13 +1650,20 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             if (mx > -__builtin_inff()) { const uint32_t k = order_key(mx); if (k > __atomic_load_n(st + 2, __ATOMIC_RELAXED)) atomicMax(st + 2, k); }
         }
     };
-    auto finish_block = [&](int m, bool valid, const BlockAcc &ba, const TileQ &tq) {  // a finished token block: its trackers join the wave's (padding rows of the last tile do not), its row sums go out
+    int ps_pending = -1;                                              // PS range pass: the sequence whose trackers lie in ps_red, to be committed by wave 0 behind the next barrier
+    auto finish_block = [&](int m, bool valid, const BlockAcc &ba, const TileQ &tq, bool seq_end) {  // a finished token block: its trackers join the wave's (padding rows of the last tile do not), its row sums go out
         if (!QUANT) {
-            if (PS) { if (a.mm_out) commit_range(a.mm_out + 4 * tq.slot, valid ? ba.dl : 0xFFFFFFFFu, valid ? ba.dr : 0xFFFFFFFFu, valid ? ba.mx : -__builtin_inff()); }
-            else {
-                w_dl = min(w_dl, valid ? ba.dl : 0xFFFFFFFFu);
-                w_dr = min(w_dr, valid ? ba.dr : 0xFFFFFFFFu);
-                xmax = fmaxf(xmax, valid ? ba.mx : -__builtin_inff());
+            w_dl = min(w_dl, valid ? ba.dl : 0xFFFFFFFFu);
+            w_dr = min(w_dr, valid ? ba.dr : 0xFFFFFFFFu);
+            xmax = fmaxf(xmax, valid ? ba.mx : -__builtin_inff());
+            if (PS && seq_end) {                                      // (uniform) the sequence's last block: the wave's trackers -> LDS, and start afresh
+                for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                    xmax = fmaxf(xmax, __shfl_xor(xmax, ofs));
+                    w_dl = min(w_dl, (uint32_t)__shfl_xor((int)w_dl, ofs)); w_dr = min(w_dr, (uint32_t)__shfl_xor((int)w_dr, ofs));
+                }
+                if (lane == 0) { ps_red[wave * 4] = w_dl; ps_red[wave * 4 + 1] = w_dr; ps_red[wave * 4 + 2] = __float_as_uint(xmax); }
+                w_dl = 0xFFFFFFFFu; w_dr = 0xFFFFFFFFu; xmax = -__builtin_inff();
+                ps_pending = tq.slot;
             }
         } else if (ZW && a.rs_out) {
             int ssum = ba.ssum;
@@ -1634,14 +1671,34 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             if (hi == 0 && valid) atomicAdd(a.rs_out + m, ssum);
         }
     };
+    auto ps_commit = [&]() {                                          // behind a barrier: wave 0 folds the twelve waves' trackers of sequence ps_pending and sends them off
+        if (PS && !QUANT && ps_pending >= 0) {
+            if (wave == 0 && a.mm_out) {
+                uint32_t dl = lane < 12 ? ps_red[lane * 4] : 0xFFFFFFFFu, dr = lane < 12 ? ps_red[lane * 4 + 1] : 0xFFFFFFFFu;
+                float mx = lane < 12 ? __uint_as_float(ps_red[lane * 4 + 2]) : -__builtin_inff();
+                for (int ofs = 8; ofs > 0; ofs >>= 1) {
+                    mx = fmaxf(mx, __shfl_xor(mx, ofs));
+                    dl = min(dl, (uint32_t)__shfl_xor((int)dl, ofs)); dr = min(dr, (uint32_t)__shfl_xor((int)dr, ofs));
+                }
+                uint32_t *st = a.mm_out + 4 * ps_pending;
+                if (lane == 0) {
+                    if (dl <= 0xFF800000u - XSB) atomicMax(st, order_key(__uint_as_float(XSB + dl)));
+                    if (dr <= XSB - 0x80000000u) atomicMin(st + 1, order_key(__uint_as_float(XSB - dr)));
+                    if (mx > -__builtin_inff()) atomicMax(st + 2, order_key(mx));
+                }
+            }
+            ps_pending = -1;
+        }
+    };
     const BlockAcc ba_init = {0xFFFFFFFFu, 0xFFFFFFFFu, -__builtin_inff(), 0};
     TileQ tq_cur = tile_params(0), tq_p1 = tq_cur;                    // (not PS: the kernel-wide constants)
-    for (; t < n_tiles; t += n_workers, ++it) {
+    const int tps_mask = (1 << tps_log2) - 1;
+    for (; t < n_tiles; t = tile_at(++it)) {
         if (QUANT) { if (it > 1) store_out_tile(t_p2, (it - 2) % 3); }
-        if (PS) { tq_p1 = tq_cur; tq_cur = tile_params(t); }
+        if (PS) { tq_p1 = tq_cur; tq_cur = tile_params(it); }
         const unsigned char *buf = smem + cur * S8_TILE;
         const uint32_t pfb = cur + PF >= S8_NBUF ? cur + PF - S8_NBUF : cur + PF;
-        const int pt = t + PF * n_workers < n_tiles ? t + PF * n_workers : t;
+        const int pt = tile_at(it + PF) < n_tiles ? tile_at(it + PF) : t;
         const unsigned char *psrc = uniform_ptr(xb + (size_t)pt * S8_TILE);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * S8_TILE));
         const int rsa_p1 = rsa_b1;                                  // row sums of the previous tile's block 1 (its slot is the one being refilled now: taken while it was this tile)
@@ -1679,7 +1736,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
                 for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            finish_block(m, valid, ba, tq_p1);
+            finish_block(m, valid, ba, tq_p1, ((it - 1) & tps_mask) == tps_mask);      // (block 1 of the sequence's last tile ends the sequence)
         }
         // ---- phase 2: block 1 accumulates; block 0 of this tile is post-processed from acc0
         {
@@ -1696,13 +1753,14 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
                 for (int j = 0; j < 3; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, QUANT ? 20 : 10, 0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            finish_block(m, valid, ba, tq_cur);
+            finish_block(m, valid, ba, tq_cur, false);
         }
         // the next tile must have landed before the barrier (counted wait: everything younger than that tile's DMA is this tile's NPC pieces)
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");      // (wave 0's row-sum piece of this iteration was requested BEFORE the two tile pieces: it is older than the NPC allowed to stay out and simply lands an iteration early; a wave-dependent count behind a branch here made the register allocator spill the weight fragments)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        ps_commit();
         cur = cur + 1 == S8_NBUF ? 0 : cur + 1;
         t_p2 = t_p1; t_p1 = t;
     }
@@ -1716,7 +1774,12 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         BlockAcc ba = ba_init;
 #pragma unroll
         for (int g = 0; g < 4; ++g) epi_chunk(acc1, g, rsa, orow, ba, tq_cur);      // (the last tile this worker ran)
-        finish_block(m, valid, ba, tq_cur);
+        finish_block(m, valid, ba, tq_cur, true);
+        if (PS && !QUANT) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            ps_commit();
+        }
         if (QUANT) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
