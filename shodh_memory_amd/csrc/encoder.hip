@@ -594,17 +594,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 // ---- the same for SHODH_QUANT_SCOPE_PER_TEXT: one workgroup per SEQUENCE of `rows` positions, so that the sequence's output range is reduced on chip
 // and written once (with one pair of global atomics per token, as embed_ln_kernel commits the batch tensor's range, a forward of 4096 texts spent
 // 9 ms here: 2M atomics on 4096 slots, eight of them per cache line). f32 out, (H & 3) == 0, H <= 512; the arithmetic is embed_ln_kernel's vector path.
-__global__ __launch_bounds__(256) void embed_ln_seq_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ tok_seq, const int32_t *__restrict__ tok_pos,
+__global__ __launch_bounds__(1024) void embed_ln_seq_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ tok_seq, const int32_t *__restrict__ tok_pos,
                                                            const float *__restrict__ word, const float *__restrict__ pos, const float *__restrict__ type0,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ out, int rows, int H, int max_len, int vocab,
                                                            float eps, const int8_t *__restrict__ word_q, const float *__restrict__ word_scale, uint32_t *__restrict__ mm /* [sequences][2] */) {
-    __shared__ uint32_t red[8];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint32_t red[32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;          // sixteen waves: sixteen tokens of the sequence in flight
     const int h4 = H >> 2;
     const float wsc = word_q ? word_scale[0] : 0.0f;
     const int wzp = word_q ? (int)word_scale[1] : 0;              // zero point in signed-storage terms
     uint32_t klo = 0xFFFFFFFFu, khi = 0u;
-    for (int r = wv; r < rows; r += 4) {
+    for (int r = wv; r < rows; r += 16) {
         const int tok = blockIdx.x * rows + r;
         const int sq = tok_seq[tok], p = tok_pos[tok];
         int id = ids[(size_t)sq * max_len + p];
@@ -656,8 +656,9 @@ __global__ __launch_bounds__(256) void embed_ln_seq_kernel(const int32_t *__rest
     if (lane == 0) { red[2 * wv] = klo; red[2 * wv + 1] = khi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mm[2 * blockIdx.x] = min(min(red[0], red[2]), min(red[4], red[6]));
-        mm[2 * blockIdx.x + 1] = max(max(red[1], red[3]), max(red[5], red[7]));
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int w = 0; w < 16; ++w) { lo = min(lo, red[2 * w]); hi = max(hi, red[2 * w + 1]); }
+        mm[2 * blockIdx.x] = lo; mm[2 * blockIdx.x + 1] = hi;
     }
 }
 
@@ -1254,7 +1255,7 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
     hipLaunchKernelGGL(init_ranges_kernel, dim3((uint32_t)std::min(ceil_div((size_t)n_pairs * S, 256), (size_t)1024)), dim3(256), 0, st, e->mmr, n_pairs * S, (int)e->cfg.layers * S);
     auto mm_of = [&](int t) { return e->mmr + (size_t)2 * S * t; };      // range keys of tensor t of the forward: [S][2]
     uint32_t *mmX = mm_of(0);                             // range of the current layer input
-    if (ps_rows) hipLaunchKernelGGL(embed_ln_seq_kernel, dim3(nseq), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
+    if (ps_rows) hipLaunchKernelGGL(embed_ln_seq_kernel, dim3(nseq), dim3(1024), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
                                     w + e->o_type, w + e->o_eg, w + e->o_eb, X, ps_rows, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX);
     else hipLaunchKernelGGL((embed_ln_kernel<float>), dim3(tok_blocks), dim3(256), 0, st, e->d_ids, e->d_tok_seq, e->d_tok_pos, w + e->o_word, w + e->o_pos,
                             w + e->o_type, w + e->o_eg, w + e->o_eb, X, ntok, H, (int)e->cfg.max_len, (int)e->cfg.vocab, eps, (const int8_t *)e->word_q, (const float *)e->word_scale, mmX, 0);

@@ -925,12 +925,14 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
         c_ws[i] = c_scale * a.wscale[i]; c_rz[i] = c_corr * a.rsz[i]; c_b[i] = a.bias[i]; c_zw[i] = zwo ? a.zw[i] : 0; c_g[i] = a.gamma[i]; c_be[i] = a.beta[i];
     }
     // ---- the sequence's ctx rows -> bytes in the staging blocks: 2 NBLK half blocks over eight waves
-#pragma unroll 1
-    for (int u = wave; u < 2 * NBLK; u += 8) {
+    {
         OT_FRESH_LANE();
-        f32x4q v[24];
-        fetch_rows16(a.ctx + (size_t)(s0 + u * 16) * H, lane, v);
-        quant_half16(v, smem + OT_STG + (u >> 1) * 12288 + (u & 1) * 6144, c_scale, (float)cp.zp, lane);
+        f32x4q v0[24], v1[24];                                           // (all of the wave's requests in flight before the first byte is converted)
+        fetch_rows16(a.ctx + (size_t)(s0 + wave * 16) * H, lane, v0);
+        if (BPW == 2) fetch_rows16(a.ctx + (size_t)(s0 + (wave + 8) * 16) * H, lane, v1);
+        __builtin_amdgcn_sched_barrier(0);
+        quant_half16(v0, smem + OT_STG + (wave >> 1) * 12288 + (wave & 1) * 6144, c_scale, (float)cp.zp, lane);
+        if (BPW == 2) { OT_FRESH_LANE(); quant_half16(v1, smem + OT_STG + ((wave + 8) >> 1) * 12288 + (wave & 1) * 6144, c_scale, (float)cp.zp, lane); }
     }
     OPROF_T(0)
     float xmin = __builtin_inff(), xmax = -__builtin_inff();
@@ -962,7 +964,6 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ks + 3 < KS) issue_wslice(ks + 3);
-            if (ks == KS - 1 && more) { issue_wslice(0); issue_wslice(1); issue_wslice(2); }      // slots 0-2 were last read at steps 8-10: every wave is past them (this step's barrier)
             OT_FRESH_LANE();
             const i32x4q xf = *reinterpret_cast<const i32x4q *>(sblk + l31 * 384 + (((2 * ks + hi) ^ (l31 & 7)) << 4));
             if (zwo) {
@@ -974,18 +975,41 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
             for (int j = 0; j < NBW; ++j)
                 reg[j] = __builtin_bit_cast(f32x16q, __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4q *>(ring + j * 1024), xf, __builtin_bit_cast(i32x16l, reg[j]), 0, 0, 0));
         });
+        __syncthreads();                                                 // every wave is through the k loop: the ring and the staging bytes of the current blocks are free
         OPROF_T(2)
-        // ---- + bias + residual; block sums
+        // ---- + bias + residual; block sums. The residual rows (this wave's half: 32 rows x 768 B) come as 24 coalesced requests -- 384-byte row segments,
+        // three whole cache lines each -- and are turned into the accumulator layout through 12 KiB of LDS (the wave's share of the ring and of the dead
+        // staging bytes; 16-byte chunks XOR-swizzled by row & 7), half of the columns at a time. Read straight in the accumulator layout an instruction
+        // touches 32 rows x 32 bytes: 25 000 cycles per block on the address path where this takes a round trip.
         OT_FRESH_LANE();
         const int rsa = zwo ? rs_t + __shfl_xor(rs_t, 32) : 0;
         float sb[NBW];
         {
-            const float *xrow = a.X + (size_t)(s0 + tb * 32 + l31) * H + fh * (NBW * 32);
-            f32x4q rr[NBW][4];                                           // the wave's half of the residual rows: all 24 requests at once
+            f32x4q rr[NBW][4];
+            {
+                const unsigned char *xb = reinterpret_cast<const unsigned char *>(a.X + (size_t)(s0 + tb * 32) * H) + fh * (NBW * 128);
 #pragma unroll
-            for (int j = 0; j < NBW; ++j)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rr[j][g] = *reinterpret_cast<const f32x4q *>(xrow + j * 32 + 8 * g + 4 * hi);
+                    for (int i = 0; i < 12; ++i) {
+                        const int p = i * 64 + lane, row = p / 24, cc = p % 24;
+                        rr[c * 3 + i / 4][i % 4] = *reinterpret_cast<const f32x4q *>(xb + (size_t)row * (H * 4) + c * 384 + cc * 16);
+                    }
+                unsigned char *lo = smem + wave * 6144, *up = sblk + fh * 6144;      // rows 0-15 | 16-31 of the tile
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int p = i * 64 + lane, row = p / 24, cc = p % 24;
+                        *reinterpret_cast<f32x4q *>((row < 16 ? lo : up) + (row & 15) * 384 + (((cc & ~7) | ((cc & 7) ^ (row & 7))) << 4)) = rr[c * 3 + i / 4][i % 4];
+                    }
+                    const unsigned char *rb = (l31 < 16 ? lo : up) + (l31 & 15) * 384;
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rr[c * 3 + jj][g] = *reinterpret_cast<const f32x4q *>(rb + ((jj * 8 + ((2 * g + hi) ^ (l31 & 7))) << 4));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
                 const i32x16l acc = __builtin_bit_cast(i32x16l, reg[j]);
@@ -1016,6 +1040,7 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
                 if (hi == 0) ex_a[pr * 32 + l31] = ch;
             }
             __syncthreads();
+            if (more) { issue_wslice(0); issue_wslice(1); issue_wslice(2); }      // (every wave is done with its share of the ring: the next pass's first slices travel under the rest of this epilogue)
             if (fh == 1) {
                 ch = ex_a[pr * 32 + l31];
 #pragma unroll
@@ -1101,15 +1126,19 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
     uint32_t ykeys[2] = {order_key(ymin), order_key(ymax)};
     if (tid == 0) { a.mm_x1[2 * seq] = ykeys[0]; a.mm_x1[2 * seq + 1] = ykeys[1]; }
     const ActQ yp = act_params(ykeys);
+    {
+        OT_FRESH_LANE();
+        f32x4q v0[24], v1[24];
+        fetch_rows16(a.X + (size_t)(s0 + wave * 16) * H, lane, v0);
+        if (BPW == 2) fetch_rows16(a.X + (size_t)(s0 + (wave + 8) * 16) * H, lane, v1);
+        __builtin_amdgcn_sched_barrier(0);
+        quant_half16(v0, smem + OT_STG + (wave >> 1) * 12288 + (wave & 1) * 6144, yp.scale, (float)yp.zp, lane);
+        if (BPW == 2) { OT_FRESH_LANE(); quant_half16(v1, smem + OT_STG + ((wave + 8) >> 1) * 12288 + (wave & 1) * 6144, yp.scale, (float)yp.zp, lane); }
+    }
 #pragma unroll 1
     for (int u = wave; u < 2 * NBLK; u += 8) {
         OT_FRESH_LANE();
         unsigned char *dst = smem + OT_STG + (u >> 1) * 12288 + (u & 1) * 6144;
-        {
-            f32x4q v[24];
-            fetch_rows16(a.X + (size_t)(s0 + u * 16) * H, lane, v);
-            quant_half16(v, dst, yp.scale, (float)yp.zp, lane);
-        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         if (a.rsq) {                                                     // row sums of the stored bytes: lane = (row lane & 15, quarter lane >> 4 of its 24 chunks)
