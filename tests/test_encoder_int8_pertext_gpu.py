@@ -139,3 +139,45 @@ def test_embedder_trait_scopes(S, tmp_path):
     batch = e8.encode_batch(texts)
     assert not batch[1].any() and not each[1].any()
     assert any(a.tobytes() != b.tobytes() for a, b in zip(batch, each))      # the batch call's ranges span all rows
+
+
+def test_first_contact_verifier_end_to_end(S, tmp_path, monkeypatch, capsys):
+    """tools/verify_real_model.py on a directory laid out like the HuggingFace repository (files written by tests/onnx_writer.py: the real ones
+    cannot be fetched here): checksums differ from the pinned ones by construction, the reader's tensor map and every GPU check run and pass."""
+    import importlib.util
+    import json
+    from shodh_memory_amd import embedder as E
+    from tests import onnx_writer as W
+    spec = importlib.util.spec_from_file_location("verify_real_model", os.path.join(ROOT, "tools", "verify_real_model.py"))
+    V = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(V)
+    cfg, sd, qm = _export_case(E, lambda w: R.quantize_weight_ort(w, per_channel=True), layers=2, vocab=30522, seed=3)
+    os.makedirs(tmp_path / "onnx")
+    W.write_bert(str(tmp_path / "onnx" / "model_quint8_avx2.onnx"), sd, cfg.layers, qmodel=qm)
+    W.write_bert(str(tmp_path / "onnx" / "model.onnx"), sd, cfg.layers)
+    monkeypatch.setenv("SHODH_VERIFY_CFG", json.dumps(dict(layers=2))); monkeypatch.setenv("SHODH_VERIFY_JSON", str(tmp_path / "rep.json"))
+    rc = V.main(["verify_real_model.py", str(tmp_path)])
+    out = capsys.readouterr().out
+    print(out)
+    rep = json.load(open(tmp_path / "rep.json"))
+    g = rep["steps"]["gpu"]
+    assert rc == 0 and g["ok"], g
+    assert g["fp32_pad128_vs_pad256_bit_identical"] and g["int8_batch_equals_n_calls"] and g["int8_weight_source"].startswith("the export")
+    assert g["full_unit_norm_max_dev"] < 1e-5 and g["quantized_unit_norm_max_dev"] < 1e-5
+    assert rep["steps"]["sha256"]["quantized"]["status"].startswith("DIFFERS")
+
+
+@pytest.mark.parametrize("export", [False, True])
+def test_per_sequence_tail_kernel_equals_the_separate_kernels(S, tmp_path, monkeypatch, export):
+    """SHODH_INT8_STAGES bit 7: attention output + LayerNorm + both quantising passes as ONE kernel per sequence (attn_out_ln_quant_seq_kernel) or as
+    the four launches with per-sequence range slots (act_quant_seq, i8_stream_kernel<RESID_LN, PS>, act_quant_seq). Same sums in the same order:
+    the same bits."""
+    from shodh_memory_amd import _lib as L
+    out = {}
+    for stages in ("0x6F", "0xEF"):
+        monkeypatch.setenv("SHODH_INT8_STAGES", stages)
+        e8, _, _, _, vocab = _embedder(S, tmp_path, export, quant_scope=L.QUANT_SCOPE_PER_TEXT)
+        ids, mask = _batch(40, 13, vocab)
+        out[stages] = e8.encode_ids(ids, mask)
+        e8.close()
+    assert out["0x6F"].tobytes() == out["0xEF"].tobytes()
