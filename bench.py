@@ -718,19 +718,23 @@ def main():
     alg_bytes = rows_live * args.dim * 4                 # LIVE rows, read once per batch at f32
     # HBM traffic of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc in separate runs, not live)
+    # `traffic` (HBM bytes per launch from the PMC counters) cannot be measured inside this run -- the counters need their own rocprofv3 --pmc passes --
+    # so the live line says null and names the committed profile the figure lives in (it went stale silently when it was copied in here).
     traffic = None
+    traffic_profile = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if (pm["config"]["rows"], pm["config"]["dim"], pm["config"]["nq"]) == (rows_local, args.dim, args.nq) and args.scan != "exact":
-            traffic = [v["traffic_bytes_per_launch"] for kk, v in pm["kernels"].items() if "mfma_scan_kernel<1" in kk][0]
+            traffic_profile = {"bytes_per_launch": [v["traffic_bytes_per_launch"] for kk, v in pm["kernels"].items() if "mfma_scan_kernel<1" in kk][0],
+                               "source": "profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (tools/pmc_traffic.py); NOT measured in this run"}
     except Exception:
-        traffic = None
+        traffic_profile = None
     roof = None
     if kern_n:
         ach = alg_bytes / (kern_mean_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": "mfma_scan_kernel<EMIT>" if args.scan != "exact" else "flat_exact_kernel",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
+                "traffic": traffic, "traffic_profiled": traffic_profile, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
                 "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes, "rows_live": rows_live, "rows_scanned": rows_local}
         ff = flat_fractions(rows_local, rows_live, args.dim, args.nq, kern_mean_us, ms_per_step)
         roof.update({"bytes_moved_fp16_shadow_per_launch": ff["bytes_moved_fp16_shadow_per_step"],

@@ -106,6 +106,10 @@ void shodh_index_destroy(shodh_index *idx);
  * SHODH_SCAN_GRAPH only: SHODH_ERR_UNSUPPORTED with "frontier overflowed" means the rows WERE added but a walk met thousands of
  * equidistant rows and the graph may differ from the reference's -- do not retry the call. */
 int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out);
+/* SHODH_SCAN_GRAPH: 1 when some add since the last build met a walk whose frontier outgrew its array (thousands of equidistant rows): the rows
+ * WERE added and the add call returned SHODH_OK -- a walk cannot be undone, and an error status would invite a retry that adds them twice --
+ * but the graph may differ from the reference's from there on (searches stay correct answers of THAT graph). Cleared by build. */
+int shodh_index_graph_overflowed(const shodh_index *idx);
 int shodh_index_add_device(shodh_index *idx, const float *d_rows, uint64_t n, uint32_t *first_id_out);
 /* build (vamana.rs:200-284) / rebuild_from_vectors (:1363-1462): replaces the contents; ids 0..n-1;
  * tombstones cleared. */

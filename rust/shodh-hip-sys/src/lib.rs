@@ -80,6 +80,9 @@ impl HipIndex {
     /// vamana.rs:175-187: the storage path only tells the reference where to mmap its vectors; rows live in HBM here
     pub fn with_storage_path(config: VamanaConfig, _storage_path: Option<std::path::PathBuf>) -> Result<Self> { Self::new(config) }
     pub fn len(&self) -> usize { unsafe { ffi::shodh_index_len(self.h) as usize } }
+    /// graph mode: some `add_vector` since the last build met a walk whose frontier outgrew its array (thousands of equidistant rows). The rows were
+    /// added (the call returned Ok, the counters are in step); the graph may differ from the reference's from there on.
+    pub fn graph_overflowed(&self) -> bool { unsafe { ffi::shodh_index_graph_overflowed(self.h) != 0 } }
     pub fn is_empty(&self) -> bool { self.len() == 0 }
 
     /// vamana.rs:200-284 (ids 0..n-1, tombstones cleared)

@@ -92,6 +92,7 @@ class SpanInfo(C.Structure):
 SYMBOLS = {
     "shodh_last_error": (C.c_char_p, []),
     "shodh_abi_version": (C.c_int, []),
+    "shodh_index_graph_overflowed": (C.c_int, [_vp]),
     "shodh_device_count": (C.c_int, []),
     "shodh_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "shodh_index_cfg_default": (None, [C.POINTER(IndexCfg)]),

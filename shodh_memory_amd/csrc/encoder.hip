@@ -1602,9 +1602,12 @@ static int apply_weightset(shodh_embedder *e, WeightSet &ws) {
     std::lock_guard<std::mutex> g(e->mu);
     SHODH_HIP_TRY(hipSetDevice(e->cfg.device));
     SHODH_HIP_TRY(hipMemcpy(e->w32, ws.blob.data(), e->n_params * 4, hipMemcpyHostToDevice));
+    // the export's tensors are COPIED into the embedder for the build and the pending set keeps its own until the build has succeeded: a failed
+    // finish (out of device memory, say) that is retried must find the export's bytes again, not quantise the dequantised floats with the fallback rule
     e->qexp.clear();
-    if (e->cfg.dtype == SHODH_DTYPE_INT8) e->qexp = std::move(ws.q);
+    if (e->cfg.dtype == SHODH_DTYPE_INT8) e->qexp = ws.q;
     const int rc = finish_weights(e);
+    if (rc != SHODH_OK) { e->qexp.clear(); e->loaded = false; return rc; }
     if (e->cfg.dtype == SHODH_DTYPE_INT8) for (auto &t : e->qexp) { t.q.clear(); t.q.shrink_to_fit(); }      // the bytes live on the device now; keep the (small) scales for shodh_embedder_weight_source
     return rc;
 }

@@ -199,6 +199,7 @@ struct shodh_index {
     uint32_t *g_deg = nullptr, *g_nbr = nullptr;   // [cap_rows], [cap_rows][g_stride]
     uint32_t *g_visited = nullptr;                 // [cap_rows / 32 + 1] visited bits of the insert / build walk
     uint32_t *g_overflow = nullptr;                // device flag: a frontier array overflowed (never in practice)
+    bool g_overflowed = false;                     // sticky host copy for graph INSERTS (shodh_index_graph_overflowed): set by add, cleared by build
     uint32_t g_stride = 0, g_medoid = 0;
     uint64_t g_nodes = 0;                          // rows that have a node in the graph (== n when the graph is usable)
 };
@@ -558,13 +559,17 @@ static int add_impl(shodh_index *idx, const float *rows, uint64_t n, uint32_t *f
     SHODH_HIP_TRY(hipDeviceSynchronize());
     idx->n += n;
     if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !skip_graph && check_graph_overflow(idx) != SHODH_OK) {
-        // the rows and their graph nodes ARE in the index at this point (a walk cannot be undone): say so, a caller that retried would add them twice
-        set_error("graph insert: a walk's frontier overflowed (thousands of equidistant rows), so the graph may differ from the reference's; the %llu rows WERE added (ids from %llu) -- do not retry",
+        // The rows and their graph nodes ARE in the index at this point (a walk cannot be undone), so the call SUCCEEDS -- an error status made the
+        // wrappers skip their bookkeeping (incremental-insert counters) and invited a retry that would add the rows twice. What happened stays
+        // queryable: shodh_index_graph_overflowed() (sticky until the next build), and the message is left in shodh_last_error().
+        idx->g_overflowed = true;
+        set_error("graph insert: a walk's frontier overflowed (thousands of equidistant rows), so the graph may differ from the reference's; the %llu rows were added (ids from %llu)",
                   (unsigned long long)n, (unsigned long long)(idx->cfg.id_base + idx->n - n));
-        return SHODH_ERR_UNSUPPORTED;
     }
     return SHODH_OK;
 }
+
+int shodh_index_graph_overflowed(const shodh_index *idx) { return idx && idx->g_overflowed ? 1 : 0; }
 
 int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out) {
     return add_impl(idx, rows, n, first_id_out, hipMemcpyHostToDevice);
@@ -585,7 +590,7 @@ static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpy
         if (idx->deleted) SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
         std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
         SHODH_HIP_TRY(hipMemset(idx->stats, 0, 16));
-        idx->g_nodes = 0; idx->g_medoid = 0;
+        idx->g_nodes = 0; idx->g_medoid = 0; idx->g_overflowed = false;
     }
     if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
         // VamanaIndex::build: store the rows, then construct the graph from a random start (vamana.rs:200-284); the start is drawn here

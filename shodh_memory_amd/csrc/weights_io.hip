@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -170,13 +172,26 @@ struct Json {
         ++p;
         return s;
     }
-    double num() { ws(); char *end = nullptr; const double v = strtod(p, &end); if (end == p) ok = false; p = end; return v; }
-    void skip() {          // any value
+    // the numbers of a safetensors header are shapes and byte offsets: non-negative integers. Read digit by digit inside [p, e) -- the header is
+    // not NUL-terminated, strtod would run past its end on a crafted file -- and anything else (sign, fraction, exponent, overflow) is malformed.
+    uint64_t num() {
         ws();
-        if (p >= e) { ok = false; return; }
+        if (p >= e || *p < '0' || *p > '9') { ok = false; return 0; }
+        uint64_t v = 0;
+        while (p < e && *p >= '0' && *p <= '9') {
+            const uint64_t d = (uint64_t)(*p - '0');
+            if (v > (UINT64_MAX - d) / 10) { ok = false; return 0; }
+            v = v * 10 + d; ++p;
+        }
+        if (p < e && (*p == '.' || *p == 'e' || *p == 'E')) { ok = false; return 0; }
+        return v;
+    }
+    void skip(int depth = 0) {          // any value (nesting bounded: a crafted __metadata__ must not overflow the stack)
+        ws();
+        if (p >= e || depth > 32) { ok = false; return; }
         if (*p == '"') { str(); return; }
-        if (*p == '{') { ++p; if (eat('}')) return; do { str(); if (!eat(':')) { ok = false; return; } skip(); } while (ok && eat(',')); if (!eat('}')) ok = false; return; }
-        if (*p == '[') { ++p; if (eat(']')) return; do { skip(); } while (ok && eat(',')); if (!eat(']')) ok = false; return; }
+        if (*p == '{') { ++p; if (eat('}')) return; do { str(); if (!eat(':')) { ok = false; return; } skip(depth + 1); } while (ok && eat(',')); if (!eat('}')) ok = false; return; }
+        if (*p == '[') { ++p; if (eat(']')) return; do { skip(depth + 1); } while (ok && eat(',')); if (!eat(']')) ok = false; return; }
         while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n') ++p;
     }
 };
@@ -202,8 +217,8 @@ int load_safetensors(const std::vector<unsigned char> &buf, const char *path, We
                 const std::string f = j.str();
                 if (!j.eat(':')) { j.ok = false; break; }
                 if (f == "dtype") en.dtype = j.str();
-                else if (f == "shape") { if (!j.eat('[')) { j.ok = false; break; } if (!j.eat(']')) { do { en.shape.push_back((uint64_t)j.num()); } while (j.ok && j.eat(',')); if (!j.eat(']')) j.ok = false; } }
-                else if (f == "data_offsets") { if (!j.eat('[')) { j.ok = false; break; } en.b = (uint64_t)j.num(); if (!j.eat(',')) j.ok = false; en.e = (uint64_t)j.num(); if (!j.eat(']')) j.ok = false; }
+                else if (f == "shape") { if (!j.eat('[')) { j.ok = false; break; } if (!j.eat(']')) { do { en.shape.push_back(j.num()); } while (j.ok && j.eat(',')); if (!j.eat(']')) j.ok = false; } }
+                else if (f == "data_offsets") { if (!j.eat('[')) { j.ok = false; break; } en.b = j.num(); if (!j.eat(',')) j.ok = false; en.e = j.num(); if (!j.eat(']')) j.ok = false; }
                 else j.skip();
             } while (j.ok && j.eat(','));
             if (!j.ok || !j.eat('}')) { set_error("%s: malformed entry %s", path, key.c_str()); return SHODH_ERR_IO; }
@@ -218,8 +233,10 @@ int load_safetensors(const std::vector<unsigned char> &buf, const char *path, We
         for (auto &kv : ent) if (name_matches(kv.first, s.name)) { en = &kv.second; break; }
         if (!en) continue;            // check_complete names it
         uint64_t n = 1;
-        for (uint64_t d : en->shape) n *= d;
+        bool wrapped = false;
+        for (uint64_t d : en->shape) { if (d && n > UINT64_MAX / d) wrapped = true; n *= d; }
         const uint64_t want = (uint64_t)s.rows * s.cols;
+        if (wrapped) { set_error("%s: tensor %s has an impossible shape", path, s.name.c_str()); return SHODH_ERR_INVALID; }
         const size_t esz = en->dtype == "F32" ? 4 : (en->dtype == "F16" || en->dtype == "BF16") ? 2 : 0;
         if (!esz) { set_error("%s: tensor %s has dtype %s (F32 / F16 / BF16 supported)", path, s.name.c_str(), en->dtype.c_str()); return SHODH_ERR_UNSUPPORTED; }
         if (n != want || en->e < en->b || en->e > data_len || en->e - en->b != n * esz) {
@@ -268,7 +285,8 @@ struct OnnxTensor {
     std::vector<float> fdata;            // float_data (field 4)
     std::vector<int32_t> idata;          // int32_data (field 5): holds uint8 / int8 / float16 elements when raw_data is absent
     bool external = false;
-    uint64_t numel() const { uint64_t n = 1; for (int64_t d : dims) n *= (uint64_t)(d < 0 ? 0 : d); return n; }
+    // UINT64_MAX = impossible (negative or overflowing dims): matches no payload size below
+    uint64_t numel() const { uint64_t n = 1; for (int64_t d : dims) { if (d < 0) return UINT64_MAX; if (d && n > (UINT64_MAX - 1) / (uint64_t)d) return UINT64_MAX; n *= (uint64_t)d; } return n; }
 };
 struct OnnxNode { std::string op, name; std::vector<std::string> in, out; };
 
@@ -305,6 +323,11 @@ bool parse_node(const unsigned char *sp, const unsigned char *se, OnnxNode &n) {
 // tensor -> f32 values (FLOAT / FLOAT16 / BFLOAT16)
 bool tensor_floats(const OnnxTensor &t, std::vector<float> &out) {
     const uint64_t n = t.numel();
+    // the element count comes from the file's dims: it is believed only when a payload of exactly that size is there (a crafted dim must not size an allocation)
+    const size_t esz = t.dtype == 1 ? 4 : 2;
+    const bool raw_ok = t.raw && n <= t.raw_n && (uint64_t)t.raw_n == n * esz;
+    const bool typed_ok = t.dtype == 1 ? (uint64_t)t.fdata.size() == n : (uint64_t)t.idata.size() == n;
+    if (!raw_ok && !typed_ok) return false;
     out.resize(n);
     if (t.dtype == 1) {
         if (t.raw && t.raw_n == n * 4) { memcpy(out.data(), t.raw, n * 4); return true; }
@@ -325,6 +348,7 @@ bool tensor_floats(const OnnxTensor &t, std::vector<float> &out) {
 bool tensor_bytes(const OnnxTensor &t, std::vector<uint8_t> &out) {
     const uint64_t n = t.numel();
     if (t.dtype != 2 && t.dtype != 3) return false;
+    if (!(t.raw && (uint64_t)t.raw_n == n) && (uint64_t)t.idata.size() != n) return false;      // (before the allocation: see tensor_floats)
     out.resize(n);
     if (t.raw && t.raw_n == n) { memcpy(out.data(), t.raw, n); return true; }
     if (t.idata.size() == n) { for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)t.idata[i]; return true; }
@@ -503,8 +527,7 @@ int load_onnx(const std::vector<unsigned char> &buf, const char *path, WeightSet
 
 }  // namespace
 
-int load_weight_file(const char *path, const shodh_embed_cfg &cfg, WeightSet &out) {
-    if (!path || !*path) { set_error("empty weights path"); return SHODH_ERR_INVALID; }
+static int load_weight_file_impl(const char *path, const shodh_embed_cfg &cfg, WeightSet &out) {
     std::vector<unsigned char> buf;
     SHODH_TRY(slurp(path, buf));
     out.init(cfg);
@@ -516,6 +539,18 @@ int load_weight_file(const char *path, const shodh_embed_cfg &cfg, WeightSet &ou
     // by content: a safetensors file starts with a small little-endian length followed by '{'
     if (buf.size() > 9) { uint64_t hl; memcpy(&hl, buf.data(), 8); if (hl < buf.size() && buf[8] == '{') return load_safetensors(buf, path, out); }
     return load_onnx(buf, path, out);
+}
+// The entry point of every file-reading ABI call (shodh_weight_file_open, shodh_embedder_load_file, shodh_embedder_create with weights_path): no C++
+// exception may cross `extern "C"` -- a file is untrusted input, and an allocation sized by it (or by a big honest model on a small host) can fail.
+int load_weight_file(const char *path, const shodh_embed_cfg &cfg, WeightSet &out) {
+    if (!path || !*path) { set_error("empty weights path"); return SHODH_ERR_INVALID; }
+    try {
+        return load_weight_file_impl(path, cfg, out);
+    } catch (const std::bad_alloc &) {
+        set_error("%s: out of host memory while reading the file", path); return SHODH_ERR_OOM;
+    } catch (const std::exception &ex) {
+        set_error("%s: malformed file (%s)", path, ex.what()); return SHODH_ERR_IO;
+    }
 }
 
 }  // namespace shodh

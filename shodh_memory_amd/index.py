@@ -270,6 +270,11 @@ class VamanaIndex:
         self._incremental += n - (1 if n and first.value == self.config.id_base else 0)      # see add_vector
         return int(first.value)
 
+    def graph_overflowed(self):
+        """graph mode: some add since the last build met a walk whose frontier outgrew its array (thousands of equidistant rows). The rows were added
+        and the counters above are in step with the device; the graph may differ from the reference's from there on (shodh_index_graph_overflowed)."""
+        return bool(L.lib().shodh_index_graph_overflowed(self.handle))
+
     # -- search (vamana.rs:764-808; exact path :1167-1188) ---------------------------------------------
     def search(self, query, k):
         """-> list[(id, distance)] ascending distance, ties by id; at most k; [] on an empty index."""

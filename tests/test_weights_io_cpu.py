@@ -149,3 +149,51 @@ def test_tensor_by_tensor_handover_needs_a_device_only_at_finish(E):
     assert (L.WEIGHT_ABSENT, L.WEIGHT_F32, L.WEIGHT_EXPORT_Q8, L.WEIGHT_SELF_Q8) == (0, 1, 2, 3)
     for s in ("shodh_embedder_load_file", "shodh_embedder_load_tensor", "shodh_embedder_load_quantized", "shodh_embedder_finish_weights", "shodh_embedder_weight_source"):
         assert hasattr(L.lib(), s)
+
+
+def test_crafted_files_are_rejected_not_fatal(E, tmp_path):
+    """a file is untrusted input. Headers whose numbers are negative, fractional, overflowing or run to the end of the header without a
+    terminator, metadata nested beyond any sane depth, shapes whose product wraps, ONNX dims that would size a huge allocation: every one is an
+    error status through the C ABI, none aborts the process or reads past the header."""
+    import json
+    import struct
+    from shodh_memory_amd import _lib as L
+    cfg = small_cfg(E)
+    blob, sd = random_sd(E, cfg)
+
+    def st_file(name, header_text, payload=b"\0" * 64):
+        h = header_text.encode()
+        p = str(tmp_path / name)
+        open(p, "wb").write(struct.pack("<Q", len(h)) + h + payload)
+        return p
+    key = "embeddings.LayerNorm.weight"
+    cases = {
+        "neg.safetensors": '{"%s":{"dtype":"F32","shape":[-128],"data_offsets":[0,512]}}' % key,
+        "frac.safetensors": '{"%s":{"dtype":"F32","shape":[128],"data_offsets":[0,5.12e2]}}' % key,
+        "huge.safetensors": '{"%s":{"dtype":"F32","shape":[99999999999999999999999],"data_offsets":[0,512]}}' % key,
+        "wrap.safetensors": '{"%s":{"dtype":"F32","shape":[4294967296,4294967296,128],"data_offsets":[0,512]}}' % key,
+        "deep.safetensors": '{"__metadata__":' + "[" * 5000 + "]" * 5000 + "}",
+        "open.safetensors": '{"%s":{"dtype":"F32","shape":[128],"data_offsets":[0,51' % key,          # the header ends inside a number: nothing behind it but the payload
+    }
+    for name, text in cases.items():
+        with pytest.raises(L.ShodhError):
+            E.WeightFile(st_file(name, text, payload=b"9" * 4096), cfg)
+    # ONNX: a scale tensor whose dims promise 2^40 elements (and a weight whose dims are negative) next to a few bytes of payload
+    good = str(tmp_path / "good.onnx")
+    qm = R.quantize_model(sd, cfg.layers, rule=lambda w: R.quantize_weight_ort(w, per_channel=True), word_rule=lambda w: R.quantize_weight_ort(w))
+    W.write_bert(good, sd, cfg.layers, qmodel=qm)
+    assert E.WeightFile(good, cfg).blob().size == blob.size
+    for bad_dims in ([1 << 40], [1 << 62, 1 << 62], [-5]):
+        t = W.tensor("x_scale", np.zeros(4, f32))
+        # rebuild the tensor proto with crafted dims: field 1 (dims, varint) repeated, then the rest of the original tensor minus its own dims
+        body = b"".join(W._vi(1, d & ((1 << 64) - 1)) for d in bad_dims) + W._vi(2, 1) + W._ld(8, b"encoder.layer.0.output.dense.weight_scale") + W._ld(9, b"\0" * 16)
+        p = str(tmp_path / ("dims_%d.onnx" % (len(bad_dims) * 7 + (bad_dims[0] & 7))))
+        raw = open(good, "rb").read()
+        # append one more initializer to the graph: model = field 7 (graph) -> graph field 5 (initializer). Appending a second graph field merges in protobuf.
+        open(p, "wb").write(raw + W._ld(7, W._ld(5, body)))
+        try:
+            wf = E.WeightFile(p, cfg)          # either the crafted tensor is ignored (never matched) ...
+            assert wf.blob().size == blob.size
+        except L.ShodhError:
+            pass                               # ... or the file is rejected: both are fine, a crash is not
+        del t
