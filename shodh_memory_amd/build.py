@@ -21,16 +21,41 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+STAMP = LIB + ".srchash"      # sha256 of every source the library was built from + the flags (travels with the .so; git-ignored like it)
+
+
+def _deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + [os.path.join(HERE, "..", "include", "shodh_hip.h")]
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True unless the library on disk was built from exactly these sources with these flags. Decided by CONTENT (a hash written next to the library
+    at build time), not by modification times: a snapshot copied to another machine keeps neither a meaningful mtime order nor a guarantee that the
+    binary riding along belongs to the sources next to it (the driver boxes ran whatever .so the push carried)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "shodh_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
+
+
+LAST_BUILD_MODE = "not run"
 
 
 def build(force=False, verbose=False):
+    global LAST_BUILD_MODE
     if not force and not needs_build():
+        LAST_BUILD_MODE = "up to date (library matches the source hash %s...)" % source_hash()[:12]
         return LIB
     objs = []
     objdir = os.path.join(HERE, "build")
@@ -55,6 +80,9 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
+    LAST_BUILD_MODE = "rebuilt (%d of %d objects recompiled)" % (len(procs), len(objs))
     return LIB
 
 

@@ -144,3 +144,19 @@ int main(void) {
     assert out.returncode == 0, out.stderr
     ver, s, g, t, k = out.stdout.split()
     assert abs(float(s) - 0.986757) < 1e-5 and float(g) == 0.5 and float(t) == 0.5 and float(k) == 30.0 and int(ver) >= 1
+
+
+def test_prebuilt_library_is_trusted_by_content_not_by_mtime(shodh, tmp_path, monkeypatch):
+    """build() reuses a library only when the hash recorded next to it equals the hash of the sources + flags on disk (a snapshot pushed to another box
+    keeps no meaningful modification times, and the .so that rides along must provably belong to the sources next to it)."""
+    from shodh_memory_amd import build as B
+    B.build()
+    assert not B.needs_build() and open(B.STAMP).read().strip() == B.source_hash()
+    real = B._deps
+    extra = tmp_path / "extra.h"
+    extra.write_text("// a changed source\n")
+    monkeypatch.setattr(B, "_deps", lambda: real() + [str(extra)])
+    assert B.needs_build()                                      # same mtimes, different content
+    monkeypatch.setattr(B, "_deps", real)
+    os.utime(B.LIB, (1, 1))                                     # an ancient library with the right content is still fine
+    assert not B.needs_build()
