@@ -1924,16 +1924,45 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
         if (kt + 1 < nkt) stage(cur ^ 1);
         __syncthreads();
     }
-    // ---- epilogue (the stage buffers are free now: red = [2][4 quarters][128 tokens] f32 at 0, wave scratch 4 KiB each behind it)
+    // ---- epilogue (the stage buffers are free now: red = [2][4 quarters][128 tokens] f32 at 0, a 12-KiB area per wave behind it: the residual tile,
+    // then -- its first 4 KiB -- the output scratch)
     float *red = reinterpret_cast<float *>(smem);
-    unsigned char *scr = smem + 4096 + wave * 4096;
+    unsigned char *scr = smem + 4096 + wave * 12288;
     uint32_t klo = 0xFFFFFFFFu, khi = 0u;
     float v[2][3][16];
     float mean[2], inv[2];
+    // The residual of this wave's two 32-token x 96-feature blocks: 2 x 12 coalesced requests (384-byte row segments, three whole cache lines each),
+    // turned into the accumulator layout through the wave's LDS area (16-byte chunks XOR-swizzled by row & 7). Read straight in the accumulator layout
+    // (round 3) an instruction touches 32 rows x 32 bytes and the address path, not HBM, sets the pace: the same change took 12 000 cycles per
+    // sequence off attn_out_ln_quant_seq_kernel.
+    f32x4q rres[2][3][4];
+    {
+        f32x4q ld[2][12];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r0 = m0 + wr * 64 + i * 32;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int p = k * 64 + lane, row = p / 24, cc = p % 24;
+                int rg = r0 + row; if (rg >= M) rg = M - 1;
+                ld[i][k] = *reinterpret_cast<const f32x4q *>(reinterpret_cast<const unsigned char *>(resid + (size_t)rg * KT_NF + wc * 96) + cc * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int p = k * 64 + lane, row = p / 24, cc = p % 24;
+                *reinterpret_cast<f32x4q *>(scr + row * 384 + (((cc & ~7) | ((cc & 7) ^ (row & 7))) << 4)) = ld[i][k];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rres[i][j][g] = *reinterpret_cast<const f32x4q *>(scr + l31 * 384 + ((j * 8 + ((2 * g + hi) ^ (l31 & 7))) << 4));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wr * 64 + i * 32 + l31;
-        const int mc = m < M ? m : M - 1;
         const int rsa = ZWK ? rs_acc[i] + __shfl_xor(rs_acc[i], 32) : 0;
         float s = 0.0f;
 #pragma unroll
@@ -1943,7 +1972,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
                 const int nl = wc * 96 + j * 32 + 8 * g + 4 * hi;
                 const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
                 const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
-                const f32x4q r4 = *reinterpret_cast<const f32x4q *>(resid + (size_t)mc * KT_NF + nl);
+                const f32x4q r4 = rres[i][j][g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = (float)(acc[j][i][4 * g + e] + corr * rz[e] - (ZWK ? z4[e] * rsa : 0)) * (a_scale * ws[e]) + b4[e] + r4[e];
