@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
                     const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = (float)(acc[4 * g + e] + rz[e] - (zwo ? z4[e] * rsa : 0)) * ws[e] + b4[e] + rr[j][g][e];
+                        const float v = (float)(acc[4 * g + e] + rz[e] - (zwo ? __mul24(z4[e], rsa) : 0)) * ws[e] + b4[e] + rr[j][g][e];
                         reg[j][4 * g + e] = v; s1 += v;
                     }
                 }
@@ -1173,6 +1173,9 @@ constexpr int S8_RED = S8_CONST + 6 * S8_NF * 4;          // [2][12 waves][64 to
 constexpr int S8_SCR = S8_RED + 2 * 12 * 64 * 4;          // 12 x 4 KiB wave scratch (LayerNorm epilogue) / 2 x 24 KiB output tiles (quantising epilogue)
 constexpr int S8_RS = S8_SCR + 12 * 4096;               // row sums of the three tiles in flight (weight zero points only): [S8_NBUF][256] int32, 64 used
 constexpr int S8_LDS = S8_RS + S8_NBUF * 1024;
+// The integer terms of the epilogues, (128 - a_zp) * (rowsum_w - K z) and z * rowsum_a, are 24-bit x 24-bit products (|128 - a_zp| <= 128, |z| <= 255,
+// |rowsum_w - K z| <= 1536 * 383 < 2^20, |rowsum_a| <= 1536 * 128 < 2^18): v_mul_i32_i24 (__mul24, full rate) gives them exactly where v_mul_lo_u32 runs at a
+// quarter of the rate -- with weight zero points every output value carries one or two of them.
 enum { SEPI_RESID_LN = 0, SEPI_GELU_RANGE = 1, SEPI_GELU_QUANT = 2 };
 
 struct S8Args {
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                         const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float x = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e];
+                            const float x = (float)(acc[4 * g + e] + rz[e] - (ZW ? __mul24(z4[e], rsa) : 0)) * ws[e] + b4[e];
                             xmax = fmaxf(xmax, x);
                             xl = fmaxf(xl, x <= GELU_ARGMIN ? x : -__builtin_inff());
                             xr = fminf(xr, x >= GELU_ARGMIN ? x : __builtin_inff());
@@ -1349,8 +1352,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {
                         f32x2q x2;
-                        x2.x = (float)(acc[4 * g + 2 * e2] + rz[2 * e2] - (ZW ? z4[2 * e2] * rsa : 0)) * ws[2 * e2] + b4[2 * e2];
-                        x2.y = (float)(acc[4 * g + 2 * e2 + 1] + rz[2 * e2 + 1] - (ZW ? z4[2 * e2 + 1] * rsa : 0)) * ws[2 * e2 + 1] + b4[2 * e2 + 1];
+                        x2.x = (float)(acc[4 * g + 2 * e2] + rz[2 * e2] - (ZW ? __mul24(z4[2 * e2], rsa) : 0)) * ws[2 * e2] + b4[2 * e2];
+                        x2.y = (float)(acc[4 * g + 2 * e2 + 1] + rz[2 * e2 + 1] - (ZW ? __mul24(z4[2 * e2 + 1], rsa) : 0)) * ws[2 * e2 + 1] + b4[2 * e2 + 1];
                         const f32x2q v2 = gelu_i8x2(x2);
                         // q = saturate(rint(v / scale) + zp) with v / scale taken as v * (1 / scale): the two differ in the last place at most, which
                         // moves a byte only when v / scale sits within 1e-7 of a rounding boundary -- the size of gelu_i8's own error
@@ -1379,8 +1382,8 @@ __global__ __launch_bounds__(768, 3) void i8_stream_kernel(const S8Args a) {
                     const f32x4q r4 = *reinterpret_cast<const f32x4q *>(a.resid + (size_t)mc * S8_NF + nl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (PS) v[4 * g + e] = (float)(acc[4 * g + e] + t_corr * rz[e] - (ZW ? z4[e] * rsa : 0)) * (t_scale * ws[e]) + b4[e] + r4[e];
-                        else v[4 * g + e] = (float)(acc[4 * g + e] + rz[e] - (ZW ? z4[e] * rsa : 0)) * ws[e] + b4[e] + r4[e];
+                        if (PS) v[4 * g + e] = (float)(acc[4 * g + e] + __mul24(t_corr, rz[e]) - (ZW ? __mul24(z4[e], rsa) : 0)) * (t_scale * ws[e]) + b4[e] + r4[e];
+                        else v[4 * g + e] = (float)(acc[4 * g + e] + rz[e] - (ZW ? __mul24(z4[e], rsa) : 0)) * ws[e] + b4[e] + r4[e];
                         s += v[4 * g + e];
                     }
                 }
@@ -1607,7 +1610,9 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             const int ql = (i >> tps_log2) & (S8G_PS_TAB - 1);
             const f32x4q ent = ps_tab[ql];
             q.slot = worker + (i >> tps_log2) * n_workers;
-            q.as = ent[0]; q.corr_f = ent[1]; q.corr = (int)ent[1]; q.o_inv = ent[2]; q.o_zpf = ent[3];
+            // (wave-uniform values: through readfirstlane they live in scalar registers -- two tiles' parameters in vector registers made the zero-point variants spill)
+            auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
+            q.as = uni(ent[0]); q.corr_f = uni(ent[1]); q.corr = (int)q.corr_f; q.o_inv = uni(ent[2]); q.o_zpf = uni(ent[3]);
         }
         return q;
     };
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
             for (int e2 = 0; e2 < 2; ++e2) {
                 f32x2q f, w, b;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) { f[e] = (float)(acc[4 * g + 2 * e2 + e] + (PS ? tq.corr * rz[2 * e2 + e] : rz[2 * e2 + e]) - z4[2 * e2 + e] * rsa); w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                for (int e = 0; e < 2; ++e) { f[e] = (float)(acc[4 * g + 2 * e2 + e] + (PS ? __mul24(tq.corr, rz[2 * e2 + e]) : rz[2 * e2 + e]) - __mul24(z4[2 * e2 + e], rsa)); w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
                 if (PS) w = w * tq.as;
                 x2[e2] = f * w + b;
             }
@@ -1975,7 +1980,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
                 const f32x4q r4 = rres[i][j][g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = (float)(acc[j][i][4 * g + e] + corr * rz[e] - (ZWK ? z4[e] * rsa : 0)) * (a_scale * ws[e]) + b4[e] + r4[e];
+                    const float x = (float)(acc[j][i][4 * g + e] + __mul24(corr, rz[e]) - (ZWK ? __mul24(z4[e], rsa) : 0)) * (a_scale * ws[e]) + b4[e] + r4[e];
                     v[i][j][4 * g + e] = x; s += x;
                 }
             }
