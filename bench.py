@@ -524,6 +524,20 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
                  "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / 1e12 / peak, 4), "mfma_peak_used": peak,
                  "flop_per_step": flop}
             done(e, t0)
+            if dname in ("bf16", "int8"):
+                # ONE text per call: what encode() / encode_query() cost a `remember` / `recall` (the reference: one session.run per text, minilm.rs:883-982;
+                # its own figure is 15-30 ms per text on a laptop CPU, BENCHMARKS.md:119-121). Device pointers + stream synchronise per call.
+                t1 = time.perf_counter()
+                one_ids, one_mask = ids[:1].contiguous(), mask[:1].contiguous()
+                one_out = torch.empty((1, args.dim), dtype=torch.float32, device=dev)
+                lat = []
+                for i in range(60):
+                    torch.cuda.synchronize(); a0 = time.perf_counter()
+                    enc.encode_ids_device(one_ids, one_mask, out=one_out)
+                    torch.cuda.synchronize(); lat.append(time.perf_counter() - a0)
+                lat = sorted(lat[10:])
+                done({"name": "encoder_%s_b1_latency" % dname, "workload": "MiniLM-L6 forward of ONE text (%d tokens%s), synchronous call through device pointers" % (int(lens[0]), ", padded to 256 positions" if dname != "bf16" else ""),
+                      "p50_ms": round(lat[len(lat) // 2] * 1e3, 4), "p95_ms": round(lat[int(len(lat) * 0.95)] * 1e3, 4), "calls": len(lat)}, t1)
             if dname not in ("bf16", "int8_pertext") or not want("cfg3_pipeline"):
                 enc.close()
                 continue

@@ -604,51 +604,80 @@ __global__ __launch_bounds__(1024) void embed_ln_seq_kernel(const int32_t *__res
     const float wsc = word_q ? word_scale[0] : 0.0f;
     const int wzp = word_q ? (int)word_scale[1] : 0;              // zero point in signed-storage terms
     uint32_t klo = 0xFFFFFFFFu, khi = 0u;
-    for (int r = wv; r < rows; r += 16) {
-        const int tok = blockIdx.x * rows + r;
-        const int sq = tok_seq[tok], p = tok_pos[tok];
-        int id = ids[(size_t)sq * max_len + p];
-        if (id < 0) id = 0;
-        if (id >= vocab) id = vocab - 1;
-        f32x4e xv[2];
-        float s = 0.0f;
+    // two tokens per wave and iteration (rows is a multiple of 32): the id -> table-row chain of the second token travels under the arithmetic of the first
+    // the wave's token ids in ONE request (lane i: position wv + 16 i of the sequence; a padded sequence is positions 0 .. rows - 1 of one input row), handed
+    // out by readlane: with the id -> table-row chain inside the loop every token cost three dependent round trips (0.77 ms per forward for 1.6 GB of rows)
+    const int sq0 = tok_seq[blockIdx.x * rows];
+    int my_id = 0;
+    if (wv + 16 * lane < rows) {
+        my_id = ids[(size_t)sq0 * max_len + wv + 16 * lane];       // (position p of a padded sequence is its p-th row: tok_pos[first + p] == p)
+        if (my_id < 0) my_id = 0;
+        if (my_id >= vocab) my_id = vocab - 1;
+    }
+    for (int r = wv; r < rows; r += 32) {
+        int tokv[2], pv[2], idv[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int g = lane + 64 * j;
-            if (g < h4) {
-                f32x4e w4;
-                if (word_q) {                                     // Gather + DequantizeLinear: (q - zp) * scale
-                    const uint32_t pk = *reinterpret_cast<const uint32_t *>(word_q + (size_t)id * H + g * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w4[e] = (float)((int)(int8_t)(pk >> (8 * e)) - wzp) * wsc;
-                } else w4 = *reinterpret_cast<const f32x4e *>(word + (size_t)id * H + g * 4);
-                const f32x4e p4 = *reinterpret_cast<const f32x4e *>(pos + (size_t)p * H + g * 4), t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { xv[j][e] = w4[e] + p4[e] + t4[e]; s += xv[j][e]; }
-            }
+        for (int t = 0; t < 2; ++t) {
+            tokv[t] = blockIdx.x * rows + r + 16 * t;
+            pv[t] = r + 16 * t;
+            idv[t] = __shfl(my_id, (r + 16 * t - wv) >> 4);
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / (float)H;
-        float v = 0.0f;
+        f32x4e xv[2][2];
+        uint32_t wq4[2][2];
+        f32x4e wf4[2][2], p4v[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; v += d * d; }
-        }
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        const float inv = 1.0f / sqrtf(v / (float)H + eps);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int g = lane + 64 * j;
-            if (g < h4) {
-                const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
-                f32x4e o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o4[e] = (xv[j][e] - mean) * inv * g4[e] + b4[e];
-                    const uint32_t kk = order_key(o4[e]); klo = min(klo, kk); khi = max(khi, kk);
+            for (int j = 0; j < 2; ++j) {
+                const int g = lane + 64 * j;
+                if (g < h4) {
+                    if (word_q) wq4[t][j] = *reinterpret_cast<const uint32_t *>(word_q + (size_t)idv[t] * H + g * 4);
+                    else wf4[t][j] = *reinterpret_cast<const f32x4e *>(word + (size_t)idv[t] * H + g * 4);
+                    p4v[t][j] = *reinterpret_cast<const f32x4e *>(pos + (size_t)pv[t] * H + g * 4);
                 }
-                *reinterpret_cast<f32x4e *>(out + (size_t)tok * H + g * 4) = o4;
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tok = tokv[t];
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = lane + 64 * j;
+                if (g < h4) {
+                    f32x4e w4;
+                    if (word_q) {                                     // Gather + DequantizeLinear: (q - zp) * scale
+                        const uint32_t pk = wq4[t][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w4[e] = (float)((int)(int8_t)(pk >> (8 * e)) - wzp) * wsc;
+                    } else w4 = wf4[t][j];
+                    const f32x4e p4 = p4v[t][j], t4 = *reinterpret_cast<const f32x4e *>(type0 + g * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xv[t][j][e] = w4[e] + p4[e] + t4[e]; s += xv[t][j][e]; }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)H;
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (lane + 64 * j < h4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = xv[t][j][e] - mean; v += d * d; }
+            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            const float inv = 1.0f / sqrtf(v / (float)H + eps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = lane + 64 * j;
+                if (g < h4) {
+                    const f32x4e g4 = *reinterpret_cast<const f32x4e *>(gamma + g * 4), b4 = *reinterpret_cast<const f32x4e *>(beta + g * 4);
+                    f32x4e o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o4[e] = (xv[t][j][e] - mean) * inv * g4[e] + b4[e];
+                        const uint32_t kk = order_key(o4[e]); klo = min(klo, kk); khi = max(khi, kk);
+                    }
+                    *reinterpret_cast<f32x4e *>(out + (size_t)tok * H + g * 4) = o4;
+                }
             }
         }
     }

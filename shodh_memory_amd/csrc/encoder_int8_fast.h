@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void attn_out_ln_quant_seq_kernel(const Att
                     const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = (float)(acc[4 * g + e] + rz[e] - (zwo ? __mul24(z4[e], rsa) : 0)) * ws[e] + b4[e] + rr[j][g][e];
+                        const float v = (float)(acc[4 * g + e] + rz[e] - (zwo ? z4[e] * rsa : 0)) * ws[e] + b4[e] + rr[j][g][e];
                         reg[j][4 * g + e] = v; s1 += v;
                     }
                 }

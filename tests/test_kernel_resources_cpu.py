@@ -1,0 +1,64 @@
+"""No register spills in the software-pipelined kernels (CPU check: hipcc cross-compiles gfx950 and reports every kernel's resources).
+
+These kernels track LDS-DMA completion by hand with counted `s_waitcnt vmcnt(N)`; a spill adds scratch loads and stores to the same counter and
+every reload becomes a full wait in front of the data path (round 4: one more integer multiply in an epilogue pushed `attn_out_ln_quant_seq_kernel`
+from 255 registers to 31 spilled ones and from 1.19 to 1.36 ms per layer without failing a single test). The zero-point variants of the per-text
+FFN-up kernels are known to spill (<= 32 registers) and are listed with that bound."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "shodh_memory_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def resources(src):
+    """{demangled-ish kernel name: (vgprs, scratch_bytes, vgpr_spills)} from -Rpass-analysis=kernel-resource-usage"""
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage",
+                          "--cuda-device-only", "-c", os.path.join(CSRC, src), "-o", "/dev/null"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1); res[cur] = {}
+            continue
+        for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("spill", r"VGPRs Spill: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur:
+                res[cur][key] = int(m.group(1))
+    return res
+
+
+def find(res, *parts):
+    hits = [k for k in res if all(p in k for p in parts)]
+    assert hits, parts
+    return hits
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_encoder_kernels_do_not_spill():
+    res = resources("encoder.hip")
+    clean = [("attn_out_ln_quant_seq_kernelILi2",), ("attn_out_ln_quant_seq_kernelILi1",), ("qkv_attn_seq_kernel",), ("i8_ktile_ln_kernel",),
+             ("i8_stream_gelu_kernelILb0ELb0ELb0",), ("i8_stream_gelu_kernelILb1ELb0ELb0",), ("i8_stream_gelu_kernelILb0ELb0ELb1",), ("i8_stream_gelu_kernelILb1ELb0ELb1",),
+             ("gemm_k384_stream_kernel",)]
+    for parts in clean:
+        for k in find(res, *parts):
+            assert res[k].get("scratch", 0) == 0 and res[k].get("spill", 0) == 0, (k, res[k])
+    # known and bounded: the zero-point variants of the FFN-up passes, the batch scope's attention-output kernel (4-15 registers), and the bf16 fused
+    # FFN, which parks y - mean in scratch in its EPILOGUE on purpose
+    for parts, bound in [(("i8_stream_gelu_kernelILb0ELb1ELb1",), 32), (("i8_stream_gelu_kernelILb1ELb1ELb1",), 32), (("i8_stream_gelu_kernelILb1ELb1ELb0",), 32),
+                         (("i8_stream_kernelILi0",), 16), (("ffn_fused_kernelILi0",), 48)]:
+        for k in find(res, *parts):
+            assert res[k].get("spill", 0) <= bound, (k, res[k])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_scan_kernels_do_not_spill():
+    res = resources("scan_mfma.hip")
+    for parts in [("mfma_scan_kernelILi1ELi24",), ("mfma_scan_kernelILi0ELi24",), ("solo_scan_kernel",), ("final_stage_kernel",)]:
+        for k in find(res, *parts):
+            assert res[k].get("spill", 0) == 0, (k, res[k])        # (the final stage keeps a small indexed array in scratch: not a spill)
