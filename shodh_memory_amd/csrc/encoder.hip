@@ -930,6 +930,7 @@ struct shodh_embedder {
     int8_t *HQ = nullptr;                // quantised GELU output [tok_cap][I] (fast INT8 path: the f32 intermediate never exists)
     int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
     bool need_rs = false;
+    int ffn_fused_min_tokens = 2048;     // bf16: forwards with fewer tokens take the three-kernel feed-forward (SHODH_FFN_FUSED_MIN_TOKENS at creation: 0 = always fused)
     uint32_t int8_stages = 0xEF;         // bit 7 (per-text scope only): attention output + LayerNorm + both quantising passes inside the per-sequence kernel (qkv_attn_seq_kernel<., TAIL>); bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
     uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][slots][2], then the GELU trackers [layers][slots][4]; slots = 1 (batch scope) or the sequences (per-text scope)
@@ -1070,7 +1071,11 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
         const __bf16 *wp = e->wp16 + (size_t)li * (4 * H + I) * H;      // fragment-major [qkv | o | ffn-up]
         const bool stream_gemm = (H == GS_DIM) && !(getenv("SHODH_ENC_TILED") && atoi(getenv("SHODH_ENC_TILED")));
         static const bool unfused = getenv("SHODH_ENC_UNFUSED") && atoi(getenv("SHODH_ENC_UNFUSED"));     // speed only: the round-1 three-kernel feed-forward
-        const bool ffn_fused = !std::is_same<T, float>::value && stream_gemm && I == FF_I && !unfused;
+        // The fused feed-forward streams ALL of W1 and W2 (2.25 MiB) through every workgroup once per 128-token tile: right when there are tiles for every CU,
+        // wrong for a handful of texts -- one text is one tile on ONE CU, 73 us per layer of a 0.62 ms forward (round 4, tools/enc_latency_probe.py).
+        // Below FFN_FUSED_MIN_TOKENS the three-kernel form spreads the weights over the CUs instead: 0.41 ms per text. (Same function, different
+        // summation order and GELU approximation: a text's bf16 embedding depends on which side of the threshold its call falls, at the 1e-3 level of bf16.)
+        const bool ffn_fused = !std::is_same<T, float>::value && stream_gemm && I == FF_I && !unfused && ntok >= e->ffn_fused_min_tokens;
         (void)wp; (void)stream_gemm; (void)ffn_fused;
         if constexpr (std::is_same<T, float>::value) {
             SHODH_TRY(gemm_f32<EPI_BIAS>(X, e->wqkv32 + (size_t)li * 3 * H * H, bqkv, nullptr, QKV, ntok, 3 * H, H, st));
@@ -1570,6 +1575,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     if (cfg->weights_path) e->weights_path = cfg->weights_path;
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
     e->quant_scope = cfg->quant_scope;
+    if (const char *fv = getenv("SHODH_FFN_FUSED_MIN_TOKENS")) e->ffn_fused_min_tokens = atoi(fv);      // speed only: which feed-forward form small forwards take
     if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0xFFu;       // speed only: which stages run the fused kernels
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }

@@ -48,8 +48,12 @@ def cos(a, b):
     return (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-30)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
-def test_golden_vectors(S, dtype):
+@pytest.mark.parametrize("dtype,ffn", [(0, None), (1, None), (1, "0"), (1, "1000000")])
+def test_golden_vectors(S, dtype, ffn, monkeypatch):
+    # ffn: bf16 forwards below SHODH_FFN_FUSED_MIN_TOKENS (default 2048) take the three-kernel feed-forward, the others the fused kernel (round 4:
+    # one text is one tile on one CU for the fused kernel): "0" = always fused, "1000000" = never -- both forms against the same fixture
+    if ffn is not None:
+        monkeypatch.setenv("SHODH_FFN_FUSED_MIN_TOKENS", ffn)
     g = np.load(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz"))
     e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
     assert e.dimension() == 384
@@ -65,8 +69,10 @@ def test_golden_vectors(S, dtype):
         assert np.allclose(np.linalg.norm(emb[lens > 0], axis=1), 1, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
-def test_random_batches_vs_torch_reference(S, ref_sd, dtype):
+@pytest.mark.parametrize("dtype,ffn", [(0, None), (1, None), (1, "0"), (1, "1000000")])
+def test_random_batches_vs_torch_reference(S, ref_sd, dtype, ffn, monkeypatch):
+    if ffn is not None:
+        monkeypatch.setenv("SHODH_FFN_FUSED_MIN_TOKENS", ffn)
     e = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dtype)
     for b, seed in ((1, 1), (7, 2), (64, 3), (130, 4)):
         ids, mask = bert_ref.synth_batch(b, 256, seed=seed)
