@@ -59,7 +59,8 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
 }
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_RESID_B16 = 3 };   // _B16: bf16 out = bf16(acc + bias + residual), may be written over the residual
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_RESID_B16 = 3,   // _B16: bf16 out = bf16(acc + bias + residual), may be written over the residual
+       EPI_PARTIAL_F32 = 4 };   // split-K: blockIdx.z takes K / gridDim.z of the sum and writes its raw f32 accumulators to out_f + z * M * N (layernorm_kernel adds the parts, bias and residual in a fixed order)
 
 // ---- bf16 MFMA GEMM: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue) ------------------------------------------
 // A, W bf16 row-major; K % 64 == 0, N % 128 == 0. 128 x 128 x 64 tiles, 4 waves x (2 x 2) 32x32 blocks,
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict
     const int hi = lane >> 5, l31 = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int klen = K / (int)gridDim.z, k0 = (int)blockIdx.z * klen;      // (gridDim.z > 1 only with EPI_PARTIAL_F32)
     // staging: 1024 chunks (128 rows x 8) per operand, 4 per thread
     u32x4 pa[4], pb[4];
     const __bf16 *ga[4], *gb[4];
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict
     for (int i = 0; i < 4; ++i) {
         const int S = i * 256 + tid, row = S >> 3, c = S & 7;
         int ra = m0 + row; if (ra >= M) ra = M - 1;
-        ga[i] = A + (size_t)ra * K + c * 8;
-        gb[i] = W + (size_t)(n0 + row) * K + c * 8;
+        ga[i] = A + (size_t)ra * K + k0 + c * 8;
+        gb[i] = W + (size_t)(n0 + row) * K + k0 + c * 8;
         loff[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
     auto gload = [&](int kt) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict
         fo_a[i] = ra * 128; sw_a[i] = (ra >> 1) & 7;
         fo_b[i] = TB + rb * 128; sw_b[i] = (rb >> 1) & 7;
     }
-    const int nkt = K / 64;
+    const int nkt = klen / 64;
     gload(0);
     stage(0);
     __syncthreads();
@@ -151,6 +153,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16 *__restrict
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nb = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
+                if (EPI == EPI_PARTIAL_F32) {
+                    f32x4e pv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = acc[j][i][4 * g + e];
+                    *reinterpret_cast<f32x4e *>(out_f + ((size_t)blockIdx.z * M + m) * N + nb) = pv;
+                    continue;
+                }
                 const f32x4e bv = *reinterpret_cast<const f32x4e *>(bias + nb);
                 f32x4e v;
 #pragma unroll
@@ -443,10 +452,12 @@ __device__ __forceinline__ void minmax_commit(uint32_t lo, uint32_t hi, uint32_t
     }
 }
 
+// n_part > 0 (the split-K feed-forward of small forwards): `in` holds n_part partial sums [n_part][ntok][H]; the row is ((p0 + p1) + ... ) + bias + residual
 template <class T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, T *__restrict__ out, int ntok, int H, float eps,
-                                                        uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */) {
+                                                        uint32_t *__restrict__ mm = nullptr /* INT8 path: min / max keys of the output */,
+                                                        int n_part = 0, const float *__restrict__ pbias = nullptr, const T *presid = nullptr) {
     const int l = threadIdx.x & 31;
     const int tok_raw = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const bool valid = tok_raw < ntok;       // a half-wave past the end redoes the last token and stores nothing (the wave stays together for the
@@ -458,7 +469,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     f32x4e xv[4];
     float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < ng) { xv[j] = x4[j * 32 + l]; s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]); }
+    for (int j = 0; j < 4; ++j) if (j < ng) {
+        xv[j] = x4[j * 32 + l];
+        if (n_part) {
+            for (int pp = 1; pp < n_part; ++pp) { const f32x4e q = *(reinterpret_cast<const f32x4e *>(in + ((size_t)pp * ntok + tok) * H) + j * 32 + l); xv[j] = xv[j] + q; }
+            const f32x4e b = *(reinterpret_cast<const f32x4e *>(pbias) + j * 32 + l);
+            xv[j] = xv[j] + b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[j][e] += to_f32(presid[(size_t)tok * H + (size_t)(j * 32 + l) * 4 + e]);
+        }
+        s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    }
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)H;
     float v = 0.0f;
@@ -1150,6 +1171,17 @@ static int forward(shodh_embedder *e, int ntok, int nseq, int max_seq, float *d_
             }
             if (stream_gemm) SHODH_TRY(gemm_k384_stream<EPI_BIAS_GELU>(X, wp + (size_t)4 * H * H, w + l.ib, nullptr, FF, nullptr, ntok, I, e->cus, st));
             else SHODH_TRY(gemm_bf16<EPI_BIAS_GELU>(X, e->w16 + l.iw, w + l.ib, nullptr, FF, nullptr, ntok, I, H, st));
+            // A handful of texts: the K = 1536 down projection is three 128 x 128 output tiles that each walk all of K (20 us per layer of a 0.40 ms
+            // single-text forward). Split over K into four parts (twelve workgroups), the parts added -- in a fixed order, with bias and residual -- by the
+            // LayerNorm kernel that follows anyway.
+            constexpr int FFN_KSPLIT = 4;
+            if (ntok <= 256 && (size_t)FFN_KSPLIT * ntok <= e->tok_cap && I % (64 * FFN_KSPLIT) == 0) {
+                dim3 grid(H / 128, (ntok + 127) / 128, FFN_KSPLIT);
+                hipLaunchKernelGGL((gemm_bf16_kernel<EPI_PARTIAL_F32>), grid, dim3(256), 0, st, (const __bf16 *)FF, e->w16 + l.dw, (const float *)nullptr, (const __bf16 *)nullptr, (__bf16 *)nullptr, e->PRE, ntok, H, I);
+                hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps, (uint32_t *)nullptr, FFN_KSPLIT, w + l.db, (const T *)X);
+                SHODH_HIP_TRY(hipGetLastError());
+                continue;
+            }
             SHODH_TRY(gemm_bf16<EPI_BIAS_RESID_F32>(FF, e->w16 + l.dw, w + l.db, X, nullptr, e->PRE, ntok, H, I, st));
         }
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ln_blocks), dim3(256), 0, st, e->PRE, w + l.ln2g, w + l.ln2b, X, ntok, H, eps);
