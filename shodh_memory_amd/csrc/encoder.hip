@@ -1335,16 +1335,20 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
         uint32_t *mmC = mm_of(4 * li + 1), *mmX1 = mm_of(4 * li + 2), *mmF = mm_of(4 * li + 3), *mmXn = mm_of(4 * li + 4);
         const QWeight &wq = e->q_qkv[li], &wo = e->q_o[li], &wu = e->q_up[li], &wd = e->q_dn[li];
         // ---- A: q | k | v projections + attention
+        // a few texts: the heads of a sequence go to several workgroups (same arithmetic per head: the same bits), so that one query's layer is not one
+        // workgroup walking twelve heads (50 us); with a sequence per CU or more there is nothing to gain
+        int head_splits = 1;
+        for (int sp : {12, 6, 4, 3, 2}) if (heads % sp == 0 && (long)nseq * sp <= (long)e->cus) { head_splits = sp; break; }
         const bool fT = ps_rows && (stages & 128u);       // per-text scope: B and both quantising passes as one kernel per sequence (attn_out_ln_quant_seq_kernel)
         if (fS) {
             if (wq.zw) {
                 SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<true>, QS_LDS));
-                hipLaunchKernelGGL((qkv_attn_seq_kernel<true>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
-                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride);
+                hipLaunchKernelGGL((qkv_attn_seq_kernel<true>), dim3(nseq * head_splits), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride, head_splits);
             } else {
                 SHODH_TRY(ensure_dynamic_lds((const void *)qkv_attn_seq_kernel<false>, QS_LDS));
-                hipLaunchKernelGGL((qkv_attn_seq_kernel<false>), dim3(nseq), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
-                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride);
+                hipLaunchKernelGGL((qkv_attn_seq_kernel<false>), dim3(nseq * head_splits), dim3(512), QS_LDS, st, (const float *)X, (const uint32_t *)mmX, (const int8_t *)wq.qp, (const uint32_t *)(e->qkv_hc + (size_t)li * heads * 512),
+                                   (const int32_t *)e->d_cu, klen, CTX, mmC, heads, mm_stride, head_splits);
             }
         } else if (fA) {
             SHODH_TRY(quantize_act(e, X, ntok, H, e->XQ, mmX, e->rsX, st));          // one quantisation feeds q, k and v (same tensor)

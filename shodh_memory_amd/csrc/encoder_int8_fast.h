@@ -521,11 +521,13 @@ template <bool ZW>
 __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__restrict__ X /* f32 layer input [M][384] */, const uint32_t *__restrict__ mmA /* its range keys */,
                                                               const int8_t *__restrict__ Wp /* fused q|k|v weight, fragment-major */, const uint32_t *__restrict__ hconsts /* pack_head_consts_kernel: [heads][4][128] */,
                                                               const int32_t *__restrict__ cu, const int32_t *__restrict__ klen /* or null */, float *__restrict__ ctx,
-                                                              uint32_t *__restrict__ mm_out, int heads, int mm_stride /* 0: one range for the batch tensor; 2: one per sequence */) {
+                                                              uint32_t *__restrict__ mm_out, int heads_all, int mm_stride /* 0: one range for the batch tensor; 2: one per sequence */,
+                                                              int head_splits /* workgroups per sequence: each takes heads_all / head_splits heads (a few texts: one sequence's twelve heads one after the other are 50 us per layer) */) {
     constexpr int H = 384, KS = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const int seq = blockIdx.x;
+    const int seq = blockIdx.x / head_splits;
+    const int heads = heads_all / head_splits, h0 = (int)(blockIdx.x % head_splits) * heads;      // this workgroup's heads: h0 .. h0 + heads - 1 (local index h below)
     const int t0 = cu[seq], P = cu[seq + 1] - t0;
     const int S = klen ? klen[seq] : P;
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -548,10 +550,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
             const int i = i0 * 8 + wave;
             if (i < 36) {
                 const int which = i / 12, ks = i % 12;
-                const unsigned char *src = uniform_ptr(wg + ((size_t)(which * 12 + h) * KS + ks) * 1024);
+                const unsigned char *src = uniform_ptr(wg + ((size_t)(which * 12 + h0 + h) * KS + ks) * 1024);
                 glds16(src, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (uint32_t)buf * QS_WB + (uint32_t)i * 1024u)));
             } else if (i < 38) {
-                const unsigned char *src = uniform_ptr(cg + (size_t)h * QS_CB + (size_t)(i - 36) * 1024);
+                const unsigned char *src = uniform_ptr(cg + (size_t)(h0 + h) * QS_CB + (size_t)(i - 36) * 1024);
                 glds16(src, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + (uint32_t)QS_OFF_C + (uint32_t)buf * QS_CB + (uint32_t)(i - 36) * 1024u)));
             }
         }
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_seq_kernel(const float *__res
                     f32x4q ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = o[4 * g + e];
-                    *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + q) * H + h * 32 + 8 * g + 4 * hi) = ov;
+                    *reinterpret_cast<f32x4q *>(ctx + (size_t)(t0 + q) * H + (h0 + h) * 32 + 8 * g + 4 * hi) = ov;
                 }
             }
         }
