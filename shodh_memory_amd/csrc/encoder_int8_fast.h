@@ -1845,6 +1845,11 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int m0 = blockIdx.x * KT_TM;
+#ifdef SHODH_KT_ABL    // diagnostic builds only (-DSHODH_KT_ABL=mask): 1 no W loads, 2 no A loads, 4 no residual loads, 8 no stores, 16 no MFMAs, 32 no LDS staging (results invalid)
+    constexpr int abl = SHODH_KT_ABL;
+#else
+    constexpr int abl = 0;
+#endif
     if (mm_rows) { const int slot = m0 / mm_rows; mmA += 2 * slot; if (mm_out) mm_out += 2 * slot; }
     float *c_ws = reinterpret_cast<float *>(smem + KT_CONST);
     int32_t *c_rz = reinterpret_cast<int32_t *>(c_ws + KT_NF);
@@ -1874,9 +1879,9 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
     }
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pa[i] = *reinterpret_cast<const u32x4qq *>(ga[i] + kt * KT_KB);
+        for (int i = 0; i < 2; ++i) if (!(abl & 2) || kt == 0) pa[i] = *reinterpret_cast<const u32x4qq *>(ga[i] + kt * KT_KB);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pw[i] = *reinterpret_cast<const u32x4qq *>(gw[i] + kt * KT_KB);
+        for (int i = 0; i < 6; ++i) if (!(abl & 1) || kt == 0) pw[i] = *reinterpret_cast<const u32x4qq *>(gw[i] + kt * KT_KB);
     };
     auto stage = [&](int buf) {
         unsigned char *base = smem + buf * KT_STAGE;
@@ -1926,9 +1931,9 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[j], fa[i], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) if (!(abl & 16)) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        if (kt + 1 < nkt) stage(cur ^ 1);
+        if (kt + 1 < nkt && !(abl & 32)) stage(cur ^ 1);
         __syncthreads();
     }
     // ---- epilogue (the stage buffers are free now: red = [2][4 quarters][128 tokens] f32 at 0, a 12-KiB area per wave behind it: the residual tile,
@@ -1952,7 +1957,8 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
             for (int k = 0; k < 12; ++k) {
                 const int p = k * 64 + lane, row = p / 24, cc = p % 24;
                 int rg = r0 + row; if (rg >= M) rg = M - 1;
-                ld[i][k] = *reinterpret_cast<const f32x4q *>(reinterpret_cast<const unsigned char *>(resid + (size_t)rg * KT_NF + wc * 96) + cc * 16);
+                if (!(abl & 4)) ld[i][k] = *reinterpret_cast<const f32x4q *>(reinterpret_cast<const unsigned char *>(resid + (size_t)rg * KT_NF + wc * 96) + cc * 16);
+                else ld[i][k] = f32x4q{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -2031,7 +2037,7 @@ __global__ __launch_bounds__(512, 2) void i8_ktile_ln_kernel(const int8_t *__res
                 const int tl = h * 8 + (lane >> 3), ch = lane & 7;
                 const f32x4q v4 = *reinterpret_cast<const f32x4q *>(scr + tl * 128 + ((ch ^ (tl & 7)) << 4));
                 const int mt = m0 + wr * 64 + i * 32 + tl;
-                if (mt < M) *reinterpret_cast<f32x4q *>(out_f + (size_t)mt * KT_NF + wc * 96 + j * 32 + ch * 4) = v4;
+                if (mt < M && !(abl & 8)) *reinterpret_cast<f32x4q *>(out_f + (size_t)mt * KT_NF + wc * 96 + j * 32 + ch * 4) = v4;
             }
         }
     }
