@@ -304,22 +304,30 @@ __global__ __launch_bounds__(256) void adc_merge_kernel(AdcMergeArgs a) {
 // A batch of queries probes the same lists over and over (configs[3]: 1024 queries x 32 probes over 4096 lists = 8 queries per list),
 // and the query-major kernel above is bound by its LDS gathers, not by HBM: a 64-lane ds_read_b32 with random 8-bit codes takes ~6.8
 // cycles (bank conflicts; tools/ubench/lds_gather.hip: 5.8 T lookups/s over the chip), two thirds of the kernel's cycles. Here:
-//   1. every query's NEAREST list is scanned by the query-major kernel (max_probes = 1): its k best keys, and with them a bound B(q) on the
-//      query's k-th best key -- the nearest list holds most of the final answer, so the bound is close to the final one;
-//   2. the other (query, probe) pairs are grouped by LIST. A workgroup takes one list (in chunks of <= LM_NT * LM_U postings) and a block of
-//      the queries that probe it: the chunk's codes and ids are read ONCE into registers and scored against every query of the block (HBM:
-//      the probed postings once per block instead of once per pair). The distance tables (T[m][c], 48 KiB per query, built once per query
-//      by adc_table_kernel) of TWO queries are interleaved entry by entry in LDS, so one ds_read_b64 gather serves two lookups at the
+//   1. a bound B(q) on every query's k-th best key: the k-th best key among the first <= 3072 postings of its nearest lists (adc_bound_kernel:
+//      one query per workgroup against its own table). The nearest list holds most of the final answer, so the bound is close to the final one;
+//   2. ALL (query, probe) pairs are grouped by LIST. A workgroup takes a chunk of <= LM_NT * LM_U postings of one list and a block of the
+//      queries that probe it: the chunk's codes and ids are read ONCE into registers and scored against every query of the block (HBM: the
+//      probed postings once per block instead of once per pair). The distance tables (T[m][c], 48 KiB per query, built once per query by
+//      adc_table_kernel) of TWO queries are interleaved entry by entry in LDS, so one ds_read_b64 gather serves two lookups at the
 //      instruction rate of one (the same benchmark: 11.3 T lookups/s); they arrive in 24-sub-quantiser tiles (48 KiB) staged through
-//      registers one tile ahead. Every distance is still its own sum in m order from 0 (pq.rs:358-368): the same bits. A key under B(q)
-//      is appended to the query's candidate list in HBM (a few per query); nothing is selected inside this kernel;
-//   3. a query whose candidate list overflowed (a nearest list with fewer than k postings gives no bound) is recomputed from scratch by the
-//      query-major kernel (SHODH_ADC_LM_CAP forces that in the tests); lm_merge_kernel picks the k best of {nearest list's k} + candidates.
-// (First form of this path, measured and dropped: the k best of every (query, list) pair selected inside the list kernel -- group minima,
-// bound, gather, rank, two more barriers per pair: the selection cost more than the scoring, 1.80 ms against the query-major kernel's 1.31.)
+//      registers one tile ahead. Every distance is still its own sum in m order from 0 (pq.rs:358-368): the same bits. A key at or under
+//      B(q) is appended to the query's candidate list in HBM (a hundred or two per query); nothing is selected inside this kernel;
+//   3. a query whose candidate list overflowed (an outlier whose nearest lists say little about the others) is recomputed from scratch by the
+//      query-major kernel (SHODH_ADC_LM_CAP forces that in the tests); lm_merge_kernel picks the k best of the candidates.
+// Measured and dropped on the way: the k best of every (query, list) pair selected inside the list kernel (group minima, bound, gather, rank, two
+// more barriers per pair: the selection cost more than the scoring, 1.80 ms against the query-major kernel's 1.31); the nearest lists scanned WHOLE
+// by the bound kernel and left out of the list-major pass (the nearest list is the long one -- 4 500 postings on average where the mean list has
+// 2 441 -- and one query per workgroup gathers at half the rate: 110 us where a 3 072-posting prefix takes 30).
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 typedef float f32x2q __attribute__((ext_vector_type(2)));
-constexpr int LM_NT = 1024, LM_U = 3, LM_QB = 4, LM_MT = 24;
+#ifndef SHODH_LM_U      // (diagnostic builds time other shapes)
+#define SHODH_LM_U 3
+#endif
+#ifndef SHODH_LM_QB
+#define SHODH_LM_QB 4
+#endif
+constexpr int LM_NT = 1024, LM_U = SHODH_LM_U, LM_QB = SHODH_LM_QB, LM_MT = 24;
 constexpr int LM_TILE = LM_MT * 256 * 8;                       // 48 KiB: 24 sub-quantisers x 256 entries x 2 queries
 constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM)
 constexpr int LM_LDS = 2 * LM_TILE + 2 * LM_QB * 8 + 2 * LM_QB * 4;
@@ -335,18 +343,9 @@ __global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict
     tables[(size_t)blockIdx.x * 12288 + e] = sum;
 }
 
-// pairs (query, probe rank >= r0) grouped by list: count, scan (+ work items), fill
-__global__ void lm_count_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, const uint32_t *__restrict__ r0, uint32_t P, uint32_t *__restrict__ cnt) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * nprobe) return;
-    const uint32_t q = i / nprobe, r = i - q * nprobe;
-    if (r < r0[q] || r >= probe_cnt[q]) return;
-    const uint32_t p = probes[i];
-    if (p < P) atomicAdd(&cnt[p], 1u);
-}
-__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off) {
+// pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (+ work items), fill
+__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off, uint32_t *__restrict__ item_list) {
     // exclusive scans over the lists: pairs, and work items (a block of <= 2 * LM_QB queries of one list x a chunk of <= LM_NT * LM_U of its postings)
-    __shared__ uint32_t part[2][1024];
     const uint32_t tid = threadIdx.x, per = (P + 1023) / 1024, b0 = tid * per < P ? tid * per : P, b1 = (b0 + per < P) ? b0 + per : P;
     auto items_of = [&](uint32_t p) -> uint32_t {
         const uint64_t len = list_off[p + 1] - list_off[p];
@@ -354,89 +353,99 @@ __global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restric
     };
     uint32_t a = 0, it = 0;
     for (uint32_t p = b0; p < b1; ++p) { a += cnt[p]; it += items_of(p); }
-    part[0][tid] = a; part[1][tid] = it;
+    typedef hipcub::BlockScan<uint32_t, 1024> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    uint32_t ta, ti;
+    Scan(tmp).ExclusiveSum(a, a, ta);
     __syncthreads();
-    if (tid == 0) {
-        uint32_t x = 0, y = 0;
-        for (int i = 0; i < 1024; ++i) { const uint32_t u = part[0][i], v = part[1][i]; part[0][i] = x; part[1][i] = y; x += u; y += v; }
-        pair_off[P] = x; item_off[P] = y;
+    Scan(tmp).ExclusiveSum(it, it, ti);
+    if (tid == 0) { pair_off[P] = ta; item_off[P] = ti; }
+    for (uint32_t p = b0; p < b1; ++p) {
+        pair_off[p] = a; cursor[p] = a; item_off[p] = it;
+        const uint32_t ni = items_of(p);
+        for (uint32_t i = 0; i < ni; ++i) item_list[it + i] = p;       // (a work item finds its list with one load instead of a 12-step search through item_off: 6 000 cycles per item)
+        a += cnt[p]; it += ni;
     }
-    __syncthreads();
-    a = part[0][tid]; it = part[1][tid];
-    for (uint32_t p = b0; p < b1; ++p) { pair_off[p] = a; cursor[p] = a; item_off[p] = it; a += cnt[p]; it += items_of(p); }
 }
-__global__ void lm_items_kernel(const uint32_t *__restrict__ item_off, uint32_t P, uint32_t *__restrict__ item_list) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;      // (a work item finds its list with one load instead of a 12-step search through item_off: 6 000 cycles per item)
-    if (p >= P) return;
-    for (uint32_t i = item_off[p]; i < item_off[p + 1]; ++i) item_list[i] = p;
-}
-__global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, const uint32_t *__restrict__ r0, uint32_t P, uint32_t *__restrict__ cursor, uint32_t *__restrict__ pairs) {
+__global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, uint32_t P, uint32_t *__restrict__ cursor, uint32_t *__restrict__ pairs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * nprobe) return;
     const uint32_t q = i / nprobe, r = i - q * nprobe;
-    if (r < r0[q] || r >= probe_cnt[q]) return;
+    if (r >= probe_cnt[q]) return;
     const uint32_t p = probes[i];
     if (p < P) pairs[atomicAdd(&cursor[p], 1u)] = q;      // the order inside a list is arbitrary: every query's result is computed on its own
 }
 
-// The bound: every query's nearest lists -- as many as it takes to see near_min postings, at least one, whole lists -- scored against its own table
-// (plain ds_read_b32 gathers: one query per workgroup, a few per cent of the postings); their k best keys go to best[q][k] (ascending, KEY_NONE-padded)
-// and the number of lists taken to r0[q]: the list-major pass covers probe ranks r0[q] and up. The fewer postings stand behind the bound, the more keys
-// of the other lists pass it (about k * probed postings / postings behind the bound on featureless data).
-// A segment of LM_NEAR_NT * LM_NEAR_U postings is scored with its keys in registers (all code loads of a lane in flight at once); selection is
-// block_select_topk's scheme on registers: the k-th smallest of the lanes' minima bounds the segment's k-th best key, the keys at or under it (and the
-// best of the earlier segments) go through the TopKBuf.
-constexpr int LM_NEAR_NT = 512, LM_NEAR_U = 6, LM_NEAR_MAXL = 64;      // (77 KiB of LDS at k = 10: two workgroups per CU)
+#ifdef SHODH_LMPROF      // diagnostic build: phase timers of a few workgroups
+#define LPROF_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64(); const long long t00_ = tq_;
+#define LPROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
+#define NPROF_END if (tid == 0 && (blockIdx.x % 257) == 3) printf("boundprof q %d lists %u postings %u total %lld : table+walk %lld | codes+score %lld | bound %lld | push %lld | sort %lld | tail %lld\n", (int)blockIdx.x, r0, total, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
+#define LPROF_END if (lane == 0 && (wave == 0 || wave == 9) && (blockIdx.x % 997) == 5) printf("lmprof blk %d wave %d queries %u postings %u total %lld : setup+codes %lld | tile0 %lld | score %lld | store %lld | bar %lld | push %lld\n", (int)blockIdx.x, wave, pqn, (unsigned)len, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
+#else
+#define LPROF_DECL
+#define LPROF_T(i)
+#define LPROF_END
+#define NPROF_END
+#endif
+// The bound: the first <= max_postings (<= LM_NEAR_NT * LM_NEAR_U) postings of the query's nearest lists -- the nearest list's head, or several short
+// lists -- scored against its own table (plain ds_read_b32 gathers: one query per workgroup, a few per cent of the postings), keys in registers (all
+// code loads of a lane in flight at once). The k-th smallest of G >= k group minima bounds the segment's k-th best key; the few keys at or under it go
+// through the TopKBuf and are ranked by counting: bound[q] = the k-th best key seen (KEY_NONE: fewer than k postings seen, no bound). The fewer postings
+// stand behind the bound, the more keys of the other lists pass it (about k * probed postings / postings behind the bound on featureless data).
+// The kernel also counts the query's pairs per list for the list-major pass (every probed list: the postings scored here are scored again there).
+constexpr int LM_NEAR_NT = 512, LM_NEAR_U = 6, LM_NEAR_MAXL = 64;      // (75 KiB of LDS at k = 10: two workgroups per CU)
 struct NearArgs {
     const float *tables; const uint64_t *list_off; const uint32_t *ids; const uint8_t *codes;
     const uint32_t *probes; const uint32_t *probe_cnt;
-    uint32_t nprobe_k, k, cap, P, near_min;
-    uint64_t *best; uint32_t *r0;
+    uint32_t nprobe_k, k, cap, P, max_postings;
+    uint64_t *bound; uint32_t *list_cnt;
 };
-__global__ __launch_bounds__(LM_NEAR_NT) void adc_near_kernel(const NearArgs a) {
+__global__ __launch_bounds__(LM_NEAR_NT) void adc_bound_kernel(const NearArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *table = reinterpret_cast<float *>(smem);                                   // [48][256]
-    uint64_t *bkeys = reinterpret_cast<uint64_t *>(smem + 49152);                      // [cap] TopKBuf (cap >= 2 k + 2 LM_NEAR_NT)
-    uint64_t *mins = bkeys + a.cap;                                                    // [LM_NEAR_NT]
-    uint64_t *bestk = mins + LM_NEAR_NT;                                               // [1024] the best so far, ascending
-    uint64_t *seg_base = bestk + 1024;                                                 // [LM_NEAR_MAXL]
+    uint64_t *bkeys = reinterpret_cast<uint64_t *>(smem + 49152);                      // [cap] TopKBuf (cap >= k + 2 LM_NEAR_NT)
+    uint64_t *mins = bkeys + a.cap;                                                    // [2 LM_NEAR_NT] group minima; rank-sort output
+    uint64_t *seg_base = mins + 2 * LM_NEAR_NT;                                        // [LM_NEAR_MAXL]
     uint64_t *thr = seg_base + LM_NEAR_MAXL;
     uint32_t *seg_start = reinterpret_cast<uint32_t *>(thr + 1);                       // [LM_NEAR_MAXL + 1]
     uint32_t *cnt = seg_start + LM_NEAR_MAXL + 1;
     uint32_t *nl = cnt + 1;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x, k = a.k;
+    LPROF_DECL
     {
         const f32x4q *tq = reinterpret_cast<const f32x4q *>(a.tables + (size_t)q * 12288);
 #pragma unroll
         for (int i = 0; i < 3072 / LM_NEAR_NT; ++i) reinterpret_cast<f32x4q *>(table)[i * LM_NEAR_NT + tid] = tq[i * LM_NEAR_NT + tid];
     }
-    uint32_t np = a.probe_cnt[q] < (uint32_t)ADC_MAXP ? a.probe_cnt[q] : (uint32_t)ADC_MAXP;
-    if (np > (uint32_t)LM_NEAR_MAXL) np = LM_NEAR_MAXL;
-    if (tid == 0) {
-        uint32_t acc = 0, r = 0;
-        while (r < np && (r == 0 || acc < a.near_min)) {
-            const uint32_t p = a.probes[(size_t)q * a.nprobe_k + r];
-            uint64_t lo = 0, len = 0;
-            if (p < a.P) { lo = a.list_off[p]; len = a.list_off[p + 1] - lo; }
-            seg_base[r] = lo; seg_start[r] = acc; acc += (uint32_t)len; ++r;
-        }
-        seg_start[r] = acc; *nl = r;
-        a.r0[q] = r;
+    const uint32_t npq = a.probe_cnt[q];
+    uint32_t np = npq < (uint32_t)LM_NEAR_MAXL ? npq : (uint32_t)LM_NEAR_MAXL;
+    // the lengths of the nearest lists (one lane each), then lane 0 lays the first of them end to end until max_postings are covered
+    if ((uint32_t)tid < np) {
+        const uint32_t p = a.probes[(size_t)q * a.nprobe_k + tid];
+        uint64_t lo = 0, len = 0;
+        if (p < a.P) { lo = a.list_off[p]; len = a.list_off[p + 1] - lo; }
+        seg_base[tid] = lo; seg_start[tid] = (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull);
     }
     __syncthreads();
-    const uint32_t r0 = *nl, total = seg_start[r0];
+    if (tid == 0) {
+        uint32_t acc = 0, r = 0;
+        while (r < np && acc < a.max_postings) { const uint32_t len = seg_start[r]; seg_start[r] = acc; acc = (len > a.max_postings - acc) ? a.max_postings : acc + len; ++r; }
+        seg_start[r] = acc; *nl = r;
+    }
+    __syncthreads();
+    const uint32_t r0 = *nl, total = seg_start[r0], n = total;                        // n <= max_postings <= LM_NEAR_NT * LM_NEAR_U
+    LPROF_T(0)
     TopKBuf buf{bkeys, cnt, thr, a.cap, k};
-    uint32_t nbest = 0;
-    for (uint32_t base = 0; base < total; base += LM_NEAR_NT * LM_NEAR_U) {
-        const uint32_t n = (total - base) < (uint32_t)(LM_NEAR_NT * LM_NEAR_U) ? (total - base) : (uint32_t)(LM_NEAR_NT * LM_NEAR_U);
+    uint64_t bound = KEY_NONE;
+    if (n) {
         uint4 c3[LM_NEAR_U][3];
         uint32_t idv[LM_NEAR_U];
         uint64_t rk[LM_NEAR_U];
 #pragma unroll
         for (int u = 0; u < LM_NEAR_U; ++u) {
             const uint32_t i = u * LM_NEAR_NT + tid;
-            const uint32_t g = base + (i < n ? i : n - 1);
+            const uint32_t g = i < n ? i : n - 1;
             uint32_t lo_ = 0, hi_ = r0;                 // largest r with seg_start[r] <= g
             while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (seg_start[mid] <= g) lo_ = mid; else hi_ = mid; }
             const uint64_t e = seg_base[lo_] + (g - seg_start[lo_]);
@@ -460,13 +469,13 @@ __global__ __launch_bounds__(LM_NEAR_NT) void adc_near_kernel(const NearArgs a) 
             rk[u] = (u * LM_NEAR_NT + tid < n) ? make_key(d, idv[u]) : KEY_NONE;
             tmin = rk[u] < tmin ? rk[u] : tmin;
         }
-        // bound of this segment: the k-th smallest of G >= k group minima (G = 16 .. 1024 groups of 64 .. 1 lanes; every lane of a full pass holds a key).
-        // A rank over all 1024 lane minima -- block_select_topk's form -- costs 16 000 broadcast reads per segment: 27 us; 16 wave minima cost nothing
-        // and let ~1.5 k keys through instead of k.)
+        LPROF_T(1)
+        // the k-th smallest of G >= k group minima (G = 16 .. 512 groups of 32 .. 1 lanes) bounds the k-th best key from above. (A rank over all the lane
+        // minima -- block_select_topk's form -- costs thousands of broadcast reads; 16 group minima cost nothing and let ~1.5 k keys through instead of k.)
         uint64_t T = KEY_NONE;
         if (k <= (uint32_t)LM_NEAR_NT) {
             uint32_t G = 16; while (G < k) G <<= 1;
-            const uint32_t gw = LM_NEAR_NT / G;         // lanes per group (64 .. 1)
+            const uint32_t gw = LM_NEAR_NT / G;         // lanes per group (32 .. 1)
             uint64_t gm = tmin;
             for (uint32_t ofs = 1; ofs < gw; ofs <<= 1) {
                 const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(gm >> 32), (int)ofs) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)gm, (int)ofs);
@@ -487,19 +496,29 @@ __global__ __launch_bounds__(LM_NEAR_NT) void adc_near_kernel(const NearArgs a) 
         }
         if (tid == 0) { *cnt = 0; *thr = (T == KEY_NONE) ? KEY_NONE : T + 1; }
         __syncthreads();
+        LPROF_T(2)
 #pragma unroll
         for (int u = 0; u < LM_NEAR_U; ++u) {
             if (rk[u] != KEY_NONE) topk_push(buf, rk[u]);
-            if ((u & 1) == 1) topk_compact_if_short<LM_NEAR_NT>(buf, 2 * LM_NEAR_NT + k);      // at most 2 LM_NEAR_NT pushes between checks (+ the best so far behind the last)
+            if ((u & 1) == 1) topk_compact_if_short<LM_NEAR_NT>(buf, 2 * LM_NEAR_NT);      // at most 2 LM_NEAR_NT pushes between checks
         }
-        for (uint32_t i = tid; i < nbest; i += LM_NEAR_NT) topk_push(buf, bestk[i]);
+        const uint32_t left = *buf.cnt;
         __syncthreads();
-        topk_compact<LM_NEAR_NT>(buf);                  // sorts what is left (a few keys), keeps the k best
-        nbest = *buf.cnt;
-        for (uint32_t i = tid; i < nbest; i += LM_NEAR_NT) bestk[i] = bkeys[i];
-        __syncthreads();
+        LPROF_T(3)
+        if (left <= 2u * LM_NEAR_NT) {                  // the usual case (a few dozen keys): order them by counting, no sorting network (21 barriers for 64 keys)
+            rank_sort_lds<LM_NEAR_NT>(bkeys, mins, left);
+            if (left >= k) bound = mins[k - 1];
+        } else {
+            topk_compact<LM_NEAR_NT>(buf);
+            if (*buf.cnt >= k) bound = bkeys[k - 1];
+        }
+        LPROF_T(4)
     }
-    for (uint32_t i = tid; i < k; i += LM_NEAR_NT) a.best[(size_t)q * k + i] = i < nbest ? bestk[i] : KEY_NONE;
+    if (tid == 0) a.bound[q] = bound;
+    // the query's probed lists: one more pair for each of them (the list-major pass groups the pairs by list)
+    for (uint32_t r = tid; r < npq; r += LM_NEAR_NT) { const uint32_t p = a.probes[(size_t)q * a.nprobe_k + r]; if (p < a.P) atomicAdd(&a.list_cnt[p], 1u); }
+    LPROF_T(5)
+    NPROF_END
 }
 
 struct LmArgs {
@@ -511,21 +530,12 @@ struct LmArgs {
     const uint32_t *item_off;  // [P + 1]
     const uint32_t *item_list; // [items] the list of every work item
     const uint32_t *pairs;     // queries, grouped by list
-    const uint64_t *best;      // [nq][k] the k best keys of every query's nearest list, ascending: best[q][k - 1] is the bound (KEY_NONE: none)
-    uint32_t P, k, cand_cap;
+    const uint64_t *bound;     // [nq] keys at or under it are candidates (KEY_NONE: no bound)
+    uint32_t P, cand_cap;
     uint64_t *cand;            // [nq][cand_cap] keys under the bound
     uint32_t *cand_cnt;        // [nq] (may exceed cand_cap: the query is redone)
 };
 
-#ifdef SHODH_LMPROF      // diagnostic build: phase timers of a few workgroups
-#define LPROF_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64(); const long long t00_ = tq_;
-#define LPROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
-#define LPROF_END if (lane == 0 && (wave == 0 || wave == 9) && (blockIdx.x % 997) == 5) printf("lmprof blk %d wave %d queries %u postings %u total %lld : setup+codes %lld | tile0 %lld | score %lld | store %lld | bar %lld | push %lld\n", (int)blockIdx.x, wave, pqn, (unsigned)len, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
-#else
-#define LPROF_DECL
-#define LPROF_T(i)
-#define LPROF_END
-#endif
 __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *bql = reinterpret_cast<uint64_t *>(smem + 2 * LM_TILE);                   // [2 * LM_QB] ... and their bounds
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
     const uint32_t npair = (pqn + 1) >> 1;
     if (tid < 2 * LM_QB) {                                                  // an odd block repeats its last query (scored, not pushed twice)
         const uint32_t q = a.pairs[pq0 + ((uint32_t)tid < pqn ? (uint32_t)tid : pqn - 1)];
-        pql[tid] = q; bql[tid] = a.best[(size_t)q * a.k + (a.k - 1)];
+        pql[tid] = q; bql[tid] = a.bound[q];
     }
     {
         const uint64_t c0 = lo + len * ch / nchunk;
@@ -633,18 +643,19 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
             }
             // keys under the query's bound join its candidates
             // (distance first: the 32-bit order keys decide all but the rare equal-distance case; most lanes have nothing to push)
-            const uint64_t ba = bql[2 * j], bb = (qb != qa) ? bql[2 * j + 1] : 0;
+            const uint64_t ba = bql[2 * j], bb = bql[2 * j + 1];
+            const bool two = qb != qa;
             const uint32_t da = (uint32_t)(ba >> 32), db = (uint32_t)(bb >> 32);
 #pragma unroll
             for (int u = 0; u < LM_U; ++u) {
                 if (valid[u]) {
                     if (order_key(sum[u][0]) <= da) {
                         const uint64_t ka = make_key(sum[u][0], idv[u]);
-                        if (ka < ba) { const uint32_t slot = atomicAdd(&a.cand_cnt[qa], 1u); if (slot < a.cand_cap) a.cand[(size_t)qa * a.cand_cap + slot] = ka; }
+                        if (ka <= ba) { const uint32_t slot = atomicAdd(&a.cand_cnt[qa], 1u); if (slot < a.cand_cap) a.cand[(size_t)qa * a.cand_cap + slot] = ka; }
                     }
-                    if (order_key(sum[u][1]) <= db) {
+                    if (two && order_key(sum[u][1]) <= db) {
                         const uint64_t kb = make_key(sum[u][1], idv[u]);
-                        if (kb < bb) { const uint32_t slot = atomicAdd(&a.cand_cnt[qb], 1u); if (slot < a.cand_cap) a.cand[(size_t)qb * a.cand_cap + slot] = kb; }
+                        if (kb <= bb) { const uint32_t slot = atomicAdd(&a.cand_cnt[qb], 1u); if (slot < a.cand_cap) a.cand[(size_t)qb * a.cand_cap + slot] = kb; }
                     }
                 }
             }
@@ -664,8 +675,8 @@ __global__ __launch_bounds__(1024) void lm_overflow_kernel(const uint32_t *__res
     if (threadIdx.x == 0) *redo_n = n;
 }
 
-// the k best of {the nearest list's k best} + {the candidates of the other lists}
-struct LmMergeArgs { const uint64_t *best; const uint64_t *cand; const uint32_t *cand_cnt; const uint64_t *redo /* [nq][redo_split][k] */; uint32_t k, cap, cand_cap, redo_split; uint32_t *ids; float *dist; uint32_t *counts; };
+// the k best of a query's candidates (or of its redo blocks)
+struct LmMergeArgs { const uint64_t *cand; const uint32_t *cand_cnt; const uint64_t *redo /* [nq][redo_split][k] */; uint32_t k, cap, cand_cap, redo_split; uint32_t *ids; float *dist; uint32_t *counts; };
 __global__ __launch_bounds__(256) void lm_merge_kernel(LmMergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
@@ -677,9 +688,9 @@ __global__ __launch_bounds__(256) void lm_merge_kernel(LmMergeArgs a) {
     TopKBuf buf{keys, cnt, thr, a.cap, a.k};
     const bool redone = a.cand_cnt[q] > a.cand_cap;                 // its candidate list overflowed: the query-major kernel scanned all its lists again, redo_split k-blocks
     const uint32_t nc = a.cand_cnt[q];
-    const uint64_t *b0 = a.best + (size_t)q * a.k, *c0 = a.cand + (size_t)q * a.cand_cap, *r0 = a.redo + (size_t)q * a.redo_split * a.k;
-    auto key_at = [&](uint64_t i) -> uint64_t { return redone ? r0[i] : (i < a.k ? b0[i] : c0[i - a.k]); };
-    const uint32_t m = block_select_topk<256>(key_at, redone ? (uint64_t)a.redo_split * a.k : (uint64_t)a.k + nc, buf, mins);
+    const uint64_t *c0 = a.cand + (size_t)q * a.cand_cap, *r0 = a.redo + (size_t)q * a.redo_split * a.k;
+    auto key_at = [&](uint64_t i) -> uint64_t { return redone ? r0[i] : c0[i]; };
+    const uint32_t m = block_select_topk<256>(key_at, redone ? (uint64_t)a.redo_split * a.k : (uint64_t)nc, buf, mins);
     for (uint32_t i = tid; i < a.k; i += 256) {
         if (i < m) {
             const uint64_t key = buf.keys[i];
@@ -754,7 +765,7 @@ static int upload_postings(IvfpqState *s) {
     return SHODH_OK;
 }
 
-struct IvfpqLayout { uint32_t nprobe, cap, split, gx; bool list_major; uint32_t lm_chunk; size_t o_probe_ids, o_probe_dist, o_probe_cnt, o_partial, o_flat, o_tables, o_lm, o_pairs, o_cand, o_cand_cnt, o_items, o_redo, o_redo_list, o_r0, bytes; };
+struct IvfpqLayout { uint32_t nprobe, cap, split, gx; bool list_major; uint32_t lm_chunk; size_t o_probe_ids, o_probe_dist, o_probe_cnt, o_partial, o_flat, o_tables, o_lm, o_pairs, o_cand, o_items, o_redo, o_redo_list, o_r0, bytes; };
 constexpr uint32_t LM_REDO_SPLIT = 32, LM_REDO_COLS = 16;      // redo launch: 16 x 32 workgroups, a query per column at a time
 constexpr uint32_t LM_QCHUNK = 4096;       // queries per list-major pass (their tables: 192 MiB)
 // The list-major scan pays when lists are shared: at least two probing queries per list on average (and the table / code shapes it is written for).
@@ -787,18 +798,17 @@ static IvfpqLayout ivfpq_layout(const IvfpqState *s, const shodh_index_cfg &cfg,
     const uint32_t pslots = L.list_major ? 1 : L.split;                 // partial keys per query: one k-block per split (list-major: the nearest list's k best)
     L.o_partial = take((size_t)nq * pslots * (k ? k : 1) * 8);
     L.o_flat = take(part_probe + 256);
-    L.o_tables = L.o_lm = L.o_pairs = L.o_cand = L.o_cand_cnt = L.o_items = L.o_redo = L.o_redo_list = L.o_r0 = 0;
+    L.o_tables = L.o_lm = L.o_pairs = L.o_cand = L.o_items = L.o_redo = L.o_redo_list = L.o_r0 = 0;
     if (L.list_major) {
         L.o_tables = take((size_t)L.lm_chunk * 12288 * 4);
-        L.o_lm = take((size_t)4 * (s->P + 1) * 4);                     // counts, pair offsets, fill cursors, item offsets
+        L.o_lm = take((size_t)(s->P + 1 + L.lm_chunk) * 4 + (size_t)3 * (s->P + 1) * 4);      // list counts + candidate counts (one memset), pair offsets, fill cursors, item offsets
         L.o_pairs = take((size_t)L.lm_chunk * L.nprobe * 4);
         L.o_cand = take((size_t)L.lm_chunk * LM_CANDS * 8);
-        L.o_cand_cnt = take((size_t)L.lm_chunk * 4);
         const uint64_t max_chunks = (s->max_list_len + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U);
         L.o_items = take((((size_t)L.lm_chunk * L.nprobe / (2 * LM_QB) + s->P + 1) * (max_chunks ? max_chunks : 1) + 1) * 4);
         L.o_redo = take((size_t)L.lm_chunk * LM_REDO_SPLIT * (k ? k : 1) * 8);
         L.o_redo_list = take((size_t)(L.lm_chunk + 1) * 4);
-        L.o_r0 = take((size_t)L.lm_chunk * 4);
+        L.o_r0 = take((size_t)L.lm_chunk * 8);                         // the bounds
     }
     L.bytes = o;
     return L;
@@ -831,29 +841,28 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
                                     probe_ids, probe_dist, probe_cnt, nullptr, nullptr, st));
     }
     if (L.list_major) {
-        // 2'. nearest list query-major (the bound), the other pairs list-major, overflowed queries again query-major, merge
+        // 2'. tables, bounds, every pair list-major, overflowed queries query-major, merge
         const char *ecap = getenv("SHODH_ADC_LM_CAP");                  // tests (read per call): a tiny candidate list makes every query overflow
         const int env_cap = ecap ? atoi(ecap) : 0;
         const uint32_t cand_cap = (env_cap > 0 && env_cap < LM_CANDS) ? (uint32_t)env_cap : (uint32_t)LM_CANDS;
-        const char *emin = getenv("SHODH_ADC_LM_NEAR_MIN");             // tests: postings behind the bound (1 = the nearest list alone, whatever its length)
-        const uint32_t near_min = (emin && atoi(emin) > 0) ? (uint32_t)atoi(emin) : (1024u > 128u * k ? 1024u : 128u * k);      // featureless data: ~k * probed / near_min candidates
+        const char *emax = getenv("SHODH_ADC_LM_BOUND_POSTINGS");       // tests: postings behind the bound (fewer: looser bound, more candidates; under k: no bound)
+        const uint32_t bound_max = (emax && atoi(emax) > 0 && atoi(emax) < LM_NEAR_NT * LM_NEAR_U) ? (uint32_t)atoi(emax) : (uint32_t)(LM_NEAR_NT * LM_NEAR_U);
         float *tables = (float *)(scratch + L.o_tables);
-        uint32_t *lcnt = (uint32_t *)(scratch + L.o_lm), *pair_off = lcnt + (s->P + 1), *cursor = pair_off + (s->P + 1), *item_off = cursor + (s->P + 1);
+        uint32_t *lcnt = (uint32_t *)(scratch + L.o_lm), *cand_cnt = lcnt + (s->P + 1), *pair_off = cand_cnt + L.lm_chunk, *cursor = pair_off + (s->P + 1), *item_off = cursor + (s->P + 1);
         uint32_t *pairs = (uint32_t *)(scratch + L.o_pairs);
         uint64_t *cand = (uint64_t *)(scratch + L.o_cand);
-        uint32_t *cand_cnt = (uint32_t *)(scratch + L.o_cand_cnt);
         uint32_t *item_list = (uint32_t *)(scratch + L.o_items);
         uint64_t *redo = (uint64_t *)(scratch + L.o_redo);
-        uint32_t *r0 = (uint32_t *)(scratch + L.o_r0);
+        uint64_t *bound = (uint64_t *)(scratch + L.o_r0);                 // [m]
         uint32_t *redo_list = (uint32_t *)(scratch + L.o_redo_list);     // [m] + the count
         uint32_t cap_redo = next_pow2(k + (uint32_t)(ADC_NT * ADC_U));
         if (cap_redo < cap) cap_redo = cap;
         const size_t lds_redo = (size_t)s->M * s->ncent * 4 + (size_t)cap_redo * 8 + 8 + 8 + (size_t)s->dim * 4 + 8 + (size_t)ADC_MAXP * 8 + (size_t)(ADC_MAXP + 1) * 4 + 16;
-        uint32_t cap_near = next_pow2(2 * k + 2u * LM_NEAR_NT);        // the k kept + two rounds of pushes between checks + the best so far
-        const size_t lds_near = 49152 + (size_t)cap_near * 8 + (size_t)LM_NEAR_NT * 8 + 1024 * 8 + (size_t)LM_NEAR_MAXL * 8 + 8 + (size_t)(LM_NEAR_MAXL + 1) * 4 + 4 + 4 + 16;
+        uint32_t cap_near = next_pow2(k + 2u * LM_NEAR_NT);            // the k kept + two rounds of pushes between checks
+        const size_t lds_near = 49152 + (size_t)cap_near * 8 + (size_t)2 * LM_NEAR_NT * 8 + (size_t)LM_NEAR_MAXL * 8 + 8 + (size_t)(LM_NEAR_MAXL + 1) * 4 + 4 + 4 + 16;
         if (lds_redo > 160 * 1024 || lds_near > 160 * 1024) { set_error("IVF-PQ: dim/k too large for LDS (%zu B)", lds_redo > lds_near ? lds_redo : lds_near); return SHODH_ERR_UNSUPPORTED; }
         if (nprobe > (uint32_t)ADC_MAXP) { set_error("IVF-PQ: nprobe %u > %d", nprobe, ADC_MAXP); return SHODH_ERR_UNSUPPORTED; }
-        SHODH_TRY(ensure_dynamic_lds((const void *)adc_near_kernel, lds_near));
+        SHODH_TRY(ensure_dynamic_lds((const void *)adc_bound_kernel, lds_near));
         SHODH_TRY(ensure_dynamic_lds((const void *)adc_scan_kernel<true, ADC_NT, true>, lds_redo));
         SHODH_TRY(ensure_dynamic_lds((const void *)adc_list_kernel, LM_LDS));
         const size_t mlds2 = (size_t)cap * 8 + 512 * 8 + 8 + 4 + 16;
@@ -863,28 +872,24 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             const uint32_t m = (nq - b) < L.lm_chunk ? (nq - b) : L.lm_chunk;
             const float *qb = d_q + (size_t)b * s->dim;
             const uint32_t *pids = probe_ids + (size_t)b * nprobe, *pcnt = probe_cnt + b;
-            uint64_t *best = partial + (size_t)b * k;
-            SHODH_HIP_TRY(hipMemsetAsync(lcnt, 0, (size_t)(s->P + 1) * 4, st));
-            SHODH_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)m * 4, st));
+            SHODH_HIP_TRY(hipMemsetAsync(lcnt, 0, (size_t)(s->P + 1 + m) * 4, st));      // list counters + candidate counters (adjacent)
             hipLaunchKernelGGL(adc_table_kernel, dim3(m, 12), dim3(1024), 0, st, qb, s->codebook, s->dim, tables);
-            NearArgs na{tables, s->list_off, s->ids, s->codes, pids, pcnt, nprobe, k, cap_near, s->P, near_min, best, r0};
-            hipLaunchKernelGGL(adc_near_kernel, dim3(m), dim3(LM_NEAR_NT), lds_near, st, na);
+            NearArgs na{tables, s->list_off, s->ids, s->codes, pids, pcnt, nprobe, k, cap_near, s->P, bound_max, bound, lcnt};
+            hipLaunchKernelGGL(adc_bound_kernel, dim3(m), dim3(LM_NEAR_NT), lds_near, st, na);
             const uint32_t np = m * nprobe;
-            hipLaunchKernelGGL(lm_count_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, (const uint32_t *)r0, s->P, lcnt);
-            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, lcnt, s->list_off, s->P, pair_off, cursor, item_off);
-            hipLaunchKernelGGL(lm_fill_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, (const uint32_t *)r0, s->P, cursor, pairs);
-            hipLaunchKernelGGL(lm_items_kernel, dim3((s->P + 255) / 256), dim3(256), 0, st, item_off, s->P, item_list);
-            LmArgs la{tables, s->list_off, s->ids, s->codes, pair_off, item_off, item_list, pairs, best, s->P, k, cand_cap, cand, cand_cnt};
+            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)lcnt, s->list_off, s->P, pair_off, cursor, item_off, item_list);
+            hipLaunchKernelGGL(lm_fill_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, s->P, cursor, pairs);
+            LmArgs la{tables, s->list_off, s->ids, s->codes, pair_off, item_off, item_list, pairs, bound, s->P, cand_cap, cand, cand_cnt};
             // work items <= (pairs / (2 LM_QB) + one partly filled block per list) x the chunks of the longest list; workgroups past the count leave at once
             const uint64_t max_items = ((uint64_t)np / (2 * LM_QB) + (np < s->P ? np : s->P)) * (max_chunks ? max_chunks : 1);
             hipLaunchKernelGGL(adc_list_kernel, dim3((uint32_t)(max_items ? max_items : 1)), dim3(LM_NT), LM_LDS, st, la);
 #ifdef SHODH_LMPROF
             {
-                std::vector<uint32_t> hc(m), hr(m);
-                hipStreamSynchronize(st); hipMemcpy(hc.data(), cand_cnt, (size_t)m * 4, hipMemcpyDeviceToHost); hipMemcpy(hr.data(), r0, (size_t)m * 4, hipMemcpyDeviceToHost);
-                uint64_t sum = 0, sr = 0; uint32_t mx = 0, over = 0, big = 0, mq = 0;
-                for (uint32_t i = 0; i < m; ++i) { const uint32_t v = hc[i]; sum += v; sr += hr[i]; if (v > mx) { mx = v; mq = i; } over += v > cand_cap; big += v > 512; }
-                fprintf(stderr, "lmprof candidates: mean %.1f max %u (query %u, r0 %u) over-cap %u (>512: %u) of %u queries, mean r0 %.2f\n", (double)sum / m, mx, mq, hr[mq], over, big, m, (double)sr / m);
+                std::vector<uint32_t> hc(m);
+                hipStreamSynchronize(st); hipMemcpy(hc.data(), cand_cnt, (size_t)m * 4, hipMemcpyDeviceToHost);
+                uint64_t sum = 0; uint32_t mx = 0, over = 0, big = 0, mq = 0;
+                for (uint32_t i = 0; i < m; ++i) { const uint32_t v = hc[i]; sum += v; if (v > mx) { mx = v; mq = i; } over += v > cand_cap; big += v > 512; }
+                fprintf(stderr, "lmprof candidates: mean %.1f max %u (query %u) over-cap %u (>512: %u) of %u queries\n", (double)sum / m, mx, mq, over, big, m);
             }
 #endif
             // queries whose candidate list overflowed (an outlier whose nearest lists say little about the others): from scratch, every probed list,
@@ -892,7 +897,7 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             hipLaunchKernelGGL(lm_overflow_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)cand_cnt, m, cand_cap, redo_list, redo_list + m);
             AdcArgs a2{qb, s->codebook, s->list_off, s->ids, s->codes, pids, pcnt, m, s->dim, s->M, s->ncent, nprobe, k, cap_redo, LM_REDO_SPLIT, redo, redo_list, redo_list + m, tables};
             hipLaunchKernelGGL((adc_scan_kernel<true, ADC_NT, true>), dim3(LM_REDO_COLS, LM_REDO_SPLIT), dim3(ADC_NT), lds_redo, st, a2);
-            LmMergeArgs mm{best, cand, cand_cnt, redo, k, cap, cand_cap, LM_REDO_SPLIT, d_ids + (size_t)b * k, d_dist + (size_t)b * k, d_counts + b};
+            LmMergeArgs mm{cand, cand_cnt, redo, k, cap, cand_cap, LM_REDO_SPLIT, d_ids + (size_t)b * k, d_dist + (size_t)b * k, d_counts + b};
             hipLaunchKernelGGL(lm_merge_kernel, dim3(m), dim3(256), mlds2, st, mm);
             SHODH_HIP_TRY(hipGetLastError());
         }

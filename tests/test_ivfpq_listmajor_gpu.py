@@ -1,5 +1,5 @@
-"""The list-major batch scan of the IVF-PQ path (adc_near_kernel: the bound from every query's nearest lists; adc_list_kernel: pairs grouped
-by list, codes in registers, two queries' tables interleaved in LDS, keys under the bound -> candidates; redo of overflowed queries;
+"""The list-major batch scan of the IVF-PQ path (adc_bound_kernel: a bound from the head of every query's nearest lists; adc_list_kernel: pairs
+grouped by list, codes in registers, two queries' tables interleaved in LDS, keys at or under the bound -> candidates; redo of overflowed queries;
 lm_merge_kernel) against the oracle's SpannIndex::search (spann.rs:574-693, pq.rs:358-368) and against the query-major kernel: same ids
 and distances, bit for bit, whichever kernel the batch shape selects."""
 import numpy as np
@@ -30,14 +30,14 @@ def state(oracle):
     return rows, st
 
 
-@pytest.fixture(autouse=True, params=["1", "60", None], ids=["bound=nearest-list", "bound=60-postings", "bound=default"])
-def near_min(request, monkeypatch):
-    """how many postings stand behind the bound (the nearest lists scanned query by query): with the default (2048) the small fixtures
-    never reach the list-major kernel, so every test also runs with the nearest list alone and with ~2 lists"""
+@pytest.fixture(autouse=True, params=["7", "60", None], ids=["bound=7-postings", "bound=60-postings", "bound=default"])
+def bound_postings(request, monkeypatch):
+    """how many postings of the nearest lists stand behind the bound: the default (3072) covers the small fixtures entirely, so every test
+    also runs with a bound drawn from 60 postings (loose: many candidates) and from 7 (fewer than k = 10: no bound at all)"""
     if request.param is None:
-        monkeypatch.delenv("SHODH_ADC_LM_NEAR_MIN", raising=False)
+        monkeypatch.delenv("SHODH_ADC_LM_BOUND_POSTINGS", raising=False)
     else:
-        monkeypatch.setenv("SHODH_ADC_LM_NEAR_MIN", request.param)
+        monkeypatch.setenv("SHODH_ADC_LM_BOUND_POSTINGS", request.param)
 
 
 def _index(S, st, nprobe):

@@ -62,3 +62,17 @@ def test_scan_kernels_do_not_spill():
     for parts in [("mfma_scan_kernelILi1ELi24",), ("mfma_scan_kernelILi0ELi24",), ("solo_scan_kernel",), ("final_stage_kernel",)]:
         for k in find(res, *parts):
             assert res[k].get("spill", 0) == 0, (k, res[k])        # (the final stage keeps a small indexed array in scratch: not a spill)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_ivfpq_kernels_keep_their_occupancy():
+    """The query-major list scan needs <= 64 registers (two 1024-thread workgroups per CU: as a run-time loop over queries it took 95 and configs[3]
+    went from 1.41 to 1.73 ms -- the loop lives in a separate REDO instantiation); the list-major scan and the bound kernel hold a lane's codes in
+    registers on purpose (<= 128: sixteen waves per CU) and must not spill around them (without the opaque code words the compiler hoists 144 table
+    offsets per lane out of the query loop: 157 spilled registers)."""
+    res = resources("ivfpq.hip")
+    for k in find(res, "adc_scan_kernelILb1ELi1024ELb0"):
+        assert res[k]["vgprs"] <= 64 and res[k].get("spill", 0) == 0, (k, res[k])
+    for parts in [("adc_list_kernel",), ("adc_bound_kernel",)]:
+        for k in find(res, *parts):
+            assert res[k]["vgprs"] <= 128 and res[k].get("scratch", 0) == 0 and res[k].get("spill", 0) == 0, (k, res[k])
