@@ -463,6 +463,18 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         qp = [synth_rows(torch, nq, args.dim, SEED + 42 + i, dev) for i in range(2)]
         out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq,), dtype=torch.int32, device=dev))
         dt = timed_steps(torch, lambda i: idx.search_batch_device(qp[i % 2], k, out=out), 20, 3)
+        # other batch sizes through the same call (the library picks the list-major scan when the batch shares lists: queries x nprobe >= 2 nlist);
+        # SHODH_BENCH_IVFPQ_AB=1 also times both scans at every size (SHODH_ADC_LIST_MAJOR = 0 / 1)
+        sweep = {}
+        for nqs in (1, 64, 256, 512, 2048, 4096):
+            qs_ = synth_rows(torch, nqs, args.dim, SEED + 47, dev)
+            outs = (torch.empty((nqs, k), dtype=torch.int32, device=dev), torch.empty((nqs, k), dtype=torch.float32, device=dev), torch.empty((nqs,), dtype=torch.int32, device=dev))
+            modes = [("", None)] + ([("_query_major", "0"), ("_list_major", "1")] if os.environ.get("SHODH_BENCH_IVFPQ_AB") else [])
+            for suffix, env in modes:
+                if env is not None:
+                    os.environ["SHODH_ADC_LIST_MAJOR"] = env
+                sweep["b%d%s" % (nqs, suffix)] = round(timed_steps(torch, lambda i: idx.search_batch_device(qs_, k, out=outs), 10, 2) * 1e3, 4)
+                os.environ.pop("SHODH_ADC_LIST_MAJOR", None)
         lens = torch.from_numpy(np.diff(off.astype(np.int64))).to(dev)
         probes = (1.0 - qp[0] @ cent.T).topk(nprobe, dim=1, largest=False).indices          # byte accounting only
         alg = int(lens[probes].sum().item()) * (M + 4) + P * args.dim * 4                     # probed postings x 52 B + the centroid table once per batch
@@ -470,7 +482,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
              "workload": "configs[3]: %d memories, IVF-PQ nlist %d, nprobe %d, %d-d, top-%d, batch %d" % (n, P, nprobe, args.dim, k, nq),
              "ms_per_step": round(dt * 1e3, 4), "queries_per_s": round(nq / dt, 1), "steps": 20,
              "algorithmic_bytes_per_step": alg, "step_hbm_frac_algorithmic": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
-             "postings_scanned_per_query": round(float(lens[probes].sum().item()) / nq, 1),
+             "postings_scanned_per_query": round(float(lens[probes].sum().item()) / nq, 1), "batch_sweep_ms_per_step": sweep,
              "list_len_mean": round(float(lens.float().mean()), 1), "list_len_max": int(lens.max()),
              "encode_all_rows_s (nearest centroid + PQ encode, host rows in)": round(t_enc, 2)}
         idx.close(); del idx

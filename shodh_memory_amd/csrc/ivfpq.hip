@@ -768,14 +768,14 @@ static int upload_postings(IvfpqState *s) {
 struct IvfpqLayout { uint32_t nprobe, cap, split, gx; bool list_major; uint32_t lm_chunk; size_t o_probe_ids, o_probe_dist, o_probe_cnt, o_partial, o_flat, o_tables, o_lm, o_pairs, o_cand, o_items, o_redo, o_redo_list, o_r0, bytes; };
 constexpr uint32_t LM_REDO_SPLIT = 32, LM_REDO_COLS = 16;      // redo launch: 16 x 32 workgroups, a query per column at a time
 constexpr uint32_t LM_QCHUNK = 4096;       // queries per list-major pass (their tables: 192 MiB)
-// The list-major scan pays when lists are shared: at least two probing queries per list on average (and the table / code shapes it is written for).
+// The list-major scan is the default wherever its shapes hold (48 sub-quantisers of 256 codewords: what the reference builds at 384-d). Measured at
+// configs[3]'s index against the query-major scan, ms per batch of 1 / 64 / 256 / 1024 / 4096 queries: 0.088 / 0.23 / 0.43 / 1.08 / 3.44 against
+// 0.096 / 0.32 / 0.52 / 1.41 / 4.73 -- even one query spreads its 32 lists over 32 workgroups.
 static bool use_list_major(const IvfpqState *s, uint32_t nq, uint32_t nprobe, uint32_t k) {
-    const char *ev = getenv("SHODH_ADC_LIST_MAJOR");                    // diagnostic / tests (read per call): 0 = never, 1 = whenever the shapes allow
-    const int env = ev ? atoi(ev) : -1;
-    const bool shapes = s->ncent == 256 && s->M == 48 && k >= 1 && k <= 1024 && nprobe >= 2;
-    if (!shapes || env == 0) return false;
-    if (env == 1) return true;
-    return (uint64_t)nq * nprobe >= 2ull * s->P;
+    (void)nq;
+    const char *ev = getenv("SHODH_ADC_LIST_MAJOR");                    // diagnostic / tests (read per call): 0 = the query-major scan
+    if (ev && atoi(ev) == 0) return false;
+    return s->ncent == 256 && s->M == 48 && k >= 1 && k <= 1024 && nprobe >= 1;
 }
 static IvfpqLayout ivfpq_layout(const IvfpqState *s, const shodh_index_cfg &cfg, uint32_t nq, uint32_t k) {
     IvfpqLayout L{};

@@ -51,7 +51,7 @@ def test_list_major_matches_oracle_and_query_major(S, oracle, state, monkeypatch
     q = np.concatenate([rows[:3], synth.queries(37)])
     for nprobe in (1, 7, 45):
         idx = _index(S, st, nprobe)
-        for k in (1, 10, 16, 17, 40, 64, 120):              # 120 > 64: the query-major kernel either way
+        for k in (1, 10, 16, 17, 40, 64, 120, 600):
             monkeypatch.setenv("SHODH_ADC_LIST_MAJOR", "0")
             a = idx.search_batch(q, k)
             monkeypatch.setenv("SHODH_ADC_LIST_MAJOR", "1")
@@ -63,8 +63,8 @@ def test_list_major_matches_oracle_and_query_major(S, oracle, state, monkeypatch
         check(oracle, idx, st, q[:5], 33, nprobe)
 
 
-def test_list_major_default_choice_by_batch_shape(S, oracle, state, monkeypatch):
-    """no environment: 300 queries x 20 probes over 45 lists share lists (list-major), one query does not (query-major)"""
+def test_list_major_is_the_default_for_every_batch_size(S, oracle, state, monkeypatch):
+    """no environment: the list-major scan, whatever the batch size -- 300 queries and one query give the same answers, equal to the query-major scan's"""
     rows, st = state
     monkeypatch.delenv("SHODH_ADC_LIST_MAJOR", raising=False)
     idx = _index(S, st, 20)
@@ -73,6 +73,9 @@ def test_list_major_default_choice_by_batch_shape(S, oracle, state, monkeypatch)
     for i in (0, 17, 299):
         one = idx.search_batch(q[i:i + 1], 10)
         assert one[0][0].tolist() == ids[i].tolist() and one[1][0].tobytes() == dist[i].tobytes()
+    monkeypatch.setenv("SHODH_ADC_LIST_MAJOR", "0")
+    qm = idx.search_batch(q, 10)
+    assert qm[0].tobytes() == ids.tobytes() and qm[1].tobytes() == dist.tobytes()
     check(oracle, idx, st, q[:6], 10, 20)
 
 
