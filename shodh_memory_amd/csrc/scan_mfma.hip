@@ -622,6 +622,279 @@ __global__ __launch_bounds__(256, 1) void mfma_scan_big_kernel(MfmaArgs a) {
     if (MODE == MF_MODE_EMIT) drain();
 }
 
+// ---- dimensions 768 and 1024, round 4: two waves per SIMD by splitting K ------------------------------------------------------------
+// mfma_scan_big_kernel leaves a SIMD idle whenever its one wave waits (first A fragments after a barrier, the staging writes, the epilogue):
+// a half tile takes ~5 500 cycles where its 48 MFMAs take 1 536. The resident query fragments are what forces one wave per SIMD -- 32
+// queries x 768 dimensions are 192 registers -- unless the two waves of a SIMD share the SAME 32 queries and split the DIMENSIONS:
+// wave w (0-3: first half of the k-steps, 4-7: second half; w & 3 = the query block, w and w + 4 sit on the same SIMD) holds 96 / 128
+// registers of fragments, reads only its half of every row from LDS (the same LDS bytes in total), runs half of the chain, and the
+// upper wave hands its sixteen partial sums to the lower one through LDS (4 KiB per pair and half tile, double-buffered): the lower wave adds them after the barrier that ends the half tile anyway and runs the unchanged epilogue while the
+// upper wave is already multiplying the next half. The pre-scan's scores are approximate by contract (|s~ - s| <= eps covers any
+// summation order of the fp16 products in f32), so the split changes no result. Data movement: HBM -> registers two halves ahead ->
+// ds_write into the other buffer, both inside the chain. Measured at 1M x 768, 256 queries, one box: 528 us against the one-wave kernel's
+// 586 (the step: 0.632 against 0.685 ms) -- far from the 2x the idle SIMDs suggested: with the loads, the staging writes and the exchange
+// compiled out the chains alone still take 386 us where their MFMAs take 190 (tools/r4_bigdim_ablate.sh). At 1024 dimensions the 128
+// fragment registers + two staging sets do not fit 256 registers (22 / 80 spilled: 1.49 against 0.89 ms): that size keeps the one-wave kernel.
+#ifdef SHODH_BIGPROF     // diagnostic build: per-phase wave cycles of one workgroup
+#define BPROF_DECL long long bp_[6] = {0, 0, 0, 0, 0, 0}, bq_ = clock64();
+#define BPROF_T(i) { const long long t_ = clock64(); bp_[i] += t_ - bq_; bq_ = t_; }
+#else
+#define BPROF_DECL
+#define BPROF_T(i)
+#endif
+template <int MODE, int KSTEPS>
+__global__ __launch_bounds__(512, 1) void mfma_scan_big2_kernel(MfmaArgs a) {
+#ifdef SHODH_BIG_ABL      // diagnostic builds (-DSHODH_BIG_ABL=mask, results invalid): 16 no global loads after the prologue, 32 no staging writes, 64 no exchange, 128 no MFMAs
+    constexpr int BIG_ABL = SHODH_BIG_ABL;
+#else
+    constexpr int BIG_ABL = 0;
+#endif
+    constexpr int NT = 512;
+    constexpr int DIM = KSTEPS * 16;
+    constexpr int CPR = KSTEPS * 2;
+    constexpr int PITCH = DIM * 2;
+    constexpr int HALF_BYTES = MFB_TR * PITCH;
+    constexpr int NPC = MFB_TR * CPR / NT;     // 16-B pieces per thread and half tile (6)
+    constexpr int KH = KSTEPS / 2;             // k-steps per wave
+    constexpr int D = 6, RING = 8;
+    constexpr int XBUFS = 2;
+    static_assert(2 * HALF_BYTES + XBUFS * 16384 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024, "LDS: two half tiles + the double-buffered exchange (768 dimensions)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xch = reinterpret_cast<float *>(smem + 2 * HALF_BYTES);                     // [XBUFS][4 pairs][16 values][64 lanes]
+    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + 2 * HALF_BYTES + XBUFS * 16384);
+    uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
+    uint32_t *qcount = eq_q + MF_EQ_CAP;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = wave & 3, kh = wave >> 2;
+    const uint32_t pass = blockIdx.y >> 1, sub = blockIdx.y & 1;
+    const uint32_t q_local = sub * 128 + qb * 32 + l31;
+    const bool active = (uint32_t)(pass * MF_BPAD + sub * 128 + qb * 32) < a.nq;       // wave-uniform, the same for both waves of a pair
+    if ((uint32_t)(pass * MF_BPAD + sub * 128) >= a.nq) {        // a sub-pass of nothing but padding: no reason to stream the corpus for it
+        if (MODE != MF_MODE_EMIT)
+            for (uint32_t sel = blockIdx.x; sel < a.n_sel_tiles; sel += gridDim.x)
+                if (tid < 128) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + sub * 128 + tid] = 0.0f;
+        return;
+    }
+    if (MODE == MF_MODE_EMIT) {
+        if (tid < MF_BPAD) qcount[tid] = 0;
+        if (tid < 128) {
+            uint64_t *sl = a.slots + (((size_t)pass * MF_BPAD + sub * 128 + tid) * gridDim.x + blockIdx.x) * MF_SLOTS;
+#pragma unroll
+            for (int j = 0; j < MF_SLOTS; ++j) sl[j] = KEY_NONE;
+        }
+    }
+    // piece p = i * NT + tid of a half tile: LDS chunk (row, slot) <- global chunk (row, slot ^ (row & 15) within its group of 16)
+    uint32_t srcoff[NPC], dstoff[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int pc = i * NT + tid, row = pc / CPR, slot = pc % CPR;
+        const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
+        srcoff[i] = (uint32_t)(row * PITCH + c * 16);
+        dstoff[i] = (uint32_t)(row * PITCH + slot * 16);
+    }
+    const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
+    const size_t tile_bytes_g = (size_t)a.tile_stride * MF_TR * DIM * 2;
+
+    half8 bq[KH];
+    {
+        const half8 *qp = reinterpret_cast<const half8 *>(a.q_h) + ((size_t)pass * 8 + sub * 4 + qb) * KSTEPS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) bq[ks] = qp[(kh * KH + ks) * 64];
+    }
+    float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
+    if (a.ablate & 8u) thr_l = __builtin_inff();
+    const int sw = l31 & 15;
+    int aoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4) + (kh * KH >> 3) * 256;      // (KH is a multiple of 8: the wave's k-steps start at a 256-byte group)
+
+    // survivors: the lower wave of a pair owns the queue and the candidate slots of its query block (as the one wave did in mfma_scan_big_kernel)
+    uint64_t *wq_key = eq_key + qb * MF_WQ_CAP;
+    uint32_t *wq_q = eq_q + qb * MF_WQ_CAP;
+    uint32_t wq_n = 0;
+    uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;
+    auto emit_direct = [&](uint64_t key, uint32_t ql) {
+        const uint32_t row = (uint32_t)key;
+        if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) return;      // tombstoned (vamana.rs:1175-1177)
+        const uint32_t s_ = atomicAdd(qcount + ql, 1u);
+        if (s_ < (uint32_t)MF_SLOTS) {
+            my_slots[(size_t)ql * gridDim.x * MF_SLOTS + s_] = key;
+        } else {
+            const size_t qi = (size_t)pass * MF_BPAD + ql;
+            const uint32_t slot = atomicAdd(a.cand_cnt + qi, 1u);
+            if (slot < a.cand_cap) a.cand[qi * a.cand_cap + slot] = key;
+        }
+    };
+    auto drain = [&]() {
+        const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
+        for (uint32_t i = lane; i < n; i += 64) emit_direct(wq_key[i], wq_q[i]);
+        wq_n = 0;
+    };
+    auto emit_block = [&](const floatx16 &c, uint64_t brow0) {
+        const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
+        const uint32_t lim = left < 64 ? (uint32_t)left : 64u;
+        const uint32_t wq_n0 = wq_n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t roff = (r & 3) + 8 * (r >> 2);
+            const bool hit = c[r] >= thr_l && roff < lim;
+            const uint64_t b = __builtin_amdgcn_ballot_w64(hit);
+            if (__builtin_expect(b != 0, 0)) {
+                const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (hit && slot < (uint32_t)MF_WQ_CAP) {
+                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    wq_q[slot] = q_local;
+                }
+                wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
+            }
+        }
+        if (__builtin_expect(wq_n > (uint32_t)MF_WQ_CAP, 0)) {      // a dense block: straight to the candidate slots (see mfma_scan_kernel)
+            wq_n = wq_n0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t roff = (r & 3) + 8 * (r >> 2);
+                if (c[r] >= thr_l && roff < lim) emit_direct(make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff)), q_local);
+            }
+        }
+    };
+
+    const uint32_t step = gridDim.x;
+    const uint32_t n_mine = blockIdx.x < a.n_sel_tiles ? (a.n_sel_tiles - blockIdx.x + step - 1) / step : 0u;
+    const uint32_t n_half = 2 * n_mine;
+    u32x4 stg_a[NPC], stg_b[NPC];
+    auto src_of = [&](uint32_t u) -> const unsigned char * {
+        const uint32_t uc = u < n_half ? u : n_half - 1;              // past the end: a harmless repeat of the last half
+        const uint32_t sel = blockIdx.x + (uc >> 1) * step;
+        return rows_b + (size_t)sel * tile_bytes_g + (size_t)(uc & 1) * HALF_BYTES;      // the shadow slab is padded to whole tiles
+    };
+    auto stage = [&](uint32_t buf, const u32x4 *stg) {
+        if (BIG_ABL & 32) return;
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) *reinterpret_cast<u32x4 *>(smem + buf * HALF_BYTES + dstoff[i]) = stg[i];
+    };
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float tile_m = -__builtin_inff();
+    // the wave's half of the chain over LDS buffer `h`; the upper wave leaves its sums in the exchange area. In the MFMAs' shadows (all eight waves run
+    // the same phase at the same time, so whatever sits between two barriers outside the chain is paid in full: the staging writes and the loads cost
+    // 128 + 116 us of the kernel's 552 at 1M x 768 that way): every fourth step one 16-byte piece of the half tile loaded a half tile ago goes to the
+    // OTHER LDS buffer (free since the last barrier), and one piece of the half tile two ahead is requested from HBM.
+    auto chain = [&](uint32_t h, uint32_t u, const u32x4 *stg_w, u32x4 *stg_l, const unsigned char *src_l) -> floatx16 {
+        const unsigned char *buf = smem + h * HALF_BYTES;
+        unsigned char *wbuf = smem + (h ^ 1) * HALF_BYTES;
+        floatx16 acc = zero16;
+        half8 ring[RING];
+#pragma unroll
+        for (int st = 0; st < D; ++st) ring[st % RING] = *reinterpret_cast<const half8 *>(buf + aoff[st & 7] + (st >> 3) * 256);
+#pragma unroll
+        for (int st = 0; st < KH; ++st) {
+            if (st + D < KH) ring[(st + D) % RING] = *reinterpret_cast<const half8 *>(buf + aoff[(st + D) & 7] + ((st + D) >> 3) * 256);
+            if (BIG_ABL & 128) acc[st & 15] += (float)ring[st % RING][0]; else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], acc, 0, 0, 0);
+            if ((st & 3) == 1 && (st >> 2) < NPC && !(BIG_ABL & 32)) *reinterpret_cast<u32x4 *>(wbuf + dstoff[st >> 2]) = stg_w[st >> 2];
+            if ((st & 3) == 3 && (st >> 2) < NPC && !(BIG_ABL & 16)) stg_l[st >> 2] = *reinterpret_cast<const u32x4 *>(src_l + srcoff[st >> 2]);
+            __builtin_amdgcn_sched_barrier(0);      // keeps the A fragments D steps ahead
+        }
+        if (BIG_ABL & 64) return acc;
+        if (kh) {
+            float *x = xch + ((size_t)((u & 1) * 4 + qb) * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r * 64] = acc[r];
+        }
+        return acc;
+    };
+    // lower wave, after the barrier that ends half tile u: add the partner's sums, then the epilogue of mfma_scan_big_kernel
+    auto finish = [&](floatx16 acc, uint32_t h, uint32_t u, uint32_t sel) {
+        const float *x = xch + ((size_t)((u & 1) * 4 + qb) * 16) * 64 + lane;
+        if (!(BIG_ABL & 64))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc[r] + x[r * 64];
+        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + h * MFB_TR;
+        if (MODE == MF_MODE_EMIT) {
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            if (__builtin_amdgcn_ballot_w64(m >= thr_l) != 0) emit_block(acc, row0);
+            if (wq_n >= (uint32_t)MF_WQ_CAP / 2) drain();
+        } else {
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t g0 = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (g0 < a.n_rows) m = fmaxf(m, acc[r]);
+            }
+            tile_m = fmaxf(tile_m, m);
+            if (h) {
+                tile_m = fmaxf(tile_m, __shfl_xor(tile_m, 32));
+                if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = tile_m * MF_INV_SCALE2;
+                tile_m = -__builtin_inff();
+            }
+        }
+    };
+    if (n_mine) {
+        {
+            const unsigned char *s0 = src_of(0), *s1 = src_of(1);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) stg_a[i] = *reinterpret_cast<const u32x4 *>(s0 + srcoff[i]);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) stg_b[i] = *reinterpret_cast<const u32x4 *>(s1 + srcoff[i]);
+        }
+        stage(0, stg_a);
+    }
+    __syncthreads();
+    floatx16 pend = zero16;                          // lower wave: its own sums of the half tile whose partner sums arrive behind the barrier
+    BPROF_DECL
+    static_assert(NPC <= KH / 4, "one staging write and one load per four chain steps");
+    for (uint32_t i = 0; i < n_mine; ++i) {
+        const uint32_t sel = blockIdx.x + i * step;
+        {   // half 0 from buffer 0; set B (half 1 of this tile) goes to buffer 1, set A takes half 0 of the next tile
+            const unsigned char *sn = src_of(2 * i + 2);
+            BPROF_T(0)
+            if (active) {
+                if (!kh && i > 0) finish(pend, 1, 2 * i - 1, sel - step);
+                BPROF_T(1)
+                pend = chain(0, 2 * i, stg_b, stg_a, sn);
+                BPROF_T(2)
+            } else {
+                if (MODE != MF_MODE_EMIT && !kh && i > 0 && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + (sel - step)) * MF_BPAD + q_local] = 0.0f;      // padding queries: defined values
+                stage(1, stg_b);
+#pragma unroll
+                for (int j = 0; j < NPC; ++j) stg_a[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
+            }
+            BPROF_T(3)
+            __syncthreads();
+            BPROF_T(4)
+        }
+        {   // half 1 from buffer 1; set A goes to buffer 0, set B takes half 1 of the next tile
+            const unsigned char *sn = src_of(2 * i + 3);
+            BPROF_T(0)
+            if (active) {
+                if (!kh) finish(pend, 0, 2 * i, sel);
+                BPROF_T(1)
+                pend = chain(1, 2 * i + 1, stg_a, stg_b, sn);
+                BPROF_T(2)
+            } else {
+                stage(0, stg_a);
+#pragma unroll
+                for (int j = 0; j < NPC; ++j) stg_b[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
+            }
+            BPROF_T(3)
+            __syncthreads();
+            BPROF_T(4)
+        }
+    }
+    if (n_mine) {
+        const uint32_t sel = blockIdx.x + (n_mine - 1) * step;
+        if (active) { if (!kh) finish(pend, 1, 2 * n_mine - 1, sel); }
+        else if (MODE != MF_MODE_EMIT && !kh && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;
+    }
+    if (MODE == MF_MODE_EMIT && !kh) drain();
+#ifdef SHODH_BIGPROF
+    if (MODE == MF_MODE_EMIT && blockIdx.x == 37 && blockIdx.y == 0 && lane == 0 && n_half)
+        printf("bigprof wave %d halves %u | per half: issue loads %lld finish %lld chain %lld stage %lld barrier %lld\n", wave, n_half, bp_[0] / n_half, bp_[1] / n_half, bp_[2] / n_half, bp_[3] / n_half, bp_[4] / n_half);
+#endif
+}
+
 // ---- conversions ------------------------------------------------------------------------------------
 // rows f32 -> fp16(256 x) shadow; also folds max row norm^2, max |x| and a non-finite flag into stats.
 // stats[0] = max norm^2 (float bits, atomicMax on uint works for non-negative floats)
@@ -1309,9 +1582,30 @@ template <int MODE>
 // separate hipEventRecord calls are extra packets in the stream and cost 3-5 us each between two kernels)
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     if (a.dim > 512) {
-        const size_t lds = 2ull * MFB_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
         dim3 grid((uint32_t)p.grid_x, p.passes * 2);
         if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
+        // 768 dimensions: the K-split kernel (two waves per SIMD; 528 against 586 us per 256 queries at 1M rows on one box). At 1024 dimensions its 128
+        // fragment registers + two staging sets do not fit 256 registers (22 / 80 spilled, 1.49 against 0.89 ms): the round-2 kernel stays.
+        // SHODH_BIG_SCAN_V1=1 (diagnostic): the round-2 kernel at 768 dimensions too.
+        static const int big_v1 = getenv("SHODH_BIG_SCAN_V1") ? atoi(getenv("SHODH_BIG_SCAN_V1")) : 0;
+        if (!big_v1 && p.ksteps == 48) {
+            const size_t half = (size_t)MFB_TR * a.dim * 2;
+            const size_t lds2 = 2 * half + 2 * 16384 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
+#define SHODH_LAUNCH_BIG2(KS)                                                                                       \
+    case KS:                                                                                                       \
+        SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big2_kernel<MODE, KS>, lds2));                         \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((mfma_scan_big2_kernel<MODE, KS>), grid, dim3(512), (uint32_t)lds2, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL((mfma_scan_big2_kernel<MODE, KS>), grid, dim3(512), lds2, st, a);                   \
+        break;
+            switch (p.ksteps) {
+                SHODH_LAUNCH_BIG2(48)
+                default: set_error("MFMA scan: unsupported dim %u", a.dim); return SHODH_ERR_UNSUPPORTED;
+            }
+#undef SHODH_LAUNCH_BIG2
+            SHODH_HIP_TRY(hipGetLastError());
+            return SHODH_OK;
+        }
+        const size_t lds = 2ull * MFB_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
 #define SHODH_LAUNCH_BIG(KS)                                                                                        \
     case KS:                                                                                                       \
         SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big_kernel<MODE, KS>, lds));                           \
