@@ -952,7 +952,7 @@ struct shodh_embedder {
     int32_t *rsX = nullptr, *rsH = nullptr;   // row sums of XQ / HQ (only read when a weight carries a non-zero zero point)
     bool need_rs = false;
     int ffn_fused_min_tokens = 2048;     // bf16: forwards with fewer tokens take the three-kernel feed-forward (SHODH_FFN_FUSED_MIN_TOKENS at creation: 0 = always fused)
-    uint32_t int8_stages = 0xEF;         // bit 7 (per-text scope only): attention output + LayerNorm + both quantising passes inside the per-sequence kernel (qkv_attn_seq_kernel<., TAIL>); bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
+    uint32_t int8_stages = 0x1EF;        // bit 8: weight zero points handled in float arithmetic where a tensor's integers provably stay below 2^24 (same bits, no integer multiply per value); bit 7 (per-text scope only): attention output + LayerNorm + both quantising passes inside the per-sequence kernel (qkv_attn_seq_kernel<., TAIL>); bit 6 (with 2): the FFN-up passes with the epilogue of one token block under the MFMAs of the next (i8_stream_gelu_kernel); bit 5 (with 0): that fusion per sequence instead of per (sequence, head), quantising the layer input itself; bit 0 q|k|v + attention fused, 1 attention output + LayerNorm fused, 2 FFN up as range pass + quantising pass, 3 FFN down + LayerNorm fused
     bool int8_all_fast = false;          // all four on and the shape is the fused kernels' (hidden 384, FFN 1536, max_len <= 256)
     uint32_t *mmr = nullptr;             // range keys of every quantised tensor of a forward: [4 * layers + 2][slots][2], then the GELU trackers [layers][slots][4]; slots = 1 (batch scope) or the sequences (per-text scope)
     size_t mmr_slots = 0;
@@ -1250,22 +1250,28 @@ static int launch_i8_stream_gelu(const S8Args &a, int cus, hipStream_t st) {
         if (n_workers > ((nseq + 7) & ~7)) n_workers = (nseq + 7) & ~7;
         if ((size_t)nseq > (size_t)S8G_PS_TAB * n_workers) { set_error("INT8 per-text forward: %d sequences exceed %d per worker", nseq, S8G_PS_TAB); return SHODH_ERR_UNSUPPORTED; }
         const size_t ldp = lds + S8G_PS_EXTRA;
-        if (a.zw && a.rsA) {
-            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true, true>, ldp));
-            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
+        if (a.zw && a.rsA && a.zw_float) {
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 2, true>, ldp));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 2, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
+        } else if (a.zw && a.rsA) {
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 1, true>, ldp));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 1, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
         } else {
-            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false, true>, ldp));
-            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
+            SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 0, true>, ldp));
+            hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 0, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), ldp, st, a);
         }
         SHODH_HIP_TRY(hipGetLastError());
         return SHODH_OK;
     }
-    if (a.zw && a.rsA) {
-        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, true>, lds));
-        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, true>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+    if (a.zw && a.rsA && a.zw_float) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 2>, lds));
+        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 2>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+    } else if (a.zw && a.rsA) {
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 1>, lds));
+        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 1>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
     } else {
-        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, false>, lds));
-        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, false>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
+        SHODH_TRY(ensure_dynamic_lds((const void *)i8_stream_gelu_kernel<QUANT, 0>, lds));
+        hipLaunchKernelGGL((i8_stream_gelu_kernel<QUANT, 0>), dim3(a.n_groups * n_workers), dim3(S8_NT), lds, st, a);
     }
     SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
@@ -1393,6 +1399,7 @@ static int forward_int8(shodh_embedder *e, int ntok, int nseq, int max_keys, con
             a.mm_rows = ps_rows;
             a.XQ = e->XQ; a.rsA = e->rsX; a.mmA = mmX1; a.Wp = wu.qp; a.wscale = wu.scale; a.rsz = wu.rsz; a.zw = wu.zw; a.bias = w + l.ib;
             a.M = ntok; a.N = I; a.n_groups = I / S8_NF;
+            a.zw_float = (stages & 0x100u) && wu.zw && wu.zw_bound < (1 << 24);      // the zero-point terms as exact float arithmetic (stage bit 8; proven per tensor)
             uint32_t *stats = e->mmr + (size_t)2 * S * n_pairs + (size_t)4 * S * li;     // {nearest pre-activation left of gelu's argmin, right of it, largest}: see gelu_range_finalize_kernel
             a.mm_out = stats;
             const bool piped = stages & 64u;
@@ -1457,6 +1464,14 @@ static int install_qweight_rows(QWeight &q, int row0, int N, const QTensor *t, c
         std::vector<int32_t> zp(N);
         bool any = false;
         for (int n = 0; n < N; ++n) { sc[n] = t->scale[t->n_scale == 1 ? 0 : n]; zp[n] = t->zp[t->n_scale == 1 ? 0 : n]; any |= zp[n] != 0; }
+        for (int n = 0; n < N; ++n) {          // how large the integers of the zero-point epilogue can get for this tensor (see QWeight::zw_bound)
+            const int8_t *row = reinterpret_cast<const int8_t *>(t->q.data()) + (size_t)n * K;
+            int64_t sa = 0, sr = 0;
+            for (int k = 0; k < K; ++k) { sa += row[k] < 0 ? -(int64_t)row[k] : (int64_t)row[k]; sr += row[k]; }
+            const int64_t rsz = sr - (int64_t)K * zp[n];
+            const int64_t b = 128 * sa + 128 * (rsz < 0 ? -rsz : rsz) + 128 * (int64_t)K * (zp[n] < 0 ? -(int64_t)zp[n] : (int64_t)zp[n]);
+            if (b > q.zw_bound) q.zw_bound = b;
+        }
         SHODH_HIP_TRY(hipMemcpy(q.q + (size_t)row0 * K, t->q.data(), (size_t)N * K, hipMemcpyHostToDevice));
         SHODH_HIP_TRY(hipMemcpy(q.scale + row0, sc.data(), (size_t)N * 4, hipMemcpyHostToDevice));
         SHODH_HIP_TRY(hipMemcpy(q.zw_buf + row0, zp.data(), (size_t)N * 4, hipMemcpyHostToDevice));
@@ -1612,7 +1627,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     e->cfg.weights_path = nullptr;       // the caller's string is not ours to keep
     e->quant_scope = cfg->quant_scope;
     if (const char *fv = getenv("SHODH_FFN_FUSED_MIN_TOKENS")) e->ffn_fused_min_tokens = atoi(fv);      // speed only: which feed-forward form small forwards take
-    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0xFFu;       // speed only: which stages run the fused kernels
+    if (const char *sv = getenv("SHODH_INT8_STAGES")) e->int8_stages = (uint32_t)strtoul(sv, nullptr, 0) & 0x1FFu;       // speed only: which stages run the fused kernels
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);

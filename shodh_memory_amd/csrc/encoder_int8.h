@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(const int8_t *__restrict__
 // one quantised weight matrix on the device
 // q: row-major [N][K] signed storage; qp: the same bytes fragment-major (pack_i8_frag_kernel); scale[N]; rowsum[N] = sum_k q; zw[N] = zero points
 // in signed-storage terms (null when all zero: the symmetric case); rsz[N] = rowsum - K * zw; from_export: the bytes are a file's own
-struct QWeight { int8_t *q = nullptr, *qp = nullptr; float *scale = nullptr; int32_t *rowsum = nullptr, *rsz = nullptr, *zw = nullptr /* = zw_buf when any entry is non-zero */, *zw_buf = nullptr; int N = 0, K = 0; bool from_export = false; };
+struct QWeight { int8_t *q = nullptr, *qp = nullptr; float *scale = nullptr; int32_t *rowsum = nullptr, *rsz = nullptr, *zw = nullptr /* = zw_buf when any entry is non-zero */, *zw_buf = nullptr; int N = 0, K = 0; bool from_export = false;
+                 int64_t zw_bound = 0; /* max over the installed rows of 128 sum_k |q| + 128 |rsz| + 128 K |zw|: below 2^24 every partial sum of the zero-point epilogue is an exactly representable float (i8_stream_gelu_kernel<., 2, .>) */ };
 
 // quantises rows [0, N) of `w` (f32 [N][K], device) into dst rows starting at row `row0` (a fused matrix may hold several tensors,
 // each with its own per-tensor scale: the scale array has one entry per output feature)

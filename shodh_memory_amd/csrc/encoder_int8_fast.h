@@ -1187,6 +1187,7 @@ struct S8Args {
     const uint32_t *mmO; int8_t *out_q; int32_t *rs_out;              // SEPI_GELU_QUANT: the output's range (from the RANGE pass), bytes [M][N], row sums (atomicAdd; or null)
     uint32_t *mm_out;                                                  // SEPI_RESID_LN / SEPI_GELU_RANGE: range keys of the output
     int M, N, n_groups;
+    int zw_float;                                                      // i8_stream_gelu_kernel: the zero-point terms in float arithmetic (exact for this tensor: QWeight::zw_bound < 2^24)
     int mm_rows;                                                       // PS kernels: rows per sequence (a multiple of the 64-row tile); range slot of row m = m / mm_rows: mmA / mmO / mm_out are [sequences][2], the GELU stats [sequences][4]
 };
 // range slot (in uint32 words, pairs) of the tile that starts at row m
@@ -1481,7 +1482,11 @@ constexpr int S8G_LDS_RANGE = S8_RED, S8G_LDS_QUANT = S8_RED + 3 * S8_TILE;
 //  * the range pass keeps its three trackers in the wave across the tiles of a sequence and hands them over at the sequence's LAST token block: twelve
 //    waves -> LDS -> wave 0 -> three unconditional atomics per sequence and feature group (stats [sequences][4]).
 constexpr int S8G_PS_TAB = 128, S8G_PS_EXTRA = S8G_PS_TAB * 16 + 12 * 16;      // LDS behind the kernel's own: the table, then [12 waves][4] words of range hand-over
-template <bool QUANT, bool ZW, bool PS = false>
+// ZW: 0 no weight zero points; 1 zero points, integer epilogue (an integer multiply + subtract + add per value before the conversion: the FFN-up passes are
+// VALU-bound, 1.27 -> 1.90 and 0.75 -> 1.32 ms per layer in the per-text scope); 2 zero points whose terms provably stay below 2^24 for THIS tensor
+// (QWeight::zw_bound, from the tensor's own bytes at load time): acc, corr * rowsum and zw * rowsum_a are then exactly representable floats and so is
+// every partial sum, so float(acc) + corr * rsz - zw * rsa is the same number -- two packed fused multiply-adds per pair of values.
+template <bool QUANT, int ZW, bool PS = false>
 __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) {
     constexpr int KS = S8_KS, NS = 2 * KS, D = 3, RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1529,8 +1534,9 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
     // |term| <= 128 * 384 * 128 are integers below 2^23, so is their sum -- the float addition is exact and equals float(acc + term) (one conversion and
     // half a packed add per value instead of an integer add and a conversion). With zero points the terms outgrow that and stay integer.
     for (int i = tid; i < S8_NF; i += S8_NT) {
-        c_ws[i] = a_scale * a.wscale[nbase + i]; c_b[i] = a.bias[nbase + i]; c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
-        if (ZW) c_rz[i] = corr * a.rsz[nbase + i]; else reinterpret_cast<float *>(c_rz)[i] = (float)(corr * a.rsz[nbase + i]);
+        c_ws[i] = a_scale * a.wscale[nbase + i]; c_b[i] = a.bias[nbase + i];
+        if (ZW == 2) reinterpret_cast<float *>(c_zw)[i] = (float)a.zw[nbase + i]; else c_zw[i] = a.zw ? a.zw[nbase + i] : 0;
+        if (ZW == 1) c_rz[i] = corr * a.rsz[nbase + i]; else reinterpret_cast<float *>(c_rz)[i] = (float)(corr * a.rsz[nbase + i]);
     }
     float o_inv = 1.0f, o_zpf = 0.0f;
     if (QUANT && !PS) { const ActQ op = act_params(a.mmO); o_inv = 1.0f / op.scale; o_zpf = (float)op.zp; }
@@ -1622,7 +1628,19 @@ __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) 
         const int nl = wave * 32 + 8 * g + 4 * hi;
         const f32x4q ws = *reinterpret_cast<const f32x4q *>(c_ws + nl), b4 = *reinterpret_cast<const f32x4q *>(c_b + nl);
         f32x2q x2[2];
-        if (ZW) {
+        if (ZW == 2) {
+            const f32x2q nrsa = (f32x2q)(-(float)rsa);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const f32x2q r = *reinterpret_cast<const f32x2q *>(reinterpret_cast<const float *>(c_rz) + nl + 2 * e2), z = *reinterpret_cast<const f32x2q *>(reinterpret_cast<const float *>(c_zw) + nl + 2 * e2);
+                f32x2q f, w, b;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { f[e] = (float)acc[4 * g + 2 * e2 + e]; w[e] = ws[2 * e2 + e]; b[e] = b4[2 * e2 + e]; }
+                f32x2q t = PS ? __builtin_elementwise_fma((f32x2q)tq.corr_f, r, f) : f + r;      // integers below 2^24 at every step (see the template comment): exact
+                t = __builtin_elementwise_fma(nrsa, z, t);
+                x2[e2] = t * (PS ? w * tq.as : w) + b;
+            }
+        } else if (ZW) {
             const i32x4q rz = *reinterpret_cast<const i32x4q *>(c_rz + nl), z4 = *reinterpret_cast<const i32x4q *>(c_zw + nl);
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {

@@ -181,3 +181,19 @@ def test_per_sequence_tail_kernel_equals_the_separate_kernels(S, tmp_path, monke
         out[stages] = e8.encode_ids(ids, mask)
         e8.close()
     assert out["0x6F"].tobytes() == out["0xEF"].tobytes()
+
+
+@pytest.mark.parametrize("scope", ["batch", "per_text"])
+def test_zero_point_terms_in_float_arithmetic_are_the_same_bits(S, tmp_path, monkeypatch, scope):
+    """SHODH_INT8_STAGES bit 8: with an export's weight zero points the FFN-up passes form float(acc) + corr * rsz - zw * rowsum_a in float arithmetic
+    (i8_stream_gelu_kernel<., 2, .>) where the tensor's own bytes prove every partial sum an integer below 2^24 (QWeight::zw_bound), instead of an
+    integer multiply + subtract + add per value before the conversion. Exact either way: the same embeddings, byte for byte."""
+    from shodh_memory_amd import _lib as L
+    out = {}
+    for stages in ("0xEF", "0x1EF"):
+        monkeypatch.setenv("SHODH_INT8_STAGES", stages)
+        e8, _, _, _, vocab = _embedder(S, tmp_path, True, quant_scope=L.QUANT_SCOPE_PER_TEXT if scope == "per_text" else L.QUANT_SCOPE_BATCH)
+        ids, mask = _batch(48, 17, vocab)
+        out[stages] = e8.encode_ids(ids, mask)
+        e8.close()
+    assert out["0xEF"].tobytes() == out["0x1EF"].tobytes()
