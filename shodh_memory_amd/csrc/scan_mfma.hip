@@ -622,54 +622,46 @@ __global__ __launch_bounds__(256, 1) void mfma_scan_big_kernel(MfmaArgs a) {
     if (MODE == MF_MODE_EMIT) drain();
 }
 
-// ---- dimensions 768 and 1024, round 4: two waves per SIMD by splitting K ------------------------------------------------------------
-// mfma_scan_big_kernel leaves a SIMD idle whenever its one wave waits (first A fragments after a barrier, the staging writes, the epilogue):
-// a half tile takes ~5 500 cycles where its 48 MFMAs take 1 536. The resident query fragments are what forces one wave per SIMD -- 32
-// queries x 768 dimensions are 192 registers -- unless the two waves of a SIMD share the SAME 32 queries and split the DIMENSIONS:
-// wave w (0-3: first half of the k-steps, 4-7: second half; w & 3 = the query block, w and w + 4 sit on the same SIMD) holds 96 / 128
-// registers of fragments, reads only its half of every row from LDS (the same LDS bytes in total), runs half of the chain, and the
-// upper wave hands its sixteen partial sums to the lower one through LDS (4 KiB per pair and half tile, double-buffered): the lower wave adds them after the barrier that ends the half tile anyway and runs the unchanged epilogue while the
-// upper wave is already multiplying the next half. The pre-scan's scores are approximate by contract (|s~ - s| <= eps covers any
-// summation order of the fp16 products in f32), so the split changes no result. Data movement: HBM -> registers two halves ahead ->
-// ds_write into the other buffer, both inside the chain. Measured at 1M x 768, 256 queries, one box: 528 us against the one-wave kernel's
-// 586 (the step: 0.632 against 0.685 ms) -- far from the 2x the idle SIMDs suggested: with the loads, the staging writes and the exchange
-// compiled out the chains alone still take 386 us where their MFMAs take 190 (tools/r4_bigdim_ablate.sh). At 1024 dimensions the 128
-// fragment registers + two staging sets do not fit 256 registers (22 / 80 spilled: 1.49 against 0.89 ms): that size keeps the one-wave kernel.
-#ifdef SHODH_BIGPROF     // diagnostic build: per-phase wave cycles of one workgroup
-#define BPROF_DECL long long bp_[6] = {0, 0, 0, 0, 0, 0}, bq_ = clock64();
-#define BPROF_T(i) { const long long t_ = clock64(); bp_[i] += t_ - bq_; bq_ = t_; }
-#else
-#define BPROF_DECL
-#define BPROF_T(i)
-#endif
+// ---- dimensions 768 and 1024, round 4: sixteen queries per wave ---------------------------------------------------------------------------
+// mfma_scan_big_kernel leaves a SIMD idle whenever its one wave waits (first A fragments after a barrier, the staging writes, the epilogue): a half
+// tile takes ~5 500 cycles where its 48 MFMAs take 1 536. What forces one wave per SIMD there is the resident query fragments -- 32 queries x 768
+// dimensions are 192 registers. v_mfma_f32_16x16x32_f16 halves them: a wave holds SIXTEEN queries (dim/32 fragments of 4 registers: 96 / 128),
+// eight waves = the 128 queries of a sub-pass, no exchange between waves, the accumulators of a 32-row half tile are 2 x 4 registers. Every
+// wave reads the whole half tile from LDS (twice the LDS traffic per flop of the 32-query shape: 384 KiB per half tile at 768 dimensions =
+// 1536 LDS cycles at the 256 B/clk of ds_read_b128, as many as the SIMD's 96 MFMAs of 16 cycles take), which the freed registers pay for: the
+// half tiles arrive by LDS-DMA through a ring of three buffers two ahead (768) or two buffers one ahead (1024: 64 KiB per half tile) as in
+// mfma_scan_kernel -- no staging registers, no ds_write pass -- and the DMA pieces are issued inside the chain. Measured at 1M rows, 256 queries, one
+// box, kernel us / step ms: 768 dimensions 474 / 0.577 against the one-wave kernel's 607 / 0.709; 1024 dimensions 557 / 0.668 against 891 / 1.006.
+// (Also built and measured at 768 dimensions, then dropped: the 32-query shape with the DIMENSIONS split over the two waves of a SIMD and their partial
+// sums exchanged through LDS behind the half-tile barrier -- 537 us; it keeps the register staging and does not fit 1024 dimensions.)
+// C layout (16x16): lane l holds query l & 15 and rows 4 (l >> 4) .. + 3 of the 16-row block.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int KSTEPS>
+__host__ __device__ constexpr int big3_nbuf() { return (3 * MFB_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2; }
 template <int MODE, int KSTEPS>
-__global__ __launch_bounds__(512, 1) void mfma_scan_big2_kernel(MfmaArgs a) {
-#ifdef SHODH_BIG_ABL      // diagnostic builds (-DSHODH_BIG_ABL=mask, results invalid): 16 no global loads after the prologue, 32 no staging writes, 64 no exchange, 128 no MFMAs
-    constexpr int BIG_ABL = SHODH_BIG_ABL;
-#else
-    constexpr int BIG_ABL = 0;
-#endif
+__global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
     constexpr int NT = 512;
     constexpr int DIM = KSTEPS * 16;
-    constexpr int CPR = KSTEPS * 2;
+    constexpr int CPR = KSTEPS * 2;            // 16-B chunks per row
     constexpr int PITCH = DIM * 2;
     constexpr int HALF_BYTES = MFB_TR * PITCH;
-    constexpr int NPC = MFB_TR * CPR / NT;     // 16-B pieces per thread and half tile (6)
-    constexpr int KH = KSTEPS / 2;             // k-steps per wave
+    constexpr int NPC = HALF_BYTES / (NT * 16); // DMA pieces per thread and half tile (6 / 8)
+    constexpr int KS32 = KSTEPS / 2;           // k-steps of 32
+    constexpr int NS = 2 * KS32;               // MFMAs per wave and half tile (row block rb = st / KS32)
     constexpr int D = 6, RING = 8;
-    constexpr int XBUFS = 2;
-    static_assert(2 * HALF_BYTES + XBUFS * 16384 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024, "LDS: two half tiles + the double-buffered exchange (768 dimensions)");
+    constexpr int NBUF = big3_nbuf<KSTEPS>();
+    constexpr int PF = NBUF - 1;
+    static_assert(NPC * 6 <= NS, "DMA issue slots: one piece every sixth step");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xch = reinterpret_cast<float *>(smem + 2 * HALF_BYTES);                     // [XBUFS][4 pairs][16 values][64 lanes]
-    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + 2 * HALF_BYTES + XBUFS * 16384);
+    uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + NBUF * HALF_BYTES);
     uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
     uint32_t *qcount = eq_q + MF_EQ_CAP;
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = wave & 3, kh = wave >> 2;
     const uint32_t pass = blockIdx.y >> 1, sub = blockIdx.y & 1;
-    const uint32_t q_local = sub * 128 + qb * 32 + l31;
-    const bool active = (uint32_t)(pass * MF_BPAD + sub * 128 + qb * 32) < a.nq;       // wave-uniform, the same for both waves of a pair
+    const uint32_t q_local = sub * 128 + wave * 16 + l15;
+    const bool active = (uint32_t)(pass * MF_BPAD + sub * 128 + wave * 16) < a.nq;      // wave-uniform
     if ((uint32_t)(pass * MF_BPAD + sub * 128) >= a.nq) {        // a sub-pass of nothing but padding: no reason to stream the corpus for it
         if (MODE != MF_MODE_EMIT)
             for (uint32_t sel = blockIdx.x; sel < a.n_sel_tiles; sel += gridDim.x)
@@ -684,34 +676,53 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big2_kernel(MfmaArgs a) {
             for (int j = 0; j < MF_SLOTS; ++j) sl[j] = KEY_NONE;
         }
     }
-    // piece p = i * NT + tid of a half tile: LDS chunk (row, slot) <- global chunk (row, slot ^ (row & 15) within its group of 16)
-    uint32_t srcoff[NPC], dstoff[NPC];
+    // DMA: piece p = i * NT + tid lands at LDS byte p * 16 of the buffer (lane-linear); the lane that owns chunk (row, slot) fetches global chunk
+    // (row, slot ^ (row & 15) within its group of 16)
+    uint32_t srcoff[NPC];
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
         const int pc = i * NT + tid, row = pc / CPR, slot = pc % CPR;
         const int c = (slot & ~15) | ((slot & 15) ^ (row & 15));
         srcoff[i] = (uint32_t)(row * PITCH + c * 16);
-        dstoff[i] = (uint32_t)(row * PITCH + slot * 16);
     }
     const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
     const size_t tile_bytes_g = (size_t)a.tile_stride * MF_TR * DIM * 2;
-
-    half8 bq[KH];
-    {
-        const half8 *qp = reinterpret_cast<const half8 *>(a.q_h) + ((size_t)pass * 8 + sub * 4 + qb) * KSTEPS * 64 + lane;
+    const uint32_t wave_lds = smem_lds + (uint32_t)wave * 1024u;
+    const uint32_t step = gridDim.x;
+    const uint32_t n_mine = blockIdx.x < a.n_sel_tiles ? (a.n_sel_tiles - blockIdx.x + step - 1) / step : 0u;
+    const uint32_t n_half = 2 * n_mine;
+    auto src_of = [&](uint32_t u) -> const unsigned char * {
+        const uint32_t uc = u < n_half ? u : (n_half ? n_half - 1 : 0);      // past the end: a harmless repeat of the last half
+        const uint32_t sel = blockIdx.x + (uc >> 1) * step;
+        return uniform_ptr(rows_b + (size_t)sel * tile_bytes_g + (size_t)(uc & 1) * HALF_BYTES);      // the shadow slab is padded to whole tiles
+    };
+    if (n_half) {
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks) bq[ks] = qp[(kh * KH + ks) * 64];
+        for (int b = 0; b < PF; ++b) {
+            const unsigned char *src = src_of(b);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * HALF_BYTES + i * (NT * 16));
+        }
+    }
+    // resident B fragments of the 16x16x32 shape, gathered from the 32x32x16 fragment-major copy of the queries (convert_queries_kernel): lane l wants
+    // query l & 15 of its wave, k = 32 ks + 8 (l >> 4) .. + 8 = k-step 2 ks + (l >> 5) of the 16-wide layout, half (l >> 4) & 1
+    half8 bq[KS32];
+    {
+        const uint32_t ql = sub * 128 + wave * 16 + l15;
+        const half8 *qp = reinterpret_cast<const half8 *>(a.q_h) + ((size_t)pass * 8 + (ql >> 5)) * KSTEPS * 64 + (ql & 31) + 32 * (lg & 1);
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) bq[ks] = qp[(2 * ks + (lg >> 1)) * 64];
     }
     float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
     if (a.ablate & 8u) thr_l = __builtin_inff();
-    const int sw = l31 & 15;
-    int aoff[8];
+    // A fragment of row block rb, k-step ks: row rb * 16 + l15, chunk 4 ks + lg, swizzled by row & 15 = l15 inside its group of 16 chunks
+    int aoff[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) aoff[j] = l31 * PITCH + (((2 * j + hi) ^ sw) << 4) + (kh * KH >> 3) * 256;      // (KH is a multiple of 8: the wave's k-steps start at a 256-byte group)
+    for (int j = 0; j < 4; ++j) aoff[j] = l15 * PITCH + (((4 * j + lg) ^ l15) << 4);
 
-    // survivors: the lower wave of a pair owns the queue and the candidate slots of its query block (as the one wave did in mfma_scan_big_kernel)
-    uint64_t *wq_key = eq_key + qb * MF_WQ_CAP;
-    uint32_t *wq_q = eq_q + qb * MF_WQ_CAP;
+    // survivors: wave-private queues and the workgroup's candidate slots, as in mfma_scan_kernel
+    uint64_t *wq_key = eq_key + wave * MF_WQ_CAP;
+    uint32_t *wq_q = eq_q + wave * MF_WQ_CAP;
     uint32_t wq_n = 0;
     uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;
     auto emit_direct = [&](uint64_t key, uint32_t ql) {
@@ -731,19 +742,19 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big2_kernel(MfmaArgs a) {
         for (uint32_t i = lane; i < n; i += 64) emit_direct(wq_key[i], wq_q[i]);
         wq_n = 0;
     };
-    auto emit_block = [&](const floatx16 &c, uint64_t brow0) {
-        const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
-        const uint32_t lim = left < 64 ? (uint32_t)left : 64u;
+    // the survivors of one 16-row block (entered by the whole wave): value r of a lane is row 4 lg + r
+    auto emit_block = [&](const floatx4 &c, uint64_t brow0) {
+        const uint64_t left = a.n_rows > brow0 + 4 * lg ? a.n_rows - (brow0 + 4 * lg) : 0;
+        const uint32_t lim = left < 4 ? (uint32_t)left : 4u;
         const uint32_t wq_n0 = wq_n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t roff = (r & 3) + 8 * (r >> 2);
-            const bool hit = c[r] >= thr_l && roff < lim;
+        for (int r = 0; r < 4; ++r) {
+            const bool hit = c[r] >= thr_l && (uint32_t)r < lim;
             const uint64_t b = __builtin_amdgcn_ballot_w64(hit);
             if (__builtin_expect(b != 0, 0)) {
                 const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
                 if (hit && slot < (uint32_t)MF_WQ_CAP) {
-                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * lg + r));
                     wq_q[slot] = q_local;
                 }
                 wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
@@ -752,147 +763,80 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big2_kernel(MfmaArgs a) {
         if (__builtin_expect(wq_n > (uint32_t)MF_WQ_CAP, 0)) {      // a dense block: straight to the candidate slots (see mfma_scan_kernel)
             wq_n = wq_n0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t roff = (r & 3) + 8 * (r >> 2);
-                if (c[r] >= thr_l && roff < lim) emit_direct(make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff)), q_local);
-            }
+            for (int r = 0; r < 4; ++r)
+                if (c[r] >= thr_l && (uint32_t)r < lim) emit_direct(make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * lg + r)), q_local);
         }
     };
 
-    const uint32_t step = gridDim.x;
-    const uint32_t n_mine = blockIdx.x < a.n_sel_tiles ? (a.n_sel_tiles - blockIdx.x + step - 1) / step : 0u;
-    const uint32_t n_half = 2 * n_mine;
-    u32x4 stg_a[NPC], stg_b[NPC];
-    auto src_of = [&](uint32_t u) -> const unsigned char * {
-        const uint32_t uc = u < n_half ? u : n_half - 1;              // past the end: a harmless repeat of the last half
-        const uint32_t sel = blockIdx.x + (uc >> 1) * step;
-        return rows_b + (size_t)sel * tile_bytes_g + (size_t)(uc & 1) * HALF_BYTES;      // the shadow slab is padded to whole tiles
-    };
-    auto stage = [&](uint32_t buf, const u32x4 *stg) {
-        if (BIG_ABL & 32) return;
-#pragma unroll
-        for (int i = 0; i < NPC; ++i) *reinterpret_cast<u32x4 *>(smem + buf * HALF_BYTES + dstoff[i]) = stg[i];
-    };
-    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float tile_m = -__builtin_inff();
-    // the wave's half of the chain over LDS buffer `h`; the upper wave leaves its sums in the exchange area. In the MFMAs' shadows (all eight waves run
-    // the same phase at the same time, so whatever sits between two barriers outside the chain is paid in full: the staging writes and the loads cost
-    // 128 + 116 us of the kernel's 552 at 1M x 768 that way): every fourth step one 16-byte piece of the half tile loaded a half tile ago goes to the
-    // OTHER LDS buffer (free since the last barrier), and one piece of the half tile two ahead is requested from HBM.
-    auto chain = [&](uint32_t h, uint32_t u, const u32x4 *stg_w, u32x4 *stg_l, const unsigned char *src_l) -> floatx16 {
-        const unsigned char *buf = smem + h * HALF_BYTES;
-        unsigned char *wbuf = smem + (h ^ 1) * HALF_BYTES;
-        floatx16 acc = zero16;
-        half8 ring[RING];
-#pragma unroll
-        for (int st = 0; st < D; ++st) ring[st % RING] = *reinterpret_cast<const half8 *>(buf + aoff[st & 7] + (st >> 3) * 256);
-#pragma unroll
-        for (int st = 0; st < KH; ++st) {
-            if (st + D < KH) ring[(st + D) % RING] = *reinterpret_cast<const half8 *>(buf + aoff[(st + D) & 7] + ((st + D) >> 3) * 256);
-            if (BIG_ABL & 128) acc[st & 15] += (float)ring[st % RING][0]; else
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], acc, 0, 0, 0);
-            if ((st & 3) == 1 && (st >> 2) < NPC && !(BIG_ABL & 32)) *reinterpret_cast<u32x4 *>(wbuf + dstoff[st >> 2]) = stg_w[st >> 2];
-            if ((st & 3) == 3 && (st >> 2) < NPC && !(BIG_ABL & 16)) stg_l[st >> 2] = *reinterpret_cast<const u32x4 *>(src_l + srcoff[st >> 2]);
-            __builtin_amdgcn_sched_barrier(0);      // keeps the A fragments D steps ahead
-        }
-        if (BIG_ABL & 64) return acc;
-        if (kh) {
-            float *x = xch + ((size_t)((u & 1) * 4 + qb) * 16) * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r * 64] = acc[r];
-        }
-        return acc;
-    };
-    // lower wave, after the barrier that ends half tile u: add the partner's sums, then the epilogue of mfma_scan_big_kernel
-    auto finish = [&](floatx16 acc, uint32_t h, uint32_t u, uint32_t sel) {
-        const float *x = xch + ((size_t)((u & 1) * 4 + qb) * 16) * 64 + lane;
-        if (!(BIG_ABL & 64))
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = acc[r] + x[r * 64];
-        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + h * MFB_TR;
-        if (MODE == MF_MODE_EMIT) {
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            if (__builtin_amdgcn_ballot_w64(m >= thr_l) != 0) emit_block(acc, row0);
-            if (wq_n >= (uint32_t)MF_WQ_CAP / 2) drain();
-        } else {
-            float m = -__builtin_inff();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint64_t g0 = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (g0 < a.n_rows) m = fmaxf(m, acc[r]);
-            }
-            tile_m = fmaxf(tile_m, m);
-            if (h) {
-                tile_m = fmaxf(tile_m, __shfl_xor(tile_m, 32));
-                if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = tile_m * MF_INV_SCALE2;
-                tile_m = -__builtin_inff();
-            }
-        }
-    };
-    if (n_mine) {
-        {
-            const unsigned char *s0 = src_of(0), *s1 = src_of(1);
-#pragma unroll
-            for (int i = 0; i < NPC; ++i) stg_a[i] = *reinterpret_cast<const u32x4 *>(s0 + srcoff[i]);
-#pragma unroll
-            for (int i = 0; i < NPC; ++i) stg_b[i] = *reinterpret_cast<const u32x4 *>(s1 + srcoff[i]);
-        }
-        stage(0, stg_a);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    floatx16 pend = zero16;                          // lower wave: its own sums of the half tile whose partner sums arrive behind the barrier
-    BPROF_DECL
-    static_assert(NPC <= KH / 4, "one staging write and one load per four chain steps");
-    for (uint32_t i = 0; i < n_mine; ++i) {
-        const uint32_t sel = blockIdx.x + i * step;
-        {   // half 0 from buffer 0; set B (half 1 of this tile) goes to buffer 1, set A takes half 0 of the next tile
-            const unsigned char *sn = src_of(2 * i + 2);
-            BPROF_T(0)
-            if (active) {
-                if (!kh && i > 0) finish(pend, 1, 2 * i - 1, sel - step);
-                BPROF_T(1)
-                pend = chain(0, 2 * i, stg_b, stg_a, sn);
-                BPROF_T(2)
-            } else {
-                if (MODE != MF_MODE_EMIT && !kh && i > 0 && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + (sel - step)) * MF_BPAD + q_local] = 0.0f;      // padding queries: defined values
-                stage(1, stg_b);
+    const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float tile_m = -__builtin_inff();
+    uint32_t cur = 0;
+    for (uint32_t u = 0; u < n_half; ++u) {
+        const uint32_t sel = blockIdx.x + (u >> 1) * step, h = u & 1;
+        const unsigned char *buf = smem + cur * HALF_BYTES;
+        const uint32_t pfb = cur + PF >= NBUF ? cur + PF - NBUF : cur + PF;
+        const unsigned char *psrc = src_of(u + PF);
+        const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * HALF_BYTES));
+        const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + h * MFB_TR;
+        if (active) {
+            floatx4 acc0 = zero4, acc1 = zero4;
+            half8 ring[RING];
+            auto rd = [&](int st) {
+                const int rb = st / KS32, ks = st % KS32;
+                ring[st % RING] = *reinterpret_cast<const half8 *>(buf + rb * 16 * PITCH + aoff[ks & 3] + (ks >> 2) * 256);
+            };
 #pragma unroll
-                for (int j = 0; j < NPC; ++j) stg_a[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
-            }
-            BPROF_T(3)
-            __syncthreads();
-            BPROF_T(4)
-        }
-        {   // half 1 from buffer 1; set A goes to buffer 0, set B takes half 1 of the next tile
-            const unsigned char *sn = src_of(2 * i + 3);
-            BPROF_T(0)
-            if (active) {
-                if (!kh) finish(pend, 0, 2 * i, sel);
-                BPROF_T(1)
-                pend = chain(1, 2 * i + 1, stg_a, stg_b, sn);
-                BPROF_T(2)
-            } else {
-                stage(0, stg_a);
+            for (int st = 0; st < D; ++st) rd(st);
 #pragma unroll
-                for (int j = 0; j < NPC; ++j) stg_b[j] = *reinterpret_cast<const u32x4 *>(sn + srcoff[j]);
+            for (int st = 0; st < NS; ++st) {
+                if (st + D < NS) rd(st + D);
+                if (st < KS32) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[st % RING], bq[st], acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[st % RING], bq[st - KS32], acc1, 0, 0, 0);
+                if (st % 6 == 2 && st / 6 < NPC) glds16(psrc, srcoff[st / 6], pdst + (st / 6) * (NT * 16));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            BPROF_T(3)
-            __syncthreads();
-            BPROF_T(4)
+            if (MODE == MF_MODE_EMIT) {
+                const float m0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])), m1 = fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3]));
+                bool emitted = false;
+                if (__builtin_amdgcn_ballot_w64(m0 >= thr_l) != 0) { emit_block(acc0, row0); emitted = true; }
+                if (__builtin_amdgcn_ballot_w64(m1 >= thr_l) != 0) { emit_block(acc1, row0 + 16); emitted = true; }
+                if (wq_n >= (uint32_t)MF_WQ_CAP / 2) { drain(); emitted = true; }
+                if (emitted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores / atomics share the VM counter with the DMA: nothing of them may be pending at the counted wait
+            } else {
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t g0 = row0 + 4 * lg + r;
+                    if (g0 < a.n_rows) m = fmaxf(m, acc0[r]);
+                    if (g0 + 16 < a.n_rows) m = fmaxf(m, acc1[r]);
+                }
+                tile_m = fmaxf(tile_m, m);
+                if (h) {
+                    tile_m = fmaxf(tile_m, __shfl_xor(tile_m, 16));
+                    tile_m = fmaxf(tile_m, __shfl_xor(tile_m, 32));
+                    if (lg == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = tile_m * MF_INV_SCALE2;
+                    tile_m = -__builtin_inff();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * (NT * 16));
+            if (MODE != MF_MODE_EMIT && h && lane < 16) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;      // padding queries: defined values
         }
+        // hand-over: the next half tile must have landed (with three buffers the pieces issued during this half tile may stay in flight)
+        // (the sample pass stores its maxima every other half tile: stores and loads share the counter and may return out of order with each other, so it waits for everything)
+        if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
-    if (n_mine) {
-        const uint32_t sel = blockIdx.x + (n_mine - 1) * step;
-        if (active) { if (!kh) finish(pend, 1, 2 * n_mine - 1, sel); }
-        else if (MODE != MF_MODE_EMIT && !kh && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;
-    }
-    if (MODE == MF_MODE_EMIT && !kh) drain();
-#ifdef SHODH_BIGPROF
-    if (MODE == MF_MODE_EMIT && blockIdx.x == 37 && blockIdx.y == 0 && lane == 0 && n_half)
-        printf("bigprof wave %d halves %u | per half: issue loads %lld finish %lld chain %lld stage %lld barrier %lld\n", wave, n_half, bp_[0] / n_half, bp_[1] / n_half, bp_[2] / n_half, bp_[3] / n_half, bp_[4] / n_half);
-#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the clamped tail DMA before the LDS is released
+    if (MODE == MF_MODE_EMIT) drain();
 }
 
 // ---- conversions ------------------------------------------------------------------------------------
@@ -1584,24 +1528,23 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
     if (a.dim > 512) {
         dim3 grid((uint32_t)p.grid_x, p.passes * 2);
         if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
-        // 768 dimensions: the K-split kernel (two waves per SIMD; 528 against 586 us per 256 queries at 1M rows on one box). At 1024 dimensions its 128
-        // fragment registers + two staging sets do not fit 256 registers (22 / 80 spilled, 1.49 against 0.89 ms): the round-2 kernel stays.
-        // SHODH_BIG_SCAN_V1=1 (diagnostic): the round-2 kernel at 768 dimensions too.
-        static const int big_v1 = getenv("SHODH_BIG_SCAN_V1") ? atoi(getenv("SHODH_BIG_SCAN_V1")) : 0;
-        if (!big_v1 && p.ksteps == 48) {
+        static const int big_v1 = getenv("SHODH_BIG_SCAN_V1") ? atoi(getenv("SHODH_BIG_SCAN_V1")) : 0;      // diagnostic: 1 = the round-2 kernel (one wave per SIMD)
+        if (!big_v1) {
             const size_t half = (size_t)MFB_TR * a.dim * 2;
-            const size_t lds2 = 2 * half + 2 * 16384 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
-#define SHODH_LAUNCH_BIG2(KS)                                                                                       \
+            const size_t nb = (3 * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
+            const size_t lds3 = nb * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
+#define SHODH_LAUNCH_BIG3(KS)                                                                                       \
     case KS:                                                                                                       \
-        SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big2_kernel<MODE, KS>, lds2));                         \
-        if (ev0 && ev1) hipExtLaunchKernelGGL((mfma_scan_big2_kernel<MODE, KS>), grid, dim3(512), (uint32_t)lds2, st, ev0, ev1, 0u, a);  \
-        else hipLaunchKernelGGL((mfma_scan_big2_kernel<MODE, KS>), grid, dim3(512), lds2, st, a);                   \
+        SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big3_kernel<MODE, KS>, lds3));                         \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((mfma_scan_big3_kernel<MODE, KS>), grid, dim3(512), (uint32_t)lds3, st, ev0, ev1, 0u, a);  \
+        else hipLaunchKernelGGL((mfma_scan_big3_kernel<MODE, KS>), grid, dim3(512), lds3, st, a);                   \
         break;
             switch (p.ksteps) {
-                SHODH_LAUNCH_BIG2(48)
+                SHODH_LAUNCH_BIG3(48)
+                SHODH_LAUNCH_BIG3(64)
                 default: set_error("MFMA scan: unsupported dim %u", a.dim); return SHODH_ERR_UNSUPPORTED;
             }
-#undef SHODH_LAUNCH_BIG2
+#undef SHODH_LAUNCH_BIG3
             SHODH_HIP_TRY(hipGetLastError());
             return SHODH_OK;
         }

@@ -60,13 +60,11 @@ def test_encoder_kernels_do_not_spill():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_scan_kernels_do_not_spill():
     res = resources("scan_mfma.hip")
-    for parts in [("mfma_scan_kernelILi1ELi24",), ("mfma_scan_kernelILi0ELi24",), ("solo_scan_kernel",), ("final_stage_kernel",), ("mfma_scan_big2_kernelILi0ELi48",)]:
+    for parts in [("mfma_scan_kernelILi1ELi24",), ("mfma_scan_kernelILi0ELi24",), ("solo_scan_kernel",), ("final_stage_kernel",), ("mfma_scan_big3_kernel",)]:
         for k in find(res, *parts):
             assert res[k].get("spill", 0) == 0, (k, res[k])        # (the final stage keeps a small indexed array in scratch: not a spill)
-    # the 768-dimension K-split kernel in its emit form parks a few loop-invariant pointers of the (rare) survivor walk: stored before the first MFMA,
-    # reloaded only inside emit_block -- nothing in the chains
-    for k in find(res, "mfma_scan_big2_kernelILi1ELi48"):
-        assert res[k].get("spill", 0) <= 8, (k, res[k])
+    for k in find(res, "mfma_scan_big3_kernel"):                   # sixteen queries per wave: two waves per SIMD (that is the point of the shape)
+        assert res[k]["vgprs"] <= 256, (k, res[k])
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
