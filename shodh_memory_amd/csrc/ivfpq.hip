@@ -327,7 +327,11 @@ typedef float f32x2q __attribute__((ext_vector_type(2)));
 #ifndef SHODH_LM_QB
 #define SHODH_LM_QB 4
 #endif
+#ifndef SHODH_LM_PRUNE
+#define SHODH_LM_PRUNE 1
+#endif
 constexpr int LM_NT = 1024, LM_U = SHODH_LM_U, LM_QB = SHODH_LM_QB, LM_MT = 24;
+constexpr bool LM_PRUNE = SHODH_LM_PRUNE;      // partial-sum pruning (see adc_list_kernel)
 constexpr int LM_TILE = LM_MT * 256 * 8;                       // 48 KiB: 24 sub-quantisers x 256 entries x 2 queries
 constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM)
 constexpr int LM_LDS = 2 * LM_TILE + 2 * LM_QB * 8 + 2 * LM_QB * 4;
@@ -608,6 +612,11 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
         LPROF_T(1)
         for (uint32_t j = 0; j < npair; ++j) {
             const uint32_t qa = pql[2 * j], qb = pql[2 * j + 1];
+            // keys at or under these bounds are candidates; a posting whose PARTIAL sums already lie above both (every table entry is a sum of squares: the
+            // sums only grow) can never become one, and a wave whose 64 postings are all in that state skips the rest of their lookups
+            const uint64_t ba = bql[2 * j], bb = bql[2 * j + 1];
+            const uint32_t da = (uint32_t)(ba >> 32), db = (uint32_t)(bb >> 32);
+            const bool two = qb != qa;
             f32x2q sum[LM_U];
 #pragma unroll
             for (int u = 0; u < LM_U; ++u) { sum[u][0] = 0.0f; sum[u][1] = 0.0f; }
@@ -624,14 +633,19 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
                         asm volatile("" : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]));
 #pragma unroll
                         for (int h = 0; h < 3; ++h) {                        // eight gathers in flight, then their adds strictly in m order (pq.rs:358-368)
-                            f32x2q tv[8];
+                            // (from the 16th sub-quantiser on: a lane whose partial sums lie above both bounds stops looking up -- its sums stay partial, above the
+                            // bounds, and are never pushed; fewer active lanes are also fewer bank conflicts for the others)
+                            const bool alive = !LM_PRUNE || !(t == 1 || h == 2) || (valid[u] && (order_key(sum[u][0]) <= da || order_key(sum[u][1]) <= db));
+                            if (alive) {
+                                f32x2q tv[8];
 #pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) {
-                                const uint32_t c = (word[2 * h + (jj >> 2)] >> ((jj & 3) * 8)) & 0xFFu;
-                                tv[jj] = *reinterpret_cast<const f32x2q *>(tb + (8 * h + jj) * 2048 + c * 8);
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    const uint32_t c = (word[2 * h + (jj >> 2)] >> ((jj & 3) * 8)) & 0xFFu;
+                                    tv[jj] = *reinterpret_cast<const f32x2q *>(tb + (8 * h + jj) * 2048 + c * 8);
+                                }
+#pragma unroll
+                                for (int jj = 0; jj < 8; ++jj) sum[u] = sum[u] + tv[jj];
                             }
-#pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) sum[u] = sum[u] + tv[jj];
                         }
                     }
                 }
@@ -643,9 +657,6 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
             }
             // keys under the query's bound join its candidates
             // (distance first: the 32-bit order keys decide all but the rare equal-distance case; most lanes have nothing to push)
-            const uint64_t ba = bql[2 * j], bb = bql[2 * j + 1];
-            const bool two = qb != qa;
-            const uint32_t da = (uint32_t)(ba >> 32), db = (uint32_t)(bb >> 32);
 #pragma unroll
             for (int u = 0; u < LM_U; ++u) {
                 if (valid[u]) {

@@ -648,7 +648,10 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
     constexpr int NPC = HALF_BYTES / (NT * 16); // DMA pieces per thread and half tile (6 / 8)
     constexpr int KS32 = KSTEPS / 2;           // k-steps of 32
     constexpr int NS = 2 * KS32;               // MFMAs per wave and half tile (row block rb = st / KS32)
-    constexpr int D = 6, RING = 8;
+#ifndef SHODH_BIG3_D      // (diagnostic builds time other fragment distances)
+#define SHODH_BIG3_D 6
+#endif
+    constexpr int D = SHODH_BIG3_D, RING = 8;
     constexpr int NBUF = big3_nbuf<KSTEPS>();
     constexpr int PF = NBUF - 1;
     static_assert(NPC * 6 <= NS, "DMA issue slots: one piece every sixth step");
