@@ -1613,6 +1613,7 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
     uint32_t nt = (nt_env == 256 || nt_env == 512) ? (uint32_t)nt_env : (nq >= 1024 ? 256u : 512u);
     uint32_t tcap = 0;
     size_t flds = 0;
+    const uint32_t stage_cap0 = stage_cap, fcap0 = fcap;
     for (;;) {
         // the selection buffer takes up to 2 * nt pushes between two compaction checks on top of the k keys it keeps (topk.h: a push past the capacity is dropped)
         tcap = k + 2 * nt;
@@ -1622,7 +1623,13 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
         // qs[dim] | keys[tcap] | mins[2 nt] | ekeys[fcap] | thr | flist[fcap] | cnt, fcnt | region | sel32 | skey, srow [stage_cap]   (every part a multiple of 8 B; region at 16 B)
         flds = (size_t)dim * 4 + (size_t)tcap * 8 + (size_t)2 * nt * 8 + (size_t)fcap * 8 + 8 + (size_t)fcap * 4 + 8 +
                final_stage_region_bytes(dim, order, ch_rows, nt) + (size_t)KTH_SCRATCH_U32 * 4 + (size_t)stage_cap * 8 + 16;
-        if (nt == 512 && flds > 160 * 1024) { nt = 256; continue; }
+        if (nt == 512 && flds > 160 * 1024) {
+            // 768 dimensions: the 512-thread layout misses 160 KiB by the generous key staging and re-score list of small batches -- halve them first
+            // (a query that outgrows them re-reads keys from global memory or takes the level-2 filter, like any other overflow): 36 -> 20 us per step
+            if (stage_cap > 1024 && k <= 128) { stage_cap = 1024; continue; }
+            if (fcap > 1024 && 4u * k <= 1024u) { fcap = 1024; continue; }
+            nt = 256; stage_cap = stage_cap0; fcap = fcap0; continue;
+        }
         break;
     }
     FinalArgs f{rows, dim, d_q, nq, k, tcap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
