@@ -336,15 +336,33 @@ constexpr int LM_TILE = LM_MT * 256 * 8;                       // 48 KiB: 24 sub
 constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM)
 constexpr int LM_LDS = 2 * LM_TILE + 2 * LM_QB * 8 + 2 * LM_QB * 4;
 
-__global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict__ q, const float *__restrict__ codebook, uint32_t dim, float *__restrict__ tables) {
-    // build_distance_table (pq.rs:329-351) for query blockIdx.x: entry e = m * 256 + c, 8 sequential terms (the arithmetic of adc_scan_kernel's table)
-    const uint32_t e = blockIdx.y * 1024 + threadIdx.x, m = e >> 8;
-    const float *cb = codebook + (size_t)e * 8;
-    const float *qq = q + (size_t)blockIdx.x * dim + m * 8;
-    float sum = 0.0f;
+constexpr int LM_TQ = 8;      // queries per workgroup of the table kernel (a codebook row is loaded once for all of them)
+__global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict__ q, const float *__restrict__ codebook, uint32_t dim, uint32_t nq, float *__restrict__ tables) {
+    // build_distance_table (pq.rs:329-351) for queries blockIdx.x * LM_TQ ..: entry e = m * 256 + c, 8 sequential terms (the arithmetic of adc_scan_kernel's table)
+    __shared__ float qs[LM_TQ][32];                              // the four sub-vectors (m = 4 blockIdx.y ..) of each query
+    const uint32_t e = blockIdx.y * 1024 + threadIdx.x, m = e >> 8, q0 = blockIdx.x * LM_TQ;
+    if (threadIdx.x < LM_TQ * 32) {
+        const uint32_t qi = threadIdx.x >> 5, j = threadIdx.x & 31;
+        qs[qi][j] = (q0 + qi < nq) ? q[(size_t)(q0 + qi) * dim + blockIdx.y * 32 + j] : 0.0f;
+    }
+    float cb[8];
+    {
+        const f32x4q *cp = reinterpret_cast<const f32x4q *>(codebook + (size_t)e * 8);
+        const f32x4q c0 = cp[0], c1 = cp[1];
+        cb[0] = c0[0]; cb[1] = c0[1]; cb[2] = c0[2]; cb[3] = c0[3]; cb[4] = c1[0]; cb[5] = c1[1]; cb[6] = c1[2]; cb[7] = c1[3];
+    }
+    __syncthreads();
+    const float *qq0 = &qs[0][(m & 3) * 8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = qq[j] - cb[j]; sum = sum + d * d; }
-    tables[(size_t)blockIdx.x * 12288 + e] = sum;
+    for (int qi = 0; qi < LM_TQ; ++qi) {
+        if (q0 + qi < nq) {
+            const float *qq = qq0 + qi * 32;
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = qq[j] - cb[j]; sum = sum + d * d; }
+            tables[(size_t)(q0 + qi) * 12288 + e] = sum;
+        }
+    }
 }
 
 // pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (+ work items), fill
@@ -884,7 +902,7 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             const float *qb = d_q + (size_t)b * s->dim;
             const uint32_t *pids = probe_ids + (size_t)b * nprobe, *pcnt = probe_cnt + b;
             SHODH_HIP_TRY(hipMemsetAsync(lcnt, 0, (size_t)(s->P + 1 + m) * 4, st));      // list counters + candidate counters (adjacent)
-            hipLaunchKernelGGL(adc_table_kernel, dim3(m, 12), dim3(1024), 0, st, qb, s->codebook, s->dim, tables);
+            hipLaunchKernelGGL(adc_table_kernel, dim3((m + LM_TQ - 1) / LM_TQ, 12), dim3(1024), 0, st, qb, s->codebook, s->dim, m, tables);
             NearArgs na{tables, s->list_off, s->ids, s->codes, pids, pcnt, nprobe, k, cap_near, s->P, bound_max, bound, lcnt};
             hipLaunchKernelGGL(adc_bound_kernel, dim3(m), dim3(LM_NEAR_NT), lds_near, st, na);
             const uint32_t np = m * nprobe;
