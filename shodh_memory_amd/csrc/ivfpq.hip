@@ -415,7 +415,10 @@ __global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32
 // through the TopKBuf and are ranked by counting: bound[q] = the k-th best key seen (KEY_NONE: fewer than k postings seen, no bound). The fewer postings
 // stand behind the bound, the more keys of the other lists pass it (about k * probed postings / postings behind the bound on featureless data).
 // The kernel also counts the query's pairs per list for the list-major pass (every probed list: the postings scored here are scored again there).
-constexpr int LM_NEAR_NT = 512, LM_NEAR_U = 6, LM_NEAR_MAXL = 64;      // (75 KiB of LDS at k = 10: two workgroups per CU)
+#ifndef SHODH_LM_NEAR_U      // (diagnostic builds: postings per lane behind the bound)
+#define SHODH_LM_NEAR_U 6
+#endif
+constexpr int LM_NEAR_NT = 512, LM_NEAR_U = SHODH_LM_NEAR_U, LM_NEAR_MAXL = 64;      // (75 KiB of LDS at k = 10: two workgroups per CU)
 struct NearArgs {
     const float *tables; const uint64_t *list_off; const uint32_t *ids; const uint8_t *codes;
     const uint32_t *probes; const uint32_t *probe_cnt;
