@@ -1488,7 +1488,7 @@ constexpr int S8G_PS_TAB = 128, S8G_PS_EXTRA = S8G_PS_TAB * 16 + 12 * 16;      /
 // every partial sum, so float(acc) + corr * rsz - zw * rsa is the same number -- two packed fused multiply-adds per pair of values.
 template <bool QUANT, int ZW, bool PS = false>
 __global__ __launch_bounds__(768, 3) void i8_stream_gelu_kernel(const S8Args a) {
-    constexpr int KS = S8_KS, NS = 2 * KS, D = 3, RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles)
+    constexpr int KS = S8_KS, NS = 2 * KS, D = (ZW == 2 ? 2 : 3), RING = 4, PF = S8_NBUF - 1, NPC = 2, OUT0 = S8_RED;      // (fragments three steps ahead: with the epilogue between the MFMAs a step is > 100 cycles; two in the float zero-point form, whose epilogue holds more registers: 9 / 14 -> 4 spilled in the quantising pass, 40.8 -> 40.3 ms per forward)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
