@@ -18,6 +18,11 @@
  *  - thread-safety mirrors the reference's RwLock use (retrieval.rs:680,:712,:912):
  *    *_search / *_encode may run concurrently on one handle; *_add / *_build /
  *    *_mark_deleted / *_clear_deleted take the handle exclusively.
+ *  - concurrent host-pointer calls that carry ONE item (a query, a text) -- the only call pattern the
+ *    reference's `recall` / `remember` have (recall.rs:512-513, retrieval.rs:912-918,
+ *    minilm.rs:889-897) -- are coalesced: calls that arrive while a device pass is in flight share
+ *    the next pass and every caller gets the bytes its own call would have produced
+ *    (*_set_coalesce, SHODH_COALESCE=0 to turn it off). A caller that is alone is not delayed.
  *  - the library is HIP/gfx950 only.  There is no CPU fallback: without a usable device every
  *    create call fails with SHODH_ERR_DEVICE.
  */
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SHODH_HIP_ABI_VERSION 4
+#define SHODH_HIP_ABI_VERSION 5
 
 typedef enum {
     SHODH_OK = 0,
@@ -103,8 +108,9 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out);    /* Vam
 void shodh_index_destroy(shodh_index *idx);
 /* add_vector (vamana.rs:853-974): appends n rows, ids are dense and sequential; *first_id_out =
  * id of rows[0] (= len() before the call, + id_base). rows: host [n][dim] row-major f32.
- * SHODH_SCAN_GRAPH only: SHODH_ERR_UNSUPPORTED with "frontier overflowed" means the rows WERE added but a walk met thousands of
- * equidistant rows and the graph may differ from the reference's -- do not retry the call. */
+ * SHODH_SCAN_GRAPH only: when a walk meets thousands of equidistant rows and its frontier overflows, the rows ARE added and the call returns
+ * SHODH_OK (an error status would invite a retry that adds them twice); shodh_index_graph_overflowed() then reports 1 and
+ * shodh_last_error() holds the message -- see below. */
 int shodh_index_add(shodh_index *idx, const float *rows, uint64_t n, uint32_t *first_id_out);
 /* SHODH_SCAN_GRAPH: 1 when some add since the last build met a walk whose frontier outgrew its array (thousands of equidistant rows): the rows
  * WERE added and the add call returned SHODH_OK -- a walk cannot be undone, and an error status would invite a retry that adds them twice --
@@ -130,6 +136,13 @@ int shodh_index_brute_force_search(shodh_index *idx, const float *q, uint32_t nq
  * equidistant rows; the answer may then differ from the reference's) -- mask it off; the host-pointer entry point reports it as an error */
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k,
                               uint32_t *d_ids, float *d_dist, uint32_t *d_counts, void *stream);
+/* Coalescing front of the host-pointer search (on by default): concurrent shodh_index_search calls with nq <= 32 on a FLAT (non-graph) or IVF-PQ
+ * index that arrive while a pass is in flight are gathered into ONE pass of up to 256 queries (k = the largest asked; a caller with a smaller k
+ * gets the first k entries of its rows, which is its exact answer) and fanned back out -- `recall` is one query per call from many threads
+ * (recall.rs:512-513, retrieval.rs:912-918). linger_us: how long a pass that could start waits for the callers of the pass that just ended
+ * (default 30; a caller that is alone never waits). stats4: passes, calls served, largest pass, passes that lingered -- since the last reset. */
+int shodh_index_set_coalesce(shodh_index *idx, int enabled, uint32_t linger_us);
+int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats4, int reset);
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */
 /* mark_deleted for n ids in one call (one bitmask upload, one kernel over the shadow rows): *n_marked_out = ids that were
  * valid and not yet tombstoned. Same result as n mark_deleted calls. */
@@ -196,7 +209,9 @@ int shodh_topk_merge_strided_device(const uint32_t *d_in_ids, const float *d_in_
  * shards on one GPU, e.g. for testing on a single-GPU host); the exchange then uses device-to-device copies.
  * FLAT: ids stay dense and sequential (vamana.rs:854-855) and are dealt to the shards in blocks of 2^block_log2 rows, round robin,
  * so appends stay balanced. IVFPQ: every posting list is cut into G pieces, shard g holds piece g of every list.
- * One call at a time per handle (calls are serialised internally). */
+ * Searches may run concurrently on one handle: every call takes its own set of streams and exchange buffers on every shard (up to
+ * SHODH_SHARD_SLOTS = 4 in flight); only the enqueue of a call's commands is serialised (RCCL wants one issue order per communicator).
+ * Concurrent host-pointer searches of a few queries are coalesced like shodh_index_search's (one pass over the shards, ONE exchange). */
 enum { SHODH_EXCHANGE_AUTO = 0,    /* RCCL when the devices are distinct and librccl loads, device copies otherwise */
        SHODH_EXCHANGE_RCCL = 1,    /* RCCL or fail */
        SHODH_EXCHANGE_COPY = 2 };  /* hipMemcpyAsync device-to-device into the first device */
@@ -232,6 +247,8 @@ int shodh_sharded_index_extract_rows(shodh_sharded_index *s, uint64_t first, uin
 int shodh_sharded_index_set_ivfpq(shodh_sharded_index *s, const float *centroids, uint32_t P, const float *codebook, uint32_t M,
                                   uint32_t ncent, const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes);
 int shodh_sharded_index_ivfpq_insert(shodh_sharded_index *s, uint32_t vector_id, const float *row);             /* spann.rs:1006-1051, shard = id % G */
+int shodh_sharded_index_set_coalesce(shodh_sharded_index *s, int enabled, uint32_t linger_us);     /* see shodh_index_set_coalesce */
+int shodh_sharded_index_coalesce_stats(shodh_sharded_index *s, uint64_t *stats4, int reset);
 /* host wall clock of the last search, microseconds: enqueue of the shard searches, exchange enqueue, merge + wait, total */
 int shodh_sharded_index_host_timings(const shodh_sharded_index *s, float *us4);
 /* which librccl was bound and its version ("<path> version <n>"); SHODH_ERR_DEVICE if none could be loaded */
@@ -352,6 +369,20 @@ uint32_t shodh_embedder_dimension(const shodh_embedder *e);                    /
 int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out);
 int shodh_embedder_encode_ids_device(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b,
                                      float *d_out, void *stream);
+/* The same with the scope of THIS call as an argument (SHODH_QUANT_SCOPE_*), read nowhere else: concurrent callers with different scopes cannot
+ * disturb each other (set_quant_scope + encode + restore cannot be made atomic by a caller). INT8: which tensor the DynamicQuantizeLinear ranges
+ * span. fp32 / bf16: PER_TEXT (and every call with b = 1) runs the kernel forms a single text takes whatever the size of the batch, so a text's
+ * embedding is the same BYTES alone, in encode_each, or coalesced with other callers; BATCH lets the library pick the fastest forms for the
+ * batch (same function, bf16 rounding-level differences between forms). */
+int shodh_embedder_encode_ids_scoped(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, uint32_t scope, float *out);
+int shodh_embedder_encode_ids_device_scoped(shodh_embedder *e, const int32_t *d_ids, const uint8_t *d_mask, uint32_t b, uint32_t scope,
+                                            float *d_out, void *stream);
+/* Coalescing front of the host-pointer encode (on by default): concurrent calls with b = 1 -- `remember` / `recall` embed one text per call behind
+ * Mutex<Session> (minilm.rs:889-897) -- share ONE per-text forward (a one-text call is the same function under either scope, and PER_TEXT makes a
+ * forward over N texts N x that function): every caller gets the bytes its own call would have produced. Up to SHODH_ENC_SLOTS = 2 forwards are in
+ * flight per handle (calls with b > 1 run on their own). stats4 as for shodh_index_coalesce_stats. */
+int shodh_embedder_set_coalesce(shodh_embedder *e, int enabled, uint32_t linger_us);
+int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats4, int reset);
 /* switch the INT8 quantisation scope of later encode calls (cfg.quant_scope; no reallocation, no effect on fp32 / bf16): a host calls
  * PER_TEXT for bulk `remember` ingest (N x encode()) and BATCH where the reference itself calls encode_batch (memory/mod.rs:8443, :8838) */
 int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope);

@@ -414,7 +414,7 @@ pub trait Tokenize: Send + Sync {
 /// GEMM operand type of the encoder. `Int8` is the reference's default model (SHODH_USE_QUANTIZED_MODEL unset, minilm.rs:205-220).
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum EncoderDtype { Fp32, Bf16, Int8 }
-pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize, scope_mu: std::sync::Mutex<()> }
+pub struct HipEmbedder<T: Tokenize> { h: *mut ffi::shodh_embedder, tok: T, dim: usize, max_len: usize }
 unsafe impl<T: Tokenize> Send for HipEmbedder<T> {}
 unsafe impl<T: Tokenize> Sync for HipEmbedder<T> {}
 impl<T: Tokenize> HipEmbedder<T> {
@@ -443,7 +443,7 @@ impl<T: Tokenize> HipEmbedder<T> {
         cfg.weights_path = path.map_or(std::ptr::null(), |p| p.as_ptr());
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::shodh_embedder_create(&cfg, &mut h) })?;
-        Ok(Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize, scope_mu: std::sync::Mutex::new(()) })
+        Ok(Self { h, tok, dim: cfg.hidden as usize, max_len: cfg.max_len as usize })
     }
     pub fn dimension(&self) -> usize { self.dim }
     pub fn encode(&self, text: &str) -> Result<Vec<f32>> {
@@ -459,8 +459,8 @@ impl<T: Tokenize> HipEmbedder<T> {
     /// every range spans one text's padded tensor; bit-identical to calling `encode` N times. fp32 / bf16: the same as `encode_batch`.
     pub fn encode_each(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> { self.encode_scoped(texts, ffi::SHODH_QUANT_SCOPE_PER_TEXT as u32) }
     fn encode_scoped(&self, texts: &[&str], scope: u32) -> Result<Vec<Vec<f32>>> {
-        let _g = self.scope_mu.lock().map_err(|_| anyhow!("embedder scope lock poisoned"))?;
-        check(unsafe { ffi::shodh_embedder_set_quant_scope(self.h, scope) })?;
+        // the scope travels with the call (ABI v5): concurrent encode / encode_each / encode_batch callers cannot disturb each other, and
+        // concurrent one-text calls are coalesced by the library into one per-text forward (same bytes per text)
         let b = texts.len();
         let (mut ids, mut mask) = (vec![0i32; b * self.max_len], vec![0u8; b * self.max_len]);
         for (r, text) in texts.iter().enumerate() {
@@ -472,7 +472,7 @@ impl<T: Tokenize> HipEmbedder<T> {
             }
         }
         let mut out = vec![0f32; b * self.dim];
-        check(unsafe { ffi::shodh_embedder_encode_ids(self.h, ids.as_ptr(), mask.as_ptr(), b as u32, out.as_mut_ptr()) })?;
+        check(unsafe { ffi::shodh_embedder_encode_ids_scoped(self.h, ids.as_ptr(), mask.as_ptr(), b as u32, scope, out.as_mut_ptr()) })?;
         Ok(out.chunks(self.dim.max(1)).map(|c| c.to_vec()).collect())
     }
     pub fn count_tokens(&self, text: &str) -> usize { self.tok.count(text) }

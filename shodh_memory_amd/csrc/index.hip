@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "combiner.h"
 
 namespace shodh {
 
@@ -123,6 +124,7 @@ struct Workspace {
     // host-pointer calls: queries in, and ONE output block [ids | dist | counts] with a pinned host mirror, so that the results come back in
     // a single copy (three small copies plus their API calls were a visible part of a single query's latency)
     float *h_q = nullptr;                // one-query host calls: the query in pinned, device-visible host memory (the kernels read it from there: no H2D copy command)
+    float *h_qb = nullptr; size_t h_qb_floats = 0;   // coalesced calls (combiner.h): the members' queries gathered in pinned memory, one H2D copy
     float *d_q = nullptr; uint32_t *d_out = nullptr, *h_out = nullptr; uint32_t *d_ids = nullptr; float *d_dist = nullptr; uint32_t *d_counts = nullptr, *d_stats = nullptr;
     size_t q_floats = 0, out_words = 0;
     // ring of (start, end) events around the dominant scan kernel of each search, for
@@ -150,6 +152,14 @@ struct Workspace {
         bytes = need;
         return SHODH_OK;
     }
+    int reserve_gather(size_t qf) {
+        if (qf <= h_qb_floats) return SHODH_OK;
+        if (h_qb) hipHostFree(h_qb);
+        h_qb = nullptr; h_qb_floats = 0;
+        SHODH_HIP_TRY(hipHostMalloc((void **)&h_qb, qf * 4));
+        h_qb_floats = qf;
+        return SHODH_OK;
+    }
     int reserve_io(size_t qf, size_t oe, size_t nq) {
         if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
         const size_t words = 2 * oe + nq + 4;          // + the four pipeline statistics (scan_stats), so that they come back in the same copy
@@ -164,7 +174,7 @@ struct Workspace {
     void destroy() {
         if (buf) hipFree(buf);
         if (solo_cnt) hipFree(solo_cnt);
-        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); if (h_q) hipHostFree(h_q);
+        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); if (h_q) hipHostFree(h_q); if (h_qb) hipHostFree(h_qb);
         for (auto &e : ev) if (e) hipEventDestroy(e);
         if (last_use) hipEventDestroy(last_use);
         for (auto &r : ring) { if (r[0]) hipEventDestroy(r[0]); if (r[1]) hipEventDestroy(r[1]); }
@@ -202,6 +212,9 @@ struct shodh_index {
     bool g_overflowed = false;                     // sticky host copy for graph INSERTS (shodh_index_graph_overflowed): set by add, cleared by build
     uint32_t g_stride = 0, g_medoid = 0;
     uint64_t g_nodes = 0;                          // rows that have a node in the graph (== n when the graph is usable)
+    // coalescing front for concurrent host-pointer searches of a few queries each (combiner.h): SHODH_COALESCE=0 / shodh_index_set_coalesce turn it off
+    bool coalesce = true;
+    Combiner co;
 };
 
 namespace shodh {
@@ -482,6 +495,8 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
     shodh_index *idx = new shodh_index();
     idx->cfg = *cfg;
     idx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *cv = getenv("SHODH_COALESCE")) idx->coalesce = atoi(cv) != 0;
+    if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) idx->co.linger_us = (uint32_t)atoi(lv);
     if (cfg->scan_mode > SHODH_SCAN_GRAPH) { delete idx; set_error("unknown scan mode %u", cfg->scan_mode); return SHODH_ERR_INVALID; }
     if (cfg->scan_mode == SHODH_SCAN_GRAPH) {
         if (cfg->kind != SHODH_INDEX_FLAT || cfg->order > SHODH_ORDER_AVX2 || cfg->dim % 8 != 0 || cfg->max_degree == 0 || cfg->max_degree > 126 ||
@@ -603,10 +618,25 @@ static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpy
 int shodh_index_build(shodh_index *idx, const float *rows, uint64_t n) { return build_impl(idx, rows, n, hipMemcpyHostToDevice); }
 int shodh_index_build_device(shodh_index *idx, const float *d_rows, uint64_t n) { return build_impl(idx, d_rows, n, hipMemcpyDeviceToDevice); }
 
-static int search_common(shodh_index *idx, const float *q, bool q_on_device, uint32_t nq, uint32_t k,
-                         uint32_t *ids, float *dist, uint32_t *counts, hipStream_t user_stream, bool sync_host, bool force_exact = false) {
-    if (!idx || (nq && (!q || !counts)) || (nq && k && (!ids || !dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+// One caller's part of a search: its queries, its k, its output pointers. A host-pointer call normally is one segment; a coalesced pass
+// (combiner.h) carries one segment per member.
+struct SearchSeg { const float *q; uint32_t nq, k; uint32_t *ids; float *dist; uint32_t *counts; };
+
+// The segments are searched as ONE batch of nq = sum(nq) queries with k = max(k): a row's top-k' is the first k' entries of its top-k for every
+// k' <= k (the order (dist total_cmp, id) is total and both are the exact answer), so a member with a smaller k gets the prefix of its rows.
+// Device-pointer calls (sync_host = false) have one segment.
+static int search_common(shodh_index *idx, const SearchSeg *segs, size_t n_segs, hipStream_t user_stream, bool sync_host, bool force_exact = false) {
+    if (!idx || !segs || n_segs == 0 || (n_segs > 1 && !sync_host)) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    uint32_t nq = 0, k = 0;
+    for (size_t i = 0; i < n_segs; ++i) {
+        const SearchSeg &g = segs[i];
+        if ((g.nq && (!g.q || !g.counts)) || (g.nq && g.k && (!g.ids || !g.dist))) { set_error("null argument"); return SHODH_ERR_INVALID; }
+        nq += g.nq;
+        if (g.nq && g.k > k) k = g.k;
+    }
     if (nq == 0) return SHODH_OK;
+    const float *q = segs[0].q;
+    uint32_t *ids = segs[0].ids; float *dist = segs[0].dist; uint32_t *counts = segs[0].counts;     // (used as such by single-segment calls only)
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     SHODH_TRY(set_device(idx));
     const uint32_t dim = idx->cfg.dim;
@@ -615,16 +645,22 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
         // SpannIndex::search on an unbuilt index: centroids empty -> Ok(vec![]) (spann.rs:575-578)
     }
     if (empty || k == 0) {
-        if (sync_host) { for (uint32_t i = 0; i < nq; ++i) counts[i] = 0; for (size_t i = 0; i < (size_t)nq * k; ++i) { ids[i] = 0xFFFFFFFFu; dist[i] = INFINITY; } }
-        else {
+        if (sync_host) {
+            for (size_t s = 0; s < n_segs; ++s) {
+                const SearchSeg &g = segs[s];
+                for (uint32_t i = 0; i < g.nq; ++i) g.counts[i] = 0;
+                for (size_t i = 0; i < (size_t)g.nq * g.k; ++i) { g.ids[i] = 0xFFFFFFFFu; g.dist[i] = INFINITY; }
+            }
+        } else {
             SHODH_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nq * 4, user_stream));
             if (k) { SHODH_HIP_TRY(hipMemsetAsync(ids, 0xFF, (size_t)nq * k * 4, user_stream)); SHODH_HIP_TRY(hipMemsetAsync(dist, 0x7F, (size_t)nq * k * 4, user_stream)); }
         }
         return SHODH_OK;
     }
     if (sync_host) {
-        for (size_t i = 0; i < (size_t)nq * dim; ++i)
-            if (!(fabsf(q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
+        for (size_t s = 0; s < n_segs; ++s)
+            for (size_t i = 0; i < (size_t)segs[s].nq * dim; ++i)
+                if (!(fabsf(segs[s].q[i]) <= 3.0e38f)) { set_error("query contains non-finite values"); return SHODH_ERR_NONFINITE; }
     }
     Workspace *w = ws_acquire(idx, user_stream, sync_host);
     if (!w) return SHODH_ERR_DEVICE;
@@ -656,7 +692,14 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
                 stats_mirror = w->h_out + 2 * oe + nq;
                 stats_mirror[0] = stats_mirror[1] = stats_mirror[2] = stats_mirror[3] = 0;       // (paths without a final stage leave them alone)
             } else {
-                if (hipMemcpyAsync(w->d_q, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
+                const float *src = q;
+                if (n_segs > 1) {       // coalesced pass: the members' queries gathered in pinned memory (one DMA, no staging by the runtime)
+                    if ((rc = w->reserve_gather((size_t)nq * dim)) != SHODH_OK) break;
+                    size_t at = 0;
+                    for (size_t s = 0; s < n_segs; ++s) { memcpy(w->h_qb + at, segs[s].q, (size_t)segs[s].nq * dim * 4); at += (size_t)segs[s].nq * dim; }
+                    src = w->h_qb;
+                }
+                if (hipMemcpyAsync(w->d_q, src, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
                 d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
             }
         }
@@ -694,8 +737,23 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
                 e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             }
-            memcpy(ids, w->h_out, oe * 4); memcpy(dist, w->h_out + oe, oe * 4); memcpy(counts, w->h_out + 2 * oe, (size_t)nq * 4);
             const bool graph_call = idx->cfg.scan_mode == SHODH_SCAN_GRAPH && idx->cfg.kind == SHODH_INDEX_FLAT && !force_exact;
+            if (n_segs == 1 && segs[0].k == k) {
+                memcpy(ids, w->h_out, oe * 4); memcpy(dist, w->h_out + oe, oe * 4); memcpy(counts, w->h_out + 2 * oe, (size_t)nq * 4);
+            } else {
+                // fan the rows out to their callers: row r of the pass is row r - first of its member, the first k_member entries of it
+                const uint32_t *o_ids = w->h_out, *o_cnt = w->h_out + 2 * oe;
+                const float *o_dist = reinterpret_cast<const float *>(w->h_out + oe);
+                size_t r = 0;
+                for (size_t s = 0; s < n_segs; ++s) {
+                    const SearchSeg &g = segs[s];
+                    for (uint32_t j = 0; j < g.nq; ++j, ++r) {
+                        memcpy(g.ids + (size_t)j * g.k, o_ids + r * k, (size_t)g.k * 4);
+                        memcpy(g.dist + (size_t)j * g.k, o_dist + r * k, (size_t)g.k * 4);
+                        g.counts[j] = o_cnt[r] < g.k ? o_cnt[r] : g.k;
+                    }
+                }
+            }
             if (graph_call) {
                 // a walk whose frontier overflowed says so in the top bit of its count (vg_search_kernel)
                 bool ovf = false;
@@ -721,16 +779,62 @@ static int search_common(shodh_index *idx, const float *q, bool q_on_device, uin
     return rc;
 }
 
+// ---- coalescing front (combiner.h) -------------------------------------------------------------------------------------------------------
+// `recall` asks one query per call from many threads at once (recall.rs:512-513, retrieval.rs:912-918). Host-pointer searches of a few queries
+// that arrive while a pass is in flight share the NEXT pass; a caller that is alone runs exactly the single call it always ran.
+constexpr uint32_t CO_MAX_CALL_NQ = 32;      // calls with more queries than this already amortise the pass: they run on their own
+constexpr uint32_t CO_MAX_PASS_NQ = 256;     // one MFMA pass (MF_BPAD)
+static bool coalescable(const shodh_index *idx, const float *q, uint32_t nq, uint32_t k, const uint32_t *ids, const float *dist, const uint32_t *counts) {
+    if (!idx || !idx->coalesce || !q || !ids || !dist || !counts || nq == 0 || nq > CO_MAX_CALL_NQ || k == 0 || k > 2048) return false;
+    if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH) return false;       // a walk per query: nothing to share
+    const size_t n = (size_t)nq * idx->cfg.dim;
+    for (size_t i = 0; i < n; ++i) if (!(fabsf(q[i]) <= 3.0e38f)) return false;      // (the direct call reports it; one member's bad input must not fail the others)
+    return true;
+}
+static int coalesced_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
+    SearchSeg mine{q, nq, k, ids, dist, counts};
+    std::string err;
+    const int rc = idx->co.submit(&mine, nq, CO_MAX_PASS_NQ,
+        [idx](const std::vector<void *> &reqs) {
+            if (reqs.size() == 1) return search_common(idx, static_cast<const SearchSeg *>(reqs[0]), 1, nullptr, true);
+            std::vector<SearchSeg> segs;
+            segs.reserve(reqs.size());
+            for (void *r : reqs) segs.push_back(*static_cast<const SearchSeg *>(r));
+            return search_common(idx, segs.data(), segs.size(), nullptr, true);
+        },
+        []() { return std::string(last_error_of_this_thread()); }, &err);
+    if (rc != SHODH_OK) set_error("%s", err.c_str());
+    return rc;
+}
+
 int shodh_index_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
-    return search_common(idx, q, false, nq, k, ids, dist, counts, nullptr, true);
+    if (coalescable(idx, q, nq, k, ids, dist, counts)) return coalesced_search(idx, q, nq, k, ids, dist, counts);
+    const SearchSeg s{q, nq, k, ids, dist, counts};
+    return search_common(idx, &s, 1, nullptr, true);
 }
 int shodh_index_brute_force_search(shodh_index *idx, const float *q, uint32_t nq, uint32_t k, uint32_t *ids, float *dist, uint32_t *counts) {
     if (idx && idx->cfg.kind != SHODH_INDEX_FLAT) { set_error("brute_force_search is for FLAT indexes"); return SHODH_ERR_STATE; }
-    return search_common(idx, q, false, nq, k, ids, dist, counts, nullptr, true, true);
+    const SearchSeg s{q, nq, k, ids, dist, counts};
+    return search_common(idx, &s, 1, nullptr, true, true);
 }
 int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, uint32_t k, uint32_t *d_ids, float *d_dist,
                               uint32_t *d_counts, void *stream) {
-    return search_common(idx, d_q, true, nq, k, d_ids, d_dist, d_counts, (hipStream_t)stream, false);
+    const SearchSeg s{d_q, nq, k, d_ids, d_dist, d_counts};
+    return search_common(idx, &s, 1, (hipStream_t)stream, false);
+}
+
+int shodh_index_set_coalesce(shodh_index *idx, int enabled, uint32_t linger_us) {
+    if (!idx) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    idx->coalesce = enabled != 0;
+    idx->co.linger_us = linger_us;
+    return SHODH_OK;
+}
+int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats4, int reset) {
+    if (!idx || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+    const CombinerStats c = idx->co.stats();
+    stats4[0] = c.batches; stats4[1] = c.members; stats4[2] = c.max_members; stats4[3] = c.lingered;
+    if (reset) idx->co.reset_stats();
+    return SHODH_OK;
 }
 
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid) {

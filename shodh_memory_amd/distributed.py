@@ -227,6 +227,14 @@ class MultiGpuIndex:
         v = self._rows(vector)
         L.check(L.lib().shodh_sharded_index_ivfpq_insert(self._h, int(vector_id), v.ctypes.data))
 
+    def set_coalesce(self, enabled, linger_us=30):
+        L.check(L.lib().shodh_sharded_index_set_coalesce(self._h, int(bool(enabled)), int(linger_us)))
+
+    def coalesce_stats(self, reset=False):
+        a = (C.c_uint64 * 4)()
+        L.check(L.lib().shodh_sharded_index_coalesce_stats(self._h, C.byref(a), int(bool(reset))))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
+
     def host_timings_us(self):
         a = (C.c_float * 4)()
         L.check(L.lib().shodh_sharded_index_host_timings(self._h, C.byref(a)))

@@ -252,30 +252,16 @@ class MiniLMEmbedder(Embedder):
     def quant_scope(self):
         return int(L.lib().shodh_embedder_quant_scope(self._h))
 
-    def _scoped(self, scope):
-        """context: run the calls inside with `scope` (None = the handle's current one), then restore"""
-        emb = self
-
-        class _Ctx:
-            def __enter__(self_):
-                self_.prev = None
-                if scope is not None and emb._h and emb._h.value:
-                    self_.prev = emb.quant_scope()
-                    emb.set_quant_scope(scope)
-
-            def __exit__(self_, *a):
-                if self_.prev is not None:
-                    emb.set_quant_scope(self_.prev)
-        return _Ctx()
-
     def encode_ids(self, ids, mask, scope=None):
         """ids int32 [b, max_len], mask uint8 [b, max_len] -> float32 [b, dim] unit rows (zeros if mask empty).
         scope (INT8 only): L.QUANT_SCOPE_BATCH / L.QUANT_SCOPE_PER_TEXT for this call; None = the handle's setting."""
         ids = np.ascontiguousarray(ids, np.int32).reshape(-1, self.max_length)
         mask = np.ascontiguousarray(mask, np.uint8).reshape(-1, self.max_length)
         out = np.zeros((ids.shape[0], self._dim), np.float32)
-        with self._scoped(scope):
+        if scope is None:
             L.check(L.lib().shodh_embedder_encode_ids(self._h, ids.ctypes.data, mask.ctypes.data, ids.shape[0], out.ctypes.data))
+        else:       # the scope travels with the call (no set / restore on the handle: concurrent callers cannot disturb each other)
+            L.check(L.lib().shodh_embedder_encode_ids_scoped(self._h, ids.ctypes.data, mask.ctypes.data, ids.shape[0], int(scope), out.ctypes.data))
         return out
 
     def encode_ids_device(self, ids, mask, out=None, stream=None, scope=None):
@@ -284,9 +270,20 @@ class MiniLMEmbedder(Embedder):
         if out is None:
             out = torch.empty((b, self._dim), dtype=torch.float32, device=ids.device)
         st = stream if stream is not None else torch.cuda.current_stream(ids.device).cuda_stream
-        with self._scoped(scope):
+        if scope is None:
             L.check(L.lib().shodh_embedder_encode_ids_device(self._h, ids.data_ptr(), mask.data_ptr(), b, out.data_ptr(), C.c_void_p(st)))
+        else:
+            L.check(L.lib().shodh_embedder_encode_ids_device_scoped(self._h, ids.data_ptr(), mask.data_ptr(), b, int(scope), out.data_ptr(), C.c_void_p(st)))
         return out
+
+    def set_coalesce(self, enabled, linger_us=30):
+        """concurrent one-text encode calls share one per-text forward (shodh_embedder_set_coalesce; on by default)"""
+        L.check(L.lib().shodh_embedder_set_coalesce(self._h, int(bool(enabled)), int(linger_us)))
+
+    def coalesce_stats(self, reset=False):
+        a = (C.c_uint64 * 4)()
+        L.check(L.lib().shodh_embedder_coalesce_stats(self._h, C.byref(a), int(bool(reset))))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
 
     def stage_timings_us(self):
         a = (C.c_float * 2)()
@@ -329,7 +326,8 @@ class MiniLMEmbedder(Embedder):
         """N x encode() in one device call -- the function `remember` / `index_memory` / `recall` compute, text by text (memory/mod.rs:1037,
         retrieval.rs:673, :708, :878: one session.run on [1, max_len] per text, minilm.rs:883-982). INT8: SHODH_QUANT_SCOPE_PER_TEXT, every
         DynamicQuantizeLinear range spans ONE text's padded tensor, so the result is bit-identical to [encode(t) for t in texts] whatever the
-        batch. fp32 / bf16: the same numbers as encode_batch (texts never interact there)."""
+        batch. fp32 / bf16: texts never interact; this call (like every one-text call) runs the kernel forms a single text takes whatever the size of
+        the batch, so the bytes equal [encode(t) for t in texts] too (encode_batch may pick faster forms for a big batch: bf16 rounding-level differences)."""
         return self.encode_batch(texts, _scope=L.QUANT_SCOPE_PER_TEXT)
 
     def encode_batch(self, texts, _scope=L.QUANT_SCOPE_BATCH):        # minilm.rs:1247-1376

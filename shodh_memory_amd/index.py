@@ -470,6 +470,15 @@ class VamanaIndex:
         L.check(L.lib().shodh_index_kernel_timing(self.handle, int(reset), C.byref(m), C.byref(mn), C.byref(c)))
         return m.value, mn.value, c.value
 
+    def set_coalesce(self, enabled, linger_us=30):
+        """concurrent host-pointer searches of a few queries share one pass (shodh_index_set_coalesce; on by default)"""
+        L.check(L.lib().shodh_index_set_coalesce(self.handle, int(bool(enabled)), int(linger_us)))
+
+    def coalesce_stats(self, reset=False):
+        a = (C.c_uint64 * 4)()
+        L.check(L.lib().shodh_index_coalesce_stats(self.handle, C.byref(a), int(bool(reset))))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
+
     def scan_stats(self):
         a = (C.c_uint64 * 8)()
         L.check(L.lib().shodh_index_scan_stats(self.handle, C.byref(a)))
@@ -641,6 +650,16 @@ class SpannIndex:
         L.check(L.lib().shodh_index_search_device(self.handle, queries.data_ptr(), nq, k, ids.data_ptr(), dist.data_ptr(),
                                                   counts.data_ptr(), C.c_void_p(st)))
         return ids, dist, counts
+
+
+    def set_coalesce(self, enabled, linger_us=30):
+        """concurrent host-pointer searches of a few queries share one pass (shodh_index_set_coalesce; on by default)"""
+        L.check(L.lib().shodh_index_set_coalesce(self.handle, int(bool(enabled)), int(linger_us)))
+
+    def coalesce_stats(self, reset=False):
+        a = (C.c_uint64 * 4)()
+        L.check(L.lib().shodh_index_coalesce_stats(self.handle, C.byref(a), int(bool(reset))))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
 
 
 class VectorIndexBackend:

@@ -80,7 +80,9 @@ class RetrievalEngine:
             if r.was_chunked:
                 chunks = r.chunks
         if chunks:
-            vecs = self.embedder.encode_batch(chunks)            # the reference encodes the chunks one by one (:671-679): same vectors
+            # the reference encodes the chunks one by one (:668-676, one encode() each): N x encode() in one device call. INT8: every
+            # DynamicQuantizeLinear range spans ONE chunk, so the vectors do not depend on the other chunks (encode_batch's would)
+            vecs = self.embedder.encode_each(chunks)
         else:
             vecs = [np.asarray(embedding, np.float32) if embedding is not None else self.embedder.encode(content)]
         ids = [self.vector_index.add_vector(v) for v in vecs]

@@ -42,7 +42,7 @@ def test_header_symbols_are_exported(shodh):
 
 def test_abi_version_and_structs(shodh):
     from shodh_memory_amd import _lib
-    assert _lib.lib().shodh_abi_version() == 4
+    assert _lib.lib().shodh_abi_version() == 5
     cfg = _lib.IndexCfg()
     _lib.lib().shodh_index_cfg_default(C.byref(cfg))
     assert (cfg.dim, cfg.metric, cfg.kind, cfg.order, cfg.nprobe) == (384, 0, 0, 0, 20)
