@@ -243,6 +243,83 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         e.update(run_flat_config(torch, dev, main_index, main_qpool, 120, 30, 5, main_rows_total, main_rows_live, args.dim))
         done(e, t0)
 
+    # -- the reference's REAL call pattern: many callers, one query each, on one handle (recall.rs:512-513 spawn_blocking + one search under the read
+    #    lock, retrieval.rs:912-918; k = 120 is what a top-10 recall asks the index). T host threads (tools/callers.c, pthreads, no Python in the loop)
+    #    call shodh_index_search(nq = 1) in a closed loop; every result is compared byte for byte with the query's solo answer. `coalesce: false` is
+    #    the round-4 behaviour (every caller launches its own pass over the corpus), `true` the coalescing front (csrc/combiner.h).
+    if want("concurrent_callers"):
+        t0 = time.perf_counter()
+        import sys as _sys
+        if ROOT not in _sys.path:
+            _sys.path.insert(0, ROOT)
+        from tools import callers as CL
+        qh = main_qpool[0].cpu().numpy()
+        e = {"name": "concurrent_callers", "workload": "the contract corpus (1M x %d-d, 5 %% tombstoned): T host threads, each calling shodh_index_search(nq = 1) in a closed loop on ONE handle; "
+             "aggregate queries/s and per-call latency; every result checked against the query's solo answer" % args.dim, "host": cpu_info, "runs": []}
+        for k in (120, 10):
+            main_index.set_coalesce(False)
+            ex_ids = np.empty((qh.shape[0], k), np.uint32); ex_dist = np.empty((qh.shape[0], k), np.float32)
+            for i in range(qh.shape[0]):
+                a_, b_, _ = main_index.search_batch(qh[i:i + 1], k)
+                ex_ids[i], ex_dist[i] = a_[0], b_[0]
+            for co in (False, True):
+                main_index.set_coalesce(co)
+                for T, calls in ((1, 300), (4, 200), (16, 120), (64, 100), (256, 40)):
+                    if k == 10 and T not in (1, 16, 64):
+                        continue
+                    if not co and T > 64:
+                        continue
+                    main_index.coalesce_stats(reset=True)
+                    r = CL.search(L.lib(), main_index.handle, qh, k, threads=T, calls_per_thread=calls, warmup=3, expect=(ex_ids, ex_dist))
+                    st = main_index.coalesce_stats()
+                    d = {"k": k, "threads": T, "coalesce": co}
+                    d.update(r.as_dict("queries"))
+                    if co:
+                        d.update({"passes": st["passes"], "mean_callers_per_pass": round(st["calls"] / max(st["passes"], 1), 2), "largest_pass": st["largest"]})
+                    e["runs"].append(d)
+        main_index.set_coalesce(True)
+        solo120 = [r for r in e["runs"] if r["k"] == 120 and r["threads"] == 1 and r["coalesce"]][0]
+        t64 = [r for r in e["runs"] if r["k"] == 120 and r["threads"] == 64 and r["coalesce"]][0]
+        t64_off = [r for r in e["runs"] if r["k"] == 120 and r["threads"] == 64 and not r["coalesce"]][0]
+        e["summary"] = {"k120_64_callers_queries_per_s": t64["queries_per_s"], "k120_64_callers_p50_over_solo_p50": round(t64["p50_us"] / solo120["p50_us"], 2),
+                        "k120_64_callers_speedup_over_uncoalesced": round(t64["queries_per_s"] / max(t64_off["queries_per_s"], 1e-9), 2),
+                        "all_results_equal_solo": all(r["mismatches"] == 0 and r["errors"] == 0 for r in e["runs"])}
+        done(e, t0)
+
+    # -- the same pattern on the encoder: T threads, one text per call (minilm.rs:889-897: encode() behind Mutex<Session>) ------------------------------
+    if want("concurrent_encode_callers") and not args.skip_encoder:
+        t0 = time.perf_counter()
+        import sys as _sys
+        if ROOT not in _sys.path:
+            _sys.path.insert(0, ROOT)
+        from tools import callers as CL
+        e = {"name": "concurrent_encode_callers", "workload": "T host threads, each calling shodh_embedder_encode_ids(b = 1) in a closed loop on ONE handle (texts of 8-128 tokens, max_len 256); "
+             "texts/s and per-call latency; every vector checked byte for byte against the text's solo embedding", "runs": []}
+        g = torch.Generator(device=dev).manual_seed(SEED + 90)
+        t_ids, t_mask, _ = synth_tokens(torch, 256, 256, g, dev)
+        h_ids, h_mask = t_ids.cpu().numpy(), t_mask.cpu().numpy()
+        for dname, dt in (("int8", L.DTYPE_INT8), ("bf16", L.DTYPE_BF16)):
+            emb = S.MiniLMEmbedder(synthetic_seed=1234, dtype=dt)
+            emb.set_coalesce(False)
+            solo = np.concatenate([emb.encode_ids(h_ids[i:i + 1], h_mask[i:i + 1]) for i in range(h_ids.shape[0])], 0)
+            for co in (False, True):
+                emb.set_coalesce(co)
+                for T, calls in ((1, 100), (4, 80), (16, 50), (64, 30), (256, 10)):
+                    if not co and T > 64:
+                        continue
+                    emb.coalesce_stats(reset=True)
+                    r = CL.encode(L.lib(), emb._h, h_ids, h_mask, 384, threads=T, calls_per_thread=calls, warmup=2, expect=solo)
+                    st = emb.coalesce_stats()
+                    d = {"dtype": dname, "threads": T, "coalesce": co}
+                    d.update(r.as_dict("texts"))
+                    if co:
+                        d.update({"forwards": st["passes"], "mean_texts_per_forward": round(st["calls"] / max(st["passes"], 1), 2), "largest_forward": st["largest"]})
+                    e["runs"].append(d)
+            emb.close()
+        e["summary"] = {"int8_64_callers_texts_per_s": [r for r in e["runs"] if r["dtype"] == "int8" and r["threads"] == 64 and r["coalesce"]][0]["texts_per_s"],
+                        "all_vectors_equal_solo": all(r["mismatches"] == 0 and r["errors"] == 0 for r in e["runs"])}
+        done(e, t0)
+
     # -- 10M flat, B = 256: north_star's ">= 10M-memory recall at >= 70 % HBM roofline" (= one shard of configs[4]) ----------
     if want("flat_10M_b256") and not args.skip_10m:
         t0 = time.perf_counter()
