@@ -274,8 +274,10 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
                     st = main_index.coalesce_stats()
                     d = {"k": k, "threads": T, "coalesce": co}
                     d.update(r.as_dict("queries"))
+                    d["device_stages_us_last_pass"] = {kk: round(v, 1) for kk, v in main_index.stage_timings_us().items()}
                     if co:
-                        d.update({"passes": st["passes"], "mean_callers_per_pass": round(st["calls"] / max(st["passes"], 1), 2), "largest_pass": st["largest"]})
+                        d.update({"passes": st["passes"], "mean_callers_per_pass": round(st["calls"] / max(st["passes"], 1), 2), "largest_pass": st["largest"],
+                                  "mean_pass_us": round(st["pass_us"] / max(st["passes"], 1), 1), "mean_linger_us": round(st["linger_us"] / max(st["passes"], 1), 1)})
                     e["runs"].append(d)
         main_index.set_coalesce(True)
         solo120 = [r for r in e["runs"] if r["k"] == 120 and r["threads"] == 1 and r["coalesce"]][0]
@@ -313,7 +315,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
                     d = {"dtype": dname, "threads": T, "coalesce": co}
                     d.update(r.as_dict("texts"))
                     if co:
-                        d.update({"forwards": st["passes"], "mean_texts_per_forward": round(st["calls"] / max(st["passes"], 1), 2), "largest_forward": st["largest"]})
+                        d.update({"forwards": st["passes"], "mean_texts_per_forward": round(st["calls"] / max(st["passes"], 1), 2), "largest_forward": st["largest"],
+                                  "mean_forward_us": round(st["pass_us"] / max(st["passes"], 1), 1), "mean_linger_us": round(st["linger_us"] / max(st["passes"], 1), 1)})
                     e["runs"].append(d)
             emb.close()
         e["summary"] = {"int8_64_callers_texts_per_s": [r for r in e["runs"] if r["dtype"] == "int8" and r["threads"] == 64 and r["coalesce"]][0]["texts_per_s"],

@@ -140,9 +140,10 @@ int shodh_index_search_device(shodh_index *idx, const float *d_q, uint32_t nq, u
  * index that arrive while a pass is in flight are gathered into ONE pass of up to 256 queries (k = the largest asked; a caller with a smaller k
  * gets the first k entries of its rows, which is its exact answer) and fanned back out -- `recall` is one query per call from many threads
  * (recall.rs:512-513, retrieval.rs:912-918). linger_us: how long a pass that could start waits for the callers of the pass that just ended
- * (default 30; a caller that is alone never waits). stats4: passes, calls served, largest pass, passes that lingered -- since the last reset. */
+ * (default 30; a caller that is alone never waits). stats6: passes, calls served, largest pass, passes that lingered, microseconds spent inside
+ * passes, microseconds spent lingering -- since the last reset. */
 int shodh_index_set_coalesce(shodh_index *idx, int enabled, uint32_t linger_us);
-int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats4, int reset);
+int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats6, int reset);
 int shodh_index_mark_deleted(shodh_index *idx, uint32_t id, int *was_valid);   /* vamana.rs:813-820 */
 /* mark_deleted for n ids in one call (one bitmask upload, one kernel over the shadow rows): *n_marked_out = ids that were
  * valid and not yet tombstoned. Same result as n mark_deleted calls. */
@@ -248,7 +249,7 @@ int shodh_sharded_index_set_ivfpq(shodh_sharded_index *s, const float *centroids
                                   uint32_t ncent, const uint64_t *list_off, const uint32_t *ids, const uint8_t *codes);
 int shodh_sharded_index_ivfpq_insert(shodh_sharded_index *s, uint32_t vector_id, const float *row);             /* spann.rs:1006-1051, shard = id % G */
 int shodh_sharded_index_set_coalesce(shodh_sharded_index *s, int enabled, uint32_t linger_us);     /* see shodh_index_set_coalesce */
-int shodh_sharded_index_coalesce_stats(shodh_sharded_index *s, uint64_t *stats4, int reset);
+int shodh_sharded_index_coalesce_stats(shodh_sharded_index *s, uint64_t *stats6, int reset);
 /* host wall clock of the last search, microseconds: enqueue of the shard searches, exchange enqueue, merge + wait, total */
 int shodh_sharded_index_host_timings(const shodh_sharded_index *s, float *us4);
 /* which librccl was bound and its version ("<path> version <n>"); SHODH_ERR_DEVICE if none could be loaded */
@@ -380,9 +381,9 @@ int shodh_embedder_encode_ids_device_scoped(shodh_embedder *e, const int32_t *d_
 /* Coalescing front of the host-pointer encode (on by default): concurrent calls with b = 1 -- `remember` / `recall` embed one text per call behind
  * Mutex<Session> (minilm.rs:889-897) -- share ONE per-text forward (a one-text call is the same function under either scope, and PER_TEXT makes a
  * forward over N texts N x that function): every caller gets the bytes its own call would have produced. Up to SHODH_ENC_SLOTS = 2 forwards are in
- * flight per handle (calls with b > 1 run on their own). stats4 as for shodh_index_coalesce_stats. */
+ * flight per handle (calls with b > 1 run on their own). stats6 as for shodh_index_coalesce_stats. */
 int shodh_embedder_set_coalesce(shodh_embedder *e, int enabled, uint32_t linger_us);
-int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats4, int reset);
+int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats6, int reset);
 /* switch the INT8 quantisation scope of later encode calls (cfg.quant_scope; no reallocation, no effect on fp32 / bf16): a host calls
  * PER_TEXT for bulk `remember` ingest (N x encode()) and BATCH where the reference itself calls encode_batch (memory/mod.rs:8443, :8838) */
 int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope);

@@ -106,7 +106,7 @@ SYMBOLS = {
     "shodh_index_brute_force_search": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "shodh_index_search_device": (C.c_int, [_vp, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p, _vp]),
     "shodh_index_set_coalesce": (C.c_int, [_vp, C.c_int, C.c_uint32]),
-    "shodh_index_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4), C.c_int]),
+    "shodh_index_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 6), C.c_int]),
     "shodh_index_mark_deleted": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
     "shodh_index_mark_deleted_batch": (C.c_int, [_vp, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "shodh_index_is_deleted": (C.c_int, [_vp, C.c_uint32]),
@@ -148,7 +148,7 @@ SYMBOLS = {
     "shodh_sharded_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
     "shodh_sharded_index_ivfpq_insert": (C.c_int, [_vp, C.c_uint32, _fp]),
     "shodh_sharded_index_set_coalesce": (C.c_int, [_vp, C.c_int, C.c_uint32]),
-    "shodh_sharded_index_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4), C.c_int]),
+    "shodh_sharded_index_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 6), C.c_int]),
     "shodh_sharded_index_host_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
     "shodh_rccl_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "shodh_index_set_ivfpq": (C.c_int, [_vp, _fp, C.c_uint32, _fp, C.c_uint32, C.c_uint32, _u64p, _u32p, _u8p]),
@@ -203,7 +203,7 @@ SYMBOLS = {
     "shodh_embedder_encode_ids_scoped": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, C.c_uint32, _fp]),
     "shodh_embedder_encode_ids_device_scoped": (C.c_int, [_vp, _i32p, _u8p, C.c_uint32, C.c_uint32, _fp, _vp]),
     "shodh_embedder_set_coalesce": (C.c_int, [_vp, C.c_int, C.c_uint32]),
-    "shodh_embedder_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4), C.c_int]),
+    "shodh_embedder_coalesce_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 6), C.c_int]),
     "shodh_embedder_set_quant_scope": (C.c_int, [_vp, C.c_uint32]),
     "shodh_embedder_quant_scope": (C.c_uint32, [_vp]),
     "shodh_weights_default": (None, [C.POINTER(Weights)]),

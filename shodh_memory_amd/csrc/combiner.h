@@ -25,6 +25,7 @@
 // quant_scope PER_TEXT makes a batch N x encode() by construction).
 #pragma once
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -32,11 +33,13 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <cstdio>
 #include <cstdint>
 #include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace shodh {
@@ -57,18 +60,94 @@ static inline uint64_t mono_ns() {
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
-// sleep until *word != 0 (a short poll first: a wake-up through the kernel costs 5-10 us, a pass 150-400 us)
-static inline void futex_wait_nonzero(std::atomic<uint32_t> *word, int spin = 64) {
+// sleep until *word != 0 (a short poll first: a wake-up through the kernel costs 5-10 us, a pass 150-400 us).
+// Waking is a TREE: the finishing leader wakes WAKE_ROOT sleepers and every sleeper that was woken wakes WAKE_FAN more before it goes on -- one thread
+// waking 63 sleepers with a single FUTEX_WAKE spends ~1.5 us per sleeper inside that system call, so the last caller of a 64-caller pass used to
+// come back ~90 us after the first (measured: the next leader lingered 87 us to collect 62.8 of 64); with the tree the last one is ~5 levels away.
+constexpr int WAKE_ROOT = 1, WAKE_FAN = 2;      // (per shard of CoBatch::done)
+static inline void futex_wait_nonzero(std::atomic<uint32_t> *word, int spin = 64, bool relay = false) {
     for (int i = 0; i < spin; ++i) {
         if (word->load(std::memory_order_acquire) != 0) return;
         cpu_relax();
     }
-    while (word->load(std::memory_order_acquire) == 0) syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+    bool slept = false;
+    while (word->load(std::memory_order_acquire) == 0) { syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0); slept = true; }
+    if (slept && relay) syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, WAKE_FAN, nullptr, nullptr, 0);
 }
 static inline void futex_set_and_wake_all(std::atomic<uint32_t> *word) {
     word->store(1u, std::memory_order_release);
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
 }
+// (sleepers use futex_wait_nonzero(.., relay = true))
+static inline void futex_set_and_wake_tree(std::atomic<uint32_t> *word) {
+    word->store(1u, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, WAKE_ROOT, nullptr, nullptr, 0);
+}
+
+// A member's wait for its pass, predictive: the end of the pass is known to within a few percent from the passes before it (the device work is
+// HBM-bound and does not depend on who asked), so the member sleeps with a TIMEOUT that ends `margin` before the expected end -- the way back
+// through the kernel (timer, C-state exit, scheduling: 10-50 us) then overlaps with the pass instead of following it -- and polls the last
+// stretch. If the prediction was early the polling is bounded (`overrun`), after which the member sleeps again and is woken through the tree; if it
+// was late the tree wakes it as before. end_est_ns: the expected end on the mono_ns clock, kept up to date by the leader (0 = not known yet:
+// plain sleep until it is or until the pass is done).
+static inline void futex_wait_predictive(std::atomic<uint32_t> *word, const std::atomic<uint64_t> *end_est_ns, uint64_t first_guess_ns, uint64_t margin_ns, uint64_t overrun_ns) {
+    for (int i = 0; i < 64; ++i) {
+        if (word->load(std::memory_order_acquire) != 0) return;
+        cpu_relax();
+    }
+    bool slept = false;
+    uint64_t polled_ns = 0;
+    while (word->load(std::memory_order_acquire) == 0) {
+        const uint64_t now = mono_ns();
+        uint64_t end = end_est_ns->load(std::memory_order_acquire);
+        if (end == 0) end = first_guess_ns;
+        if (end != 0 && now + margin_ns >= end && polled_ns < overrun_ns + margin_ns) {
+            // the last stretch: poll
+            const uint64_t t0 = now;
+            while (word->load(std::memory_order_acquire) == 0) {
+                cpu_relax();
+                const uint64_t t = mono_ns();
+                if (t > end + overrun_ns || (t - t0) + polled_ns > overrun_ns + margin_ns) break;
+            }
+            polled_ns += mono_ns() - t0;
+            continue;
+        }
+        timespec ts, *tp = nullptr;
+        if (end != 0 && polled_ns < overrun_ns + margin_ns) {      // sleep until margin before the expected end
+            const uint64_t d = end - margin_ns - now;
+            ts.tv_sec = (time_t)(d / 1000000000ull); ts.tv_nsec = (long)(d % 1000000000ull);
+            tp = &ts;
+        }
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, 0u, tp, nullptr, 0);
+        slept = true;
+    }
+    // part of the wake-up tree (a no-op when nobody sleeps)
+    if (slept) syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, WAKE_FAN, nullptr, nullptr, 0);
+}
+
+// The front's own lock. Its critical sections are ~50-100 ns (append a pointer, pop a batch), but 60 callers come back from a pass within a few
+// microseconds of each other. Behind a pthread mutex the losers sleep in the kernel and are woken one per unlock -- a convoy that took ~80 us to
+// let 57 callers rejoin. A test-and-test-and-set lock lets them through in ~0.5-1 us each and does not care when a waiter is descheduled. Measured
+// alternatives (64 callers, 1M x 384, k = 120): an MCS queue lock hands over fastest (all 63 rejoined within 40 us instead of 60) but with 256 callers
+// on 256 hardware threads one preempted waiter stalled the queue behind it (p99 38 ms); exponential back-off made the rejoin SLOWER (75 us).
+class SpinLock {
+public:
+    void lock() {
+        for (uint32_t spins = 0;;) {
+            if (!f.load(std::memory_order_relaxed) && !f.exchange(true, std::memory_order_acquire)) return;
+            cpu_relax();
+            if (++spins > 4096) { sched_yield(); spins = 0; }      // (an oversubscribed machine: the holder is not running)
+        }
+    }
+    void unlock() { f.store(false, std::memory_order_release); }
+private:
+    std::atomic<bool> f{false};
+};
+struct LockGuard {
+    SpinLock &l;
+    explicit LockGuard(SpinLock &lk) : l(lk) { l.lock(); }
+    ~LockGuard() { l.unlock(); }
+};
 
 struct CoBatch {
     std::vector<void *> reqs;              // members' requests in arrival order (the leader's first); guarded by Combiner::m until closed
@@ -76,16 +155,32 @@ struct CoBatch {
     uint32_t units = 0;                    // queries / texts held
     bool closed = false;
     std::atomic<uint32_t> go{0};           // the leader may start (previous batch done)
-    std::atomic<uint32_t> done{0};         // results are in the members' buffers
+    // results are in the members' buffers. SHARDED: member i sleeps on word i % DONE_SHARDS -- all sleepers of one futex word are queued behind one
+    // kernel hash-bucket lock and leave it one after the other (~1.1 us each, measured: the 63 members of a pass rejoined evenly spread over 70 us
+    // whether they were woken by one call, by a tree, or polled part of the time); eight words are eight independent queues
+    static constexpr uint32_t DONE_SHARDS = 8;
+    struct alignas(64) DoneWord { std::atomic<uint32_t> v{0}; };
+    DoneWord done[DONE_SHARDS];
+    std::atomic<uint64_t> end_est_ns{0};   // expected end of this batch's pass (set when the pass starts)
+    std::vector<uint64_t> arrive_ns;       // SHODH_COALESCE_TRACE: when each member joined
     int rc = 0;
     std::string err;
 };
 
-struct CombinerStats { uint64_t batches = 0, members = 0, max_members = 0, lingered = 0; };
+struct CombinerStats { uint64_t batches = 0, members = 0, max_members = 0, lingered = 0, exec_ns = 0, linger_ns = 0; };
 
 class Combiner {
 public:
-    uint32_t linger_us = 30;
+    uint32_t linger_us = 30, quiet_us = 12;
+    // predictive (SHODH_COALESCE_PREDICTIVE=1; off by default): members wake `margin_us` before the expected end of the pass and poll, at most `overrun_us`
+    // past it (futex_wait_predictive) -- only while the callers are few enough to poll without taking the cores from each other (half the hardware
+    // threads). Measured on the 256-thread EPYC host of the GPU boxes, 64 callers: the pass after a shared one starts ~20 us after it instead of
+    // ~70 us when the estimate is good (a sleeper's way back is 60-80 us there), +3 % aggregate throughput, for ~10 % of a core per waiting caller.
+    // Not worth being the default.
+    bool predictive = false;
+    bool trace = false;
+    uint32_t margin_us = 40, overrun_us = 40;
+    uint32_t spin_callers_max = std::max(1u, std::thread::hardware_concurrency() / 2u);
 
     // exec(reqs) runs ONE device pass for all requests, writes every member's outputs and returns the status shared by all of them
     // (`err_of_leader` is copied to the members when it is not SHODH_OK). Returns the batch status; *led = this caller ran the pass.
@@ -93,27 +188,44 @@ public:
     int submit(void *req, uint32_t units, uint32_t max_units, Exec &&exec, ErrFn &&last_error, std::string *err_out) {
         std::shared_ptr<CoBatch> b;
         bool leader = false;
+        uint64_t est_pass = 0, first_guess = 0;
+        uint32_t members_hint = 0, my_index = 0;
+        // a batch object in case this caller has to open one: allocated OUTSIDE the lock (the hint is only a hint; the common case under load is to join)
+        std::shared_ptr<CoBatch> fresh;
+        if (!joinable_hint.load(std::memory_order_relaxed)) { fresh = std::make_shared<CoBatch>(); fresh->reqs.reserve(64); }
         {
-            std::lock_guard<std::mutex> g(m);
+            LockGuard g(m);
+            // when this caller's pass will probably end (members: futex_wait_predictive): after the running pass, if any, plus one pass
+            est_pass = pass_est_ns;
+            if (est_pass) first_guess = (running ? std::max<uint64_t>(cur_end_est_ns, mono_ns()) : mono_ns()) + est_pass;
+            members_hint = want_members.load(std::memory_order_relaxed);
             if (!open.empty() && !open.back()->closed && open.back()->units + units <= max_units) {
                 b = open.back();
             } else {
-                b = std::make_shared<CoBatch>();
+                if (!fresh) { fresh = std::make_shared<CoBatch>(); fresh->reqs.reserve(64); }       // (stale hint: rare)
+                b = fresh;
                 leader = true;
                 if (!running && open.empty()) b->go.store(1u, std::memory_order_relaxed);
                 open.push_back(b);
+                joinable_hint.store(true, std::memory_order_relaxed);
             }
+            my_index = (uint32_t)b->reqs.size();
             b->reqs.push_back(req);
+            if (trace) b->arrive_ns.push_back(mono_ns());
             b->units += units;
             b->units_now.store(b->units, std::memory_order_release);
             b->members.fetch_add(1u, std::memory_order_release);
         }
         if (!leader) {
-            futex_wait_nonzero(&b->done);
+            std::atomic<uint32_t> *done = &b->done[my_index % CoBatch::DONE_SHARDS].v;
+            if (predictive && est_pass && members_hint <= spin_callers_max) futex_wait_predictive(done, &b->end_est_ns, first_guess, (uint64_t)margin_us * 1000ull, (uint64_t)overrun_us * 1000ull);
+            else futex_wait_nonzero(done, 64, true);
             if (b->rc != 0 && err_out) *err_out = b->err;
             return b->rc;
         }
-        futex_wait_nonzero(&b->go);
+        // (the running pass's expected end is known: the same predictive wait as the members' -- a sleeper's way back costs 60-80 us on this class of host)
+        if (predictive && est_pass) futex_wait_predictive(&b->go, &cur_end_est_atomic, 0, (uint64_t)margin_us * 1000ull, (uint64_t)overrun_us * 1000ull);
+        else futex_wait_nonzero(&b->go);
         // linger (see the header)
         if (linger_us) {
             uint32_t target = std::max<uint32_t>(want_members.load(std::memory_order_relaxed), b->expect.load(std::memory_order_relaxed));
@@ -126,31 +238,64 @@ public:
                 // sleeper's way back through the kernel takes 5-10 us on bare metal but 50+ us inside a VM
                 const uint64_t cap_ns = std::max<uint64_t>((uint64_t)linger_us * 1000ull, last_pass_ns.load(std::memory_order_relaxed) / 4);
                 const uint64_t t_end = now + cap_ns;
-                while (b->units_now.load(std::memory_order_acquire) < target && mono_ns() < t_end) cpu_relax();
+                // ... and once callers have started to arrive, no longer than quiet_us after the last arrival: the stragglers of a big pass (a thread
+                // that was descheduled, a caller that went away) are not worth a quarter of a pass
+                uint32_t seen = here;
+                uint64_t t_last = 0;
+                for (;;) {
+                    const uint32_t u = b->units_now.load(std::memory_order_acquire);
+                    const uint64_t t = mono_ns();
+                    if (u >= target || t >= t_end) break;
+                    if (u != seen) { seen = u; t_last = t; }
+                    else if (quiet_us && t_last && t - t_last > (uint64_t)quiet_us * 1000ull) break;
+                    cpu_relax();
+                }
                 n_lingered.fetch_add(1u, std::memory_order_relaxed);
+                linger_ns.fetch_add(mono_ns() - now, std::memory_order_relaxed);
             }
         }
         std::vector<void *> reqs;
         uint32_t units_run = 0;
         {
-            std::lock_guard<std::mutex> g(m);
+            LockGuard g(m);
             b->closed = true;
             reqs = b->reqs;                 // (copied: the pass runs without the lock)
+            if (trace && b->arrive_ns.size() > 1) {
+                // diagnostics: when the members joined, relative to the end of the previous pass (us): first, median, last; then when the pass started
+                std::vector<uint64_t> a = b->arrive_ns;
+                std::sort(a.begin(), a.end());
+                const uint64_t e0 = last_end_ns.load(std::memory_order_relaxed);
+                auto rel = [&](uint64_t t) { return ((double)t - (double)e0) / 1e3; };
+                fprintf(stderr, "[combiner] pass of %zu: joined %+.1f / %+.1f / %+.1f us after the previous pass ended, started at %+.1f (previous pass %.1f us)\n", a.size(), rel(a.front()),
+                        rel(a[a.size() / 2]), rel(a.back()), rel(mono_ns()), (double)last_pass_ns.load(std::memory_order_relaxed) / 1e3);
+            }
             units_run = b->units;
             open.pop_front();               // b is the front: batches start in the order they were opened
+            joinable_hint.store(!open.empty(), std::memory_order_relaxed);
             running = true;
+            if (pass_est_ns) { cur_end_est_ns = mono_ns() + pass_est_ns; b->end_est_ns.store(cur_end_est_ns, std::memory_order_release); cur_end_est_atomic.store(cur_end_est_ns, std::memory_order_release); }
         }
         const uint64_t t_pass0 = mono_ns();
         b->rc = exec(reqs);
-        last_pass_ns.store(mono_ns() - t_pass0, std::memory_order_relaxed);
+        const uint64_t pass_ns = mono_ns() - t_pass0;
+        last_pass_ns.store(pass_ns, std::memory_order_relaxed);
         if (b->rc != 0) { b->err = last_error(); if (err_out) *err_out = b->err; }
         // the members first (their way back through the kernel is the longest part of the cycle), then the next leader
-        if (reqs.size() > 1) futex_set_and_wake_all(&b->done);
-        else b->done.store(1u, std::memory_order_release);
+        for (uint32_t sh = 0; sh < CoBatch::DONE_SHARDS; ++sh) b->done[sh].v.store(1u, std::memory_order_release);
+        // one sleeper per shard from here, the rest through the sleepers themselves (member 0 is this thread: shard i has sleepers if the pass had more than i + (i == 0) members)
+        for (uint32_t sh = 0; sh < CoBatch::DONE_SHARDS; ++sh) {
+            const uint32_t first_sleeper = sh == 0 ? CoBatch::DONE_SHARDS : sh;       // member indices of shard sh: sh, sh + 8, ... (member 0 is this thread)
+            if (first_sleeper < reqs.size()) syscall(SYS_futex, reinterpret_cast<uint32_t *>(&b->done[sh].v), FUTEX_WAKE_PRIVATE, WAKE_ROOT, nullptr, nullptr, 0);
+        }
         std::shared_ptr<CoBatch> next;
         {
-            std::lock_guard<std::mutex> g(m);
+            LockGuard g(m);
             running = false;
+            // passes of one workload take the same time to within a few percent, and what disturbs one (a workspace that grows) makes it LONGER: the shortest of
+            // the last eight is the estimate
+            pass_ring[pass_ring_at++ & 7u] = pass_ns;
+            pass_est_ns = pass_ns;
+            for (uint64_t v : pass_ring) if (v && v < pass_est_ns) pass_est_ns = v;
             // what later leaders wait for: (b) the largest of the last four passes; (a) for the batch that waited behind this pass, this pass's callers
             // plus the ones waiting in it now
             recent[recent_at++ & 3u] = (uint32_t)units_run;
@@ -159,6 +304,7 @@ public:
             last_end_ns.store(mono_ns(), std::memory_order_relaxed);
             st.batches++; st.members += reqs.size(); if (reqs.size() > st.max_members) st.max_members = reqs.size();
             st.lingered = n_lingered.load(std::memory_order_relaxed);
+            st.exec_ns += pass_ns; st.linger_ns = linger_ns.load(std::memory_order_relaxed);
             if (!open.empty()) next = open.front();
         }
         if (next) futex_set_and_wake_all(&next->go);      // (outside the lock: the wake-up is a system call, and the woken leader wants the lock)
@@ -166,23 +312,27 @@ public:
     }
 
     CombinerStats stats() {
-        std::lock_guard<std::mutex> g(m);
+        LockGuard g(m);
         return st;
     }
     void reset_stats() {
-        std::lock_guard<std::mutex> g(m);
+        LockGuard g(m);
         st = CombinerStats();
-        n_lingered.store(0);
+        n_lingered.store(0); linger_ns.store(0);
     }
 
 private:
-    std::mutex m;
+    SpinLock m;
     std::deque<std::shared_ptr<CoBatch>> open;     // batches not yet started, oldest first (the front one may hold `go`)
     bool running = false;
     std::atomic<uint32_t> want_members{1};
+    std::atomic<bool> joinable_hint{false};
     uint32_t recent[4] = {1, 1, 1, 1}, recent_at = 0;      // units of the last four passes (guarded by m)
-    std::atomic<uint64_t> last_end_ns{0}, last_pass_ns{0};
+    std::atomic<uint64_t> last_end_ns{0}, last_pass_ns{0}, cur_end_est_atomic{0};
+    uint64_t pass_est_ns = 0, cur_end_est_ns = 0;          // guarded by m
+    uint64_t pass_ring[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t pass_ring_at = 0;
     std::atomic<uint32_t> n_lingered{0};
+    std::atomic<uint64_t> linger_ns{0};
     CombinerStats st;
 };
 

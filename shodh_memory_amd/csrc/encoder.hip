@@ -1681,6 +1681,10 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     if (const char *sv = getenv("SHODH_ENC_SLOTS")) { const int v = atoi(sv); if (v >= 1 && v <= 16) e->sc_max = (uint32_t)v; }      // forwards in flight per handle (each owns a scratch set)
     if (const char *cv = getenv("SHODH_COALESCE")) e->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) e->co.linger_us = (uint32_t)atoi(lv);
+    if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) e->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
+    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) e->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
+    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) e->co.margin_us = (uint32_t)atoi(mv);
+    if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) e->co.trace = atoi(tv2) != 0;
     if (!e->weights_path.empty()) {      // shodh_embed_cfg.weights_path: MiniLMEmbedder::new loads the model file itself (minilm.rs:652-690)
         const int rc = shodh_embedder_load_file(e, e->weights_path.c_str());
         if (rc != SHODH_OK) { shodh_embedder_destroy(e); return rc; }
@@ -2047,10 +2051,10 @@ int shodh_embedder_set_coalesce(shodh_embedder *e, int enabled, uint32_t linger_
     e->co.linger_us = linger_us;
     return SHODH_OK;
 }
-int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats4, int reset) {
-    if (!e || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats6, int reset) {
+    if (!e || !stats6) { set_error("null argument"); return SHODH_ERR_INVALID; }
     const CombinerStats c = e->co.stats();
-    stats4[0] = c.batches; stats4[1] = c.members; stats4[2] = c.max_members; stats4[3] = c.lingered;
+    stats6[0] = c.batches; stats6[1] = c.members; stats6[2] = c.max_members; stats6[3] = c.lingered; stats6[4] = c.exec_ns / 1000; stats6[5] = c.linger_ns / 1000;
     if (reset) e->co.reset_stats();
     return SHODH_OK;
 }

@@ -140,7 +140,11 @@ struct Workspace {
         for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }
         for (auto &r : ring) { SHODH_HIP_TRY(hipEventCreate(&r[0])); SHODH_HIP_TRY(hipEventCreate(&r[1])); }
         SHODH_HIP_TRY(hipMalloc((void **)&solo_cnt, 256));
-        SHODH_HIP_TRY(hipMemset(solo_cnt, 0, 256));
+        // hipMemset on device memory is not synchronous with the host and the workspace's stream is non-blocking: without the synchronisation the FIRST search
+        // on a new workspace could start before the counter was cleared and have it zeroed under its feet -- survivors lost, a wrong list (seen once in
+        // 6400 calls with 64 threads each creating their workspace while the device was busy: bench.py concurrent_callers, round 5)
+        SHODH_HIP_TRY(hipMemsetAsync(solo_cnt, 0, 256, stream));
+        SHODH_HIP_TRY(hipStreamSynchronize(stream));
         SHODH_HIP_TRY(hipHostMalloc((void **)&h_q, 4096));
         return SHODH_OK;
     }
@@ -497,6 +501,10 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
     idx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *cv = getenv("SHODH_COALESCE")) idx->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) idx->co.linger_us = (uint32_t)atoi(lv);
+    if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) idx->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
+    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) idx->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
+    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) idx->co.margin_us = (uint32_t)atoi(mv);
+    if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) idx->co.trace = atoi(tv2) != 0;
     if (cfg->scan_mode > SHODH_SCAN_GRAPH) { delete idx; set_error("unknown scan mode %u", cfg->scan_mode); return SHODH_ERR_INVALID; }
     if (cfg->scan_mode == SHODH_SCAN_GRAPH) {
         if (cfg->kind != SHODH_INDEX_FLAT || cfg->order > SHODH_ORDER_AVX2 || cfg->dim % 8 != 0 || cfg->max_degree == 0 || cfg->max_degree > 126 ||
@@ -829,10 +837,10 @@ int shodh_index_set_coalesce(shodh_index *idx, int enabled, uint32_t linger_us) 
     idx->co.linger_us = linger_us;
     return SHODH_OK;
 }
-int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats4, int reset) {
-    if (!idx || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+int shodh_index_coalesce_stats(shodh_index *idx, uint64_t *stats6, int reset) {
+    if (!idx || !stats6) { set_error("null argument"); return SHODH_ERR_INVALID; }
     const CombinerStats c = idx->co.stats();
-    stats4[0] = c.batches; stats4[1] = c.members; stats4[2] = c.max_members; stats4[3] = c.lingered;
+    stats6[0] = c.batches; stats6[1] = c.members; stats6[2] = c.max_members; stats6[3] = c.lingered; stats6[4] = c.exec_ns / 1000; stats6[5] = c.linger_ns / 1000;
     if (reset) idx->co.reset_stats();
     return SHODH_OK;
 }
@@ -921,6 +929,7 @@ int shodh_index_clear_deleted(shodh_index *idx) {
     if (idx->shadow) SHODH_TRY(launch_shadow_restore_deleted(idx->rows, idx->rows_h, idx->deleted, idx->n, idx->cfg.dim, nullptr));
     SHODH_HIP_TRY(hipDeviceSynchronize());
     SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
+    SHODH_HIP_TRY(hipDeviceSynchronize());       // (hipMemset does not wait; the next search runs on a non-blocking stream)
     std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
     idx->n_deleted = 0;
     return SHODH_OK;

@@ -370,6 +370,10 @@ int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devi
     if (rc != SHODH_OK) { shodh_sharded_index_destroy(s); return rc; }
     if (const char *cv = getenv("SHODH_COALESCE")) s->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) s->co.linger_us = (uint32_t)atoi(lv);
+    if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) s->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
+    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) s->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
+    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) s->co.margin_us = (uint32_t)atoi(mv);
+    if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) s->co.trace = atoi(tv2) != 0;
     if (const char *sv = getenv("SHODH_SHARD_SLOTS")) { const int v = atoi(sv); if (v >= 1 && v <= 64) s->slots_max = (uint32_t)v; }
     const char *tv = getenv("SHODH_SHARD_THREADS");
     if (n_devices > 1 && !(tv && atoi(tv) == 0)) s->pool.start(n_devices);
@@ -708,10 +712,10 @@ int shodh_sharded_index_set_coalesce(shodh_sharded_index *s, int enabled, uint32
     s->co.linger_us = linger_us;
     return SHODH_OK;
 }
-int shodh_sharded_index_coalesce_stats(shodh_sharded_index *s, uint64_t *stats4, int reset) {
-    if (!s || !stats4) { set_error("null argument"); return SHODH_ERR_INVALID; }
+int shodh_sharded_index_coalesce_stats(shodh_sharded_index *s, uint64_t *stats6, int reset) {
+    if (!s || !stats6) { set_error("null argument"); return SHODH_ERR_INVALID; }
     const CombinerStats c = s->co.stats();
-    stats4[0] = c.batches; stats4[1] = c.members; stats4[2] = c.max_members; stats4[3] = c.lingered;
+    stats6[0] = c.batches; stats6[1] = c.members; stats6[2] = c.max_members; stats6[3] = c.lingered; stats6[4] = c.exec_ns / 1000; stats6[5] = c.linger_ns / 1000;
     if (reset) s->co.reset_stats();
     return SHODH_OK;
 }

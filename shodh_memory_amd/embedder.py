@@ -281,9 +281,9 @@ class MiniLMEmbedder(Embedder):
         L.check(L.lib().shodh_embedder_set_coalesce(self._h, int(bool(enabled)), int(linger_us)))
 
     def coalesce_stats(self, reset=False):
-        a = (C.c_uint64 * 4)()
+        a = (C.c_uint64 * 6)()
         L.check(L.lib().shodh_embedder_coalesce_stats(self._h, C.byref(a), int(bool(reset))))
-        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]), pass_us=int(a[4]), linger_us=int(a[5]))
 
     def stage_timings_us(self):
         a = (C.c_float * 2)()

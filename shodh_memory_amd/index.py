@@ -475,9 +475,9 @@ class VamanaIndex:
         L.check(L.lib().shodh_index_set_coalesce(self.handle, int(bool(enabled)), int(linger_us)))
 
     def coalesce_stats(self, reset=False):
-        a = (C.c_uint64 * 4)()
+        a = (C.c_uint64 * 6)()
         L.check(L.lib().shodh_index_coalesce_stats(self.handle, C.byref(a), int(bool(reset))))
-        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]), pass_us=int(a[4]), linger_us=int(a[5]))
 
     def scan_stats(self):
         a = (C.c_uint64 * 8)()
@@ -657,9 +657,9 @@ class SpannIndex:
         L.check(L.lib().shodh_index_set_coalesce(self.handle, int(bool(enabled)), int(linger_us)))
 
     def coalesce_stats(self, reset=False):
-        a = (C.c_uint64 * 4)()
+        a = (C.c_uint64 * 6)()
         L.check(L.lib().shodh_index_coalesce_stats(self.handle, C.byref(a), int(bool(reset))))
-        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]))
+        return dict(passes=int(a[0]), calls=int(a[1]), largest=int(a[2]), lingered=int(a[3]), pass_us=int(a[4]), linger_us=int(a[5]))
 
 
 class VectorIndexBackend:

@@ -59,6 +59,25 @@ def test_concurrent_single_query_callers_get_their_solo_bytes(S, oracle, scan_mo
     idx.close()
 
 
+def test_first_search_on_a_fresh_workspace_under_load(S):
+    """64 threads make their FIRST call at the same moment (coalescing off: every caller creates its own workspace while the device is busy with the
+    others). The workspace's survivor counter is cleared with a memset that has to be complete before the first kernel reads it -- round 5 found one
+    wrong list in 6400 such calls (bench.py concurrent_callers, coalesce off), a race that had been there since the single-query scan was written."""
+    from shodh_memory_amd import _lib as L
+    from tools import callers
+    q = synth.queries(64)
+    rows = synth.corpus(150_000, queries=q)
+    ref = S.VamanaIndex(S.VamanaConfig(dimension=384)); ref.build(rows)
+    e120 = _solo(ref, q, 120)
+    ref.close()
+    for rep in range(5):
+        idx = S.VamanaIndex(S.VamanaConfig(dimension=384)); idx.build(rows)
+        idx.set_coalesce(False)
+        r = callers.search(L.lib(), idx.handle, q, 120, threads=64, calls_per_thread=6, warmup=0, expect=e120)
+        assert r.errors == 0 and r.mismatches == 0, "fresh index %d: %d of %d first calls wrong" % (rep, r.mismatches, r.calls)
+        idx.close()
+
+
 def test_mixed_k_and_small_batches_share_a_pass(S):
     """members with different k (a recall at limit 10 asks k = 120, a dedup lookup k = 5) and calls with a few queries: each gets exactly its own answer"""
     n = 120_000
