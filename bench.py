@@ -143,6 +143,51 @@ def host_cpu_info():
 
 
 # ---- timing helpers ----------------------------------------------------------------------------------------------------
+def read_sclk_mhz(local_rank=0):
+    """current shader clock of this rank's GPU from sysfs (pp_dpm_sclk: the line marked `*`), MHz, or None. Explains box-to-box spreads of the kernel time
+    (180 vs 202 us for the same kernel): the device runs wherever its power / thermal state lets it."""
+    import glob
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if not cards:
+            return None
+        path = cards[min(local_rank, len(cards) - 1)]
+        for line in open(path).read().splitlines():
+            if line.strip().endswith("*"):
+                return float(line.split(":")[1].strip().split("M")[0])
+    except Exception:
+        return None
+    return None
+
+
+class ClockSampler:
+    """samples read_sclk_mhz every `period_s` on a thread while a region runs"""
+    def __init__(self, local_rank=0, period_s=0.02):
+        import threading
+        self.v, self.stop, self.rank, self.period = [], threading.Event(), local_rank, period_s
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop.is_set():
+            c = read_sclk_mhz(self.rank)
+            if c is not None:
+                self.v.append(c)
+            self.stop.wait(self.period)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set(); self.t.join()
+
+    def summary(self):
+        if not self.v:
+            return None
+        v = sorted(self.v)
+        return {"samples": len(v), "min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+
+
 def timed_steps(torch, fn, steps, warmup):
     for i in range(warmup):
         fn(i)
@@ -793,6 +838,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_mean_us, kern_min_us, kern_n = index.kernel_timing(reset=True)
+    sclk_after_timed = read_sclk_mhz(local_rank)
 
     # sanity: results are well-formed (full parity is the job of tests/)
     last_q = qpool[(args.steps - 1) % len(qpool)]
@@ -813,10 +859,12 @@ def main():
             n_sus = int(tn.item())
         barrier(); torch.cuda.synchronize()
         ts0 = time.perf_counter()
-        for i in range(n_sus):
-            step(i)
-        torch.cuda.synchronize(); barrier()
+        with ClockSampler(local_rank) as clk:
+            for i in range(n_sus):
+                step(i)
+            torch.cuda.synchronize(); barrier()
         ts = time.perf_counter() - ts0
+        sclk_sustained = clk.summary()
         sk_mean, _, sk_n = index.kernel_timing(reset=True)
         sustained = {"seconds": round(ts, 3), "steps": n_sus, "ms_per_step": round(ts / n_sus * 1e3, 4), "queries_per_s": round(args.nq * n_sus / ts, 1),
                      "scan_kernel_us_mean_last_%d" % sk_n: round(sk_mean, 2)}
@@ -829,8 +877,13 @@ def main():
     traffic = None
     traffic_profile = None
     try:
+        import hashlib
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if (pm["config"]["rows"], pm["config"]["dim"], pm["config"]["nq"]) == (rows_local, args.dim, args.nq) and args.scan != "exact":
+        src_now = hashlib.sha256(open(os.path.join(ROOT, "shodh_memory_amd", "csrc", "scan_mfma.hip"), "rb").read()).hexdigest()
+        if pm.get("scan_mfma_hip_sha256") != src_now:
+            # the committed counters belong to ANOTHER version of the kernel's source: say so instead of quoting them
+            traffic_profile = {"stale": True, "reason": "profiles/pmc_traffic.json was collected for scan_mfma.hip %s..., this run has %s...; re-run tools/r5_profiles.sh" % (str(pm.get("scan_mfma_hip_sha256"))[:12], src_now[:12])}
+        elif (pm["config"]["rows"], pm["config"]["dim"], pm["config"]["nq"]) == (rows_local, args.dim, args.nq) and args.scan != "exact":
             traffic_profile = {"bytes_per_launch": [v["traffic_bytes_per_launch"] for kk, v in pm["kernels"].items() if "mfma_scan_kernel<1" in kk][0],
                                "source": "profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (tools/pmc_traffic.py); NOT measured in this run"}
     except Exception:
@@ -841,7 +894,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "mfma_scan_kernel<EMIT>" if args.scan != "exact" else "flat_exact_kernel",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_profiled": traffic_profile, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
-                "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes, "rows_live": rows_live, "rows_scanned": rows_local}
+                "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes, "rows_live": rows_live, "rows_scanned": rows_local,
+                "gpu_sclk_mhz": {"after_timed_region": sclk_after_timed, "during_sustained_run": sclk_sustained if args.sustained_s > 0 else None,
+                                 "source": "/sys/class/drm/card*/device/pp_dpm_sclk (the active level); the kernel time scales with it, which is the box-to-box spread"}}
         ff = flat_fractions(rows_local, rows_live, args.dim, args.nq, kern_mean_us, ms_per_step)
         roof.update({"bytes_moved_fp16_shadow_per_launch": ff["bytes_moved_fp16_shadow_per_step"],
                      "frac_actual_bytes": ff.get("kernel_hbm_frac_actual_bytes"), "mfma_tflops": ff.get("kernel_mfma_tflops"),

@@ -943,7 +943,15 @@ struct EncScratch {
     int32_t *d_ids = nullptr; int32_t *d_tok_seq = nullptr, *d_tok_pos = nullptr, *d_cu = nullptr; float *d_out = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // one-text INT8 forward replayed from a hipGraph (encode_one_graph): the instantiated graph holds THIS scratch set's buffer addresses, so it is dropped
+    // whenever one of them is reallocated; the pinned block is [ids max_len | real length | out hidden]
+    hipGraphExec_t g1 = nullptr;
+    int32_t *h_pin = nullptr;
+    bool one_text_consts = false;        // d_cu / d_tok_seq / d_tok_pos / d_orow hold the constants of a one-text padded forward (any other forward overwrites them)
+    void drop_graph() { if (g1) { hipGraphExecDestroy(g1); g1 = nullptr; } }
     void destroy() {
+        drop_graph();
+        if (h_pin) hipHostFree(h_pin);
         hipFree(X); hipFree(QKV); hipFree(CTX); hipFree(FF); hipFree(PRE); hipFree(XQ); hipFree(HQ); hipFree(rsX); hipFree(rsH); hipFree(mmr); hipFree(act_params);
         hipFree(d_klen); hipFree(d_orow); hipFree(d_ids); hipFree(d_tok_seq); hipFree(d_tok_pos); hipFree(d_cu); hipFree(d_out);
         if (ev0) hipEventDestroy(ev0);
@@ -994,6 +1002,7 @@ struct shodh_embedder {
     // coalescing front for concurrent one-text calls (combiner.h): N x encode() arriving together run as ONE per-text forward
     bool coalesce = true;
     Combiner co;
+    bool enc_graph = true;               // one-text INT8 calls replay a captured hipGraph (SHODH_ENC_GRAPH=0: plain launches)
 };
 
 namespace shodh {
@@ -1018,6 +1027,7 @@ static void layout(shodh_embedder *e) {
 static int reserve(shodh_embedder *e, EncScratch *sc, size_t ntok, size_t nseq, size_t pre_tok) {
     const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
     const size_t es = e->cfg.dtype == SHODH_DTYPE_BF16 ? 2 : 4;
+    if (ntok > sc->tok_cap || pre_tok > sc->pre_cap || nseq > sc->seq_cap) sc->drop_graph();      // (the graph holds the old addresses)
     if (ntok > sc->tok_cap) {
         hipFree(sc->X); hipFree(sc->QKV); hipFree(sc->CTX); hipFree(sc->FF); hipFree(sc->d_tok_seq); hipFree(sc->d_tok_pos); hipFree(sc->XQ);
         hipFree(sc->HQ); hipFree(sc->rsX); hipFree(sc->rsH);
@@ -1354,6 +1364,7 @@ static int forward_int8(shodh_embedder *e, EncScratch *sc, int ntok, int nseq, i
     const int S = ps_rows ? nseq : 1;                     // range slots per tensor
     const int mm_stride = ps_rows ? 2 : 0;
     if ((size_t)S > sc->mmr_slots) {
+        sc->drop_graph();
         hipFree(sc->mmr); sc->mmr = nullptr; sc->mmr_slots = 0;
         const size_t cap = (size_t)S + (size_t)S / 4 + 16;
         SHODH_HIP_TRY(hipMalloc((void **)&sc->mmr, ((size_t)n_pairs * 8 + (size_t)e->cfg.layers * 16) * cap));
@@ -1679,6 +1690,7 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
         shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
     }
     if (const char *sv = getenv("SHODH_ENC_SLOTS")) { const int v = atoi(sv); if (v >= 1 && v <= 16) e->sc_max = (uint32_t)v; }      // forwards in flight per handle (each owns a scratch set)
+    if (const char *gv = getenv("SHODH_ENC_GRAPH")) e->enc_graph = atoi(gv) != 0;
     if (const char *cv = getenv("SHODH_COALESCE")) e->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) e->co.linger_us = (uint32_t)atoi(lv);
     if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) e->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
@@ -1854,6 +1866,68 @@ static void sc_release(shodh_embedder *e, EncScratch *c) {
     e->sc_cv.notify_one();
 }
 
+// ONE text, INT8, padded tensor: `encode()` as the reference's hot path calls it (minilm.rs:883-982). The forward is 32 launches of a few microseconds
+// each plus six small copies -- launch-bound (0.65 ms, of which the device works ~0.3). Its shape never changes (max_len positions, one sequence), so the
+// whole call is captured ONCE per scratch set as a hipGraph -- ids and real length in from a pinned block, the kernels, the pooled vector out into the
+// same block -- and replayed: one launch per text. Same kernels, same arguments, same bytes (tests/test_concurrent_gpu.py compares with SHODH_ENC_GRAPH=0).
+static int encode_one_graph(shodh_embedder *e, EncScratch *sc, const int32_t *ids, int len, float *out, float *us_out) {
+    const uint32_t ML = e->cfg.max_len, H = e->cfg.hidden;
+    hipStream_t st = sc->stream;
+    SHODH_TRY(reserve(e, sc, ML, 1, ML));
+    if (!sc->h_pin) SHODH_HIP_TRY(hipHostMalloc((void **)&sc->h_pin, ((size_t)ML + 1 + H) * 4));
+    int32_t *h_ids = sc->h_pin, *h_klen = sc->h_pin + ML;
+    float *h_out = reinterpret_cast<float *>(sc->h_pin + ML + 1);
+    memcpy(h_ids, ids, (size_t)ML * 4);
+    *h_klen = len;
+    auto body = [&]() -> int {
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_ids, h_ids, (size_t)ML * 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_klen, h_klen, 4, hipMemcpyHostToDevice, st));
+        SHODH_TRY(forward_int8(e, sc, (int)ML, 1, 128, sc->d_klen, sc->d_orow, sc->d_out, st, 0));
+        SHODH_HIP_TRY(hipMemcpyAsync(h_out, sc->d_out, (size_t)H * 4, hipMemcpyDeviceToHost, st));
+        return SHODH_OK;
+    };
+    const uint64_t t0 = mono_ns();
+    if (!sc->one_text_consts) {
+        std::vector<int32_t> cu{0, (int32_t)ML}, tseq(ML, 0), tpos(ML), orow{0};
+        for (uint32_t p = 0; p < ML; ++p) tpos[p] = (int32_t)p;
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_cu, cu.data(), 8, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_tok_seq, tseq.data(), (size_t)ML * 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_tok_pos, tpos.data(), (size_t)ML * 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipMemcpyAsync(sc->d_orow, orow.data(), 4, hipMemcpyHostToDevice, st));
+        SHODH_HIP_TRY(hipStreamSynchronize(st));
+        sc->one_text_consts = true;
+    }
+    if (!sc->g1) {
+        // one plain run first (kernel attributes, range buffers: nothing may be allocated while capturing)
+        SHODH_TRY(body());
+        SHODH_HIP_TRY(hipStreamSynchronize(st));
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rc = body();
+            const hipError_t ee = hipStreamEndCapture(st, &graph);
+            ok = rc == SHODH_OK && ee == hipSuccess && graph != nullptr && hipGraphInstantiate(&sc->g1, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) hipGraphDestroy(graph);
+        }
+        if (!ok) {          // no graphs on this runtime: the plain path from now on (the run above already produced this call's vector)
+            (void)hipGetLastError();
+            sc->g1 = nullptr;
+            e->enc_graph = false;
+            memcpy(out, h_out, (size_t)H * 4);
+            return SHODH_OK;
+        }
+    }
+    SHODH_HIP_TRY(hipGraphLaunch(sc->g1, st));
+    const hipError_t er = hipStreamSynchronize(st);
+    if (er != hipSuccess) { set_error("encode failed on device: %s", hipGetErrorString(er)); return SHODH_ERR_DEVICE; }
+    memcpy(out, h_out, (size_t)H * 4);
+    const float us = (float)(mono_ns() - t0) / 1e3f;
+    std::lock_guard<std::mutex> sg(e->stat_mu);
+    e->last_us[0] = us; e->last_us[1] = (float)ML;
+    if (us_out) { us_out[0] = us; us_out[1] = (float)ML; }
+    return SHODH_OK;
+}
+
 // scope: SHODH_QUANT_SCOPE_* of this call (INT8 only). PER_TEXT runs the per-sequence kernels when the shape allows (per_text_fast_ok); when it
 // does not, returns ENC_RETRY_EACH before touching the device and the caller runs the texts one per forward -- which is the same function by
 // definition (a batch of one text has one range per tensor either way).
@@ -1910,6 +1984,8 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
     const int ntok = cu.back();
     const bool per_text = int8 && scope == SHODH_QUANT_SCOPE_PER_TEXT && nseq_c > 1;      // (one text: the two scopes are the same function, and the batch kernels take every shape)
     if (per_text && !per_text_fast_ok(e, max_seq)) return ENC_RETRY_EACH;
+    if (e->enc_graph && int8 && !device_io && b == 1 && nseq_c == 1 && per_text_fast_ok(e, max_seq)) return encode_one_graph(e, sc, idp, klen[0], out, us_out);
+    sc->one_text_consts = false;         // (this forward writes its own token maps)
     // fp32 / bf16: texts never interact, but WHICH kernels run used to depend on the size of the forward (fused feed-forward from 2048 tokens, K-split
     // down projection up to 256), so encode(t) and encode_batch([t, ...])[0] differed at bf16 rounding level. One-text calls and PER_TEXT-scope calls
     // (encode_each, coalesced encode() calls) take the forms a single text takes, whatever the batch: the same bytes per text.

@@ -213,6 +213,32 @@ def test_a_text_has_one_embedding_whoever_shares_its_forward(S, dtype):
     e.close()
 
 
+def test_one_text_int8_graph_replay_equals_plain_launches(S, monkeypatch):
+    """encode() of ONE text on the INT8 model replays a captured hipGraph (encoder.hip: encode_one_graph). Same kernels, same arguments: the vectors are
+    byte-equal to plain launches (SHODH_ENC_GRAPH=0), also when other forwards use the same scratch set in between (they overwrite the token maps the
+    graph reads and may reallocate what it points at) and for texts the graph does not take (more than 128 tokens)."""
+    from shodh_memory_amd import _lib as L
+    n = 24
+    ids, mask = _tokens(n, seed=8)
+    ids[5, :200] = np.arange(1000, 1200); ids[5, 0] = 101; ids[5, 199] = 102; mask[5, :200] = 1          # beyond the tokenizer's window: plain path
+    monkeypatch.setenv("SHODH_ENC_GRAPH", "0")
+    plain = S.MiniLMEmbedder(synthetic_seed=1234, dtype=L.DTYPE_INT8)
+    monkeypatch.setenv("SHODH_ENC_GRAPH", "1")
+    monkeypatch.setenv("SHODH_ENC_SLOTS", "1")          # one scratch set: every call below lands on the one that holds the graph
+    graph = S.MiniLMEmbedder(synthetic_seed=1234, dtype=L.DTYPE_INT8)
+    ref = np.concatenate([plain.encode_ids(ids[i:i + 1], mask[i:i + 1]) for i in range(n)], 0)
+    got = np.concatenate([graph.encode_ids(ids[i:i + 1], mask[i:i + 1]) for i in range(n)], 0)
+    assert got.tobytes() == ref.tobytes()
+    b_ref = plain.encode_ids(ids[:7], mask[:7])
+    for rep in range(3):
+        assert graph.encode_ids(ids[:7], mask[:7]).tobytes() == b_ref.tobytes()                         # a batch call in between (same scratch set)
+        big = np.tile(np.arange(n), 40 * (rep + 1))
+        graph.encode_ids(ids[big], mask[big], scope=L.QUANT_SCOPE_PER_TEXT)                             # ... and one that makes the scratch set grow
+        again = np.concatenate([graph.encode_ids(ids[i:i + 1], mask[i:i + 1]) for i in range(n)], 0)
+        assert again.tobytes() == ref.tobytes()
+    plain.close(); graph.close()
+
+
 def _word_tokenizer():
     from tokenizers import Tokenizer, models, pre_tokenizers, processors
     words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]"] + ["w%d" % i for i in range(400)]

@@ -12,7 +12,10 @@ def load(d, counter):
 f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-latency`",
        "correction": "gfx950: FETCH_SIZE reports exactly half of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section) -> doubled; units KB; WRITE_SIZE taken as is",
-       "config": {"rows": int(sys.argv[3]), "dim": int(sys.argv[4]), "nq": int(sys.argv[5]), "k": int(sys.argv[6])}, "kernels": {}}
+       "config": {"rows": int(sys.argv[3]), "dim": int(sys.argv[4]), "nq": int(sys.argv[5]), "k": int(sys.argv[6])},
+       # the counters belong to THIS version of the kernel's source: bench.py refuses to quote them for another one
+       "scan_mfma_hip_sha256": __import__("hashlib").sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shodh_memory_amd", "csrc", "scan_mfma.hip"), "rb").read()).hexdigest(),
+       "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fr, wr = f.get(k, 0.0), w.get(k, 0.0)
     out["kernels"][k] = {"fetch_size_kb_raw": round(fr, 1), "write_size_kb_raw": round(wr, 1), "traffic_bytes_per_launch": int(fr * 2 * 1024 + wr * 1024)}
