@@ -143,21 +143,49 @@ def host_cpu_info():
 
 
 # ---- timing helpers ----------------------------------------------------------------------------------------------------
-def read_sclk_mhz(local_rank=0):
-    """current shader clock of this rank's GPU from sysfs (pp_dpm_sclk: the line marked `*`), MHz, or None. Explains box-to-box spreads of the kernel time
-    (VERDICT r4: 180 vs 202 us for the same kernel): the device runs wherever its power / thermal state lets it."""
+_SCLK_PATH = {}
+
+
+def _sclk_path(local_rank=0):
+    """pp_dpm_sclk of the GPU this rank computes on. A container sees every card of the host under /sys/class/drm, so the card is matched by PCI address
+    (torch's pci_bus_id / pci_device_id of the device) and, failing that, taken to be the card with the highest active clock while we are busy."""
     import glob
+    if local_rank in _SCLK_PATH:
+        return _SCLK_PATH[local_rank]
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    path = None
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if not cards:
-            return None
-        path = cards[min(local_rank, len(cards) - 1)]
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank if torch.cuda.device_count() > local_rank else 0)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        for c in cards:
+            if want in os.path.realpath(os.path.dirname(c)).lower():
+                path = c
+                break
+    except Exception:
+        path = None
+    _SCLK_PATH[local_rank] = (path, cards)
+    return _SCLK_PATH[local_rank]
+
+
+def _active_mhz(path):
+    try:
         for line in open(path).read().splitlines():
             if line.strip().endswith("*"):
                 return float(line.split(":")[1].strip().split("M")[0])
     except Exception:
         return None
     return None
+
+
+def read_sclk_mhz(local_rank=0):
+    """current shader clock of this rank's GPU from sysfs (pp_dpm_sclk: the line marked `*`), MHz, or None. Explains box-to-box spreads of the kernel time
+    (VERDICT r4: 180 vs 202 us for the same kernel): the device runs wherever its power / thermal state lets it."""
+    path, cards = _sclk_path(local_rank)
+    if path:
+        return _active_mhz(path)
+    vals = [v for v in (_active_mhz(c) for c in cards) if v is not None]          # unmatched: the busiest card is ours (the others idle at ~100 MHz)
+    return max(vals) if vals else None
 
 
 class ClockSampler:
@@ -896,7 +924,8 @@ def main():
                 "traffic": traffic, "traffic_profiled": traffic_profile, "launch_us_mean": round(kern_mean_us, 2), "launch_us_min": round(kern_min_us, 2),
                 "launches_timed": kern_n, "algorithmic_bytes_per_launch": alg_bytes, "rows_live": rows_live, "rows_scanned": rows_local,
                 "gpu_sclk_mhz": {"after_timed_region": sclk_after_timed, "during_sustained_run": sclk_sustained if args.sustained_s > 0 else None,
-                                 "source": "/sys/class/drm/card*/device/pp_dpm_sclk (the active level); the kernel time scales with it, which is the box-to-box spread"}}
+                                 "card_matched_by_pci": bool(_sclk_path(local_rank)[0]),
+                                 "source": "/sys/class/drm/card*/device/pp_dpm_sclk (the active level) of the card with this device's PCI address; the kernel time scales with it, which is the box-to-box spread"}}
         ff = flat_fractions(rows_local, rows_live, args.dim, args.nq, kern_mean_us, ms_per_step)
         roof.update({"bytes_moved_fp16_shadow_per_launch": ff["bytes_moved_fp16_shadow_per_step"],
                      "frac_actual_bytes": ff.get("kernel_hbm_frac_actual_bytes"), "mfma_tflops": ff.get("kernel_mfma_tflops"),
