@@ -738,7 +738,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
             e = {"name": "cfg3_pipeline" if dname == "bf16" else "cfg3_pipeline_int8",
                  "workload": "configs[2]: %d synthetic texts -> MiniLM-L6 %s -> add_vectors -> recall top-10 of 256 query TEXTS" % (n_texts, "bf16" if dname == "bf16" else "INT8, quant_scope PER_TEXT (every text and every query is one encode() of the reference: padded [1, 256] tensor, its own ranges)"),
                  "parity": "timing only at this size; the chained parity test (HIP MiniLM -> add_vectors -> recall, bit-equal to the oracle on the device-produced embeddings) "
-                           "runs 50 000 texts: tests/test_round2_gpu.py::test_configs2_chained_encode_add_recall",
+                           + ("runs 50 000 texts: tests/test_round2_gpu.py::test_configs2_chained_encode_add_recall" if dname == "bf16" else
+                              "runs 12 000 texts in this dtype and scope: tests/test_concurrent_gpu.py::test_configs2_chained_int8_per_text_encode_add_recall"),
                  "ingest_texts_per_s": round(n_texts / t_ingest, 1), "ingest_s": round(t_ingest, 3), "encode_s": round(t_enc, 3), "insert_s": round(t_add, 3),
                  "tokens": tok, "recall_ms_per_step_incl_query_encode": round(dt * 1e3, 4), "recall_queries_per_s_incl_query_encode": round(256 / dt, 1),
                  "search_only_ms_per_step": round(dts * 1e3, 4), "survivors_emitted_per_query": round(st["emitted"] / 256, 1),
