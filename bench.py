@@ -280,6 +280,28 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         entry["wall_s"] = round(time.perf_counter() - t0, 2)
         cfgs.append(entry)
 
+    def callers_run(index, qh, k, threads, calls):
+        """T host threads x one query per call on `index` (tools/callers.c), coalescing front on; every result byte-checked against the query's solo answer"""
+        import sys as _sys
+        if ROOT not in _sys.path:
+            _sys.path.insert(0, ROOT)
+        from tools import callers as CL
+        index.set_coalesce(False)
+        ex_ids = np.empty((qh.shape[0], k), np.uint32); ex_dist = np.empty((qh.shape[0], k), np.float32)
+        for i in range(qh.shape[0]):
+            a_, b_, _ = index.search_batch(qh[i:i + 1], k)
+            ex_ids[i], ex_dist[i] = a_[0], b_[0]
+        solo = CL.search(L.lib(), index.handle, qh, k, threads=1, calls_per_thread=max(10, calls // 2), warmup=2, expect=(ex_ids, ex_dist))
+        index.set_coalesce(True)
+        index.coalesce_stats(reset=True)
+        r = CL.search(L.lib(), index.handle, qh, k, threads=threads, calls_per_thread=calls, warmup=2, expect=(ex_ids, ex_dist))
+        st = index.coalesce_stats()
+        d = {"k": k, "threads": threads, "solo_p50_us": round(solo.p50_us, 1), "solo_queries_per_s": round(solo.calls / solo.wall_s, 1)}
+        d.update(r.as_dict("queries"))
+        d.update({"mean_callers_per_pass": round(st["calls"] / max(st["passes"], 1), 2), "mean_pass_us": round(st["pass_us"] / max(st["passes"], 1), 1),
+                  "all_results_equal_solo": bool(r.mismatches == 0 and r.errors == 0 and solo.mismatches == 0)})
+        return d
+
     # -- configs[0]: 10k memories, B = 1, top-10: the reference's CPU path, and the same shape on the GPU ------------------
     if want("cfg1_10k_b1"):
         t0 = time.perf_counter()
@@ -413,6 +435,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         q1 = qp[0][:1].contiguous()
         o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
         e["single_query_ms"] = round(timed_steps(torch, lambda i: idx.search_batch_device(q1, 10, out=o1), 20, 3) * 1e3, 4)
+        # the reference's call pattern at the north-star size: 64 threads x one query (k = 120) on the 10M index
+        e["callers_64_k120"] = callers_run(idx, qp[0][:64].cpu().numpy(), 120, 64, 12)
         idx.close(); del idx
         torch.cuda.empty_cache()
         done(e, t0)
@@ -638,6 +662,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
              "postings_scanned_per_query": round(float(lens[probes].sum().item()) / nq, 1), "batch_sweep_ms_per_step": sweep,
              "list_len_mean": round(float(lens.float().mean()), 1), "list_len_max": int(lens.max()),
              "encode_all_rows_s (nearest centroid + PQ encode, host rows in)": round(t_enc, 2)}
+        # SpannIndex::search is one query per call too (spann.rs:574): 64 threads x one query on the same index
+        e["callers_64_k10"] = callers_run(idx, qp[0][:64].cpu().numpy(), k, 64, 20)
         idx.close(); del idx
         torch.cuda.empty_cache()
         done(e, t0)

@@ -9,7 +9,7 @@
 //   * a caller that finds no open batch opens one and becomes its leader; later callers join the open batch (as long as it has room) and
 //     sleep on the batch's `done` word;
 //   * a leader waits for the previous batch to finish (`go`), closes its batch, runs ONE device pass for all members, scatters the results
-//     to the members' own output pointers, hands `go` to the next batch's leader and wakes its members (one futex wake for all of them);
+//     to the members' own output pointers, wakes its members (a tree over eight futex words, see CoBatch::done) and hands `go` to the next batch's leader;
 //   * a caller that is alone (no pass in flight, nobody else arriving) starts at once: its call is the same single-item call as without
 //     the front, plus two uncontended mutex operations;
 //   * linger: a leader that may start waits up to `linger_us` (30 us against a 150-400 us pass; a quarter of the last pass if that is more)
@@ -182,8 +182,9 @@ public:
     uint32_t margin_us = 40, overrun_us = 40;
     uint32_t spin_callers_max = std::max(1u, std::thread::hardware_concurrency() / 2u);
 
-    // exec(reqs) runs ONE device pass for all requests, writes every member's outputs and returns the status shared by all of them
-    // (`err_of_leader` is copied to the members when it is not SHODH_OK). Returns the batch status; *led = this caller ran the pass.
+    // exec(reqs) runs ONE device pass for all requests (reqs[0] is the leader's own), writes every member's outputs and returns the status shared by all
+    // of them; last_error() is the leader thread's message, copied to every member through *err_out when the status is not 0. Returns the batch status.
+    // A request must be valid on its own (the callers screen their inputs before they submit): one member's bad input must not fail the others.
     template <class Exec, class ErrFn>
     int submit(void *req, uint32_t units, uint32_t max_units, Exec &&exec, ErrFn &&last_error, std::string *err_out) {
         std::shared_ptr<CoBatch> b;

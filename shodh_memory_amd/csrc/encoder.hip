@@ -1000,7 +1000,7 @@ struct shodh_embedder {
     std::mutex stat_mu;
     float last_us[2] = {0, 0};
     // coalescing front for concurrent one-text calls (combiner.h): N x encode() arriving together run as ONE per-text forward
-    bool coalesce = true;
+    std::atomic<bool> coalesce{true};
     Combiner co;
     bool enc_graph = true;               // one-text INT8 calls replay a captured hipGraph (SHODH_ENC_GRAPH=0: plain launches)
 };

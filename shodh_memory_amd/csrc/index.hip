@@ -217,7 +217,7 @@ struct shodh_index {
     uint32_t g_stride = 0, g_medoid = 0;
     uint64_t g_nodes = 0;                          // rows that have a node in the graph (== n when the graph is usable)
     // coalescing front for concurrent host-pointer searches of a few queries each (combiner.h): SHODH_COALESCE=0 / shodh_index_set_coalesce turn it off
-    bool coalesce = true;
+    std::atomic<bool> coalesce{true};
     Combiner co;
 };
 

@@ -218,7 +218,7 @@ struct shodh_sharded_index {
     std::mutex stat_mu;
     float last_us[4] = {0, 0, 0, 0};   // search, exchange, merge, total (host wall clock of the last search)
     EnqueuePool pool;              // per-shard enqueue workers (SHODH_SHARD_THREADS=0: the calling thread issues every shard, as before round 4)
-    bool coalesce = true;          // concurrent host-pointer searches of a few queries share one pass over the shards and ONE exchange (combiner.h)
+    std::atomic<bool> coalesce{true};   // concurrent host-pointer searches of a few queries share one pass over the shards and ONE exchange (combiner.h)
     Combiner co;
 };
 

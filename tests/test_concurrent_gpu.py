@@ -78,6 +78,51 @@ def test_first_search_on_a_fresh_workspace_under_load(S):
         idx.close()
 
 
+def test_searches_coalesce_while_the_index_grows(S):
+    """readers and a writer on one handle (the reference: recall under vector_index.read(), remember under .write(), retrieval.rs:680-712, :912): 12 threads
+    search one query per call while another thread appends rows batch by batch. A pass runs under the index' shared lock, an append under the exclusive
+    one, so every answer must be the exact top-k of SOME prefix the index went through -- never a mixture, never a torn list."""
+    n0, step, n_steps, k = 60_000, 5_000, 8, 10
+    q = synth.queries(32)
+    rows = synth.corpus(n0 + step * n_steps, queries=q)
+    states = []
+    ref = S.VamanaIndex(S.VamanaConfig(dimension=384))
+    ref.build(rows[:n0])
+    for i in range(n_steps + 1):
+        if i:
+            ref.add_vectors(rows[n0 + (i - 1) * step:n0 + i * step])
+        ids, dist, _ = ref.search_batch(q, k)
+        states.append((ids.copy(), dist.copy()))
+    ref.close()
+    idx = S.VamanaIndex(S.VamanaConfig(dimension=384))
+    idx.build(rows[:n0])
+    bad, seen_states = [], set()
+    stop = threading.Event()
+
+    def reader(t):
+        i = t
+        while not stop.is_set():
+            j = i % 32
+            ids, dist, _ = idx.search_batch(q[j:j + 1], k)
+            hit = [s for s in range(n_steps + 1) if np.array_equal(ids[0], states[s][0][j]) and dist[0].tobytes() == states[s][1][j].tobytes()]
+            if not hit:
+                bad.append((t, j))
+            else:
+                seen_states.add(hit[-1])
+            i += 12
+    th = [threading.Thread(target=reader, args=(t,)) for t in range(12)]
+    for x in th: x.start()
+    for i in range(1, n_steps + 1):
+        idx.add_vectors(rows[n0 + (i - 1) * step:n0 + i * step])
+    stop.set()
+    for x in th: x.join()
+    assert not bad, bad[:5]
+    ids, dist, _ = idx.search_batch(q, k)
+    assert np.array_equal(ids, states[-1][0]) and dist.tobytes() == states[-1][1].tobytes()
+    print("index states seen by the readers while it grew:", sorted(seen_states), idx.coalesce_stats())
+    idx.close()
+
+
 def test_mixed_k_and_small_batches_share_a_pass(S):
     """members with different k (a recall at limit 10 asks k = 120, a dedup lookup k = 5) and calls with a few queries: each gets exactly its own answer"""
     n = 120_000
