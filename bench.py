@@ -280,6 +280,20 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         entry["wall_s"] = round(time.perf_counter() - t0, 2)
         cfgs.append(entry)
 
+    def callers_available():
+        """tools/callers.c is compiled with gcc at run time: without a C compiler the concurrent entries are left out (with a note) instead of failing the line"""
+        import sys as _sys
+        if ROOT not in _sys.path:
+            _sys.path.insert(0, ROOT)
+        try:
+            from tools import callers as CL
+            CL.lib()
+            return True
+        except Exception as ex:      # noqa: BLE001
+            if not any(c.get("name") == "concurrent_callers_unavailable" for c in cfgs):
+                cfgs.append({"name": "concurrent_callers_unavailable", "reason": "tools/callers.c could not be built: %s" % str(ex)[:200]})
+            return False
+
     def callers_run(index, qh, k, threads, calls):
         """T host threads x one query per call on `index` (tools/callers.c), coalescing front on; every result byte-checked against the query's solo answer"""
         import sys as _sys
@@ -342,7 +356,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
     #    lock, retrieval.rs:912-918; k = 120 is what a top-10 recall asks the index). T host threads (tools/callers.c, pthreads, no Python in the loop)
     #    call shodh_index_search(nq = 1) in a closed loop; every result is compared byte for byte with the query's solo answer. `coalesce: false` is
     #    the round-4 behaviour (every caller launches its own pass over the corpus), `true` the coalescing front (csrc/combiner.h).
-    if want("concurrent_callers"):
+    if want("concurrent_callers") and callers_available():
         t0 = time.perf_counter()
         import sys as _sys
         if ROOT not in _sys.path:
@@ -384,7 +398,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         done(e, t0)
 
     # -- the same pattern on the encoder: T threads, one text per call (minilm.rs:889-897: encode() behind Mutex<Session>) ------------------------------
-    if want("concurrent_encode_callers") and not args.skip_encoder:
+    if want("concurrent_encode_callers") and not args.skip_encoder and callers_available():
         t0 = time.perf_counter()
         import sys as _sys
         if ROOT not in _sys.path:
@@ -436,7 +450,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
         o1 = (torch.empty((1, 10), dtype=torch.int32, device=dev), torch.empty((1, 10), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
         e["single_query_ms"] = round(timed_steps(torch, lambda i: idx.search_batch_device(q1, 10, out=o1), 20, 3) * 1e3, 4)
         # the reference's call pattern at the north-star size: 64 threads x one query (k = 120) on the 10M index
-        e["callers_64_k120"] = callers_run(idx, qp[0][:64].cpu().numpy(), 120, 64, 12)
+        if callers_available():
+            e["callers_64_k120"] = callers_run(idx, qp[0][:64].cpu().numpy(), 120, 64, 12)
         idx.close(); del idx
         torch.cuda.empty_cache()
         done(e, t0)
@@ -663,7 +678,8 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
              "list_len_mean": round(float(lens.float().mean()), 1), "list_len_max": int(lens.max()),
              "encode_all_rows_s (nearest centroid + PQ encode, host rows in)": round(t_enc, 2)}
         # SpannIndex::search is one query per call too (spann.rs:574): 64 threads x one query on the same index
-        e["callers_64_k10"] = callers_run(idx, qp[0][:64].cpu().numpy(), k, 64, 20)
+        if callers_available():
+            e["callers_64_k10"] = callers_run(idx, qp[0][:64].cpu().numpy(), k, 64, 20)
         idx.close(); del idx
         torch.cuda.empty_cache()
         done(e, t0)
