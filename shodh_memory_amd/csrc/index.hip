@@ -166,7 +166,7 @@ struct Workspace {
     }
     int reserve_io(size_t qf, size_t oe, size_t nq) {
         if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
-        const size_t words = 2 * oe + nq + 4;          // + the four pipeline statistics (scan_stats), so that they come back in the same copy
+        const size_t words = 2 * oe + nq + 8;          // + the four pipeline statistics (scan_stats), so that they come back in the same copy (+ the final stage's arrival counter)
         if (words > out_words) {
             if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); d_out = nullptr; h_out = nullptr; out_words = 0;
             SHODH_HIP_TRY(hipMalloc((void **)&d_out, words * 4)); SHODH_HIP_TRY(hipHostMalloc((void **)&h_out, words * 4)); out_words = words;
@@ -689,7 +689,15 @@ static int search_common(shodh_index *idx, const SearchSeg *segs, size_t n_segs,
         // block (<= 1 KiB) is written by the last kernel straight into the pinned mirror -- no H2D and no D2H copy command around ~160 us of kernels.
         // The four statistics words stay in device memory (they are updated with atomics) and the one final-stage workgroup mirrors them at its end.
         static const bool zc_off = getenv("SHODH_ZERO_COPY") && atoi(getenv("SHODH_ZERO_COPY")) == 0;
-        const bool zero_copy = sync_host && !zc_off && nq == 1 && (size_t)dim * 4 <= 4096 && idx->cfg.kind == SHODH_INDEX_FLAT && (idx->cfg.scan_mode != SHODH_SCAN_GRAPH || force_exact);
+        const bool flat_scan = idx->cfg.kind == SHODH_INDEX_FLAT && (idx->cfg.scan_mode != SHODH_SCAN_GRAPH || force_exact);
+        const bool zero_copy = sync_host && !zc_off && nq == 1 && (size_t)dim * 4 <= 4096 && flat_scan;
+        // A FEW queries through host pointers on the pre-scan pipeline (a coalesced pass of <= 128 callers, round 5): the same idea -- the queries are read
+        // from the pinned gather block by the two kernels that read them once (query conversion, final stage) and the final stage writes the rows straight
+        // into the pinned mirror; its last workgroup mirrors the statistics. A copy command on either side of the kernels is a hand-over between the DMA
+        // engine's queue and the compute queue (~15 us each way). Not for the exact-order scan: every workgroup of it reads the queries.
+        static const uint32_t zc_max_nq = getenv("SHODH_ZERO_COPY_MAX_NQ") ? (uint32_t)atoi(getenv("SHODH_ZERO_COPY_MAX_NQ")) : 128u;
+        const bool zero_copy_multi = sync_host && !zc_off && !zero_copy && nq > 1 && nq <= zc_max_nq && flat_scan && !force_exact && use_mfma(idx, nq, k) &&
+                                     !solo_supported(nq, k, idx->n, idx->cus, mfma_plan(idx->n, dim, nq, k, idx->cus));
         uint32_t *stats_mirror = nullptr;
         if (sync_host) {
             if ((rc = w->reserve_io((size_t)nq * dim, (size_t)nq * k, nq)) != SHODH_OK) break;
@@ -701,14 +709,21 @@ static int search_common(shodh_index *idx, const SearchSeg *segs, size_t n_segs,
                 stats_mirror[0] = stats_mirror[1] = stats_mirror[2] = stats_mirror[3] = 0;       // (paths without a final stage leave them alone)
             } else {
                 const float *src = q;
-                if (n_segs > 1) {       // coalesced pass: the members' queries gathered in pinned memory (one DMA, no staging by the runtime)
+                if (n_segs > 1 || zero_copy_multi) {       // the members' queries gathered in pinned memory (one DMA, or none at all)
                     if ((rc = w->reserve_gather((size_t)nq * dim)) != SHODH_OK) break;
                     size_t at = 0;
                     for (size_t s = 0; s < n_segs; ++s) { memcpy(w->h_qb + at, segs[s].q, (size_t)segs[s].nq * dim * 4); at += (size_t)segs[s].nq * dim; }
                     src = w->h_qb;
                 }
-                if (hipMemcpyAsync(w->d_q, src, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
-                d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
+                if (zero_copy_multi) {
+                    const size_t oe = (size_t)nq * k;
+                    d_q = w->h_qb; d_ids = w->h_out; d_dist = reinterpret_cast<float *>(w->h_out + oe); d_counts = w->h_out + 2 * oe;
+                    stats_mirror = w->h_out + 2 * oe + nq;
+                    stats_mirror[0] = stats_mirror[1] = stats_mirror[2] = stats_mirror[3] = 0;
+                } else {
+                    if (hipMemcpyAsync(w->d_q, src, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D copy of queries failed"); rc = SHODH_ERR_DEVICE; break; }
+                    d_q = w->d_q; d_ids = w->d_ids; d_dist = w->d_dist; d_counts = w->d_counts;
+                }
             }
         }
         if (idx->cfg.kind == SHODH_INDEX_FLAT && idx->cfg.scan_mode == SHODH_SCAN_GRAPH && !force_exact) {
@@ -734,14 +749,15 @@ static int search_common(shodh_index *idx, const SearchSeg *segs, size_t n_segs,
         if (rc != SHODH_OK) break;
         if (sync_host) {
             const size_t oe = (size_t)nq * k;
-            const size_t out_bytes = (2 * oe + nq + 4) * 4;
-            if (!zero_copy && hipMemcpyAsync(w->h_out, w->d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+            const size_t out_bytes = (2 * oe + nq + 4) * 4;          // (the four statistics words ride along)
+            const bool no_copy = zero_copy || zero_copy_multi;
+            if (!no_copy && hipMemcpyAsync(w->h_out, w->d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             if (fc.deferred && w->h_out[2 * oe + nq + 2] != 0) {
                 // some query could not be settled by the pre-scan (unquantisable values, thousands of near-duplicates, an unusable threshold): exact scan now
                 if ((rc = enqueue_flat_fallback(idx, w, fc, d_q, nq, k, d_ids, d_dist, d_counts, st)) != SHODH_OK) break;
-                if (!zero_copy && hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
+                if (!no_copy && hipMemcpyAsync(w->h_out, w->d_out, (2 * oe + nq) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy of results failed"); rc = SHODH_ERR_DEVICE; break; }
                 e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { set_error("search failed on device: %s", hipGetErrorString(e)); rc = SHODH_ERR_DEVICE; break; }
             }

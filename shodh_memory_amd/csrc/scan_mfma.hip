@@ -927,7 +927,7 @@ struct QueryPrep {
 __global__ __launch_bounds__(256) void convert_queries_kernel(QueryPrep p) {
     const int lane = threadIdx.x & 63;
     const uint32_t slot = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x < 4) p.stats[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 5) p.stats[threadIdx.x] = 0;       // (word 4: arrivals of the final stage, see its end)
     if (blockIdx.x == 0 && threadIdx.x == 4) *p.fb_count = 0;
     if (slot >= p.n_slots) return;
     float ss = 0.0f, mx = 0.0f;
@@ -1436,9 +1436,19 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
         a.fb_list[s] = q;
         atomicAdd(a.stats + 2, 1u);
     }
-    if (a.stats_mirror && tid == 0 && gridDim.x == 1) {         // (thread 0 made every update of this workgroup itself)
+    if (a.stats_mirror && tid == 0) {         // (thread 0 made every update of this workgroup itself)
+        bool last = gridDim.x == 1;
+        if (!last) {
+            // several queries, results written straight into host memory (no copy command behind the kernel): the LAST workgroup to finish mirrors the four
+            // statistics words -- word 4 counts arrivals (zeroed with the others by convert_queries_kernel)
+            __threadfence();
+            last = atomicAdd(a.stats + 4, 1u) == gridDim.x - 1u;
+            if (last) __threadfence();
+        }
+        if (last) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a.stats_mirror[i] = __atomic_load_n(a.stats + i, __ATOMIC_RELAXED);
+            for (int i = 0; i < 4; ++i) a.stats_mirror[i] = __atomic_load_n(a.stats + i, __ATOMIC_RELAXED);
+        }
     }
 }
 
@@ -2000,7 +2010,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     MfmaWorkspace w;
     unpack_workspace(w, ws_base, offs);
     if (stats_ext) w.stats = stats_ext;      // host-pointer calls: the statistics words of the caller's output block
-    w.stats_mirror = nq == 1 ? stats_mirror : nullptr;
+    w.stats_mirror = stats_mirror;
 
     QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
