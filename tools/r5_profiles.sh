@@ -50,6 +50,6 @@ for C in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pi_$C; timeout 600 rocprofv3 --ke
 unset SHODH_ENC_PER_TEXT
 # 10. the whole GPU suite and the smoke test, as the driver runs them
 cd $ROOT
-timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3 > $OUT/${R}_final_gpu_tests.txt
+timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/${R}_final_gpu_tests.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> $OUT/${R}_final_gpu_tests.txt
 cat $OUT/${R}_final_gpu_tests.txt; head -c 600 $OUT/${R}_concurrent_line.json; echo; cat $OUT/${R}_small_batch.txt | head -20
