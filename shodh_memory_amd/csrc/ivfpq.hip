@@ -798,7 +798,12 @@ static int upload_postings(IvfpqState *s) {
 }
 
 struct IvfpqLayout { uint32_t nprobe, cap, split, gx; bool list_major; uint32_t lm_chunk; size_t o_probe_ids, o_probe_dist, o_probe_cnt, o_partial, o_flat, o_tables, o_lm, o_pairs, o_cand, o_items, o_redo, o_redo_list, o_r0, bytes; };
-constexpr uint32_t LM_REDO_SPLIT = 32, LM_REDO_COLS = 16;      // redo launch: 16 x 32 workgroups, a query per column at a time
+// (round 5, configs[3] step with 64 / 32 / 16 / 8 workgroups per redone query: 1.060 / 1.034 / 1.021 / 1.026 ms -- the launch is mostly empty workgroups of
+// 1024 threads and ~100 KiB of LDS, which cost their dispatch; an overflowed query is 1 of 2048)
+#ifndef SHODH_LM_REDO_SPLIT
+#define SHODH_LM_REDO_SPLIT 16
+#endif
+constexpr uint32_t LM_REDO_SPLIT = SHODH_LM_REDO_SPLIT, LM_REDO_COLS = 16;      // redo launch: 16 x 32 workgroups, a query per column at a time
 constexpr uint32_t LM_QCHUNK = 4096;       // queries per list-major pass (their tables: 192 MiB)
 // The list-major scan is the default wherever its shapes hold (48 sub-quantisers of 256 codewords: what the reference builds at 384-d). Measured at
 // configs[3]'s index against the query-major scan, ms per batch of 1 / 64 / 256 / 1024 / 4096 queries: 0.088 / 0.23 / 0.43 / 1.08 / 3.44 against
