@@ -104,12 +104,24 @@ def build(force=False, verbose=False):
             continue
         with open(keyfile, "w") as f:
             f.write(key + "\n")
-    if failed:
-        raise RuntimeError("\n".join(failed))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    tmp_lib = LIB + ".linking"
+    try:
+        if failed:
+            raise RuntimeError("\n".join(failed))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp_lib, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp_lib, LIB)            # (the library on disk is replaced only by a complete one)
+    except Exception as ex:
+        if os.path.exists(tmp_lib):
+            os.remove(tmp_lib)
+        if fresh_gpu_box and not needs_build():
+            # the once-per-box from-source compile did not go through (no room, no compiler ...): the library the push carried still matches these sources by
+            # content, so it is used -- loudly -- rather than failing every test and bench on a box problem
+            LAST_BUILD_MODE = "prebuilt library used (content hash matches) AFTER THE FROM-SOURCE BUILD FAILED on this box: %s" % str(ex)[:300]
+            return LIB
+        raise
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     LAST_BUILD_MODE = "%s from source: %d of %d objects compiled, library relinked (source hash %s...)" % (
