@@ -84,47 +84,6 @@ static inline void futex_set_and_wake_tree(std::atomic<uint32_t> *word) {
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, WAKE_ROOT, nullptr, nullptr, 0);
 }
 
-// A member's wait for its pass, predictive: the end of the pass is known to within a few percent from the passes before it (the device work is
-// HBM-bound and does not depend on who asked), so the member sleeps with a TIMEOUT that ends `margin` before the expected end -- the way back
-// through the kernel (timer, C-state exit, scheduling: 10-50 us) then overlaps with the pass instead of following it -- and polls the last
-// stretch. If the prediction was early the polling is bounded (`overrun`), after which the member sleeps again and is woken through the tree; if it
-// was late the tree wakes it as before. end_est_ns: the expected end on the mono_ns clock, kept up to date by the leader (0 = not known yet:
-// plain sleep until it is or until the pass is done).
-static inline void futex_wait_predictive(std::atomic<uint32_t> *word, const std::atomic<uint64_t> *end_est_ns, uint64_t first_guess_ns, uint64_t margin_ns, uint64_t overrun_ns) {
-    for (int i = 0; i < 64; ++i) {
-        if (word->load(std::memory_order_acquire) != 0) return;
-        cpu_relax();
-    }
-    bool slept = false;
-    uint64_t polled_ns = 0;
-    while (word->load(std::memory_order_acquire) == 0) {
-        const uint64_t now = mono_ns();
-        uint64_t end = end_est_ns->load(std::memory_order_acquire);
-        if (end == 0) end = first_guess_ns;
-        if (end != 0 && now + margin_ns >= end && polled_ns < overrun_ns + margin_ns) {
-            // the last stretch: poll
-            const uint64_t t0 = now;
-            while (word->load(std::memory_order_acquire) == 0) {
-                cpu_relax();
-                const uint64_t t = mono_ns();
-                if (t > end + overrun_ns || (t - t0) + polled_ns > overrun_ns + margin_ns) break;
-            }
-            polled_ns += mono_ns() - t0;
-            continue;
-        }
-        timespec ts, *tp = nullptr;
-        if (end != 0 && polled_ns < overrun_ns + margin_ns) {      // sleep until margin before the expected end
-            const uint64_t d = end - margin_ns - now;
-            ts.tv_sec = (time_t)(d / 1000000000ull); ts.tv_nsec = (long)(d % 1000000000ull);
-            tp = &ts;
-        }
-        syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, 0u, tp, nullptr, 0);
-        slept = true;
-    }
-    // part of the wake-up tree (a no-op when nobody sleeps)
-    if (slept) syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, WAKE_FAN, nullptr, nullptr, 0);
-}
-
 // The front's own lock. Its critical sections are ~50-100 ns (append a pointer, pop a batch), but 60 callers come back from a pass within a few
 // microseconds of each other. Behind a pthread mutex the losers sleep in the kernel and are woken one per unlock -- a convoy that took ~80 us to
 // let 57 callers rejoin. A test-and-test-and-set lock lets them through in ~0.5-1 us each and does not care when a waiter is descheduled. Measured
@@ -161,7 +120,6 @@ struct CoBatch {
     static constexpr uint32_t DONE_SHARDS = 8;
     struct alignas(64) DoneWord { std::atomic<uint32_t> v{0}; };
     DoneWord done[DONE_SHARDS];
-    std::atomic<uint64_t> end_est_ns{0};   // expected end of this batch's pass (set when the pass starts)
     std::vector<uint64_t> arrive_ns;       // SHODH_COALESCE_TRACE: when each member joined
     int rc = 0;
     std::string err;
@@ -172,15 +130,9 @@ struct CombinerStats { uint64_t batches = 0, members = 0, max_members = 0, linge
 class Combiner {
 public:
     uint32_t linger_us = 30, quiet_us = 12;
-    // predictive (SHODH_COALESCE_PREDICTIVE=1; off by default): members wake `margin_us` before the expected end of the pass and poll, at most `overrun_us`
-    // past it (futex_wait_predictive) -- only while the callers are few enough to poll without taking the cores from each other (half the hardware
-    // threads). Measured on the 256-thread EPYC host of the GPU boxes, 64 callers: the pass after a shared one starts ~20 us after it instead of
-    // ~70 us when the estimate is good (a sleeper's way back is 60-80 us there), +3 % aggregate throughput, for ~10 % of a core per waiting caller.
-    // Not worth being the default.
-    bool predictive = false;
-    bool trace = false;
-    uint32_t margin_us = 40, overrun_us = 40;
-    uint32_t spin_callers_max = std::max(1u, std::thread::hardware_concurrency() / 2u);
+    bool trace = false;       // SHODH_COALESCE_TRACE=1: print when each member of a pass joined
+    // (A predictive wait -- members wake before the expected end of their pass and poll -- was built and measured in round 5: no gain at 64 callers, -40 % at 256
+    // callers on 256 hardware threads, ~10 % of a core per waiting caller. Removed)
 
     // exec(reqs) runs ONE device pass for all requests (reqs[0] is the leader's own), writes every member's outputs and returns the status shared by all
     // of them; last_error() is the leader thread's message, copied to every member through *err_out when the status is not 0. Returns the batch status.
@@ -189,17 +141,12 @@ public:
     int submit(void *req, uint32_t units, uint32_t max_units, Exec &&exec, ErrFn &&last_error, std::string *err_out) {
         std::shared_ptr<CoBatch> b;
         bool leader = false;
-        uint64_t est_pass = 0, first_guess = 0;
-        uint32_t members_hint = 0, my_index = 0;
+        uint32_t my_index = 0;
         // a batch object in case this caller has to open one: allocated OUTSIDE the lock (the hint is only a hint; the common case under load is to join)
         std::shared_ptr<CoBatch> fresh;
         if (!joinable_hint.load(std::memory_order_relaxed)) { fresh = std::make_shared<CoBatch>(); fresh->reqs.reserve(64); }
         {
             LockGuard g(m);
-            // when this caller's pass will probably end (members: futex_wait_predictive): after the running pass, if any, plus one pass
-            est_pass = pass_est_ns;
-            if (est_pass) first_guess = (running ? std::max<uint64_t>(cur_end_est_ns, mono_ns()) : mono_ns()) + est_pass;
-            members_hint = want_members.load(std::memory_order_relaxed);
             if (!open.empty() && !open.back()->closed && open.back()->units + units <= max_units) {
                 b = open.back();
             } else {
@@ -218,15 +165,11 @@ public:
             b->members.fetch_add(1u, std::memory_order_release);
         }
         if (!leader) {
-            std::atomic<uint32_t> *done = &b->done[my_index % CoBatch::DONE_SHARDS].v;
-            if (predictive && est_pass && members_hint <= spin_callers_max) futex_wait_predictive(done, &b->end_est_ns, first_guess, (uint64_t)margin_us * 1000ull, (uint64_t)overrun_us * 1000ull);
-            else futex_wait_nonzero(done, 64, true);
+            futex_wait_nonzero(&b->done[my_index % CoBatch::DONE_SHARDS].v, 64, true);
             if (b->rc != 0 && err_out) *err_out = b->err;
             return b->rc;
         }
-        // (the running pass's expected end is known: the same predictive wait as the members' -- a sleeper's way back costs 60-80 us on this class of host)
-        if (predictive && est_pass) futex_wait_predictive(&b->go, &cur_end_est_atomic, 0, (uint64_t)margin_us * 1000ull, (uint64_t)overrun_us * 1000ull);
-        else futex_wait_nonzero(&b->go);
+        futex_wait_nonzero(&b->go);
         // linger (see the header)
         if (linger_us) {
             uint32_t target = std::max<uint32_t>(want_members.load(std::memory_order_relaxed), b->expect.load(std::memory_order_relaxed));
@@ -274,7 +217,6 @@ public:
             open.pop_front();               // b is the front: batches start in the order they were opened
             joinable_hint.store(!open.empty(), std::memory_order_relaxed);
             running = true;
-            if (pass_est_ns) { cur_end_est_ns = mono_ns() + pass_est_ns; b->end_est_ns.store(cur_end_est_ns, std::memory_order_release); cur_end_est_atomic.store(cur_end_est_ns, std::memory_order_release); }
         }
         const uint64_t t_pass0 = mono_ns();
         b->rc = exec(reqs);
@@ -292,11 +234,6 @@ public:
         {
             LockGuard g(m);
             running = false;
-            // passes of one workload take the same time to within a few percent, and what disturbs one (a workspace that grows) makes it LONGER: the shortest of
-            // the last eight is the estimate
-            pass_ring[pass_ring_at++ & 7u] = pass_ns;
-            pass_est_ns = pass_ns;
-            for (uint64_t v : pass_ring) if (v && v < pass_est_ns) pass_est_ns = v;
             // what later leaders wait for: (b) the largest of the last four passes; (a) for the batch that waited behind this pass, this pass's callers
             // plus the ones waiting in it now
             recent[recent_at++ & 3u] = (uint32_t)units_run;
@@ -329,9 +266,7 @@ private:
     std::atomic<uint32_t> want_members{1};
     std::atomic<bool> joinable_hint{false};
     uint32_t recent[4] = {1, 1, 1, 1}, recent_at = 0;      // units of the last four passes (guarded by m)
-    std::atomic<uint64_t> last_end_ns{0}, last_pass_ns{0}, cur_end_est_atomic{0};
-    uint64_t pass_est_ns = 0, cur_end_est_ns = 0;          // guarded by m
-    uint64_t pass_ring[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t pass_ring_at = 0;
+    std::atomic<uint64_t> last_end_ns{0}, last_pass_ns{0};
     std::atomic<uint32_t> n_lingered{0};
     std::atomic<uint64_t> linger_ns{0};
     CombinerStats st;

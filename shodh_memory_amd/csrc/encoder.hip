@@ -1694,8 +1694,6 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     if (const char *cv = getenv("SHODH_COALESCE")) e->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) e->co.linger_us = (uint32_t)atoi(lv);
     if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) e->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
-    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) e->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
-    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) e->co.margin_us = (uint32_t)atoi(mv);
     if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) e->co.trace = atoi(tv2) != 0;
     if (!e->weights_path.empty()) {      // shodh_embed_cfg.weights_path: MiniLMEmbedder::new loads the model file itself (minilm.rs:652-690)
         const int rc = shodh_embedder_load_file(e, e->weights_path.c_str());

@@ -502,8 +502,6 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
     if (const char *cv = getenv("SHODH_COALESCE")) idx->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) idx->co.linger_us = (uint32_t)atoi(lv);
     if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) idx->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
-    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) idx->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
-    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) idx->co.margin_us = (uint32_t)atoi(mv);
     if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) idx->co.trace = atoi(tv2) != 0;
     if (cfg->scan_mode > SHODH_SCAN_GRAPH) { delete idx; set_error("unknown scan mode %u", cfg->scan_mode); return SHODH_ERR_INVALID; }
     if (cfg->scan_mode == SHODH_SCAN_GRAPH) {

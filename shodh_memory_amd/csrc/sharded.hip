@@ -371,8 +371,6 @@ int shodh_sharded_index_create(const shodh_sharded_cfg *cfg, const int32_t *devi
     if (const char *cv = getenv("SHODH_COALESCE")) s->coalesce = atoi(cv) != 0;
     if (const char *lv = getenv("SHODH_COALESCE_LINGER_US")) s->co.linger_us = (uint32_t)atoi(lv);
     if (const char *qv = getenv("SHODH_COALESCE_QUIET_US")) s->co.quiet_us = (uint32_t)atoi(qv);      // 0 = wait out the whole linger
-    if (const char *pv = getenv("SHODH_COALESCE_PREDICTIVE")) s->co.predictive = atoi(pv) != 0;       // 1 = members wake shortly before the expected end of their pass and poll the rest (default off, see combiner.h)
-    if (const char *mv = getenv("SHODH_COALESCE_MARGIN_US")) s->co.margin_us = (uint32_t)atoi(mv);
     if (const char *tv2 = getenv("SHODH_COALESCE_TRACE")) s->co.trace = atoi(tv2) != 0;
     if (const char *sv = getenv("SHODH_SHARD_SLOTS")) { const int v = atoi(sv); if (v >= 1 && v <= 64) s->slots_max = (uint32_t)v; }
     const char *tv = getenv("SHODH_SHARD_THREADS");

@@ -29,7 +29,6 @@ int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 16, CALLS = argc > 2 ? atoi(argv[2]) : 200, PASS_US = argc > 3 ? atoi(argv[3]) : 200;
     const uint32_t MAXU = argc > 4 ? (uint32_t)atoi(argv[4]) : 256u;
     Combiner co;
-    if (argc > 5 && atoi(argv[5])) { co.predictive = true; co.spin_callers_max = 1u << 20; }      // members wake before the expected end of their pass and poll
     std::atomic<int> wrong{0}, failed{0};
     // 1. a lone caller: one pass per call, never lingers
     {

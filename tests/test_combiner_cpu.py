@@ -24,13 +24,6 @@ def test_combiner_contract(exe, threads, calls, pass_us, max_units):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("threads,pass_us", [(2, 150), (6, 200), (24, 300)])
-def test_combiner_contract_with_predictive_waits(exe, threads, pass_us):
-    """the optional predictive wait (SHODH_COALESCE_PREDICTIVE=1: members sleep until shortly before the expected end of their pass, then poll) keeps the same contract"""
-    r = subprocess.run([exe, str(threads), "150", str(pass_us), "256", "1"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
-
-
 def test_callers_share_passes(exe):
     """16 closed-loop callers against a 300 us pass: far fewer passes than calls (each pass serves several callers)"""
     r = subprocess.run([exe, "16", "200", "300", "256"], capture_output=True, text=True, timeout=120)
