@@ -279,6 +279,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
     def done(entry, t0):
         entry["wall_s"] = round(time.perf_counter() - t0, 2)
         cfgs.append(entry)
+        print("[bench] configs[%s] done in %.1f s" % (entry.get("name"), entry["wall_s"]), file=sys.stderr, flush=True)      # (if a later entry dies, the log says where)
 
     def callers_available():
         """tools/callers.c is compiled with gcc at run time: without a C compiler the concurrent entries are left out (with a note) instead of failing the line"""
