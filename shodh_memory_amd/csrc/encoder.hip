@@ -1002,7 +1002,8 @@ struct shodh_embedder {
     // coalescing front for concurrent one-text calls (combiner.h): N x encode() arriving together run as ONE per-text forward
     std::atomic<bool> coalesce{true};
     Combiner co;
-    bool enc_graph = true;               // one-text INT8 calls replay a captured hipGraph (SHODH_ENC_GRAPH=0: plain launches)
+    bool enc_graph = false;              // SHODH_ENC_GRAPH=1: one-text INT8 calls replay a captured hipGraph. Off by default: the forward is device-bound (0.59 ms of kernels), so the
+                                         // replay saves 3 % (0.650 -> 0.627 ms), and stream capture next to concurrent forwards is the newest mechanism in the library
 };
 
 namespace shodh {
