@@ -137,8 +137,7 @@ struct Workspace {
         SHODH_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto &e : ev) SHODH_HIP_TRY(hipEventCreate(&e));
         SHODH_HIP_TRY(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
-        for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }
-        for (auto &r : ring) { SHODH_HIP_TRY(hipEventCreate(&r[0])); SHODH_HIP_TRY(hipEventCreate(&r[1])); }
+        for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }      // created on first use (enqueue_flat): 64 concurrent callers used to mean 64 x 512 events up front
         SHODH_HIP_TRY(hipMalloc((void **)&solo_cnt, 256));
         // hipMemset on device memory is not synchronous with the host and the workspace's stream is non-blocking: without the synchronisation the FIRST search
         // on a new workspace could start before the counter was cleared and have it zeroed under its feet -- survivors lost, a wrong list (seen once in
@@ -382,7 +381,10 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     fc->solo = fc->used_mfma && solo_supported(nq, k, idx->n, idx->cus, p);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
     hipEvent_t rk0 = nullptr, rk1 = nullptr;
-    if (kernel_events) { rk0 = rk[0]; rk1 = rk[1]; w->ring_pos++; }
+    if (kernel_events) {
+        if (!rk[0]) { SHODH_HIP_TRY(hipEventCreate(&rk[0])); SHODH_HIP_TRY(hipEventCreate(&rk[1])); }
+        rk0 = rk[0]; rk1 = rk[1]; w->ring_pos++;
+    }
     fc->k0 = rk0; fc->k1 = rk1;
     fc->lean_events = host_call && fc->solo && kernel_events;
     const bool stage_events = host_call && !fc->lean_events;
@@ -1180,7 +1182,7 @@ int shodh_index_kernel_timing(shodh_index *idx, int reset, float *mean_us, float
         const uint32_t used = w->ring_pos < Workspace::RING ? w->ring_pos : Workspace::RING;
         for (uint32_t i = 0; i < used; ++i) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, w->ring[i][0], w->ring[i][1]) == hipSuccess && ms > 0) { sum += ms; if (ms < mn) mn = ms; ++n; }
+            if (w->ring[i][0] && w->ring[i][1] && hipEventElapsedTime(&ms, w->ring[i][0], w->ring[i][1]) == hipSuccess && ms > 0) { sum += ms; if (ms < mn) mn = ms; ++n; }
         }
         if (reset) w->ring_pos = 0;
     }
