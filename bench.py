@@ -800,7 +800,7 @@ def run_extras_in_child(args):
     """The `configs` entries (twenty-odd secondary workloads: 10M corpora, IVF-PQ, the encoder, the sharded index, concurrent callers ...) run in a CHILD process
     that appends every finished entry to a file: the contract line of this process -- already measured -- is printed whatever happens to one of them. (Round 5:
     one full run in about fifteen died with a GPU memory access fault somewhere in the secondary entries and took the whole line with it; it did not reproduce in
-    fourteen further runs.) SHODH_BENCH_EXTRAS_INPROC=1 runs them in this process as before."""
+    twenty-one further runs.) SHODH_BENCH_EXTRAS_INPROC=1 runs them in this process as before."""
     import subprocess
     import tempfile
     fd, path = tempfile.mkstemp(prefix="shodh_bench_extras_", suffix=".jsonl")
