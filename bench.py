@@ -799,7 +799,7 @@ def extra_configs(args, torch, dev, S, L, main_index, main_qpool, main_rows_tota
 def run_extras_in_child(args):
     """The `configs` entries (twenty-odd secondary workloads: 10M corpora, IVF-PQ, the encoder, the sharded index, concurrent callers ...) run in a CHILD process
     that appends every finished entry to a file: the contract line of this process -- already measured -- is printed whatever happens to one of them. (Round 5:
-    one full run in about fifteen died with a GPU memory access fault somewhere in the secondary entries and took the whole line with it; it did not reproduce in
+    one full run of the thirty-odd of the round died with a GPU memory access fault somewhere in the secondary entries and took the whole line with it; it did not reproduce in
     twenty-one further runs.) SHODH_BENCH_EXTRAS_INPROC=1 runs them in this process as before."""
     import subprocess
     import tempfile
