@@ -45,6 +45,114 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 (2x bf16; MI355X_MICROARCH.md measured >= 3944)
 
 
+# ---- the contract line --------------------------------------------------------------------------------------------------
+# The driver parses the LAST stdout line. Round 5's line had grown to 27 KB (22 `configs` entries with paragraph-long strings) and the driver could
+# not parse it (BENCH_r05.json: parsed = null). The contract line is now a bounded summary (a few KB, checked by tests/test_bench_contract_cpu.py);
+# the full record goes to stderr and to gpurun_out/bench_detail.json.
+CONTRACT_LINE_MAX_BYTES = 4096
+_CFG_TIME_KEYS = ("ms_per_step", "p50_ms", "gpu_p50_ms", "ingest_s")
+_CFG_FRAC_KEYS = ("step_hbm_frac_algorithmic", "step_hbm_frac_algorithmic_per_gpu", "mfma_frac")
+
+
+def _short(s, n=110):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _compact_config(c):
+    """one `configs` entry -> {name, <time key>, frac?, ok?}: the figure the judge quotes and nothing else"""
+    out = {"name": c.get("name")}
+    for key in _CFG_TIME_KEYS:
+        if isinstance(c.get(key), (int, float)):
+            out[key] = c[key]
+            break
+    for key in _CFG_FRAC_KEYS:
+        if isinstance(c.get(key), (int, float)):
+            out["frac"] = c[key]
+            break
+    if isinstance(c.get("summary"), dict):               # concurrent-caller entries: their few headline figures
+        for kk, vv in list(c["summary"].items())[:4]:
+            if isinstance(vv, (int, float, bool)):
+                out[kk] = vv
+    if isinstance(c.get("layouts"), list):               # sharded C path: ms per layout
+        for lay in c["layouts"][:3]:
+            if isinstance(lay, dict) and "layout" in lay and "ms_per_step" in lay:
+                out["ms_" + str(lay["layout"])] = lay["ms_per_step"]
+    for key in ("recall_at_10_vs_exact", "gpu_matches_cpu_bit_exact", "child_returncode"):
+        if key in c:
+            out[key] = c[key]
+    return out
+
+
+def claim_stdout():
+    """stdout carries exactly ONE line, the contract line: everything else that native libraries print on fd 1 (RCCL's version banner at communicator
+    creation, its exit banner, a stray printf) goes to stderr, because fd 1 is pointed at fd 2 for the rest of the process -- before AND after the
+    contract line. Returns the descriptor the line is written to."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    return json_fd
+
+
+def emit_contract(json_fd, full, detail_path=None):
+    """writes the bounded contract line (compact_line) as ONE write on the real stdout and returns it"""
+    contract = json.dumps(compact_line(full, detail_path))
+    assert len(contract) <= CONTRACT_LINE_MAX_BYTES and "\n" not in contract
+    sys.stdout.flush()
+    os.write(json_fd, (contract + "\n").encode())
+    return contract
+
+
+def compact_line(full, detail_path=None, max_bytes=CONTRACT_LINE_MAX_BYTES):
+    """The bounded contract line made from the full record: every field the driver's contract names, `roofline`, `cpu_baseline`, the single-query
+    latency and one {name, time, frac} triple per `configs` entry. No string longer than ~110 characters; the whole line <= max_bytes (entries are
+    dropped from the end of `configs`, with a count, should it ever not fit)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    line["config"] = {k: (_short(cfg[k]) if isinstance(cfg[k], str) else cfg[k]) for k in
+                      ("workload", "rows_total", "rows_per_gpu", "rows_live_per_gpu", "batch", "k", "scan", "layout") if k in cfg}
+    r = full.get("roofline")
+    if r:
+        rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_us_mean", "launch_us_min", "launches_timed",
+                                    "algorithmic_bytes_per_launch", "rows_live", "frac_actual_bytes", "mfma_frac", "step_frac_algorithmic") if k in r}
+        clk = (r.get("gpu_sclk_mhz") or {}).get("during_sustained_run")
+        if isinstance(clk, dict):
+            rr["sclk_mhz"] = clk.get("mean", clk.get("median"))
+        tp = r.get("traffic_profiled")
+        if isinstance(tp, dict):
+            rr["traffic_profiled"] = tp.get("bytes_per_launch") if not tp.get("stale") else "stale"
+        line["roofline"] = rr
+    else:
+        line["roofline"] = None
+    c = full.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {k: (_short(c[k]) if isinstance(c[k], str) else c[k]) for k in
+                                ("value", "unit", "cores", "kind", "sample", "single_thread_qps", "gpu_matches_cpu_bit_exact") if k in c}
+    else:
+        line["cpu_baseline"] = None
+    lat = full.get("latency_single_query")
+    if lat:
+        ll = {k: lat.get(k) for k in ("nq", "p50_ms", "p95_ms", "host_pointers_p50_ms") if k in lat}
+        if isinstance(lat.get("k120"), dict):
+            ll["k120_p50_ms"] = lat["k120"].get("p50_ms")
+            ll["k120_host_pointers_p50_ms"] = lat["k120"].get("host_pointers_p50_ms")
+        line["latency_single_query"] = ll
+    sus = full.get("sustained")
+    if sus:
+        line["sustained"] = {k: sus.get(k) for k in ("seconds", "steps", "ms_per_step", "queries_per_s") if k in sus}
+    if detail_path:
+        line["detail"] = detail_path
+    if full.get("configs") is not None:
+        line["configs"] = [_compact_config(c) for c in full["configs"]]
+        dropped = 0
+        while len(json.dumps(line)) > max_bytes and line["configs"]:
+            line["configs"].pop()
+            dropped += 1
+            line["configs_dropped_for_size"] = dropped
+    return line
+
+
 # ---- synthetic inputs (SURVEY.md 8d), generated in HBM -------------------------------------------------------------------
 def synth_rows(torch, n, dim, seed, device, adversarial_queries=None):
     """half correlated rows normalize(1 + 0.5 sqrt(D) e_{i mod D} + 0.3 N(0,I)) (the reference's own test_vector fixture,
@@ -869,9 +977,7 @@ def main():
 
     # stdout carries exactly ONE line, the JSON record: everything else that native libraries print there (RCCL's version banner
     # at communicator creation, for one) is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    json_fd = claim_stdout()
 
     import numpy as np
     import torch
@@ -1136,8 +1242,18 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu, "latency_single_query": lat, "sustained": sustained}
         if cfgs is not None:
             line["configs"] = cfgs
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        # the full record: stderr + gpurun_out/bench_detail.json (merged back by gpurun); the LAST stdout line is the bounded contract line
+        full = json.dumps(line)
+        detail_path = None
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            detail_path = os.path.join("gpurun_out", "bench_detail.json" if world == 1 else "bench_detail_n%d.json" % world)
+            with open(os.path.join(ROOT, detail_path), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            detail_path = None
+        print("[bench] full record (%d bytes): %s" % (len(full), full), file=sys.stderr, flush=True)
+        emit_contract(json_fd, line, detail_path)
     if world > 1:
         dist.destroy_process_group()
 

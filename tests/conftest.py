@@ -24,6 +24,23 @@ def pytest_sessionstart(session):
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build()
+    global BUILD_MODE
+    BUILD_MODE = "libshodh_hip.so: %s" % b.LAST_BUILD_MODE
+    # (with -q pytest prints no header: written here AND in the terminal summary, so that the driver's record of the run shows whether this box compiled
+    # the library from source or reused the pushed one -- VERDICT r5 weak 14)
+    sys.stderr.write("[conftest] %s\n" % BUILD_MODE)
+    sys.stderr.flush()
+
+
+BUILD_MODE = "build not run"
+
+
+def pytest_report_header(config):
+    return BUILD_MODE
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    terminalreporter.write_line("[build] %s" % BUILD_MODE)
 
 
 def has_gpu():

@@ -32,7 +32,7 @@ def test_command_line_of_the_contract():
     assert args["--cpu-seconds"] <= 30.0                          # the CPU baseline leg is a bounded sample (10 - 30 s)
 
 
-def test_committed_line_is_a_contract_line():
+def _latest_line():
     import glob
     import re
     lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")), key=lambda p: int(re.search(r"r(\d+)_bench_line", p).group(1)))
@@ -40,7 +40,11 @@ def test_committed_line_is_a_contract_line():
         pytest.skip("no committed bench line")
     path = lines[-1]                                              # the latest round's
     rnd = int(re.search(r"r(\d+)_bench_line", path).group(1))
-    d = json.loads(open(path).read().strip().splitlines()[-1])
+    raw = open(path).read().strip().splitlines()[-1]
+    return rnd, path, raw, json.loads(raw)
+
+
+def _check_contract_fields(d):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -64,9 +68,109 @@ def test_committed_line_is_a_contract_line():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "queries/s"
     lat = d.get("latency_single_query")
     assert lat and lat["nq"] == 1 and 0 < lat["p50_ms"] <= lat["p95_ms"]
+
+
+_WANTED = ("cfg1_10k_b1", "flat_10M_b256", "cfg4_ivfpq_10M", "cfg3_pipeline", "encoder_bf16_b8192", "encoder_int8_b4096", "sharded_c_abi_1M_b256",
+           "sharded_c_abi_10M_b256")
+
+
+def test_committed_line_is_a_contract_line():
+    rnd, path, raw, d = _latest_line()
+    _check_contract_fields(d)
+    if rnd >= 6:
+        # round 6 on: the committed line is what the driver parses -- the BOUNDED line (BENCH_r05.json: parsed = null on a 27 KB line)
+        assert len(raw) <= 4096, "the contract line grew to %d bytes" % len(raw)
+        assert max(len(v) for v in _strings(d)) <= 120
+        detail = path.replace("_bench_line.json", "_bench_detail.json")
+        assert os.path.exists(detail), "the full record of the same run is committed beside the line"
+        full = json.loads(open(detail).read().strip().splitlines()[-1])
+        assert full["value"] == d["value"] and full["ms_per_step"] == d["ms_per_step"]        # one run, two renderings
+    else:
+        full = d
     names = [cfg["name"] for cfg in d.get("configs", [])]
-    for want in ("cfg1_10k_b1", "flat_10M_b256", "cfg4_ivfpq_10M", "cfg3_pipeline", "encoder_bf16_b8192", "encoder_int8_b4096", "sharded_c_abi_1M_b256", "sharded_c_abi_10M_b256") \
-            + (("cfg3_pipeline_int8", "encoder_int8_pertext_b4096") if rnd >= 4 else ()):      # round 4: INT8 per text (N x encode(), what remember / recall run)
+    for want in _WANTED + (("cfg3_pipeline_int8", "encoder_int8_pertext_b4096") if rnd >= 4 else ()):      # round 4: INT8 per text (N x encode(), what remember / recall run)
         assert want in names, want
-    pipe = [c for c in d["configs"] if c["name"] == "cfg3_pipeline"][0]
+    pipe = [c for c in full["configs"] if c["name"] == "cfg3_pipeline"][0]
     assert "1000000 synthetic texts" in pipe["workload"]                                       # configs[2] at its stated size
+
+
+def _strings(x):
+    if isinstance(x, str):
+        yield x
+    elif isinstance(x, dict):
+        for v in x.values():
+            yield from _strings(v)
+    elif isinstance(x, list):
+        for v in x:
+            yield from _strings(v)
+
+
+def _bench_module():
+    """bench.py imports only the standard library at module level (torch and the GPU library are imported inside main())"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_for_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_contract_line_is_bounded_whatever_the_record_holds():
+    """compact_line() of the largest record ever produced (round 5: 27 KB, the one the driver could not parse) is a contract line under 4 KB;
+    a record with many more and much longer entries still is (entries are dropped from the end, with a count, never the contract fields)."""
+    b = _bench_module()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    line = b.compact_line(full, "gpurun_out/bench_detail.json")
+    raw = json.dumps(line)
+    assert len(raw) <= b.CONTRACT_LINE_MAX_BYTES <= 4096 and len(raw) < 8192
+    _check_contract_fields(line)
+    assert [c["name"] for c in line["configs"]] == [c["name"] for c in full["configs"]]        # nothing dropped at today's size
+    assert "configs_dropped_for_size" not in line
+    k120 = [c for c in line["configs"] if c["name"] == "flat_1M_b256_k120"][0]
+    assert k120["ms_per_step"] == 0.3776 and k120["frac"] == 0.483
+    assert max(len(v) for v in _strings(line)) <= 120
+    fat = dict(full)
+    fat["configs"] = [dict(c, name="%s_%d" % (c["name"], i), workload="x" * 5000) for i in range(12) for c in full["configs"]]
+    fat["config"] = dict(full["config"], workload="y" * 3000)
+    fat["cpu_baseline"] = dict(full["cpu_baseline"], sample="z" * 3000)
+    line = b.compact_line(fat, None)
+    assert len(json.dumps(line)) <= b.CONTRACT_LINE_MAX_BYTES
+    _check_contract_fields(line)
+    assert line["configs_dropped_for_size"] > 0 and len(line["configs"]) > 10
+    # a line of an N > 1 run (no cpu_baseline, no configs, no latency) goes through as well
+    multi = {k: full[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline")}
+    multi.update({"n_gpus": 8, "scaling": "weak", "cpu_baseline": None, "latency_single_query": None, "sustained": None})
+    line = b.compact_line(multi)
+    assert line["n_gpus"] == 8 and line["cpu_baseline"] is None and "configs" not in line
+
+
+def test_last_stdout_line_is_the_contract_line_whatever_else_is_printed(tmp_path):
+    """What the driver does: run the command, take the LAST line of stdout, json.loads it. Native libraries print on fd 1 behind Python's back -- RCCL its
+    version banner at communicator creation and a banner at exit (after the line was written) -- and Python code may print too: stdout must still be
+    exactly the one line. Run in a child process with libc printf / write(1) noise before and after the line and at interpreter exit."""
+    import subprocess
+    import sys
+    full = os.path.join(ROOT, "profiles", "r5_bench_line.json")
+    code = r"""
+import atexit, ctypes, importlib.util, json, os, sys
+spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+libc = ctypes.CDLL(None)
+fd = b.claim_stdout()
+libc.puts(b'NCCL version 2.26.6+hip7.0 (a banner printed by a native library)')
+os.write(1, b'a stray write(1)\n'); print('a stray print')
+def bye():
+    libc.puts(b'RCCL exit banner'); libc.fflush(None); os.write(1, b'{"not": "the line"}\n')
+atexit.register(bye)
+rec = json.loads(open(%r).read().strip().splitlines()[-1])
+b.emit_contract(fd, rec, 'gpurun_out/bench_detail.json')
+libc.puts(b'more noise after the line'); print('{"also": "not the line"}')
+""" % (os.path.join(ROOT, "bench.py"), full)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = p.stdout.decode()
+    assert out.endswith("\n") and len(out.splitlines()) == 1, out[-500:]
+    last = out.strip().splitlines()[-1]
+    assert len(last) <= 4096
+    d = json.loads(last)
+    _check_contract_fields(d)
+    assert "RCCL exit banner" in p.stderr.decode() and "NCCL version" in p.stderr.decode()     # the noise went to stderr
