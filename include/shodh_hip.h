@@ -539,6 +539,18 @@ size_t shodh_rank_surfaced(const shodh_weights *w, const shodh_relevance_cfg *cf
                            const float *graph_strength, const int64_t *age_hours, const int64_t *created_at_ns, const uint8_t *uuid,
                            uint32_t *out_index, float *out_score, uint8_t *out_reason);
 
+/* ---- allocation guard (diagnostics; shodh_memory_amd/csrc/guard.h) --------------------------------------------------
+ * SHODH_GUARD=1|2|3 in the environment (read at the library's first allocation) turns every device / pinned-host allocation into its own
+ * mapping fenced by unmapped pages, end-aligned (1: 16 B, 3: 256 B) or start-aligned (2): an out-of-bounds or use-after-free access by any
+ * kernel is a GPU page fault on every run. SHODH_GUARD_LOG=<file> logs every allocation for matching the fault address. Off (0): plain
+ * hipMalloc / hipHostMalloc. Not part of the reference's interface -- there is no counterpart in src/vector_db. */
+int shodh_guard_mode(void);
+int shodh_guard_stats(uint64_t *allocations, uint64_t *frees, uint64_t *live_device_bytes);
+/* torch.cuda.memory.CUDAPluggableAllocator entry points (tests/conftest.py installs them under SHODH_GUARD so that the callers' device buffers
+ * are fenced too); plain hipMalloc / hipFree when the guard is off */
+void *shodh_guard_torch_alloc(int64_t bytes, int device, void *stream);
+void shodh_guard_torch_free(void *p, int64_t bytes, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

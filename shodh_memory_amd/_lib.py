@@ -90,6 +90,10 @@ class SpanInfo(C.Structure):
 
 
 SYMBOLS = {
+    "shodh_guard_mode": (C.c_int, []),
+    "shodh_guard_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "shodh_guard_torch_alloc": (C.c_void_p, [C.c_int64, C.c_int, C.c_void_p]),
+    "shodh_guard_torch_free": (None, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "shodh_last_error": (C.c_char_p, []),
     "shodh_abi_version": (C.c_int, []),
     "shodh_index_graph_overflowed": (C.c_int, [_vp]),

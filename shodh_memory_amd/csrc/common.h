@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/shodh_hip.h"
+#include "guard.h"
 
 namespace shodh {
 

@@ -951,9 +951,9 @@ struct EncScratch {
     void drop_graph() { if (g1) { hipGraphExecDestroy(g1); g1 = nullptr; } }
     void destroy() {
         drop_graph();
-        if (h_pin) hipHostFree(h_pin);
-        hipFree(X); hipFree(QKV); hipFree(CTX); hipFree(FF); hipFree(PRE); hipFree(XQ); hipFree(HQ); hipFree(rsX); hipFree(rsH); hipFree(mmr); hipFree(act_params);
-        hipFree(d_klen); hipFree(d_orow); hipFree(d_ids); hipFree(d_tok_seq); hipFree(d_tok_pos); hipFree(d_cu); hipFree(d_out);
+        if (h_pin) pin_free(h_pin);
+        dev_free(X); dev_free(QKV); dev_free(CTX); dev_free(FF); dev_free(PRE); dev_free(XQ); dev_free(HQ); dev_free(rsX); dev_free(rsH); dev_free(mmr); dev_free(act_params);
+        dev_free(d_klen); dev_free(d_orow); dev_free(d_ids); dev_free(d_tok_seq); dev_free(d_tok_pos); dev_free(d_cu); dev_free(d_out);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (stream) hipStreamDestroy(stream);
@@ -1030,43 +1030,43 @@ static int reserve(shodh_embedder *e, EncScratch *sc, size_t ntok, size_t nseq, 
     const size_t es = e->cfg.dtype == SHODH_DTYPE_BF16 ? 2 : 4;
     if (ntok > sc->tok_cap || pre_tok > sc->pre_cap || nseq > sc->seq_cap) sc->drop_graph();      // (the graph holds the old addresses)
     if (ntok > sc->tok_cap) {
-        hipFree(sc->X); hipFree(sc->QKV); hipFree(sc->CTX); hipFree(sc->FF); hipFree(sc->d_tok_seq); hipFree(sc->d_tok_pos); hipFree(sc->XQ);
-        hipFree(sc->HQ); hipFree(sc->rsX); hipFree(sc->rsH);
+        dev_free(sc->X); dev_free(sc->QKV); dev_free(sc->CTX); dev_free(sc->FF); dev_free(sc->d_tok_seq); dev_free(sc->d_tok_pos); dev_free(sc->XQ);
+        dev_free(sc->HQ); dev_free(sc->rsX); dev_free(sc->rsH);
         sc->X = sc->QKV = sc->CTX = sc->FF = nullptr; sc->d_tok_seq = sc->d_tok_pos = nullptr; sc->XQ = nullptr; sc->HQ = nullptr; sc->rsX = sc->rsH = nullptr; sc->tok_cap = 0;
         size_t cap = ntok + ntok / 4 + 256;
         const bool int8 = e->cfg.dtype == SHODH_DTYPE_INT8;
         if (int8) {
-            SHODH_HIP_TRY(hipMalloc((void **)&sc->XQ, cap * std::max(H, I)));
-            SHODH_HIP_TRY(hipMalloc((void **)&sc->HQ, cap * I));
-            SHODH_HIP_TRY(hipMalloc((void **)&sc->rsX, (cap + 256) * 4));     // (+ 256: the streaming kernels fetch the row sums of a tile as one 1-KiB DMA piece)
-            SHODH_HIP_TRY(hipMalloc((void **)&sc->rsH, (cap + 256) * 4));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->XQ, cap * std::max(H, I)));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->HQ, cap * I));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsX, (cap + 256) * 4));     // (+ 256: the streaming kernels fetch the row sums of a tile as one 1-KiB DMA piece)
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsH, (cap + 256) * 4));
         }
         // the fast INT8 layer keeps neither the q|k|v tensor nor the f32 GELU output (encoder_int8_fast.h); they exist only for the stages
         // switched back to the round-2 kernels (SHODH_INT8_STAGES) or for shapes the fused kernels do not take
         const bool need_wide = !int8 || !e->int8_all_fast;
-        SHODH_HIP_TRY(hipMalloc(&sc->X, cap * H * es));
-        if (need_wide) SHODH_HIP_TRY(hipMalloc(&sc->QKV, cap * 3 * H * es));
-        SHODH_HIP_TRY(hipMalloc(&sc->CTX, cap * H * es));
-        if (need_wide) SHODH_HIP_TRY(hipMalloc(&sc->FF, cap * I * es));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_tok_seq, cap * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_tok_pos, cap * 4));
+        SHODH_HIP_TRY(dev_alloc(&sc->X, cap * H * es));
+        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->QKV, cap * 3 * H * es));
+        SHODH_HIP_TRY(dev_alloc(&sc->CTX, cap * H * es));
+        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->FF, cap * I * es));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_seq, cap * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_pos, cap * 4));
         sc->tok_cap = cap;
     }
     if (pre_tok > sc->pre_cap) {      // pre-LayerNorm sums; the K-split down projection (bf16, small or per-text forwards) keeps FFN_KSPLIT partial sums per token
-        hipFree(sc->PRE); sc->PRE = nullptr; sc->pre_cap = 0;
+        dev_free(sc->PRE); sc->PRE = nullptr; sc->pre_cap = 0;
         const size_t cap = pre_tok + pre_tok / 4 + 256;
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->PRE, cap * H * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->PRE, cap * H * 4));
         sc->pre_cap = cap;
     }
     if (nseq > sc->seq_cap) {
-        hipFree(sc->d_ids); hipFree(sc->d_cu); hipFree(sc->d_out); hipFree(sc->d_klen); hipFree(sc->d_orow);
+        dev_free(sc->d_ids); dev_free(sc->d_cu); dev_free(sc->d_out); dev_free(sc->d_klen); dev_free(sc->d_orow);
         sc->d_ids = nullptr; sc->d_cu = nullptr; sc->d_out = nullptr; sc->d_klen = nullptr; sc->d_orow = nullptr; sc->seq_cap = 0;
         size_t cap = nseq + nseq / 4 + 16;
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_klen, (cap + 1) * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_orow, (cap + 1) * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_ids, cap * e->cfg.max_len * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_cu, (cap + 1) * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->d_out, cap * H * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_klen, (cap + 1) * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_orow, (cap + 1) * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_ids, cap * e->cfg.max_len * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_cu, (cap + 1) * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_out, cap * H * 4));
         sc->seq_cap = cap;
     }
     return SHODH_OK;
@@ -1366,9 +1366,9 @@ static int forward_int8(shodh_embedder *e, EncScratch *sc, int ntok, int nseq, i
     const int mm_stride = ps_rows ? 2 : 0;
     if ((size_t)S > sc->mmr_slots) {
         sc->drop_graph();
-        hipFree(sc->mmr); sc->mmr = nullptr; sc->mmr_slots = 0;
+        dev_free(sc->mmr); sc->mmr = nullptr; sc->mmr_slots = 0;
         const size_t cap = (size_t)S + (size_t)S / 4 + 16;
-        SHODH_HIP_TRY(hipMalloc((void **)&sc->mmr, ((size_t)n_pairs * 8 + (size_t)e->cfg.layers * 16) * cap));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->mmr, ((size_t)n_pairs * 8 + (size_t)e->cfg.layers * 16) * cap));
         sc->mmr_slots = cap;
     }
     if (ps_rows && (!fS || !fB || !fC || !fD || !(stages & 64u) || ntok != nseq * ps_rows || ps_rows % 128 != 0)) { set_error("INT8 encoder: per-text ranges need the fused kernels and max_len-padded sequences"); return SHODH_ERR_UNSUPPORTED; }
@@ -1489,16 +1489,16 @@ static int forward_int8(shodh_embedder *e, EncScratch *sc, int ntok, int nseq, i
 
 static int alloc_qweight(QWeight &q, int N, int K) {
     q.N = N; q.K = K;
-    SHODH_HIP_TRY(hipMalloc((void **)&q.q, (size_t)N * K));
-    SHODH_HIP_TRY(hipMalloc((void **)&q.scale, (size_t)N * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&q.rowsum, (size_t)N * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&q.qp, (size_t)N * K));
-    SHODH_HIP_TRY(hipMalloc((void **)&q.rsz, (size_t)N * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&q.zw_buf, (size_t)N * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.q, (size_t)N * K));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.scale, (size_t)N * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.rowsum, (size_t)N * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.qp, (size_t)N * K));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.rsz, (size_t)N * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&q.zw_buf, (size_t)N * 4));
     SHODH_HIP_TRY(hipMemset(q.zw_buf, 0, (size_t)N * 4));
     return SHODH_OK;
 }
-static void free_qweight(QWeight &q) { hipFree(q.q); hipFree(q.qp); hipFree(q.scale); hipFree(q.rowsum); hipFree(q.rsz); hipFree(q.zw_buf); q = QWeight(); }
+static void free_qweight(QWeight &q) { dev_free(q.q); dev_free(q.qp); dev_free(q.scale); dev_free(q.rowsum); dev_free(q.rsz); dev_free(q.zw_buf); q = QWeight(); }
 
 // rows [row0, row0 + N) of a quantised matrix: the export's own tensor `t` when there is one (bytes, scales, zero points as the file
 // holds them), else the f32 rows `w` quantised here per tensor, symmetric (scale = 2 max|w| / 255, zero point 128 in uint8 terms) --
@@ -1545,8 +1545,8 @@ static int finish_weights_int8(shodh_embedder *e) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate;
     for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) { for (auto &q : *v) free_qweight(q); v->assign(e->cfg.layers, QWeight()); }
     if (!e->word_q) {
-        SHODH_HIP_TRY(hipMalloc((void **)&e->word_q, (size_t)e->cfg.vocab * H));
-        SHODH_HIP_TRY(hipMalloc((void **)&e->word_scale, 256 * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&e->word_q, (size_t)e->cfg.vocab * H));
+        SHODH_HIP_TRY(dev_alloc((void **)&e->word_scale, 256 * 4));
     }
     auto exported = [&](int slot) -> const QTensor * { return (slot >= 0 && slot < (int)e->qexp.size() && e->qexp[slot].present) ? &e->qexp[slot] : nullptr; };
     // tensor slots in blob order (weights_io.h): 0 word table, then per layer 16 slots: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b up.w up.b down.w down.b ln2.g ln2.b
@@ -1557,13 +1557,13 @@ static int finish_weights_int8(shodh_embedder *e) {
         e->word_from_export = true;
     } else {   // word table self-quantised: its row sums are not needed; borrow scratch buffers
         int32_t *tmp = nullptr;
-        SHODH_HIP_TRY(hipMalloc((void **)&tmp, (size_t)e->cfg.vocab * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&tmp, (size_t)e->cfg.vocab * 4));
         float *sc = nullptr;
-        SHODH_HIP_TRY(hipMalloc((void **)&sc, (size_t)e->cfg.vocab * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc, (size_t)e->cfg.vocab * 4));
         int rc = quantize_weight_into(e->w32 + e->o_word, (int)e->cfg.vocab, H, e->word_q, sc, tmp, e->qscratch + 2, nullptr);
         const float zero = 0.0f;
         if (rc == SHODH_OK && (hipMemcpy(e->word_scale, sc, 4, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(e->word_scale + 1, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)) rc = SHODH_ERR_DEVICE;
-        hipFree(tmp); hipFree(sc);
+        dev_free(tmp); dev_free(sc);
         if (rc != SHODH_OK) return rc;
         e->word_from_export = false;
     }
@@ -1585,7 +1585,7 @@ static int finish_weights_int8(shodh_embedder *e) {
     }
     {   // per-head constant blocks of the fused q|k|v matrices (the fused attention kernel fetches them with the head's weights)
         const uint32_t heads = e->cfg.heads;
-        if (!e->qkv_hc) SHODH_HIP_TRY(hipMalloc((void **)&e->qkv_hc, (size_t)e->cfg.layers * heads * 512 * 4));
+        if (!e->qkv_hc) SHODH_HIP_TRY(dev_alloc((void **)&e->qkv_hc, (size_t)e->cfg.layers * heads * 512 * 4));
         for (uint32_t li = 0; li < e->cfg.layers; ++li) {
             const QWeight &q = e->q_qkv[li];
             hipLaunchKernelGGL(pack_head_consts_kernel, dim3((uint32_t)ceil_div((size_t)heads * 512, 256)), dim3(256), 0, nullptr, (const float *)q.scale, (const int32_t *)q.rsz,
@@ -1679,15 +1679,15 @@ int shodh_embedder_create(const shodh_embed_cfg *cfg, shodh_embedder **out) {
     e->int8_all_fast = cfg->dtype == SHODH_DTYPE_INT8 && (e->int8_stages & 0xFu) == 0xFu && cfg->hidden == S8_NF && cfg->intermediate == 4 * S8_NF && cfg->max_len <= 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->cus = pr.multiProcessorCount; }
     layout(e);
-    if (hipMalloc((void **)&e->w32, e->n_params * 4) != hipSuccess || hipMalloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
-        hipMalloc((void **)&e->bqkv, (size_t)cfg->layers * 3 * cfg->hidden * 4) != hipSuccess ||
-        hipMalloc((void **)&e->wqkv32, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 4) != hipSuccess ||
-        hipMalloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess ||
-        hipMalloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess ||
-        hipMalloc((void **)&e->w2p16, (size_t)cfg->layers * cfg->intermediate * cfg->hidden * 2) != hipSuccess) {
+    if (dev_alloc((void **)&e->w32, e->n_params * 4) != hipSuccess || dev_alloc((void **)&e->w16, e->n_params * 2) != hipSuccess ||
+        dev_alloc((void **)&e->bqkv, (size_t)cfg->layers * 3 * cfg->hidden * 4) != hipSuccess ||
+        dev_alloc((void **)&e->wqkv32, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 4) != hipSuccess ||
+        dev_alloc((void **)&e->wqkv16, (size_t)cfg->layers * 3 * cfg->hidden * cfg->hidden * 2) != hipSuccess ||
+        dev_alloc((void **)&e->wp16, (size_t)cfg->layers * (4 * cfg->hidden + cfg->intermediate) * cfg->hidden * 2) != hipSuccess ||
+        dev_alloc((void **)&e->w2p16, (size_t)cfg->layers * cfg->intermediate * cfg->hidden * 2) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM for encoder weights"); return SHODH_ERR_OOM;
     }
-    if (cfg->dtype == SHODH_DTYPE_INT8 && hipMalloc((void **)&e->qscratch, 64) != hipSuccess) {
+    if (cfg->dtype == SHODH_DTYPE_INT8 && dev_alloc((void **)&e->qscratch, 64) != hipSuccess) {
         shodh_embedder_destroy(e); set_error("out of HBM"); return SHODH_ERR_OOM;
     }
     if (const char *sv = getenv("SHODH_ENC_SLOTS")) { const int v = atoi(sv); if (v >= 1 && v <= 16) e->sc_max = (uint32_t)v; }      // forwards in flight per handle (each owns a scratch set)
@@ -1708,10 +1708,10 @@ void shodh_embedder_destroy(shodh_embedder *e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     hipDeviceSynchronize();
-    hipFree(e->w32); hipFree(e->w16); hipFree(e->bqkv); hipFree(e->wqkv32); hipFree(e->wqkv16); hipFree(e->wp16); hipFree(e->w2p16);
+    dev_free(e->w32); dev_free(e->w16); dev_free(e->bqkv); dev_free(e->wqkv32); dev_free(e->wqkv16); dev_free(e->wp16); dev_free(e->w2p16);
     for (EncScratch *c : e->sc_free) { c->destroy(); delete c; }      // (no forward is in flight on a handle being destroyed: every scratch set is back)
     for (auto *v : {&e->q_qkv, &e->q_o, &e->q_up, &e->q_dn}) for (auto &q : *v) free_qweight(q);
-    hipFree(e->word_q); hipFree(e->word_scale); hipFree(e->qscratch); hipFree(e->qkv_hc);
+    dev_free(e->word_q); dev_free(e->word_scale); dev_free(e->qscratch); dev_free(e->qkv_hc);
     delete e;
 }
 
@@ -1853,7 +1853,7 @@ static EncScratch *sc_acquire(shodh_embedder *e) {
             lk.unlock();
             EncScratch *c = new EncScratch();
             bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-            if (ok && e->cfg.dtype == SHODH_DTYPE_INT8) ok = hipMalloc((void **)&c->act_params, 64) == hipSuccess;
+            if (ok && e->cfg.dtype == SHODH_DTYPE_INT8) ok = dev_alloc((void **)&c->act_params, 64) == hipSuccess;
             if (!ok) { set_error("encoder scratch: stream / event creation failed"); c->destroy(); delete c; lk.lock(); e->sc_made--; e->sc_cv.notify_one(); return nullptr; }
             return c;
         }
@@ -1873,7 +1873,7 @@ static int encode_one_graph(shodh_embedder *e, EncScratch *sc, const int32_t *id
     const uint32_t ML = e->cfg.max_len, H = e->cfg.hidden;
     hipStream_t st = sc->stream;
     SHODH_TRY(reserve(e, sc, ML, 1, ML));
-    if (!sc->h_pin) SHODH_HIP_TRY(hipHostMalloc((void **)&sc->h_pin, ((size_t)ML + 1 + H) * 4));
+    if (!sc->h_pin) SHODH_HIP_TRY(pin_alloc((void **)&sc->h_pin, ((size_t)ML + 1 + H) * 4));
     int32_t *h_ids = sc->h_pin, *h_klen = sc->h_pin + ML;
     float *h_out = reinterpret_cast<float *>(sc->h_pin + ML + 1);
     memcpy(h_ids, ids, (size_t)ML * 4);
@@ -2156,10 +2156,10 @@ static int int8_dense_impl(int device, const float *x, const float *w, const voi
             for (uint32_t c = 0; c < n_scale; ++c) { const int z = wq_zp ? (is_signed ? (int)((const int8_t *)wq_zp)[c] : (int)((const uint8_t *)wq_zp)[c]) : 0; qt.zp[c] = is_signed ? z : z - 128; }
             for (size_t i = 0; i < (size_t)N * K; ++i) qt.q[i] = is_signed ? ((const int8_t *)wq)[i] : (int8_t)((int)((const uint8_t *)wq)[i] - 128);
         }
-        if (hipMalloc((void **)&d_x, (size_t)M * K * 4) != hipSuccess || (w && hipMalloc((void **)&d_w, (size_t)N * K * 4) != hipSuccess) ||
-            hipMalloc((void **)&d_y, (size_t)M * N * 4) != hipSuccess || hipMalloc((void **)&d_par, 64) != hipSuccess || hipMalloc((void **)&d_rs, (size_t)M * 4) != hipSuccess ||
-            hipMalloc((void **)&d_xq, (size_t)M * K) != hipSuccess || hipMalloc((void **)&d_scr, 64) != hipSuccess ||
-            (bias && hipMalloc((void **)&d_b, (size_t)N * 4) != hipSuccess) || (acc_out && hipMalloc((void **)&d_acc, (size_t)M * N * 4) != hipSuccess)) { fail("out of HBM"); rc = SHODH_ERR_OOM; break; }
+        if (dev_alloc((void **)&d_x, (size_t)M * K * 4) != hipSuccess || (w && dev_alloc((void **)&d_w, (size_t)N * K * 4) != hipSuccess) ||
+            dev_alloc((void **)&d_y, (size_t)M * N * 4) != hipSuccess || dev_alloc((void **)&d_par, 64) != hipSuccess || dev_alloc((void **)&d_rs, (size_t)M * 4) != hipSuccess ||
+            dev_alloc((void **)&d_xq, (size_t)M * K) != hipSuccess || dev_alloc((void **)&d_scr, 64) != hipSuccess ||
+            (bias && dev_alloc((void **)&d_b, (size_t)N * 4) != hipSuccess) || (acc_out && dev_alloc((void **)&d_acc, (size_t)M * N * 4) != hipSuccess)) { fail("out of HBM"); rc = SHODH_ERR_OOM; break; }
         if ((rc = alloc_qweight(qw, (int)N, (int)K)) != SHODH_OK) break;
         if (hipMemcpy(d_x, x, (size_t)M * K * 4, hipMemcpyHostToDevice) != hipSuccess || (w && hipMemcpy(d_w, w, (size_t)N * K * 4, hipMemcpyHostToDevice) != hipSuccess) ||
             (bias && hipMemcpy(d_b, bias, (size_t)N * 4, hipMemcpyHostToDevice) != hipSuccess)) { fail("H2D copy"); break; }
@@ -2181,7 +2181,7 @@ static int int8_dense_impl(int device, const float *x, const float *w, const voi
         if (a_zp) *a_zp = (int32_t)par[1];
         if (w_scale) *w_scale = ws;
     } while (0);
-    hipFree(d_x); hipFree(d_w); hipFree(d_b); hipFree(d_y); hipFree(d_par); hipFree(d_acc); hipFree(d_xq); hipFree(d_scr); hipFree(d_rs);
+    dev_free(d_x); dev_free(d_w); dev_free(d_b); dev_free(d_y); dev_free(d_par); dev_free(d_acc); dev_free(d_xq); dev_free(d_scr); dev_free(d_rs);
     free_qweight(qw);
     return rc;
 }

@@ -104,7 +104,7 @@ int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n,
     if (n == 0) return SHODH_OK;
     SHODH_HIP_TRY(hipSetDevice(device));
     float *d = nullptr;
-    SHODH_HIP_TRY(hipMalloc((void **)&d, n * 4 * 8));
+    SHODH_HIP_TRY(dev_alloc((void **)&d, n * 4 * 8));
     const float *src[6] = {sem, ent, tag, imp, mom, gs};
     for (int i = 0; i < 6; ++i) SHODH_HIP_TRY(hipMemcpy(d + (size_t)i * n, src[i], n * 4, hipMemcpyHostToDevice));
     SHODH_HIP_TRY(hipMemcpy(d + 6 * n, acc, n * 4, hipMemcpyHostToDevice));
@@ -112,7 +112,7 @@ int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n,
                        d + 3 * n, d + 4 * n, (const uint32_t *)(d + 6 * n), d + 5 * n, d + 7 * n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d + 7 * n, n * 4, hipMemcpyDeviceToHost);
-    hipFree(d);
+    dev_free(d);
     if (e != hipSuccess) { set_error("fuse batch failed: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
     return SHODH_OK;
 }

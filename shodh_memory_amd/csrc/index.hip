@@ -138,46 +138,46 @@ struct Workspace {
         for (auto &e : ev) SHODH_HIP_TRY(hipEventCreate(&e));
         SHODH_HIP_TRY(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
         for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }      // created on first use (enqueue_flat): 64 concurrent callers used to mean 64 x 512 events up front
-        SHODH_HIP_TRY(hipMalloc((void **)&solo_cnt, 256));
+        SHODH_HIP_TRY(dev_alloc((void **)&solo_cnt, 256));
         // hipMemset on device memory is not synchronous with the host and the workspace's stream is non-blocking: without the synchronisation the FIRST search
         // on a new workspace could start before the counter was cleared and have it zeroed under its feet -- survivors lost, a wrong list (seen once in
         // 6400 calls with 64 threads each creating their workspace while the device was busy: bench.py concurrent_callers, round 5)
         SHODH_HIP_TRY(hipMemsetAsync(solo_cnt, 0, 256, stream));
         SHODH_HIP_TRY(hipStreamSynchronize(stream));
-        SHODH_HIP_TRY(hipHostMalloc((void **)&h_q, 4096));
+        SHODH_HIP_TRY(pin_alloc((void **)&h_q, 4096));
         return SHODH_OK;
     }
     int reserve(size_t need) {
         if (need <= bytes) return SHODH_OK;
-        if (buf) SHODH_HIP_TRY(hipFree(buf));
+        if (buf) SHODH_HIP_TRY(dev_free(buf));
         buf = nullptr; bytes = 0;
-        SHODH_HIP_TRY(hipMalloc((void **)&buf, need));
+        SHODH_HIP_TRY(dev_alloc((void **)&buf, need));
         bytes = need;
         return SHODH_OK;
     }
     int reserve_gather(size_t qf) {
         if (qf <= h_qb_floats) return SHODH_OK;
-        if (h_qb) hipHostFree(h_qb);
+        if (h_qb) pin_free(h_qb);
         h_qb = nullptr; h_qb_floats = 0;
-        SHODH_HIP_TRY(hipHostMalloc((void **)&h_qb, qf * 4));
+        SHODH_HIP_TRY(pin_alloc((void **)&h_qb, qf * 4));
         h_qb_floats = qf;
         return SHODH_OK;
     }
     int reserve_io(size_t qf, size_t oe, size_t nq) {
-        if (qf > q_floats) { if (d_q) hipFree(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&d_q, qf * 4)); q_floats = qf; }
+        if (qf > q_floats) { if (d_q) dev_free(d_q); d_q = nullptr; q_floats = 0; SHODH_HIP_TRY(dev_alloc((void **)&d_q, qf * 4)); q_floats = qf; }
         const size_t words = 2 * oe + nq + 8;          // + the four pipeline statistics (scan_stats), so that they come back in the same copy (+ the final stage's arrival counter)
         if (words > out_words) {
-            if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); d_out = nullptr; h_out = nullptr; out_words = 0;
-            SHODH_HIP_TRY(hipMalloc((void **)&d_out, words * 4)); SHODH_HIP_TRY(hipHostMalloc((void **)&h_out, words * 4)); out_words = words;
+            if (d_out) dev_free(d_out); if (h_out) pin_free(h_out); d_out = nullptr; h_out = nullptr; out_words = 0;
+            SHODH_HIP_TRY(dev_alloc((void **)&d_out, words * 4)); SHODH_HIP_TRY(pin_alloc((void **)&h_out, words * 4)); out_words = words;
         }
         d_ids = d_out; d_dist = reinterpret_cast<float *>(d_out + oe); d_counts = d_out + 2 * oe;      // contiguous for THIS call's sizes
         d_stats = d_out + 2 * oe + nq;
         return SHODH_OK;
     }
     void destroy() {
-        if (buf) hipFree(buf);
-        if (solo_cnt) hipFree(solo_cnt);
-        if (d_q) hipFree(d_q); if (d_out) hipFree(d_out); if (h_out) hipHostFree(h_out); if (h_q) hipHostFree(h_q); if (h_qb) hipHostFree(h_qb);
+        if (buf) dev_free(buf);
+        if (solo_cnt) dev_free(solo_cnt);
+        if (d_q) dev_free(d_q); if (d_out) dev_free(d_out); if (h_out) pin_free(h_out); if (h_q) pin_free(h_q); if (h_qb) pin_free(h_qb);
         for (auto &e : ev) if (e) hipEventDestroy(e);
         if (last_use) hipEventDestroy(last_use);
         for (auto &r : ring) { if (r[0]) hipEventDestroy(r[0]); if (r[1]) hipEventDestroy(r[1]); }
@@ -234,9 +234,9 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
     nc = (nc + 63) & ~63ull;
     const size_t dim = idx->cfg.dim;
     float *nr = nullptr; _Float16 *nh = nullptr; uint32_t *nd = nullptr;
-    if (hipMalloc((void **)&nr, nc * dim * 4) != hipSuccess) { set_error("out of HBM growing index to %llu rows", (unsigned long long)nc); return SHODH_ERR_OOM; }
-    if (idx->shadow && hipMalloc((void **)&nh, nc * dim * 2) != hipSuccess) { hipFree(nr); set_error("out of HBM (fp16 shadow)"); return SHODH_ERR_OOM; }
-    if (hipMalloc((void **)&nd, (nc / 32 + 1) * 4) != hipSuccess) { hipFree(nr); if (nh) hipFree(nh); set_error("out of HBM (tombstones)"); return SHODH_ERR_OOM; }
+    if (dev_alloc((void **)&nr, nc * dim * 4) != hipSuccess) { set_error("out of HBM growing index to %llu rows", (unsigned long long)nc); return SHODH_ERR_OOM; }
+    if (idx->shadow && dev_alloc((void **)&nh, nc * dim * 2) != hipSuccess) { dev_free(nr); set_error("out of HBM (fp16 shadow)"); return SHODH_ERR_OOM; }
+    if (dev_alloc((void **)&nd, (nc / 32 + 1) * 4) != hipSuccess) { dev_free(nr); if (nh) dev_free(nh); set_error("out of HBM (tombstones)"); return SHODH_ERR_OOM; }
     SHODH_HIP_TRY(hipMemset(nd, 0, (nc / 32 + 1) * 4));
     if (idx->n) {
         SHODH_HIP_TRY(hipMemcpy(nr, idx->rows, idx->n * dim * 4, hipMemcpyDeviceToDevice));
@@ -245,9 +245,9 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
     }
     if (idx->cfg.scan_mode == SHODH_SCAN_GRAPH) {
         uint32_t *gd = nullptr, *gn = nullptr, *gv = nullptr;
-        if (hipMalloc((void **)&gd, nc * 4) != hipSuccess || hipMalloc((void **)&gn, nc * (size_t)idx->g_stride * 4) != hipSuccess ||
-            hipMalloc((void **)&gv, (nc / 32 + 1) * 4) != hipSuccess) {
-            hipFree(gd); hipFree(gn); hipFree(gv); hipFree(nr); if (nh) hipFree(nh); hipFree(nd);      // nothing of the old slab was touched yet
+        if (dev_alloc((void **)&gd, nc * 4) != hipSuccess || dev_alloc((void **)&gn, nc * (size_t)idx->g_stride * 4) != hipSuccess ||
+            dev_alloc((void **)&gv, (nc / 32 + 1) * 4) != hipSuccess) {
+            dev_free(gd); dev_free(gn); dev_free(gv); dev_free(nr); if (nh) dev_free(nh); dev_free(nd);      // nothing of the old slab was touched yet
             set_error("out of HBM (graph)"); return SHODH_ERR_OOM;
         }
         SHODH_HIP_TRY(hipMemset(gd, 0, nc * 4));
@@ -255,14 +255,14 @@ static int grow(shodh_index *idx, uint64_t need_rows) {
             SHODH_HIP_TRY(hipMemcpy(gd, idx->g_deg, idx->g_nodes * 4, hipMemcpyDeviceToDevice));
             SHODH_HIP_TRY(hipMemcpy(gn, idx->g_nbr, idx->g_nodes * (size_t)idx->g_stride * 4, hipMemcpyDeviceToDevice));
         }
-        if (idx->g_deg) hipFree(idx->g_deg);
-        if (idx->g_nbr) hipFree(idx->g_nbr);
-        if (idx->g_visited) hipFree(idx->g_visited);
+        if (idx->g_deg) dev_free(idx->g_deg);
+        if (idx->g_nbr) dev_free(idx->g_nbr);
+        if (idx->g_visited) dev_free(idx->g_visited);
         idx->g_deg = gd; idx->g_nbr = gn; idx->g_visited = gv;
     }
-    if (idx->rows) hipFree(idx->rows);
-    if (idx->rows_h) hipFree(idx->rows_h);
-    if (idx->deleted) hipFree(idx->deleted);
+    if (idx->rows) dev_free(idx->rows);
+    if (idx->rows_h) dev_free(idx->rows_h);
+    if (idx->deleted) dev_free(idx->deleted);
     idx->rows = nr; idx->rows_h = nh; idx->deleted = nd; idx->cap_rows = nc;
     idx->deleted_host.resize(nc / 32 + 1, 0);
     return SHODH_OK;
@@ -514,11 +514,11 @@ int shodh_index_create(const shodh_index_cfg *cfg, shodh_index **out) {
             return SHODH_ERR_UNSUPPORTED;
         }
         idx->g_stride = cfg->max_degree + 1;
-        if (hipMalloc((void **)&idx->g_overflow, 64) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
+        if (dev_alloc((void **)&idx->g_overflow, 64) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
         hipMemset(idx->g_overflow, 0, 64);
     }
     idx->shadow = (cfg->kind == SHODH_INDEX_FLAT) && cfg->scan_mode != SHODH_SCAN_GRAPH && mfma_supported(cfg->dim);
-    if (hipMalloc((void **)&idx->stats, 16) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
+    if (dev_alloc((void **)&idx->stats, 16) != hipSuccess) { delete idx; set_error("hipMalloc failed"); return SHODH_ERR_OOM; }
     hipMemset(idx->stats, 0, 16);
     if (cfg->kind == SHODH_INDEX_FLAT && cfg->reserve_rows) {
         int s = grow(idx, cfg->reserve_rows);
@@ -534,14 +534,14 @@ void shodh_index_destroy(shodh_index *idx) {
     hipDeviceSynchronize();
     for (Workspace *w : idx->ws_free) { w->destroy(); delete w; }
     if (idx->ivfpq) ivfpq_destroy(idx->ivfpq);
-    if (idx->rows) hipFree(idx->rows);
-    if (idx->rows_h) hipFree(idx->rows_h);
-    if (idx->deleted) hipFree(idx->deleted);
-    if (idx->stats) hipFree(idx->stats);
-    if (idx->g_deg) hipFree(idx->g_deg);
-    if (idx->g_nbr) hipFree(idx->g_nbr);
-    if (idx->g_visited) hipFree(idx->g_visited);
-    if (idx->g_overflow) hipFree(idx->g_overflow);
+    if (idx->rows) dev_free(idx->rows);
+    if (idx->rows_h) dev_free(idx->rows_h);
+    if (idx->deleted) dev_free(idx->deleted);
+    if (idx->stats) dev_free(idx->stats);
+    if (idx->g_deg) dev_free(idx->g_deg);
+    if (idx->g_nbr) dev_free(idx->g_nbr);
+    if (idx->g_visited) dev_free(idx->g_visited);
+    if (idx->g_overflow) dev_free(idx->g_overflow);
     delete idx;
 }
 
@@ -900,11 +900,11 @@ int shodh_index_mark_deleted_batch(shodh_index *idx, const uint32_t *ids, uint64
     SHODH_HIP_TRY(hipMemcpy(idx->deleted, idx->deleted_host.data(), (idx->cap_rows / 32 + 1) * 4, hipMemcpyHostToDevice));
     if (idx->shadow) {
         uint32_t *d_list = nullptr;
-        SHODH_HIP_TRY(hipMalloc((void **)&d_list, fresh.size() * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&d_list, fresh.size() * 4));
         hipError_t e = hipMemcpy(d_list, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice);
         int rc = e == hipSuccess ? launch_shadow_zero_rows(idx->rows_h, d_list, fresh.size(), idx->cfg.dim, nullptr) : SHODH_ERR_DEVICE;
         if (hipDeviceSynchronize() != hipSuccess) rc = SHODH_ERR_DEVICE;
-        hipFree(d_list);
+        dev_free(d_list);
         if (rc != SHODH_OK) { set_error("tombstoning the shadow rows failed"); return rc; }
     }
     return SHODH_OK;
@@ -1110,20 +1110,20 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
     {
         float *d_c = nullptr; uint32_t *d_i = nullptr; float *d_d = nullptr; uint32_t *d_n = nullptr;
         SHODH_TRY(set_device(idx));
-        SHODH_HIP_TRY(hipMalloc((void **)&d_c, (size_t)idx->cfg.dim * 4 + 64));
+        SHODH_HIP_TRY(dev_alloc((void **)&d_c, (size_t)idx->cfg.dim * 4 + 64));
         d_i = (uint32_t *)(d_c + idx->cfg.dim); d_d = (float *)(d_i + 1); d_n = (uint32_t *)(d_d + 1);
         int rc = vg_launch_centroid(idx->rows, (uint32_t)n, idx->cfg.dim, d_c, nullptr);
         if (rc == SHODH_OK) {
             const uint32_t gx = exact_grid_x(n, 1, 1, idx->cus);
             unsigned char *part = nullptr;
-            if (hipMalloc((void **)&part, exact_partial_bytes(1, idx->cfg.dim, 1, gx) + 256) != hipSuccess) rc = SHODH_ERR_OOM;
+            if (dev_alloc((void **)&part, exact_partial_bytes(1, idx->cfg.dim, 1, gx) + 256) != hipSuccess) rc = SHODH_ERR_OOM;
             else {
                 rc = launch_flat_exact(idx->rows, n, idx->cfg.dim, nullptr, d_c, 1, 1, idx->cfg.order, 0, (uint64_t *)part, gx, d_i, d_d, d_n, nullptr, nullptr, nullptr);
                 if (rc == SHODH_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&medoid, d_i, 4, hipMemcpyDeviceToHost) != hipSuccess)) { set_error("medoid search failed"); rc = SHODH_ERR_DEVICE; }
-                hipFree(part);
+                dev_free(part);
             }
         }
-        hipFree(d_c);
+        dev_free(d_c);
         if (rc != SHODH_OK) return rc;
     }
     {
@@ -1133,7 +1133,7 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
         // vamana.rs:246-283: pass after pass over all nodes, at most two, stopping when a pass changed nothing. Each launch takes
         // VG_BUILD_CHUNK nodes (a node costs a few milliseconds: one launch stays in the range of seconds); the pass state lives here.
         uint32_t *d_upd = nullptr;
-        SHODH_HIP_TRY(hipMalloc((void **)&d_upd, 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&d_upd, 4));
         int rc = SHODH_OK;
         for (int pass = 1; pass <= 2 && rc == SHODH_OK; ++pass) {
             if (hipMemset(d_upd, 0, 4) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
@@ -1147,7 +1147,7 @@ int shodh_index_vamana_build(shodh_index *idx, uint64_t seed, const uint32_t *in
             if (rc == SHODH_OK && hipMemcpy(&upd, d_upd, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SHODH_ERR_DEVICE;
             if (upd == 0) break;
         }
-        hipFree(d_upd);
+        dev_free(d_upd);
         if (rc != SHODH_OK) return rc;
         idx->g_nodes = n;
         SHODH_TRY(check_graph_overflow(idx));

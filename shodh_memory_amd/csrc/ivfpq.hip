@@ -75,15 +75,15 @@ void ivfpq_destroy(IvfpqState *s) {
     if (!s) return;
     hipSetDevice(s->device);
     if (s->cent_idx) shodh_index_destroy(s->cent_idx);
-    hipFree(s->centroids); hipFree(s->codebook); hipFree(s->list_off); hipFree(s->ids); hipFree(s->codes); hipFree(s->scratch);
+    dev_free(s->centroids); dev_free(s->codebook); dev_free(s->list_off); dev_free(s->ids); dev_free(s->codes); dev_free(s->scratch);
     delete s;
 }
 
 static int ensure_scratch(IvfpqState *s, size_t bytes) {
     if (bytes <= s->scratch_bytes) return SHODH_OK;
-    if (s->scratch) hipFree(s->scratch);
+    if (s->scratch) dev_free(s->scratch);
     s->scratch = nullptr; s->scratch_bytes = 0;
-    SHODH_HIP_TRY(hipMalloc((void **)&s->scratch, bytes));
+    SHODH_HIP_TRY(dev_alloc((void **)&s->scratch, bytes));
     s->scratch_bytes = bytes;
     return SHODH_OK;
 }
@@ -781,10 +781,10 @@ static int upload_postings(IvfpqState *s) {
         std::copy(s->h_codes[p].begin(), s->h_codes[p].end(), codes.begin() + off[p] * s->M);
     }
     if (total > s->cap_total) {
-        hipFree(s->ids); hipFree(s->codes); s->ids = nullptr; s->codes = nullptr;
+        dev_free(s->ids); dev_free(s->codes); s->ids = nullptr; s->codes = nullptr;
         uint64_t nc = total + total / 4 + 1024;
-        SHODH_HIP_TRY(hipMalloc((void **)&s->ids, nc * 4));
-        SHODH_HIP_TRY(hipMalloc((void **)&s->codes, nc * s->M));
+        SHODH_HIP_TRY(dev_alloc((void **)&s->ids, nc * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&s->codes, nc * s->M));
         s->cap_total = nc;
     }
     SHODH_HIP_TRY(hipMemcpy(s->list_off, off.data(), (s->P + 1) * 8, hipMemcpyHostToDevice));
@@ -978,12 +978,12 @@ static int encode_rows(IvfpqState *s, const float *rows, uint64_t n, uint32_t *a
     const uint32_t gxc = exact_grid_x(s->P, (uint32_t)ch, 1, s->cus);
     (void)gx;
     const size_t part_bytes = exact_partial_bytes((uint32_t)ch, s->dim, 1, gxc);
-    SHODH_HIP_TRY(hipMalloc((void **)&d_rows, ch * s->dim * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&d_codes, ch * s->M));
-    SHODH_HIP_TRY(hipMalloc((void **)&d_assign, ch * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&d_ad, ch * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&d_ac, ch * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&d_part, part_bytes + 256));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_rows, ch * s->dim * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_codes, ch * s->M));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_assign, ch * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_ad, ch * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_ac, ch * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&d_part, part_bytes + 256));
     int rc = SHODH_OK;
     const uint32_t op = (s->metric == SHODH_METRIC_EUCLIDEAN) ? EX_OP_SEQ_L2 : EX_OP_SEQ_ONE_MINUS_DOT;
     for (uint64_t b = 0; b < n && rc == SHODH_OK; b += ch) {
@@ -999,7 +999,7 @@ static int encode_rows(IvfpqState *s, const float *rows, uint64_t n, uint32_t *a
             hipMemcpy(codes_out + b * s->M, d_codes, m * s->M, hipMemcpyDeviceToHost) != hipSuccess) { rc = SHODH_ERR_DEVICE; break; }
     }
     if (rc == SHODH_ERR_DEVICE) set_error("IVF-PQ encode failed on device: %s", hipGetErrorString(hipGetLastError()));
-    hipFree(d_rows); hipFree(d_codes); hipFree(d_assign); hipFree(d_ad); hipFree(d_ac); hipFree(d_part);
+    dev_free(d_rows); dev_free(d_codes); dev_free(d_assign); dev_free(d_ad); dev_free(d_ac); dev_free(d_part);
     return rc;
 }
 
@@ -1027,9 +1027,9 @@ int shodh_index_set_ivfpq(shodh_index *idx, const float *centroids, uint32_t P, 
     s->device = cfg.device; s->cus = prop.multiProcessorCount; s->dim = cfg.dim; s->P = P; s->M = M; s->ncent = ncent; s->metric = cfg.metric;
     const uint64_t total = list_off[P];
     if ((total && (!ids || !codes))) { delete s; set_error("null postings"); return SHODH_ERR_INVALID; }
-    SHODH_HIP_TRY(hipMalloc((void **)&s->centroids, (size_t)P * cfg.dim * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&s->codebook, (size_t)M * ncent * 8 * 4));
-    SHODH_HIP_TRY(hipMalloc((void **)&s->list_off, (size_t)(P + 1) * 8));
+    SHODH_HIP_TRY(dev_alloc((void **)&s->centroids, (size_t)P * cfg.dim * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&s->codebook, (size_t)M * ncent * 8 * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&s->list_off, (size_t)(P + 1) * 8));
     SHODH_HIP_TRY(hipMemcpy(s->centroids, centroids, (size_t)P * cfg.dim * 4, hipMemcpyHostToDevice));
     SHODH_HIP_TRY(hipMemcpy(s->codebook, codebook, (size_t)M * ncent * 8 * 4, hipMemcpyHostToDevice));
     if (cfg.metric != SHODH_METRIC_EUCLIDEAN) {
@@ -1175,8 +1175,8 @@ __global__ __launch_bounds__(256) void mean_update_kernel(const float *rows, uin
 
 struct Buf {
     void *p = nullptr;
-    ~Buf() { if (p) hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? SHODH_OK : SHODH_ERR_OOM; }
+    ~Buf() { if (p) dev_free(p); }
+    int alloc(size_t bytes) { return dev_alloc(&p, bytes ? bytes : 16) == hipSuccess ? SHODH_OK : SHODH_ERR_OOM; }
     template <class T> T *as() { return (T *)p; }
 };
 
@@ -1186,7 +1186,7 @@ int sorted_members(const uint32_t *keys, uint64_t n, uint32_t k, uint32_t *idx_i
     while ((1u << bits) < k) ++bits;
     size_t need = 0;
     SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
-    if (need > tmp_bytes) { if (tmp.p) hipFree(tmp.p); tmp.p = nullptr; SHODH_TRY(tmp.alloc(need)); tmp_bytes = need; }
+    if (need > tmp_bytes) { if (tmp.p) dev_free(tmp.p); tmp.p = nullptr; SHODH_TRY(tmp.alloc(need)); tmp_bytes = need; }
     SHODH_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, need, keys, keys_out, idx_in, members, (int)n, 0, bits));
     return SHODH_OK;
 }

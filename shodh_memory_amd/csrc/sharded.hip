@@ -235,12 +235,12 @@ static void slot_destroy(shodh_sharded_index *s, CallSlot *c) {
         SlotShard &h = c->sh[g];
         hipSetDevice(s->sh[g].device);
         if (h.st) hipStreamSynchronize(h.st);
-        if (h.d_q) hipFree(h.d_q); if (h.pack) hipFree(h.pack); if (h.all) hipFree(h.all); if (h.d_counts) hipFree(h.d_counts);
+        if (h.d_q) dev_free(h.d_q); if (h.pack) dev_free(h.pack); if (h.all) dev_free(h.all); if (h.d_counts) dev_free(h.d_counts);
         if (h.ev) hipEventDestroy(h.ev);
         if (h.st) hipStreamDestroy(h.st);
     }
     if (!s->sh.empty()) hipSetDevice(s->sh[0].device);
-    if (c->o_blk) hipFree(c->o_blk); if (c->h_out) hipHostFree(c->h_out); if (c->h_q) hipHostFree(c->h_q);
+    if (c->o_blk) dev_free(c->o_blk); if (c->h_out) pin_free(c->h_out); if (c->h_q) pin_free(c->h_q);
     if (c->ev_in) hipEventDestroy(c->ev_in); if (c->ev_out) hipEventDestroy(c->ev_out);
     delete c;
 }
@@ -276,22 +276,22 @@ static int reserve_buffers(shodh_sharded_index *s, CallSlot *c, uint32_t nq, uin
     for (size_t g = 0; g < G; ++g) {
         SlotShard &h = c->sh[g];
         SHODH_HIP_TRY(hipSetDevice(s->sh[g].device));
-        if ((size_t)nq * s->cfg.dim > h.q_floats) { if (h.d_q) hipFree(h.d_q); h.d_q = nullptr; h.q_floats = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.d_q, (size_t)nq * s->cfg.dim * 4)); h.q_floats = (size_t)nq * s->cfg.dim; }
-        if (words > h.pack_words) { if (h.pack) hipFree(h.pack); h.pack = nullptr; h.pack_words = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.pack, (words ? words : 1) * 4)); h.pack_words = words; }
+        if ((size_t)nq * s->cfg.dim > h.q_floats) { if (h.d_q) dev_free(h.d_q); h.d_q = nullptr; h.q_floats = 0; SHODH_HIP_TRY(dev_alloc((void **)&h.d_q, (size_t)nq * s->cfg.dim * 4)); h.q_floats = (size_t)nq * s->cfg.dim; }
+        if (words > h.pack_words) { if (h.pack) dev_free(h.pack); h.pack = nullptr; h.pack_words = 0; SHODH_HIP_TRY(dev_alloc((void **)&h.pack, (words ? words : 1) * 4)); h.pack_words = words; }
         const bool needs_all = s->use_rccl || g == 0;
-        if (needs_all && words * G > h.all_words) { if (h.all) hipFree(h.all); h.all = nullptr; h.all_words = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.all, (words * G ? words * G : 1) * 4)); h.all_words = words * G; }
-        if (nq > h.nq_cap) { if (h.d_counts) hipFree(h.d_counts); h.d_counts = nullptr; h.nq_cap = 0; SHODH_HIP_TRY(hipMalloc((void **)&h.d_counts, (size_t)nq * 4)); h.nq_cap = nq; }
+        if (needs_all && words * G > h.all_words) { if (h.all) dev_free(h.all); h.all = nullptr; h.all_words = 0; SHODH_HIP_TRY(dev_alloc((void **)&h.all, (words * G ? words * G : 1) * 4)); h.all_words = words * G; }
+        if (nq > h.nq_cap) { if (h.d_counts) dev_free(h.d_counts); h.d_counts = nullptr; h.nq_cap = 0; SHODH_HIP_TRY(dev_alloc((void **)&h.d_counts, (size_t)nq * 4)); h.nq_cap = nq; }
     }
     SHODH_HIP_TRY(hipSetDevice(s->sh[0].device));
     if (host_io) {
         const size_t ow = words + nq;
         if (ow > c->o_words) {
-            if (c->o_blk) hipFree(c->o_blk); if (c->h_out) hipHostFree(c->h_out); c->o_blk = nullptr; c->h_out = nullptr; c->o_words = 0;
-            SHODH_HIP_TRY(hipMalloc((void **)&c->o_blk, ow * 4)); SHODH_HIP_TRY(hipHostMalloc((void **)&c->h_out, ow * 4)); c->o_words = ow;
+            if (c->o_blk) dev_free(c->o_blk); if (c->h_out) pin_free(c->h_out); c->o_blk = nullptr; c->h_out = nullptr; c->o_words = 0;
+            SHODH_HIP_TRY(dev_alloc((void **)&c->o_blk, ow * 4)); SHODH_HIP_TRY(pin_alloc((void **)&c->h_out, ow * 4)); c->o_words = ow;
         }
         if ((size_t)nq * s->cfg.dim > c->h_q_floats) {
-            if (c->h_q) hipHostFree(c->h_q); c->h_q = nullptr; c->h_q_floats = 0;
-            SHODH_HIP_TRY(hipHostMalloc((void **)&c->h_q, (size_t)nq * s->cfg.dim * 4)); c->h_q_floats = (size_t)nq * s->cfg.dim;
+            if (c->h_q) pin_free(c->h_q); c->h_q = nullptr; c->h_q_floats = 0;
+            SHODH_HIP_TRY(pin_alloc((void **)&c->h_q, (size_t)nq * s->cfg.dim * 4)); c->h_q_floats = (size_t)nq * s->cfg.dim;
         }
     }
     return SHODH_OK;

@@ -95,7 +95,7 @@ int shodh_cosine_similarity_batch(int device, const float *a, const float *b, ui
     if (n == 0) return SHODH_OK;
     SHODH_HIP_TRY(hipSetDevice(device));
     float *d = nullptr;
-    SHODH_HIP_TRY(hipMalloc((void **)&d, (2 * n * dim + n) * 4));
+    SHODH_HIP_TRY(dev_alloc((void **)&d, (2 * n * dim + n) * 4));
     hipError_t e = hipMemcpy(d, a, n * dim * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + n * dim, b, n * dim * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -104,7 +104,7 @@ int shodh_cosine_similarity_batch(int device, const float *a, const float *b, ui
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n * dim, n * 4, hipMemcpyDeviceToHost);
-    hipFree(d);
+    dev_free(d);
     if (e != hipSuccess) { set_error("cosine batch failed: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
     return SHODH_OK;
 }
@@ -120,7 +120,7 @@ int shodh_top_k_similar(int device, const float *query, uint32_t query_dim, cons
     if (query_dim == dim && dim != 0) {                            // a.len() != b.len() -> 0.0 for every candidate (similarity.rs:11-13)
         SHODH_HIP_TRY(hipSetDevice(device));
         float *d = nullptr;
-        SHODH_HIP_TRY(hipMalloc((void **)&d, ((n + 1) * dim + n) * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&d, ((n + 1) * dim + n) * 4));
         hipError_t e = hipMemcpy(d, query, (size_t)dim * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d + dim, cands, n * dim * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
@@ -130,7 +130,7 @@ int shodh_top_k_similar(int device, const float *query, uint32_t query_dim, cons
             e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpy(score.data(), d_out, n * 4, hipMemcpyDeviceToHost);
         }
-        hipFree(d);
+        dev_free(d);
         if (e != hipSuccess) { set_error("top_k_similar failed: %s", hipGetErrorString(e)); return SHODH_ERR_DEVICE; }
     }
     std::vector<uint32_t> idx(n);
