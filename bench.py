@@ -111,7 +111,7 @@ def compact_line(full, detail_path=None, max_bytes=CONTRACT_LINE_MAX_BYTES):
     line = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
     line["config"] = {k: (_short(cfg[k]) if isinstance(cfg[k], str) else cfg[k]) for k in
-                      ("workload", "rows_total", "rows_per_gpu", "rows_live_per_gpu", "batch", "k", "scan", "layout") if k in cfg}
+                      ("workload", "rows_total", "rows_per_gpu", "rows_live_per_gpu", "batch", "k", "scan", "layout", "parallelism") if k in cfg}
     r = full.get("roofline")
     if r:
         rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_us_mean", "launch_us_min", "launches_timed",
@@ -986,6 +986,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if os.environ.get("SHODH_GUARD", "0") not in ("", "0"):
+        # diagnostic run under the allocation guard (csrc/guard.h, tools/r6_guard.sh): torch's tensors become fenced mappings as well; has to happen
+        # before the first device call of the process. Not a measurement.
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_shodh_build", os.path.join(ROOT, "shodh_memory_amd", "build.py"))
+        gb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gb)
+        gb.build()
+        torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(gb.LIB, "shodh_guard_torch_alloc", "shodh_guard_torch_free"))
+        print("[bench] SHODH_GUARD=%s: fenced allocations, NOT a measurement" % os.environ["SHODH_GUARD"], file=sys.stderr, flush=True)
     backend = os.environ.get("SHODH_BENCH_BACKEND", "nccl")    # "gloo" + one GPU: a functional check of the N > 1 path (not a measurement)
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)

@@ -517,6 +517,8 @@ int shodh_fuse_scores_full_batch(int device, const shodh_weights *w, uint64_t n,
  * with the tag / is a prefix of it); both sides lower-cased like str::to_lowercase (full Unicode mappings + Final_Sigma,
  * from the Unicode 13 database), words split at Unicode White_Space. */
 float shodh_calculate_tag_score(const char *context_utf8, const char *const *tags_utf8, size_t n_tags);
+/* the lower-casing step of it alone (str::to_lowercase, relevance.rs:685-689): writes at most cap - 1 bytes + NUL, returns the full length */
+size_t shodh_to_lowercase(const char *utf8, char *out, size_t cap);
 /* apply_recency_boost (:1524-1547): age_hours = (now - created_at).num_hours(), cast to u64 like the reference does
  * (a negative age becomes huge and gets no boost) */
 float shodh_apply_recency_boost(float base_score, int64_t age_hours, uint64_t boost_hours, float multiplier);

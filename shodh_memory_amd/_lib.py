@@ -90,6 +90,7 @@ class SpanInfo(C.Structure):
 
 
 SYMBOLS = {
+    "shodh_to_lowercase": (C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "shodh_guard_mode": (C.c_int, []),
     "shodh_guard_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "shodh_guard_torch_alloc": (C.c_void_p, [C.c_int64, C.c_int, C.c_void_p]),

@@ -1025,6 +1025,9 @@ static void layout(shodh_embedder *e) {
     e->n_params = o;
 }
 
+// token rows allocated beyond the usable capacity of every per-token buffer (see reserve). SHODH_ENC_ROW_PAD=0 restores the round-5 sizes: only for
+// showing, under SHODH_GUARD=1, that tests/test_guard_gpu.py catches what it is a regression test for.
+static const size_t ENC_ROW_PAD = getenv("SHODH_ENC_ROW_PAD") ? (size_t)atoi(getenv("SHODH_ENC_ROW_PAD")) : 256;
 static int reserve(shodh_embedder *e, EncScratch *sc, size_t ntok, size_t nseq, size_t pre_tok) {
     const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
     const size_t es = e->cfg.dtype == SHODH_DTYPE_BF16 ? 2 : 4;
@@ -1034,28 +1037,34 @@ static int reserve(shodh_embedder *e, EncScratch *sc, size_t ntok, size_t nseq, 
         dev_free(sc->HQ); dev_free(sc->rsX); dev_free(sc->rsH);
         sc->X = sc->QKV = sc->CTX = sc->FF = nullptr; sc->d_tok_seq = sc->d_tok_pos = nullptr; sc->XQ = nullptr; sc->HQ = nullptr; sc->rsX = sc->rsH = nullptr; sc->tok_cap = 0;
         size_t cap = ntok + ntok / 4 + 256;
+        // Every per-token buffer is allocated ENC_ROW_PAD rows LONGER than the capacity it is used up to: the streaming kernels fetch whole tiles of 64 - 256
+        // token rows (gemm_k384_stream_kernel: "the last tile may read up to 63 rows past M", the fused feed-forward 128, the INT8 streams 256) and mask what
+        // they store. The slack used to be only the head-room of the growth formula above -- gone as soon as a later forward filled the buffer to `cap`:
+        // its last tile then read past the END OF THE ALLOCATION (harmless garbage while the next pages happened to be mapped, "Memory access fault by GPU
+        // node" when they were not: the once-in-thirty-runs fault of round 5, found with SHODH_GUARD=1 -- DESIGN.md 11).
+        const size_t rows = cap + ENC_ROW_PAD;
         const bool int8 = e->cfg.dtype == SHODH_DTYPE_INT8;
         if (int8) {
-            SHODH_HIP_TRY(dev_alloc((void **)&sc->XQ, cap * std::max(H, I)));
-            SHODH_HIP_TRY(dev_alloc((void **)&sc->HQ, cap * I));
-            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsX, (cap + 256) * 4));     // (+ 256: the streaming kernels fetch the row sums of a tile as one 1-KiB DMA piece)
-            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsH, (cap + 256) * 4));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->XQ, rows * std::max(H, I)));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->HQ, rows * I));
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsX, (rows + 256) * 4));     // (+ 256: the streaming kernels fetch the row sums of a tile as one 1-KiB DMA piece)
+            SHODH_HIP_TRY(dev_alloc((void **)&sc->rsH, (rows + 256) * 4));
         }
         // the fast INT8 layer keeps neither the q|k|v tensor nor the f32 GELU output (encoder_int8_fast.h); they exist only for the stages
         // switched back to the round-2 kernels (SHODH_INT8_STAGES) or for shapes the fused kernels do not take
         const bool need_wide = !int8 || !e->int8_all_fast;
-        SHODH_HIP_TRY(dev_alloc(&sc->X, cap * H * es));
-        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->QKV, cap * 3 * H * es));
-        SHODH_HIP_TRY(dev_alloc(&sc->CTX, cap * H * es));
-        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->FF, cap * I * es));
-        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_seq, cap * 4));
-        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_pos, cap * 4));
+        SHODH_HIP_TRY(dev_alloc(&sc->X, rows * H * es));
+        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->QKV, rows * 3 * H * es));
+        SHODH_HIP_TRY(dev_alloc(&sc->CTX, rows * H * es));
+        if (need_wide) SHODH_HIP_TRY(dev_alloc(&sc->FF, rows * I * es));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_seq, rows * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->d_tok_pos, rows * 4));
         sc->tok_cap = cap;
     }
     if (pre_tok > sc->pre_cap) {      // pre-LayerNorm sums; the K-split down projection (bf16, small or per-text forwards) keeps FFN_KSPLIT partial sums per token
         dev_free(sc->PRE); sc->PRE = nullptr; sc->pre_cap = 0;
         const size_t cap = pre_tok + pre_tok / 4 + 256;
-        SHODH_HIP_TRY(dev_alloc((void **)&sc->PRE, cap * H * 4));
+        SHODH_HIP_TRY(dev_alloc((void **)&sc->PRE, (cap + ENC_ROW_PAD) * H * 4));
         sc->pre_cap = cap;
     }
     if (nseq > sc->seq_cap) {

@@ -34,7 +34,7 @@ d_ids = lib.shodh_guard_torch_alloc(nq * k * 4, 0, None); d_dist = lib.shodh_gua
 hip = C.CDLL('libamdhip64.so')
 q = np.ascontiguousarray(rows[:nq])
 hip.hipMemcpy(C.c_void_p(d_q), q.ctypes.data_as(C.c_void_p), C.c_size_t(qbytes), 1)
-rc = lib.shodh_index_search_device(idx._h, C.c_void_p(d_q), nq, k, C.c_void_p(d_ids), C.c_void_p(d_dist), C.c_void_p(d_cnt), None)
+rc = lib.shodh_index_search_device(idx.handle, C.c_void_p(d_q), nq, k, C.c_void_p(d_ids), C.c_void_p(d_dist), C.c_void_p(d_cnt), None)
 hip.hipDeviceSynchronize()
 ids = np.zeros((nq, k), np.uint32)
 hip.hipMemcpy(ids.ctypes.data_as(C.c_void_p), C.c_void_p(d_ids), C.c_size_t(ids.nbytes), 2)
@@ -66,3 +66,48 @@ def test_an_overread_of_sixteen_bytes_is_a_page_fault():
     p = _run(16)
     out = p.stdout.decode()
     assert p.returncode != 0 and "Memory access fault" in out, out[-3000:]
+
+
+ENC_CHILD = r"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from shodh_memory_amd import _lib as L
+from shodh_memory_amd.embedder import MiniLMEmbedder
+assert L.lib().shodh_guard_mode() == 1
+
+def batch(lengths, seed):
+    rng = np.random.default_rng(seed)
+    ids = np.zeros((len(lengths), 256), np.int32); mask = np.zeros((len(lengths), 256), np.uint8)
+    for i, n in enumerate(lengths):
+        ids[i, :n] = rng.integers(1000, 30521, n); ids[i, 0] = 101; ids[i, n - 1] = 102; mask[i, :n] = 1
+    return ids, mask
+
+for dtype, padded in ((L.DTYPE_BF16, 0), (L.DTYPE_FP32, 0), (L.DTYPE_INT8, 1), (L.DTYPE_INT8, 0)):
+    e = MiniLMEmbedder(synthetic_seed=3, dtype=dtype, device=0, compute_padded=padded)
+    e.set_coalesce(False)
+    ref = {}
+    # the round-5 fault: a first forward of a few tokens sizes the scratch (capacity = n + n/4 + 256 token rows), later forwards FILL it -- their last
+    # 64- / 128- / 256-row tile used to reach past the end of the allocation. Token totals around every capacity the growth formula produces.
+    for n_tok in (16, 270, 276, 277, 300, 601, 631, 632, 1000, 1506, 1507, 130, 64, 65, 1):
+        lengths = [128] * (n_tok // 128) + ([n_tok %% 128] if n_tok %% 128 else [])
+        lengths = [max(l, 2) for l in lengths] if n_tok > 1 else [2]
+        ids, mask = batch(lengths, n_tok)
+        out = e.encode_ids(ids, mask)
+        assert np.isfinite(out).all() and np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-3), (dtype, n_tok)
+        one = e.encode_ids(ids[:1], mask[:1])                  # (and a one-text forward right after a large one)
+        assert np.isfinite(one).all()
+    e.close()
+print('encoder forwards at every scratch capacity: no fault')
+"""
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_encoder_scratch_filled_to_its_capacity_under_the_guard():
+    """Regression for the round-5 'Memory access fault by GPU node' (one bench run in thirty): the encoder's per-token scratch had no tile slack beyond its
+    capacity, so a forward that filled it read up to 255 token rows past the allocation. Under SHODH_GUARD=1 that is a fault on every run."""
+    env = dict(os.environ, SHODH_GUARD="1")
+    p = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "no fault" in out, out[-3000:]
