@@ -384,8 +384,12 @@ int shodh_embedder_encode_ids_device_scoped(shodh_embedder *e, const int32_t *d_
  * flight per handle (calls with b > 1 run on their own). stats6 as for shodh_index_coalesce_stats. */
 int shodh_embedder_set_coalesce(shodh_embedder *e, int enabled, uint32_t linger_us);
 int shodh_embedder_coalesce_stats(shodh_embedder *e, uint64_t *stats6, int reset);
-/* switch the INT8 quantisation scope of later encode calls (cfg.quant_scope; no reallocation, no effect on fp32 / bf16): a host calls
- * PER_TEXT for bulk `remember` ingest (N x encode()) and BATCH where the reference itself calls encode_batch (memory/mod.rs:8443, :8838) */
+/* switch the quantisation scope of later encode calls (cfg.quant_scope; no reallocation): a host calls PER_TEXT for bulk `remember` ingest
+ * (N x encode()) and BATCH where the reference itself calls encode_batch (memory/mod.rs:8443, :8838). INT8: which tensor the activation ranges
+ * span. fp32 / bf16: the NUMBERS of a text never depend on its batch mates, but PER_TEXT selects the kernel forms a one-text call takes (three-kernel
+ * feed-forward, K-split down projection) for every batch size, so that encode_each(texts)[i] == encode(texts[i]) byte for byte; it is slower than
+ * BATCH for bulk bf16 ingest (no fused feed-forward) and runs in sub-batches of 1024 texts to bound the K-split scratch. Leave BATCH where byte
+ * equality with one-text calls is not needed. */
 int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope);
 uint32_t shodh_embedder_quant_scope(const shodh_embedder *e);
 int shodh_embedder_stage_timings(const shodh_embedder *e, float *us2);         /* StageTiming.embedding_us */

@@ -129,8 +129,9 @@ struct CombinerStats { uint64_t batches = 0, members = 0, max_members = 0, linge
 
 class Combiner {
 public:
-    uint32_t linger_us = 30, quiet_us = 12;
-    bool trace = false;       // SHODH_COALESCE_TRACE=1: print when each member of a pass joined
+    // (atomics: *_set_coalesce may change them while leaders read them)
+    std::atomic<uint32_t> linger_us{30}, quiet_us{12};
+    std::atomic<bool> trace{false};       // SHODH_COALESCE_TRACE=1: print when each member of a pass joined
     // (A predictive wait -- members wake before the expected end of their pass and poll -- was built and measured in round 5: no gain at 64 callers, -40 % at 256
     // callers on 256 hardware threads, ~10 % of a core per waiting caller. Removed)
 
@@ -159,7 +160,7 @@ public:
             }
             my_index = (uint32_t)b->reqs.size();
             b->reqs.push_back(req);
-            if (trace) b->arrive_ns.push_back(mono_ns());
+            if (trace.load(std::memory_order_relaxed)) b->arrive_ns.push_back(mono_ns());
             b->units += units;
             b->units_now.store(b->units, std::memory_order_release);
             b->members.fetch_add(1u, std::memory_order_release);
@@ -171,7 +172,8 @@ public:
         }
         futex_wait_nonzero(&b->go);
         // linger (see the header)
-        if (linger_us) {
+        const uint32_t linger = linger_us.load(std::memory_order_relaxed), quiet = quiet_us.load(std::memory_order_relaxed);
+        if (linger) {
             uint32_t target = std::max<uint32_t>(want_members.load(std::memory_order_relaxed), b->expect.load(std::memory_order_relaxed));
             const uint32_t here = b->units_now.load(std::memory_order_acquire);
             if (target > max_units) target = max_units;
@@ -179,9 +181,12 @@ public:
             if (now - last_end_ns.load(std::memory_order_relaxed) > 2000000ull) target = 0;
             if (here < target) {
                 // at most linger_us, or a quarter of the last pass if that is more: what merging two half-size passes saves is a whole pass, and a
-                // sleeper's way back through the kernel takes 5-10 us on bare metal but 50+ us inside a VM
-                const uint64_t cap_ns = std::max<uint64_t>((uint64_t)linger_us * 1000ull, last_pass_ns.load(std::memory_order_relaxed) / 4);
+                // sleeper's way back through the kernel takes 5-10 us on bare metal but 50+ us inside a VM ...
+                const uint64_t cap_ns = std::max<uint64_t>((uint64_t)linger * 1000ull, last_pass_ns.load(std::memory_order_relaxed) / 4);
                 const uint64_t t_end = now + cap_ns;
+                // ... but the quarter of a pass only once somebody HAS arrived: with nobody else around (a lone caller within 2 ms of a burst on an index whose
+                // passes take milliseconds) the wait ends after linger_us -- "a caller that is alone is not delayed" (it used to spin for pass / 4)
+                const uint64_t t_end_alone = now + (uint64_t)linger * 1000ull;
                 // ... and once callers have started to arrive, no longer than quiet_us after the last arrival: the stragglers of a big pass (a thread
                 // that was descheduled, a caller that went away) are not worth a quarter of a pass
                 uint32_t seen = here;
@@ -191,7 +196,8 @@ public:
                     const uint64_t t = mono_ns();
                     if (u >= target || t >= t_end) break;
                     if (u != seen) { seen = u; t_last = t; }
-                    else if (quiet_us && t_last && t - t_last > (uint64_t)quiet_us * 1000ull) break;
+                    else if (!t_last && t >= t_end_alone) break;
+                    else if (quiet && t_last && t - t_last > (uint64_t)quiet * 1000ull) break;
                     cpu_relax();
                 }
                 n_lingered.fetch_add(1u, std::memory_order_relaxed);
@@ -204,7 +210,7 @@ public:
             LockGuard g(m);
             b->closed = true;
             reqs = b->reqs;                 // (copied: the pass runs without the lock)
-            if (trace && b->arrive_ns.size() > 1) {
+            if (b->arrive_ns.size() > 1) {
                 // diagnostics: when the members joined, relative to the end of the previous pass (us): first, median, last; then when the pass started
                 std::vector<uint64_t> a = b->arrive_ns;
                 std::sort(a.begin(), a.end());

@@ -2042,7 +2042,7 @@ static int encode_impl(shodh_embedder *e, const int32_t *ids, const uint8_t *mas
 // (minilm.rs:588-593), so the batch is part of the function.
 // With SHODH_QUANT_SCOPE_PER_TEXT the texts are independent again (every range spans one text), so INT8 splits too: 4096 padded texts per forward
 // (1M positions; the workspace of a forward is ~13 KB per position).
-constexpr uint32_t ENC_SUB = 8192, ENC_SUB_PER_TEXT = 4096;
+constexpr uint32_t ENC_SUB = 8192, ENC_SUB_PER_TEXT = 4096, ENC_SUB_INVARIANT = 1024;
 constexpr uint32_t SCOPE_HANDLE = 0xFFFFFFFFu;       // "the handle's setting" (shodh_embedder_encode_ids)
 static int encode_chunked(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, bool device_io, hipStream_t st, uint32_t scope_arg) {
     if (!e) return encode_impl(e, ids, mask, b, out, device_io, st);
@@ -2052,7 +2052,9 @@ static int encode_chunked(shodh_embedder *e, const int32_t *ids, const uint8_t *
     // the batch-invariant kernel forms (encode_impl); the numbers of a text never depend on its batch mates there.
     const uint32_t scope = scope_arg != SCOPE_HANDLE ? scope_arg : __atomic_load_n(&e->quant_scope, __ATOMIC_RELAXED);
     const bool per_text = scope == SHODH_QUANT_SCOPE_PER_TEXT;
-    const uint32_t sub = (int8 && per_text) ? ENC_SUB_PER_TEXT : ENC_SUB;
+    // fp32 / bf16 under PER_TEXT take the text-invariant kernel forms, whose K-split down projection keeps FFN_KSPLIT f32 partial sums per token:
+    // sub-batches of ENC_SUB_INVARIANT texts bound that scratch (8192 texts would be several GB), and the fused feed-forward is not used there anyway
+    const uint32_t sub = (int8 && per_text) ? ENC_SUB_PER_TEXT : (!int8 && per_text) ? ENC_SUB_INVARIANT : ENC_SUB;
     if (b <= sub || (int8 && !per_text)) {
         const int rc = encode_impl(e, ids, mask, b, out, device_io, st, scope);
         if (rc != ENC_RETRY_EACH) return rc;
@@ -2113,8 +2115,26 @@ int shodh_embedder_set_quant_scope(shodh_embedder *e, uint32_t scope) {
     return SHODH_OK;
 }
 uint32_t shodh_embedder_quant_scope(const shodh_embedder *e) { return e ? __atomic_load_n(&e->quant_scope, __ATOMIC_RELAXED) : 0u; }
+// May this one-text call join a shared per-text forward? Only if nothing about it can fail or slow down the OTHER members of the pass (combiner.h: "one
+// member's bad input must not fail the others -- callers screen their inputs"): a valid scope argument, a mask that is a prefix of ones (encode_impl
+// rejects anything else for the whole batch, with a row number that would be another caller's), and -- INT8 -- a length and shape the per-sequence
+// kernels take: a text they do not take would turn the whole pass into one forward per member, run one after the other by the leader.
+// Whatever fails the screen runs on its own through encode_chunked, which reports the error to this caller alone.
+static bool encode_coalescable(const shodh_embedder *e, const uint8_t *mask, uint32_t scope) {
+    if (scope != SCOPE_HANDLE && scope > SHODH_QUANT_SCOPE_PER_TEXT) return false;
+    const uint32_t ML = e->cfg.max_len;
+    uint32_t len = 0;
+    for (uint32_t p = 0; p < ML; ++p) {
+        if (mask[p] == 1) {
+            if (p != len) return false;
+            ++len;
+        }
+    }
+    if (e->cfg.dtype == SHODH_DTYPE_INT8 && len > 0 && !per_text_fast_ok(e, (int)len)) return false;
+    return true;
+}
 static int encode_host(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out, uint32_t scope) {
-    if (e && b == 1 && ids && mask && out && e->loaded && e->coalesce) return coalesced_encode_one(e, ids, mask, out);
+    if (e && b == 1 && ids && mask && out && e->loaded && e->coalesce && encode_coalescable(e, mask, scope)) return coalesced_encode_one(e, ids, mask, out);
     return encode_chunked(e, ids, mask, b, out, false, nullptr, scope);
 }
 int shodh_embedder_encode_ids(shodh_embedder *e, const int32_t *ids, const uint8_t *mask, uint32_t b, float *out) {

@@ -43,7 +43,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MF_WQ_CAP = 128;    // LDS emit-queue entries per WAVE (8 private queues per workgroup)
 constexpr int MF_EQ_CAP = 8 * MF_WQ_CAP;
-constexpr int MF_SLOTS = 4;       // private candidate slots per (query, workgroup); the rest goes to the shared overflow list
+#ifndef SHODH_MF_SLOTS
+#define SHODH_MF_SLOTS 4
+#endif
+constexpr int MF_SLOTS = SHODH_MF_SLOTS;       // private candidate slots per (query, workgroup); the rest goes to the shared overflow list
 constexpr int MF_TR = 64;        // corpus rows per tile
 constexpr int MF_BPAD = 256;     // queries per pass
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)

@@ -468,7 +468,7 @@ int shodh_sharded_index_mark_deleted_batch(shodh_sharded_index *s, const uint32_
 
 int shodh_sharded_index_is_deleted(shodh_sharded_index *s, uint32_t id) {
     if (!s) { set_error("null argument"); return SHODH_ERR_INVALID; }
-    std::unique_lock<std::shared_mutex> lk(s->mu);
+    std::shared_lock<std::shared_mutex> lk(s->mu);       // a reader: it must not stall the searches (which hold the lock shared), nor starve behind them
     if (s->cfg.kind != SHODH_INDEX_FLAT || id >= s->n) return 0;
     return shodh_index_is_deleted(s->sh[shard_of(s, id)].idx, (uint32_t)local_of(s, id));
 }
@@ -490,7 +490,7 @@ int shodh_sharded_index_clear_deleted(shodh_sharded_index *s) {
 // extract_all_vectors: rows [first, first+n) by GLOBAL id, bit-for-bit (retrieval.rs:2504-2516)
 int shodh_sharded_index_extract_rows(shodh_sharded_index *s, uint64_t first, uint64_t n, float *out_rows) {
     if (!s || (!out_rows && n)) { set_error("null argument"); return SHODH_ERR_INVALID; }
-    std::unique_lock<std::shared_mutex> lk(s->mu);
+    std::shared_lock<std::shared_mutex> lk(s->mu);       // a reader (see is_deleted)
     if (s->cfg.kind != SHODH_INDEX_FLAT) { set_error("IVF-PQ keeps codes, not rows"); return SHODH_ERR_STATE; }
     if (first + n > s->n) { set_error("rows [%llu,%llu) out of range (len %llu)", (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)s->n); return SHODH_ERR_INVALID; }
     const uint64_t B = 1ull << s->cfg.block_log2;
