@@ -21,4 +21,21 @@ __device__ __forceinline__ void glds16(const void *gbase, uint32_t voff_bytes, u
                  : "memory");
 }
 
+// the same, device-coherent (sc1: the line is fetched from beyond this XCD's L2): for words other workgroups update while the kernel runs
+__device__ __forceinline__ void glds16_coherent(const void *gbase, uint32_t voff_bytes, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+// ... and 4 bytes per lane to LDS [m0 + lane*4]
+__device__ __forceinline__ void glds4_coherent(const void *gbase, uint32_t voff_bytes, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+
 }  // namespace shodh

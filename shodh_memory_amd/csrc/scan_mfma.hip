@@ -41,7 +41,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_WQ_CAP = 128;    // LDS emit-queue entries per WAVE (8 private queues per workgroup)
+constexpr int MF_WQ_CAP = 120;    // LDS emit-queue entries per WAVE (8 private queues per workgroup); 128 until the dynamic threshold needed 3 KiB of LDS
 constexpr int MF_EQ_CAP = 8 * MF_WQ_CAP;
 #ifndef SHODH_MF_SLOTS
 #define SHODH_MF_SLOTS 4
@@ -49,6 +49,12 @@ constexpr int MF_EQ_CAP = 8 * MF_WQ_CAP;
 constexpr int MF_SLOTS = SHODH_MF_SLOTS;       // private candidate slots per (query, workgroup); the rest goes to the shared overflow list
 constexpr int MF_TR = 64;        // corpus rows per tile
 constexpr int MF_BPAD = 256;     // queries per pass
+#ifndef SHODH_DYN_PERIOD
+#define SHODH_DYN_PERIOD 4
+#endif
+
+constexpr int MF_DYN_NB = 16;    // levels of the threshold that tightens DURING the emit scan (see "dynamic threshold" below)
+constexpr int MF_DYN_REP = 4;    // ... and replicas of every query's level counters (workgroup b adds to replica b % 4; the owner sums them): a query's counters are one hot line otherwise
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
 constexpr float MF_INV_SCALE2 = 1.0f / 65536.0f;   // acc -> score
 
@@ -81,10 +87,29 @@ struct MfmaArgs {
     uint32_t n_sel_tiles;
     uint32_t ablate;          // diagnostics only (SHODH_ABLATE=8: thresholds forced to +inf, nothing is emitted; results invalid)
     uint32_t nq;              // real queries of the call (the last pass may be partly padding)
+    // dynamic threshold (emit scan, dim <= 384; dcnt == nullptr: off). The sampled bound is the k-th best of a 1/S sample: its rank among all rows is ~ S k, so
+    // ~ S k rows per query survive it (1 255 at recall's k = 120 -- and the emit scan's time follows the survivor count: 168 us with none, 203 at 265 per
+    // query, 240 at 1 255). Every survivor is a ROW WITH A KNOWN SCORE, though: once k live rows with approximate score >= E have been seen -- by all
+    // workgroups together -- the k-th best is >= E and the bound may rise to E for the rest of the scan.
+    //   levels: equidistant on the order-key scale, level j <=> key <= K_B - j * step (dpar[slot] = {K_B, floor(2^32 / step)}, K_B = key of the sampled bound);
+    //   dcnt[slot][j-1] = rows seen whose HIGHEST level is j (one device-scope atomic per survivor that reaches a level its query has not passed yet);
+    //   dthr[slot][j-1] = the emit threshold level j allows (same 2 eps margin as the sampled one; +inf = level not offered);
+    //   dpub[slot]      = the published bound of the query: (threshold bits & ~31) | level, 0 = none yet.
+    // Traffic is what this has to avoid (a first form in which every wave polled its 32 queries' counters every tile -- 65 k scattered coherent loads per tile
+    // time over all workgroups -- doubled the kernel's time): query ql of a pass is OWNED by workgroup ql % gridDim.x, whose wave 6 reads that ONE query's 16
+    // counters per tile (one 64-byte line) and publishes the highest level that has reached k; wave 7 of every workgroup reads the 1 KiB of published words
+    // of the pass per tile (8 lines) into LDS, where every wave picks up its queries' bounds. Both loads are issued at the top of a tile and consumed at its
+    // end (waves 6 and 7 issue no DMA). Exactness: a count is only ever a count of distinct live rows that were really seen, so "count >= k" is a fact
+    // whoever reads it and whenever; a late or missed update only leaves the bound lower.
+    uint32_t *dcnt;           // [passes*256][MF_DYN_REP][MF_DYN_NB]
+    const float *dthr;        // [passes*256][MF_DYN_NB] scaled by 2^16 like the accumulators
+    uint32_t *dpub;           // [passes*256]
+    const uint32_t *dpar;     // [passes*256] x {K_B, step}
+    uint32_t k;
 };
 
 template <int KSTEPS>
-__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2; }
+__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 <= 160 * 1024) ? 3 : 2; }
 
 // 8 waves per workgroup (2 per SIMD), wave w owns queries [32w, 32w+32) as resident B fragments (dim/16 x 4 VGPRs).
 // Every wave runs ONE software-pipelined instruction stream per 64-row tile: 2*KSTEPS MFMAs (row block 0 into acc0 for all
@@ -125,6 +150,11 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + NBUF * TILE_BYTES);
     uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
     uint32_t *qcount = eq_q + MF_EQ_CAP;     // [MF_BPAD] entries this workgroup has written per query
+    constexpr bool DYN = MODE == MF_MODE_EMIT && KSTEPS <= 24;      // (dim 512 has no registers to spare: 256 with spills as it is)
+    constexpr uint32_t DYN_P = SHODH_DYN_PERIOD;                    // tiles per round of the dynamic threshold (a power of two)
+    uint32_t *dpar_l = qcount + MF_BPAD;     // [MF_BPAD][2] dynamic threshold: {K_B, step} of every query of the pass (kept for diagnostics; the lanes hold their own)
+    uint32_t *pub_l = dpar_l + 2 * MF_BPAD;  // [MF_BPAD] ... and its published bound (MfmaArgs::dpub), refreshed by wave 7 once per tile (LDS-DMA)
+    uint32_t *own_l = pub_l + MF_BPAD;       // [64] the counters of the queries this workgroup owns, refreshed by wave 6 once per tile (LDS-DMA)
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x;
@@ -143,6 +173,13 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         uint64_t *sl = a.slots + (((size_t)blockIdx.y * MF_BPAD + tid) * gridDim.x + blockIdx.x) * MF_SLOTS;
 #pragma unroll
         for (int j = 0; j < MF_SLOTS; ++j) sl[j] = KEY_NONE;
+    }
+    const bool dyn_on = DYN && a.dcnt != nullptr;        // uniform
+    if (DYN && tid < MF_BPAD) {
+        dpar_l[2 * tid] = dyn_on ? a.dpar[((size_t)pass * MF_BPAD + tid) * 2] : 0u;        // K_B = 0: no key is <= it, nothing is ever counted
+        dpar_l[2 * tid + 1] = dyn_on ? a.dpar[((size_t)pass * MF_BPAD + tid) * 2 + 1] : 0u;
+        pub_l[tid] = 0u;
+        if (tid < 64) own_l[tid] = 0u;
     }
 #ifdef SHODH_PROF
     const long long wc0_ = wall_clock64();
@@ -189,6 +226,16 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     }
     float thr_l = (MODE == MF_MODE_EMIT) ? a.thr[(size_t)pass * MF_BPAD + q_local] * (MF_SCALE * MF_SCALE) : 0.0f;
     if (a.ablate & 8u) thr_l = __builtin_inff();   // diagnostics: nothing is emitted
+    // dynamic threshold, the owner's side (wave 6): lane group g = lane / 16 looks after owned query blockIdx.x + g * gridDim.x, lane j = lane % 16 after its
+    // level j + 1: that level's threshold (read once) and, per tile, its counter. The readers' side (wave 7): four published words per lane.
+    const uint32_t own_q = blockIdx.x;                                                     // query of the pass this workgroup owns (queries >= gridDim.x have no owner: small corpora)
+    const bool own_ok = dyn_on && own_q < (uint32_t)MF_BPAD;
+    const uint32_t own_off = (uint32_t)((((size_t)pass * MF_BPAD + (own_ok ? own_q : 0u)) * MF_DYN_REP * MF_DYN_NB + lane) * 4);      // lane = replica * 16 + (level - 1)
+    float own_thr = __builtin_inff();
+    if (own_ok) own_thr = a.dthr[((size_t)pass * MF_BPAD + own_q) * MF_DYN_NB + (lane & 15)];
+    const unsigned char *dcnt_base = uniform_ptr(reinterpret_cast<const unsigned char *>(a.dcnt));
+    const unsigned char *dpub_base = uniform_ptr(reinterpret_cast<const unsigned char *>(a.dpub + (size_t)pass * MF_BPAD));
+    const uint32_t own_lds = smem_lds + (uint32_t)((unsigned char *)own_l - smem), pub_lds = smem_lds + (uint32_t)((unsigned char *)pub_l - smem);
 
     // LDS byte offsets of this lane's A fragments. chunk c = 2*ks + hi; swizzled chunk = c ^ (row&15)
     // = (c & ~15) | ((c & 15) ^ sw): only 8 distinct low parts per lane, the rest is an immediate.
@@ -212,9 +259,28 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint64_t key = wq_key[i];
-            const uint32_t row = (uint32_t)key;
-            if (a.deleted && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) continue;   // tombstoned (vamana.rs:1175-1177)
+            const uint32_t row = (uint32_t)key, k32 = (uint32_t)(key >> 32);
+            // tombstoned (vamana.rs:1175-1177). A tombstoned row is all zeros in the shadow copy, so its score is exactly +0: only a survivor whose score is
+            // not positive (key >= order_key(-0.0)) can be one, and only for it is the bit fetched (a load the wave would have to wait for on every drain)
+            if (a.deleted && k32 >= 0x7FFFFFFFu && ((a.deleted[row >> 5] >> (row & 31)) & 1u)) continue;
             const uint32_t ql = wq_q[i];
+            if (DYN && dyn_on) {
+                // dynamic threshold: a survivor that reaches a level its query has not passed yet is counted, ONCE, in the counter of the highest level it
+                // reaches (the counters are a histogram, the owner sums it from the top). Here and not where the survivor is found: a memory instruction
+                // issued from the scan loop stalls its wave for ~150 cycles behind the corpus DMA, and at the tile barrier all eight waves pay for it --
+                // counting each survivor as it was found cost more than the survivors it saved. One atomic INSTRUCTION per drain covers up to 64 entries.
+                const uint32_t kb = dpar_l[2 * ql];
+                if (k32 <= kb) {
+                    // levels this score reaches: (K_B - k32) / step through the multiplier floor(2^32 / step) -- the quotient may come out one short (a row
+                    // a hair above an edge counts one level lower: short is safe), never long
+                    const uint32_t lvl = pub_l[ql] & 31u;
+                    uint32_t j = __umulhi(kb - k32, dpar_l[2 * ql + 1]);
+                    if (j > (uint32_t)MF_DYN_NB) j = MF_DYN_NB;
+                    if (j > lvl)
+                        __hip_atomic_fetch_add(a.dcnt + (((size_t)pass * MF_BPAD + ql) * MF_DYN_REP + (blockIdx.x & (MF_DYN_REP - 1))) * MF_DYN_NB + (j - 1u), 1u,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             const uint32_t s_ = atomicAdd(qcount + ql, 1u);
             if (s_ < (uint32_t)MF_SLOTS) {
                 my_slots[(size_t)ql * gridDim.x * MF_SLOTS + s_] = key;
@@ -254,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (__builtin_expect(b != 0, 0)) {
                 const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
                 if (hit && slot < (uint32_t)MF_WQ_CAP) {
-                    wq_key[slot] = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    const uint64_t key_ = make_key(-(c[r] * MF_INV_SCALE2), (uint32_t)(brow0 + 4 * hi + roff));
+                    wq_key[slot] = key_;
                     wq_q[slot] = q_local;
                 }
                 wq_n = __builtin_amdgcn_readfirstlane(wq_n + (uint32_t)__builtin_popcountll(b));
@@ -290,14 +357,28 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #ifdef SHODH_PROF
     const long long wc1_ = wall_clock64();
 #endif
-    for (; sel < a.n_sel_tiles; sel += step) {
+    uint32_t tile_no = 0;                   // tiles this workgroup has done (uniform)
+    for (; sel < a.n_sel_tiles; sel += step, ++tile_no) {
         const unsigned char *buf = smem + cur * TILE_BYTES;
         const uint32_t pfb = cur + PF >= NBUF ? cur + PF - NBUF : cur + PF;      // buffer the DMA fills during this tile
         const uint32_t psel = sel + PF * step < a.n_sel_tiles ? sel + PF * step : sel;
         const unsigned char *psrc = uniform_ptr(rows_b + (size_t)psel * tile_bytes_g);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * TILE_BYTES));
 
+      if (DYN && dyn_on) {
+        // dynamic threshold: the owner's counters (wave 6) and the published bounds of the pass (wave 7) by device-coherent LDS-DMA -- no destination
+        // registers for the compiler to move around while the data is in flight -- issued now, waited for at the end of the tile (neither wave issues the
+        // corpus DMA: a plain vmcnt(0) there waits for nothing else)
+        // Once per DYN_P tiles each (the counters only move when the queues are drained, every DYN_P tiles too; a memory instruction issued from this loop
+        // stalls its wave for a few hundred cycles): drain at the end of phase DYN_P - 1, owner's look at phase 1, readers' at phase 2.
+        if (wave == 6) { if ((tile_no & (DYN_P - 1u)) == (1u & (DYN_P - 1u))) glds4_coherent(dcnt_base, own_off, own_lds); }
+        else if (wave == 7) { if ((tile_no & (DYN_P - 1u)) == (2u & (DYN_P - 1u))) glds16_coherent(dpub_base, (uint32_t)lane * 16u, pub_lds); }
+      }
       if (active) {
+        if (DYN && dyn_on) {       // this query's published bound, if any (pub_l: landed during the previous tile, before its barrier)
+            const uint32_t w_ = pub_l[q_local];
+            if (w_) thr_l = fmaxf(thr_l, __uint_as_float(w_ & ~31u));
+        }
         half8 ring[RING];
         auto rd = [&](int st) {
             const int rb = st / KSTEPS, ks = st % KSTEPS;
@@ -352,12 +433,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         if (MODE == MF_MODE_EMIT) {
             have_prev = true;
             prev_sel = sel;
-            // drain early when the queue is half full (wave-local; the stores and atomics share the VM counter with
-            // the DMA and may complete out of order with it, so everything is drained before the counted wait below)
-            if (wq_n >= (uint32_t)MF_WQ_CAP / 2) {
-                drain();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // (the queue is drained below, after the dynamic threshold's loads have been waited for)
         } else {
             // sample pass: the maximum score of this query over the whole 64-row tile
             const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
@@ -383,6 +459,41 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         }
         if (MODE != MF_MODE_EMIT && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;   // padding queries: defined values
       }
+        if (DYN && dyn_on && wave >= 6) {
+            // (before the drain below: the look issued at the top of this tile is then the only memory operation of this wave in flight, and long landed)
+            if (wave == 6 && (tile_no & (DYN_P - 1u)) == (1u & (DYN_P - 1u))) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the highest offered level of each owned query whose counter has reached k is published (one owner per query: a plain store)
+                // rows at or above level (lane % 16) + 1 = the histogram summed from the top of this lane's 16-lane row (row_shl: lane i reads lane i + n, 0 past the row)
+                uint32_t cum = own_l[lane];
+                cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x101, 0xF, 0xF, true);
+                cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x102, 0xF, 0xF, true);
+                cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x104, 0xF, 0xF, true);
+                cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x108, 0xF, 0xF, true);
+                cum += __shfl_xor(cum, 16);                    // ... over the four replicas (rows of the wave)
+                cum += __shfl_xor(cum, 32);
+                bool reached = own_ok && cum >= a.k && own_thr < 3.0e38f;
+#ifdef SHODH_DIAG
+                if (a.ablate & 16u) reached = false;      // diagnostics: everything of the mechanism runs, nothing is published (its cost at the static survivor count)
+#endif
+                const uint64_t m_ = __builtin_amdgcn_ballot_w64(reached);
+                const uint32_t grp = (uint32_t)(m_ >> (lane & 48)) & 0xFFFFu;
+                if (reached && lane < 16 && (grp >> (lane & 15)) == 1u) {
+                    const uint32_t word = (__float_as_uint(own_thr) & ~31u) | ((uint32_t)(lane & 15) + 1u);
+                    if (word > pub_l[own_q])        // (what wave 7 read a tile ago: not published yet, or not seen yet)
+                        __hip_atomic_store(a.dpub + (size_t)pass * MF_BPAD + own_q, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (wave == 7 && (tile_no & (DYN_P - 1u)) == (2u & (DYN_P - 1u))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the words are in pub_l once it returns)
+        }
+        if (MODE == MF_MODE_EMIT && active) {
+            // drain early when the queue is half full; with the dynamic threshold also at the end of every DYN_P-th tile whatever the fill, all waves on
+            // the same tile, so that the counts the bound rises on are fresh. No vmcnt(0) after it (there was one until the drains became periodic: it
+            // waited out the DMA two tiles ahead, ~1 us fifteen times per launch). The counted wait below stays SAFE with stores and atomics in flight:
+            // loads return in order, so if a piece of the NEXT tile were still outstanding, all NPC younger pieces would be too and the count could not
+            // be down to NPC; stores that are still outstanding only make the wait stricter.
+            if (wq_n >= (uint32_t)MF_WQ_CAP / 2 || (DYN && dyn_on && wq_n && (tile_no & (DYN_P - 1u)) == DYN_P - 1u)) drain();
+        }
         // hand-over: the tile after this one must have landed (the DMA issued during this tile may stay in flight
         // when there are three buffers); all LDS traffic of this wave done; then the workgroup barrier
         PROF_T(4)
@@ -977,6 +1088,12 @@ struct ThrArgs {
     float eps2_rel_maxnorm;  // level-2 (f32 FMA re-score) bound: eps2 = eps2_rel_maxnorm * |q| + eps2_abs_a * (|q| + maxnorm) + 1e-9
     float eps2_abs_a;
     float *eps2;             // [n_slots]
+    // dynamic threshold of the emit scan (MfmaArgs::dyn; nullptr = off): the level table of every query is laid out here
+    uint32_t *dcnt;          // [n_slots][MF_DYN_NB] counters, zeroed here
+    float *dthr;             // [n_slots][MF_DYN_NB] scaled emit threshold of each level (+inf: not offered)
+    uint32_t *dpub;          // [n_slots] published bounds, zeroed here
+    uint32_t *dpar;          // [n_slots] x {K_B, step}
+    uint32_t r_top;          // the sample rank at which the FINAL k-th best is expected (k x sampled fraction): the levels span [k-th, r_top-th] sampled maximum
 };
 constexpr int THR_STAGE = 4096;
 __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
@@ -990,6 +1107,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     if (tid == 0) a.eps2[slot] = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f;
     if (slot >= a.nq || a.fallback[slot]) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
+        if (a.dcnt && tid < MF_DYN_REP * MF_DYN_NB) a.dcnt[(size_t)slot * MF_DYN_REP * MF_DYN_NB + tid] = 0u;
+        if (a.dcnt && tid < MF_DYN_NB) a.dthr[(size_t)slot * MF_DYN_NB + tid] = __builtin_inff();
+        if (a.dcnt && tid == 0) { a.dpar[2 * slot] = 0u; a.dpar[2 * slot + 1] = 0u; a.dpub[slot] = 0u; }
         return;
     }
     // k-th LARGEST tile maximum == k-th smallest order_key(-max). The maxima of one query are 1 KiB apart in memory and
@@ -1007,15 +1127,64 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     auto key_at = [&](uint32_t j) -> uint32_t { return j < n_st ? staged[j] : key_glb(j); };
     bool ovf = false;
     const uint32_t kk = a.k ? block_kth_u32<256>(key_at, a.J, a.k, scratch, &ovf) : 0xFFFFFFFFu;
+    // dynamic threshold: where the levels end. The FINAL k-th best has rank ~ k among all rows = rank ~ k / S among the sampled maxima: the r_top-th
+    // largest of them (a second, much smaller selection) is where the bound is expected to end up, so the MF_DYN_NB levels are spread from the
+    // k-th maximum (level 0 = the sampled bound) to a little beyond the r_top-th.
+    // (Not a second selection -- that cost 5.6 us per step: the first one left the minima of k groups of the keys in scratch[0 .. k) when it filtered
+    // (k <= 128 and J >= 4 k, topk.h); their r_top-th smallest is the r_top-th smallest key unless two of the best r_top share a group, and then a little
+    // on the low side: good enough to place levels. Otherwise: the best sampled maximum.)
+    __shared__ uint32_t s_ktop;
+    if (tid == 0) s_ktop = 0xFFFFFFFFu;
+    __syncthreads();
+    if (a.dcnt && a.k && a.r_top && a.r_top < a.k) {
+        if (a.k <= 128u && a.J >= 4u * a.k) {
+            if ((uint32_t)tid < a.k) {
+                const uint32_t v = scratch[tid];
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < a.k; ++j) { const uint32_t w = scratch[j]; r += (w < v) || (w == v && j < (uint32_t)tid); }
+                if (r == a.r_top - 1u) s_ktop = v;
+            }
+        } else {
+            uint32_t m = 0xFFFFFFFFu;
+            for (uint32_t j = tid; j < a.J; j += 256) { const uint32_t v = key_at(j); m = v < m ? v : m; }
+            atomicMin(&s_ktop, m);
+        }
+    }
+    __syncthreads();
+    const uint32_t ktop = s_ktop;
     if (tid == 0) {
         float t = -__builtin_inff();
+        bool dyn_ok = false;
         if (kk != 0xFFFFFFFFu) {
             const float kth = -order_key_inv(kk);
             // a positive k-th tile max is backed by k LIVE rows (tombstoned rows score exactly 0)
-            if (kth > 0.0f) t = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth));
+            if (kth > 0.0f) { t = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth)); dyn_ok = true; }
         }
         a.thr[slot] = t;   // -inf => emit everything => list overflow => exact fallback
         a.eps[slot] = eps;
+        if (a.dcnt) {
+            // level j <=> order key <= K_B - j * step <=> score >= E_j = -order_key_inv(K_B - j * step); E_0 = the sampled k-th maximum
+            uint32_t kb = 0u, step = 1u;
+            if (dyn_ok && ktop != 0xFFFFFFFFu && ktop <= kk) {
+                kb = kk;
+                uint32_t span = kk - ktop;
+                if (span < 1024u) span = 1024u;
+                step = (uint32_t)(((uint64_t)span + (span >> 3) + MF_DYN_NB - 1) / MF_DYN_NB);      // the levels end 1/8 beyond the expected final bound
+            }
+            a.dpar[2 * slot] = kb; a.dpar[2 * slot + 1] = (uint32_t)(0xFFFFFFFFull / step); a.dpub[slot] = 0u;      // (floor((2^32 - 1) / step) <= floor(2^32 / step): never long)
+            for (uint32_t j = 1; j <= (uint32_t)MF_DYN_NB; ++j) {
+                float tj = __builtin_inff();
+                const uint64_t drop = (uint64_t)j * step;
+                // (keys of positive scores are > 0x3F800000-ish: a level whose edge would leave the range of scores <= 2.0 is never offered)
+                if (kb && drop < (uint64_t)kb && (kb - (uint32_t)drop) > 0x3F000000u) {
+                    const float ej = -order_key_inv(kb - (uint32_t)drop);
+                    if (ej > 0.0f && ej < 4.0f) tj = (ej - (2.001f * eps + 1e-7f * __builtin_fabsf(ej))) * (MF_SCALE * MF_SCALE);
+                    if (!(tj > 0.0f)) tj = __builtin_inff();      // (the published word orders like the float only for positive thresholds)
+                }
+                for (int rp = 0; rp < MF_DYN_REP; ++rp) a.dcnt[((size_t)slot * MF_DYN_REP + rp) * MF_DYN_NB + (j - 1)] = 0u;
+                a.dthr[(size_t)slot * MF_DYN_NB + (j - 1)] = tj;
+            }
+        }
     }
 }
 
@@ -1478,8 +1647,11 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     // re-score, so S shrinks with k: 16 up to k = 40 (k = 10: S = 8/16/32 measured 277/271/272 us per step; k = 40: 8/12/16
     // all 302), 16*sqrt(40/k) above (k = 120: S = 4/6/8/10/12/16 measured 375/364/354/350/356/400 us). SHODH_SAMPLE_STRIDE
     // overrides.
+    // Round 6: with the bound that tightens during the emit scan (MfmaArgs::dcnt: dim <= 384) the sample only has to START the bound, and for k <= 40 every
+    // 32nd tile does (k = 10, stride 16 / 24 / 32 / 48 / 64: 264.7 / 261.6 / 260.6 / 260.5 / 261.3 us per step; k = 120 keeps its 9: 345 against 352 at 24).
     static const uint32_t stride_env = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 0u;
-    uint32_t sample_stride = 16;
+    static const bool dyn_env = !(getenv("SHODH_DYN_THR") && atoi(getenv("SHODH_DYN_THR")) == 0);
+    uint32_t sample_stride = (dyn_env && dim <= 384) ? 32 : 16;
     if (k > 40) {
         sample_stride = (uint32_t)(16.0 * __builtin_sqrt(40.0 / (double)k) + 0.5);
         if (sample_stride < 2) sample_stride = 2;
@@ -1515,6 +1687,7 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
 struct MfmaWorkspace {
     _Float16 *q_h; float *qnorm; float *thr; float *eps; uint32_t *cand_cnt; uint32_t *fallback; uint32_t *fb_list;
     uint32_t *fb_count; uint32_t *stats; float *blockmax; uint64_t *cand; uint64_t *slots; float *eps2;
+    uint32_t *dcnt; float *dthr; uint32_t *dpub; uint32_t *dpar;
     uint32_t *stats_mirror = nullptr;
 };
 
@@ -1534,6 +1707,10 @@ size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs /*[MFM
     offs[10] = take((size_t)p.n_slots * p.cand_cap * 8);   // cand (shared overflow lists)
     offs[11] = take((size_t)p.n_slots * p.grid_x * MF_SLOTS * 8);   // slots (private per query and workgroup)
     offs[12] = take((size_t)p.n_slots * 4);              // eps2
+    // dynamic threshold: counters and thresholds of the levels, then {K_B, step} and the published bound per query (one block: offs[] has 16 entries)
+    offs[13] = take((size_t)p.n_slots * MF_DYN_NB * 4 * (MF_DYN_REP + 1));
+    offs[14] = take((size_t)p.n_slots * 12);
+    offs[15] = o;
     return o;
 }
 
@@ -1580,8 +1757,8 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
         SHODH_HIP_TRY(hipGetLastError());
         return SHODH_OK;
     }
-    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
-    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
+    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 <= 160 * 1024) ? 3 : 2;      // == mfma_scan_nbuf<KSTEPS>()
+    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
     if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
@@ -1910,6 +2087,8 @@ static void unpack_workspace(MfmaWorkspace &w, unsigned char *ws_base, const siz
     w.fb_list = (uint32_t *)(ws_base + offs[6]); w.fb_count = (uint32_t *)(ws_base + offs[7]); w.stats = (uint32_t *)(ws_base + offs[8]);
     w.blockmax = (float *)(ws_base + offs[9]); w.cand = (uint64_t *)(ws_base + offs[10]); w.slots = (uint64_t *)(ws_base + offs[11]);
     w.eps2 = (float *)(ws_base + offs[12]);
+    w.dcnt = (uint32_t *)(ws_base + offs[13]); w.dthr = (float *)(w.dcnt + (offs[14] - offs[13]) / 4 / (MF_DYN_REP + 1) * MF_DYN_REP);      // n_slots * REP * NB counters, then n_slots * NB thresholds
+    w.dpar = (uint32_t *)(ws_base + offs[14]); w.dpub = w.dpar + (offs[15] - offs[14]) / 12 * 2;
 }
 
 // eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
@@ -2024,13 +2203,18 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 #else
     const uint32_t ablate = 0u;
 #endif
-    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u, nq};
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, deleted, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, p.tile_stride, p.n_sel_tiles, 0u, nq, nullptr, nullptr, nullptr, nullptr, k};
+    // the threshold that tightens during the emit scan (MfmaArgs::dyn): dim <= 384 (the 512-d kernel has no registers left), SHODH_DYN_THR=0 turns it off
+    static const bool dyn_env = !(getenv("SHODH_DYN_THR") && atoi(getenv("SHODH_DYN_THR")) == 0);
+    const bool dyn = dyn_env && dim <= 384 && k >= 1;
     SHODH_TRY(launch_scan<MF_MODE_BLOCKMAX>(a, p, p.n_sel_tiles, st));
 
     const EpsCoef c = eps_coefficients(dim, order);
     const float eps_rel = c.rel, eps_abs_a = c.abs_a, eps2_rel = c.rel2, eps2_abs_a = c.abs2_a;
+    uint32_t r_top = p.tile_stride ? k / p.tile_stride : 0u;
+    if (r_top < 1) r_top = 1;
     ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps,
-              eps2_rel * maxnorm, eps2_abs_a, w.eps2};
+              eps2_rel * maxnorm, eps2_abs_a, w.eps2, dyn ? w.dcnt : nullptr, w.dthr, w.dpub, w.dpar, r_top};
     const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
     (void)tlds;
     hipLaunchKernelGGL(threshold_kernel, dim3(p.n_slots), dim3(256), 0, st, t);
@@ -2039,6 +2223,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     a.tile_stride = 1;
     a.n_sel_tiles = (uint32_t)p.n_tiles;
     a.ablate = ablate;
+    if (dyn) { a.dcnt = w.dcnt; a.dthr = w.dthr; a.dpub = w.dpub; a.dpar = w.dpar; }
     SHODH_TRY(launch_scan<MF_MODE_EMIT>(a, p, (uint32_t)p.n_tiles, st, ev_emit0, ev_emit1));
     if (ev_scan_done) SHODH_HIP_TRY(hipEventRecord(ev_scan_done, st));
 
