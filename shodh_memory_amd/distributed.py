@@ -29,7 +29,7 @@ def shard_range(n_total, world, rank):
 
 
 def merge_gathered_numpy(ids_all, dist_all, k):
-    """CPU mirror of shodh_topk_merge_device for the gloo tests: ids_all/dist_all [world, nq, k]."""
+    """CPU form of shodh_topk_merge_device (ShardedFlatIndex.merge_cpu): ids_all/dist_all [world, nq, k]."""
     world, nq, kk = ids_all.shape
     out_i = np.full((nq, k), 0xFFFFFFFF, np.uint32)
     out_d = np.full((nq, k), np.inf, np.float32)
@@ -51,28 +51,58 @@ def merge_gathered_numpy(ids_all, dist_all, k):
 
 
 class ShardedFlatIndex:
-    """One shard of a row-sharded flat index + the collective search."""
+    """One shard of a row-sharded flat index + the collective search.
 
-    def __init__(self, dim=384, n_total=0, order=L.ORDER_SCALAR4, scan_mode=L.SCAN_AUTO, device=None, group=None):
+    `index_factory(dim, order, scan_mode, device, reserve_rows, id_base)` builds the per-shard index (default: the library's VamanaIndex on this rank's
+    GPU) and `merge(pack_all, world, nq, k, out_ids, out_dist, out_counts)` folds the gathered blocks (default: shodh_topk_merge_strided_device). The
+    world-size 2 / 3 / 8 `gloo` tests (tests/test_distributed_cpu.py) inject a CPU per-shard search and the CPU merge below and run THIS class -- its
+    shard ranges, its buffers, its one all-gather per search and its merge call -- so that the first run on eight GPUs needs no code that has not run."""
+
+    def __init__(self, dim=384, n_total=0, order=L.ORDER_SCALAR4, scan_mode=L.SCAN_AUTO, device=None, group=None, index_factory=None, merge=None):
         import torch
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.device = torch.cuda.current_device() if device is None else device
+        if device is None and index_factory is None:
+            device = torch.cuda.current_device()
+        self.device = device
         self.lo, self.hi = shard_range(n_total, self.world, self.rank)
-        self.index = VamanaIndex(VamanaConfig(dimension=dim, order=order, scan_mode=scan_mode, device=self.device,
-                                              reserve_rows=max(self.hi - self.lo, 1), id_base=self.lo))
+        if index_factory is None:
+            index_factory = lambda **kw: VamanaIndex(VamanaConfig(dimension=kw["dim"], order=kw["order"], scan_mode=kw["scan_mode"], device=kw["device"],     # noqa: E731
+                                                                  reserve_rows=kw["reserve_rows"], id_base=kw["id_base"]))
+        # an empty shard (more ranks than rows, or a short tail) still takes part in every collective: it answers with empty lists
+        self.index = index_factory(dim=dim, order=order, scan_mode=scan_mode, device=self.device, reserve_rows=max(self.hi - self.lo, 1), id_base=self.lo)
+        self._merge = merge or self._merge_device
         self._bufs = {}
 
     def build_local(self, rows):
         """rows: this rank's [hi-lo, dim] slice (numpy or torch CUDA tensor)."""
         assert rows.shape[0] == self.hi - self.lo
-        self.index.build(rows)
+        if self.hi > self.lo:
+            self.index.build(rows)
+
+    @staticmethod
+    def _merge_device(pack_all, world, nq, k, out_ids, out_dist, out_counts):
+        import torch
+        st = torch.cuda.current_stream(pack_all.device).cuda_stream
+        base = pack_all.data_ptr()
+        L.check(L.lib().shodh_topk_merge_strided_device(base, base + nq * k * 4, 2 * nq * k, world, nq, k,
+                                                        out_ids.data_ptr(), out_dist.data_ptr(), out_counts.data_ptr(), C.c_void_p(st)))
+
+    @staticmethod
+    def merge_cpu(pack_all, world, nq, k, out_ids, out_dist, out_counts):
+        """the same fold on CPU tensors (merge_gathered_numpy): what the gloo tests inject"""
+        import torch
+        g = pack_all.numpy()
+        m_ids, m_dd, counts = merge_gathered_numpy(np.ascontiguousarray(g[:, 0]).view(np.uint32), np.ascontiguousarray(g[:, 1]).view(np.float32), k)
+        out_ids.copy_(torch.from_numpy(m_ids.view(np.int32)))
+        out_dist.copy_(torch.from_numpy(m_dd))
+        out_counts.copy_(torch.from_numpy(counts.view(np.int32)))
 
     def search_batch_device(self, queries, k):
-        """queries: torch CUDA [nq, dim], identical on every rank. Returns merged (ids, dist, counts)."""
+        """queries: torch tensor [nq, dim] (CUDA in production), identical on every rank. Returns merged (ids, dist, counts)."""
         import torch
         nq = queries.shape[0]
         key = (nq, k)
@@ -87,17 +117,86 @@ class ShardedFlatIndex:
                 out_ids=torch.empty((nq, k), dtype=torch.int32, device=dev), out_dist=torch.empty((nq, k), dtype=torch.float32, device=dev),
                 out_counts=torch.empty((nq,), dtype=torch.int32, device=dev))
         b = self._bufs[key]
-        self.index.search_batch_device(queries, k, out=(b["ids"], b["dist"], b["counts"]))
+        if self.hi > self.lo:
+            self.index.search_batch_device(queries, k, out=(b["ids"], b["dist"], b["counts"]))
+        else:           # an empty shard: the "no entry" markers the merge skips (ids 0xFFFFFFFF, distance +inf)
+            b["ids"].fill_(-1)
+            b["dist"].fill_(float("inf"))
+            b["counts"].zero_()
         if self.world == 1:
             return b["ids"], b["dist"], b["counts"]
         # concatenation form [world*2*nq, k] (accepted by both RCCL and gloo); same memory as [world, 2, nq, k]
         self.dist.all_gather_into_tensor(b["pack_all"].view(self.world * 2 * nq, k), b["pack"].view(2 * nq, k), group=self.group)
-        st = torch.cuda.current_stream(queries.device).cuda_stream
-        base = b["pack_all"].data_ptr()
-        L.check(L.lib().shodh_topk_merge_strided_device(base, base + nq * k * 4, 2 * nq * k, self.world, nq, k,
-                                                        b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_counts"].data_ptr(),
-                                                        C.c_void_p(st)))
+        self._merge(b["pack_all"], self.world, nq, k, b["out_ids"], b["out_dist"], b["out_counts"])
         return b["out_ids"], b["out_dist"], b["out_counts"]
+
+
+class ShardedEmbedder:
+    """Data-parallel encoder over several handles ("Encoder: pure data-parallel over texts, no collective"): one MiniLMEmbedder per device
+    (or several on one device: the single-GPU stand-in of the tests), texts dealt to the handles in contiguous, near-equal shares, every share encoded on
+    its own host thread, vectors returned in input order.
+
+    Only the calls whose result does not depend on batch mates are offered: `encode_each` / `encode_ids(scope=PER_TEXT)` (N x encode(): what `remember`
+    and `recall` compute, minilm.rs:883-982) and, for fp32 / bf16 handles, `encode_batch` (texts never interact there). An INT8 `encode_batch` under
+    SHODH_QUANT_SCOPE_BATCH is ONE function of the whole batch (the activation ranges span it, minilm.rs:588-593): it is not split, it runs on handle 0."""
+
+    def __init__(self, embedders):
+        assert embedders, "at least one handle"
+        self.embedders = list(embedders)
+
+    def dimension(self):
+        return self.embedders[0].dimension()
+
+    def close(self):
+        for e in self.embedders:
+            e.close()
+
+    def _shares(self, n):
+        g = min(len(self.embedders), max(n, 1))
+        per = (n + g - 1) // g
+        return [(i * per, min((i + 1) * per, n)) for i in range(g) if i * per < n]
+
+    def _run(self, n, call):
+        """call(handle, lo, hi) -> array [hi-lo, dim]; shares run concurrently (the library calls release the GIL), results in input order"""
+        import threading
+        shares = self._shares(n)
+        out, err = [None] * len(shares), [None] * len(shares)
+
+        def work(i, lo, hi):
+            try:
+                out[i] = call(self.embedders[i], lo, hi)
+            except Exception as ex:      # noqa: BLE001
+                err[i] = ex
+        th = [threading.Thread(target=work, args=(i, lo, hi)) for i, (lo, hi) in enumerate(shares[1:], 1)]
+        for t in th:
+            t.start()
+        if shares:
+            work(0, *shares[0])
+        for t in th:
+            t.join()
+        for ex in err:
+            if ex is not None:
+                raise ex
+        return out
+
+    def encode_ids(self, ids, mask, scope=L.QUANT_SCOPE_PER_TEXT):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, self.embedders[0].max_length)
+        mask = np.ascontiguousarray(mask, np.uint8).reshape(ids.shape)
+        if scope != L.QUANT_SCOPE_PER_TEXT and any(getattr(e, "_cfg", None) is not None and e._cfg.dtype == L.DTYPE_INT8 for e in self.embedders):
+            return self.embedders[0].encode_ids(ids, mask, scope=scope)          # one function of the whole batch: not split
+        parts = self._run(ids.shape[0], lambda e, lo, hi: e.encode_ids(ids[lo:hi], mask[lo:hi], scope=scope))
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0, self.dimension()), np.float32)
+
+    def encode_each(self, texts):
+        texts = list(texts)
+        parts = self._run(len(texts), lambda e, lo, hi: np.asarray(e.encode_each(texts[lo:hi]), np.float32).reshape(hi - lo, -1))
+        return [row for p in parts for row in p]
+
+    def encode(self, text):
+        return self.embedders[0].encode(text)
+
+    def encode_query(self, text):
+        return self.embedders[0].encode_query(text)
 
 
 class MultiGpuIndex:

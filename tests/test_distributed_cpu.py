@@ -1,7 +1,8 @@
-"""world_size-2 `gloo` test of the row-sharded search (shodh_memory_amd/distributed.py) on CPU: shard
-ranges, the all-gather of per-shard (ids, dist) blocks and the (dist total_cmp, id) merge. The per-shard
-search is played by the oracle here (no GPU in this container); the collective and the merge are the code
-under test, and the merged result must equal a single-index search over the whole corpus."""
+"""`gloo` tests of the row-sharded search on CPU, world sizes 2, 3 and 8 (the target): the REAL `ShardedFlatIndex` object (shodh_memory_amd/distributed.py)
+-- its shard ranges, buffers, the one all-gather per search and the merge call -- with the per-shard search injected: a CPU stand-in that answers with the
+oracle's exact lists (no GPU in this container; on the GPU box the per-shard search is the library's VamanaIndex and the merge the device kernel, both
+covered by the GPU suite). Short and EMPTY last shards, duplicate rows straddling every shard boundary, k larger than a shard: the merged result must
+equal a single exact search over the whole corpus, ids and distance bytes."""
 import os
 import sys
 
@@ -18,34 +19,56 @@ def _free_port():
         return so.getsockname()[1]
 
 
-def _worker(rank, world, port, tmpdir):
+class CpuShard:
+    """the VamanaIndex surface ShardedFlatIndex uses (build, search_batch_device with out=), answered by the oracle; ids = id_base + local row"""
+
+    def __init__(self, O, id_base):
+        self.O, self.id_base, self.rows = O, id_base, None
+
+    def build(self, rows):
+        self.rows = np.ascontiguousarray(rows, np.float32)
+
+    def search_batch_device(self, queries, k, out):
+        import torch
+        q = queries.numpy()
+        ids, dd = self.O.brute_force_batch(self.rows, q, k)                 # [nq, k]; a shard shorter than k fills min(k, rows) entries
+        m = min(k, self.rows.shape[0])
+        valid = np.zeros(ids.shape, bool)
+        valid[:, :m] = True
+        ids = np.where(valid, ids + np.uint32(self.id_base), np.uint32(0xFFFFFFFF)).astype(np.uint32)     # "no entry" as the library marks it
+        dd = np.where(valid, dd, np.float32(np.inf)).astype(np.float32)
+        out[0].copy_(torch.from_numpy(ids.view(np.int32).copy()))
+        out[1].copy_(torch.from_numpy(dd.copy()))
+        out[2].copy_(torch.from_numpy(valid.sum(axis=1).astype(np.int32)))
+        return out
+
+
+def _worker(rank, world, port, tmpdir, n, k):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
-    from shodh_memory_amd.distributed import merge_gathered_numpy, shard_range
+    from shodh_memory_amd.distributed import ShardedFlatIndex, shard_range
     from tests import synth
-    n, nq, k = 5003, 9, 10
+    nq = 9
     q = synth.queries(nq)
     rows = synth.corpus(n, queries=q)
-    rows[4000:4003] = rows[10]            # duplicates straddling the shard boundary: id tie-break must survive the merge
-    lo, hi = shard_range(n, world, rank)
-    ids, dd = O.brute_force_batch(rows[lo:hi], q, k)                     # this rank's shard, local ids
-    ids = (ids + np.uint32(lo)).astype(np.uint32)                         # id_base
-    # one packed [ids | dist] block per rank and ONE all-gather, the call shape of ShardedFlatIndex.search_batch_device
-    pack = torch.empty((2, nq, k), dtype=torch.int32)
-    pack[0] = torch.from_numpy(ids.view(np.int32).copy())
-    pack[1] = torch.from_numpy(dd.view(np.int32).copy())
-    pack_all = torch.empty((world, 2, nq, k), dtype=torch.int32)
-    dist.all_gather_into_tensor(pack_all.view(world * 2 * nq, k), pack.view(2 * nq, k))
-    g = pack_all.numpy()
-    all_ids = np.ascontiguousarray(g[:, 0]).view(np.uint32)
-    all_dd = np.ascontiguousarray(g[:, 1]).view(np.float32)
-    m_ids, m_dd, counts = merge_gathered_numpy(all_ids, all_dd, k)
-    e_ids, e_dd = O.brute_force_batch(rows, q, k)
-    ok = bool(np.array_equal(m_ids, e_ids) and m_dd.tobytes() == e_dd.tobytes() and (counts == k).all())
+    for r in range(1, world):                 # duplicate rows straddling EVERY shard boundary: the id tie-break must survive the merge
+        b = shard_range(n, world, r)[0]
+        if 1 <= b < n - 1:
+            rows[b - 1] = rows[0]; rows[b] = rows[0]; rows[b + 1] = rows[0]
+    sh = ShardedFlatIndex(dim=384, n_total=n, index_factory=lambda **kw: CpuShard(O, kw["id_base"]), merge=ShardedFlatIndex.merge_cpu)
+    assert (sh.lo, sh.hi) == shard_range(n, world, rank) and sh.world == world and sh.rank == rank
+    sh.build_local(rows[sh.lo:sh.hi])
+    tq = torch.from_numpy(q)
+    ok = True
+    for it in range(2):                       # (twice: the second search reuses the object's buffers)
+        m_ids, m_dd, m_cnt = sh.search_batch_device(tq, k)
+        e_ids, e_dd = O.brute_force_batch(rows, q, k)
+        want = min(k, n)
+        ok = ok and bool(np.array_equal(m_ids.numpy().view(np.uint32), e_ids) and m_dd.numpy().tobytes() == e_dd.tobytes() and (m_cnt.numpy() == want).all())
     open(os.path.join(tmpdir, "ok%d" % rank), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
@@ -61,12 +84,18 @@ def test_shard_range():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= (n + w - 1) // w
 
 
-def test_two_rank_gloo_sharded_search(tmp_path):
+@pytest.mark.parametrize("world,n,k", [(2, 5003, 10),        # two even shards
+                                        (3, 1000, 120),      # recall's own k; 334 + 334 + 332
+                                        (8, 83, 10),         # the target world size: shards of 11 rows, the last one short (6)
+                                        (8, 17, 10),         # ... 3 rows per shard, the last TWO shards empty, k larger than any shard
+                                        (8, 40003, 120)])
+def test_gloo_sharded_search_runs_the_real_object(tmp_path, world, n, k):
     import torch.multiprocessing as mp
     from shodh_memory_amd import build
     build.build()
     from oracle import oracle as O
     O.build()
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
-    assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), n, k), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        assert open(tmp_path / ("ok%d" % r)).read() == "1", "rank %d of %d" % (r, world)
