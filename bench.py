@@ -71,7 +71,7 @@ def _compact_config(c):
             out["frac"] = c[key]
             break
     if isinstance(c.get("summary"), dict):               # concurrent-caller entries: their few headline figures
-        for kk, vv in list(c["summary"].items())[:4]:
+        for kk, vv in list(c["summary"].items())[:5]:
             if isinstance(vv, (int, float, bool)):
                 out[kk] = vv
     if isinstance(c.get("layouts"), list):               # sharded C path: ms per layout

@@ -70,6 +70,7 @@ struct MfmaPlan {
     uint64_t n_tiles;
     uint32_t cand_cap, fcap, topk_cap;
     int grid_x;
+    uint32_t set_only;      // (scan_mfma.hip: FinalArgs::set_only)
 };
 bool mfma_supported(uint32_t dim);
 MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int cus);
@@ -218,9 +219,12 @@ struct shodh_index {
     // coalescing front for concurrent host-pointer searches of a few queries each (combiner.h): SHODH_COALESCE=0 / shodh_index_set_coalesce turn it off
     std::atomic<bool> coalesce{true};
     Combiner co;
+    bool probe_set_mode = false;         // IVF-PQ's private centroid index: searches return the SET of the k nearest (final_stage_kernel, set mode)
 };
 
 namespace shodh {
+
+void index_set_probe_set_mode(shodh_index *idx, bool on) { if (idx) idx->probe_set_mode = on; }
 
 static int set_device(const shodh_index *idx) {
     SHODH_HIP_TRY(hipSetDevice(idx->cfg.device));
@@ -377,7 +381,7 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     const uint32_t *del = idx->n_deleted ? idx->deleted : nullptr;
     fc->used_mfma = use_mfma(idx, nq, k);
     MfmaPlan p{};
-    if (fc->used_mfma) p = mfma_plan(idx->n, dim, nq, k, idx->cus);
+    if (fc->used_mfma) { p = mfma_plan(idx->n, dim, nq, k, idx->cus); p.set_only = idx->probe_set_mode ? 1u : 0u; }
     fc->solo = fc->used_mfma && solo_supported(nq, k, idx->n, idx->cus, p);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
     hipEvent_t rk0 = nullptr, rk1 = nullptr;

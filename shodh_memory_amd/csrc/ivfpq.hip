@@ -91,11 +91,16 @@ static int ensure_scratch(IvfpqState *s, size_t bytes) {
 // ---- nearest centroids through a flat index (SpannIndex::find_nearest_centroid / probe selection, spann.rs:545-571, :595-607) ----
 // The k smallest (compute_distance, index) pairs are exactly what a flat search in SHODH_ORDER_SEQ_1M returns: strict '<' in
 // the reference keeps the first minimum, i.e. the smallest index among equal distances.
+void index_set_probe_set_mode(shodh_index *idx, bool on);      // index.hip
 static int make_centroid_index(int device, uint32_t dim, const float *d_centroids, uint32_t P, shodh_index **out) {
     shodh_index_cfg c;
     shodh_index_cfg_default(&c);
     c.dim = dim; c.order = SHODH_ORDER_SEQ_1M; c.device = device; c.reserve_rows = P;
     if (!*out) SHODH_TRY(shodh_index_create(&c, out));
+    // only WHICH partitions are probed reaches a result (their postings are merged by (distance, id) afterwards, spann.rs:625-652, :689-690): the centroid
+    // index answers with the set of the nprobe nearest, exact distances only where membership hangs on them. SHODH_PROBE_SET=0: the full exact lists.
+    static const bool probe_set = !(getenv("SHODH_PROBE_SET") && atoi(getenv("SHODH_PROBE_SET")) == 0);
+    index_set_probe_set_mode(*out, probe_set);
     return shodh_index_build_device(*out, d_centroids, P);
 }
 static int nearest_centroids(shodh_index *ci, const float *d_q, uint64_t nq, uint32_t dim, uint32_t k, uint32_t *d_ids, float *d_dist,

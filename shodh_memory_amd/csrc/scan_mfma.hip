@@ -1215,6 +1215,13 @@ struct FinalArgs {
     uint32_t *stats;          // [0] emitted, [1] rescored, [2] overflowed queries, [3] queries that went through level 2
     uint32_t *cnt_reset;      // single-query path: its overflow counter lives across calls and is handed back zeroed (nullptr otherwise)
     uint32_t *stats_mirror;   // one-query host calls: the four statistics words are copied here (host-mapped memory) by the one workgroup, after its own updates
+    // Set mode (IVF-PQ probe selection, spann.rs:595-607: only WHICH partitions are probed reaches the result -- the postings of all of them are merged by
+    // (distance, id) afterwards): a candidate whose approximate score beats the k-th best by more than 2 eps is in the exact top-k whatever its exact
+    // distance is (at most k - 1 rows can have an exact score above kth~ + eps), one that loses by more than 2 eps is out; only the rows in between are
+    // scored in the reference's order. With the strictly sequential sum of the centroid distance -- a 384-step dependent chain per row -- that is 1-3
+    // rows per query instead of the ~50 of the whole window (the final stage was 74 of the 125 us of probe selection at 1024 queries x 4096 centroids).
+    // Output: the k ids (the sure ones first, by approximate score), distances are placeholders (sure rows: -100 - s~).
+    uint32_t set_only;
 };
 
 template <int ORDER>
@@ -1332,8 +1339,10 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
         // pass A: k-th best approximate score (only its VALUE matters, so 32-bit score keys suffice for small k)
         PROF_T(0)
         // lower end of the window around the k-th best of the current candidate scores: kth - 2 eps (-inf while fewer than k exist)
+        float kth_seen = __builtin_inff();       // the k-th best approximate score the last window_floor found (+inf: none)
         auto window_floor = [&](float eps_q) -> float {
             float lo_ = -__builtin_inff();
+            kth_seen = __builtin_inff();
             if (a.k > 0 && a.k <= 128) {
                 auto key32 = [&](uint32_t i) -> uint32_t { return i < n_st ? skey[i] : (uint32_t)(key_glb(i) >> 32); };    // empty slot -> 0xFFFFFFFF, ignored
                 bool ovf = false;
@@ -1341,6 +1350,7 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
                 if (kk != 0xFFFFFFFFu) {
                     const float kth = -order_key_inv(kk);
                     lo_ = kth - (2.001f * eps_q + 1e-7f * __builtin_fabsf(kth));
+                    kth_seen = kth;
                 }
             } else if (a.k > 0) {
                 auto key_a = [&](uint64_t i) -> uint64_t { return key_at((uint32_t)i); };
@@ -1353,9 +1363,11 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
             return lo_;
         };
         // every candidate with score >= lo_ goes to the re-score list (all of them if fewer than k exist); returns the count
-        auto collect_window = [&](float lo_, bool count_real) -> uint32_t {
+        // set mode: candidates with score > hi_ are sure members; their keys go to the END of ekeys (downwards), *scnt counts them
+        uint32_t *scnt = ecnt - 1;                       // (the word before the statistics counter in the selection scratch: unused by block_kth_u32)
+        auto collect_window = [&](float lo_, bool count_real, float hi_ = __builtin_inff()) -> uint32_t {
             __syncthreads();
-            if (tid == 0) *fcnt = 0;
+            if (tid == 0) { *fcnt = 0; *scnt = 0; }
             __syncthreads();
             uint32_t real = 0;
             for (uint32_t i = tid; i < n; i += NT) {
@@ -1363,7 +1375,10 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
                 if (key == KEY_NONE) continue;
                 ++real;
                 const float s = -order_key_inv((uint32_t)(key >> 32));
-                if (s >= lo_) {
+                if (s > hi_) {
+                    const uint32_t slot = atomicAdd(scnt, 1u);
+                    if (slot < a.fcap) ekeys[a.fcap - 1u - slot] = make_key(-100.0f - s, a.id_base + (uint32_t)key);
+                } else if (s >= lo_) {
                     const uint32_t slot = atomicAdd(fcnt, 1u);
                     if (slot < a.fcap) flist[slot] = (uint32_t)key;
                 }
@@ -1374,7 +1389,15 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
         };
         const float lo = window_floor(a.eps[q]);
         PROF_T(1)
-        uint32_t nf = collect_window(lo, true);
+        // set mode needs a k-th best to stand on (block-uniform); the margin above it is the one below it
+        const bool set_mode = a.set_only && kth_seen < 3.0e38f;
+        const float hi = set_mode ? kth_seen + (2.001f * a.eps[q] + 1e-7f * __builtin_fabsf(kth_seen)) : __builtin_inff();
+        uint32_t nf = collect_window(lo, true, hi);
+        uint32_t n_sure = set_mode ? *scnt : 0u;
+        if (nf + n_sure > a.fcap) {          // (cannot happen with n_sure < k <= fcap / 4 unless the window itself overflows: the plain path decides)
+            nf = collect_window(lo, false);
+            n_sure = 0;
+        }
         PROF_T(2)
         if (nf > a.fcap) {
             // ---- level 2 (block-uniform branch) -----------------------------------------------------------------------
@@ -1458,6 +1481,7 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
             __syncthreads();
             const float lo2 = window_floor(a.eps2[q]);
             nf = collect_window(lo2, false);
+            n_sure = 0;                        // (a window this dense is scored as a whole)
             if (tid == 0) atomicAdd(a.stats + 3, 1u);
         }
         if (nf > a.fcap) bad = true;       // block-uniform: even the f32 window is too large (thousands of near-duplicates): exact scan
@@ -1579,8 +1603,9 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
                 }
             }
             PROF_T(3)
-            auto key_b = [&](uint64_t i) -> uint64_t { return ekeys[i]; };
-            const uint32_t m = block_select_topk<NT>(key_b, nf, buf, mins);
+            // (set mode: the exact keys of the window in ekeys[0 .. nf), the sure members' placeholder keys -- all smaller -- at the end of ekeys)
+            auto key_b = [&](uint64_t i) -> uint64_t { return i < nf ? ekeys[i] : ekeys[a.fcap - 1u - (uint32_t)(i - nf)]; };
+            const uint32_t m = block_select_topk<NT>(key_b, nf + n_sure, buf, mins);
             PROF_T(4)
 #ifdef SHODH_PROF
             if (tid == 0 && (q % 37) == 0) printf("final q %u n %u nf %u | load-q %lld selectA %lld window %lld rescore %lld selectB %lld\n", q, n, nf, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4]);
@@ -1631,6 +1656,7 @@ struct MfmaPlan {
     uint64_t n_tiles;
     uint32_t cand_cap, fcap, topk_cap;
     int grid_x;
+    uint32_t set_only;      // the caller needs the SET of the k nearest, not their exact distances or order (IVF probe selection): final_stage_kernel, "set mode"
 };
 
 uint32_t topk_capacity(uint32_t k);   // flat_exact.hip
@@ -1823,7 +1849,8 @@ static int launch_final_stage(const float *rows, uint32_t dim, const float *d_q,
         break;
     }
     FinalArgs f{rows, dim, d_q, nq, k, tcap, w.slots, nb_emit, w.cand, cand_cnt, p.cand_cap, w.eps, w.eps2, fcap, stage_cap, ch_rows, order, id_base,
-                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset, w.stats_mirror};
+                w.fallback, w.fb_list, w.fb_count, d_ids, d_dist, d_counts, w.stats, cnt_reset, w.stats_mirror,
+                (p.set_only && order == SHODH_ORDER_SEQ_1M && k >= 1 && k <= 128) ? 1u : 0u};
 #define SHODH_LAUNCH_FINAL(ORD, NTV)                                                                         \
     do {                                                                                                     \
         SHODH_TRY(ensure_dynamic_lds((const void *)final_stage_kernel<ORD, NTV>, flds));                     \
