@@ -483,6 +483,36 @@ impl<T: Tokenize> Drop for HipEmbedder<T> {
     fn drop(&mut self) { unsafe { ffi::shodh_embedder_destroy(self.h) } }
 }
 
+/// Data-parallel encoder over several devices (texts are independent, no collective): one `HipEmbedder` per GPU, `encode_each` deals the
+/// texts to them in contiguous near-equal shares, one host thread per share, vectors back in input order -- byte for byte what ONE handle returns
+/// (the per-text scope: a text's vector does not depend on its batch mates). `encode` / `encode_query` / `encode_batch` go to handle 0: an INT8
+/// `encode_batch` is one function of the whole batch (its activation ranges span it, minilm.rs:588-593) and must not be split. The Python mirror
+/// (`shodh_memory_amd.distributed.ShardedEmbedder`) is tested with several handles on one GPU.
+pub struct HipShardedEmbedder<T: Tokenize> { pub handles: Vec<HipEmbedder<T>> }
+impl<T: Tokenize> HipShardedEmbedder<T> {
+    pub fn new(handles: Vec<HipEmbedder<T>>) -> Result<Self> {
+        if handles.is_empty() { return Err(anyhow!("at least one embedder handle")); }
+        Ok(Self { handles })
+    }
+    pub fn dimension(&self) -> usize { self.handles[0].dimension() }
+    pub fn encode(&self, text: &str) -> Result<Vec<f32>> { self.handles[0].encode(text) }
+    pub fn encode_query(&self, text: &str) -> Result<Vec<f32>> { self.handles[0].encode_query(text) }
+    pub fn encode_batch(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> { self.handles[0].encode_batch(texts) }
+    pub fn encode_each(&self, texts: &[&str]) -> Result<Vec<Vec<f32>>> {
+        let g = self.handles.len().min(texts.len().max(1));
+        let per = (texts.len() + g - 1) / g.max(1);
+        let parts: Vec<Result<Vec<Vec<f32>>>> = std::thread::scope(|sc| {
+            let joins: Vec<_> = texts.chunks(per.max(1)).zip(self.handles.iter()).map(|(share, h)| sc.spawn(move || h.encode_each(share))).collect();
+            joins.into_iter().map(|j| j.join().unwrap_or_else(|_| Err(anyhow!("encoder thread panicked")))).collect()
+        });
+        let mut out = Vec::with_capacity(texts.len());
+        for p in parts { out.extend(p?); }
+        Ok(out)
+    }
+    pub fn count_tokens(&self, text: &str) -> usize { self.handles[0].count_tokens(text) }
+    pub fn chunk_budget_tokens(&self) -> usize { self.handles[0].chunk_budget_tokens() }
+}
+
 /// `LearnedWeights::fuse_scores_full` (src/relevance.rs:529-594) with a `#[repr(C)]` copy of the seven weights
 pub fn fuse_scores_full(w: &ffi::shodh_weights, sem: f32, ent: f32, tag: f32, imp: f32, momentum_ema: f32, access_count: u32, graph_strength: f32) -> f32 {
     unsafe { ffi::shodh_fuse_scores_full(w, sem, ent, tag, imp, momentum_ema, access_count, graph_strength) }
