@@ -339,7 +339,15 @@ constexpr int LM_NT = 1024, LM_U = SHODH_LM_U, LM_QB = SHODH_LM_QB, LM_MT = 24;
 constexpr bool LM_PRUNE = SHODH_LM_PRUNE;      // partial-sum pruning (see adc_list_kernel)
 constexpr int LM_TILE = LM_MT * 256 * 8;                       // 48 KiB: 24 sub-quantisers x 256 entries x 2 queries
 constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM)
-constexpr int LM_LDS = 2 * LM_TILE + 2 * LM_QB * 8 + 2 * LM_QB * 4;
+#ifndef SHODH_LM_WG_PER_CU
+#define SHODH_LM_WG_PER_CU 1
+#endif
+constexpr int LM_WG_PER_CU = SHODH_LM_WG_PER_CU;               // resident workgroups of the list scan per CU (its LDS admits one)
+// A work item of the list-major scan = (a chunk of <= LM_NT * LM_U postings of one list) x (a block of <= 2 * LM_QB of the queries that probe it), described
+// in one 128-byte record: lm_scan_kernel writes the chunk, lm_fill_kernel the queries and their bounds. The scan reads the record with one 32-lane load.
+struct LmItem { uint64_t c0; uint32_t clen, pqn; uint32_t q[2 * LM_QB]; uint32_t pad[12 - 2 * LM_QB]; uint64_t bound[2 * LM_QB]; uint64_t pad2[8 - 2 * LM_QB]; };
+static_assert(sizeof(LmItem) == 128 && LM_QB <= 4, "one descriptor = 32 dwords");
+constexpr int LM_LDS = 2 * LM_TILE + 2 * (int)sizeof(LmItem) + 16;
 
 constexpr int LM_TQ = 8;      // queries per workgroup of the table kernel (a codebook row is loaded once for all of them)
 __global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict__ q, const float *__restrict__ codebook, uint32_t dim, uint32_t nq, float *__restrict__ tables) {
@@ -370,14 +378,12 @@ __global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict
     }
 }
 
-// pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (+ work items), fill
-__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off, uint32_t *__restrict__ item_list) {
+// pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (+ the chunk part of every work item's record), fill (+ the query part)
+__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off, LmItem *__restrict__ items) {
     // exclusive scans over the lists: pairs, and work items (a block of <= 2 * LM_QB queries of one list x a chunk of <= LM_NT * LM_U of its postings)
     const uint32_t tid = threadIdx.x, per = (P + 1023) / 1024, b0 = tid * per < P ? tid * per : P, b1 = (b0 + per < P) ? b0 + per : P;
-    auto items_of = [&](uint32_t p) -> uint32_t {
-        const uint64_t len = list_off[p + 1] - list_off[p];
-        return ((cnt[p] + 2 * LM_QB - 1) / (2 * LM_QB)) * (uint32_t)((len + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U));
-    };
+    auto chunks_of = [&](uint32_t p) -> uint32_t { return (uint32_t)((list_off[p + 1] - list_off[p] + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U)); };
+    auto items_of = [&](uint32_t p) -> uint32_t { return ((cnt[p] + 2 * LM_QB - 1) / (2 * LM_QB)) * chunks_of(p); };
     uint32_t a = 0, it = 0;
     for (uint32_t p = b0; p < b1; ++p) { a += cnt[p]; it += items_of(p); }
     typedef hipcub::BlockScan<uint32_t, 1024> Scan;
@@ -389,25 +395,39 @@ __global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restric
     if (tid == 0) { pair_off[P] = ta; item_off[P] = ti; }
     for (uint32_t p = b0; p < b1; ++p) {
         pair_off[p] = a; cursor[p] = a; item_off[p] = it;
-        const uint32_t ni = items_of(p);
-        for (uint32_t i = 0; i < ni; ++i) item_list[it + i] = p;       // (a work item finds its list with one load instead of a 12-step search through item_off: 6 000 cycles per item)
-        a += cnt[p]; it += ni;
+        const uint64_t lo = list_off[p], len = list_off[p + 1] - lo;
+        const uint32_t nchunk = chunks_of(p), c = cnt[p], ni = ((c + 2 * LM_QB - 1) / (2 * LM_QB)) * nchunk;
+        for (uint32_t i = 0; i < ni; ++i) {                       // item = block * nchunk + chunk
+            const uint32_t blk = i / nchunk, ch = i - blk * nchunk, left = c - blk * 2 * LM_QB;
+            const uint64_t c0 = lo + len * ch / nchunk;
+            LmItem *d = items + it + i;
+            d->c0 = c0; d->clen = (uint32_t)(lo + len * (ch + 1) / nchunk - c0); d->pqn = left < 2u * LM_QB ? left : 2u * LM_QB;
+        }
+        a += c; it += ni;
     }
 }
-__global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, uint32_t P, uint32_t *__restrict__ cursor, uint32_t *__restrict__ pairs) {
+__global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, uint32_t P, const uint64_t *__restrict__ list_off,
+                               const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ item_off, const uint64_t *__restrict__ bound, uint32_t *__restrict__ cursor, LmItem *__restrict__ items) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * nprobe) return;
     const uint32_t q = i / nprobe, r = i - q * nprobe;
     if (r >= probe_cnt[q]) return;
     const uint32_t p = probes[i];
-    if (p < P) pairs[atomicAdd(&cursor[p], 1u)] = q;      // the order inside a list is arbitrary: every query's result is computed on its own
+    if (p >= P) return;
+    // the query's place among the list's pairs (the order inside a list is arbitrary: every query's result is computed on its own) = a slot of one block:
+    // into the record of every chunk of that block
+    const uint32_t slot = atomicAdd(&cursor[p], 1u) - pair_off[p], blk = slot / (2 * LM_QB), sl = slot - blk * 2 * LM_QB;
+    const uint32_t nchunk = (uint32_t)((list_off[p + 1] - list_off[p] + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U));
+    const uint64_t b = bound[q];
+    LmItem *d = items + item_off[p] + blk * nchunk;
+    for (uint32_t ch = 0; ch < nchunk; ++ch) { d[ch].q[sl] = q; d[ch].bound[sl] = b; }
 }
 
 #ifdef SHODH_LMPROF      // diagnostic build: phase timers of a few workgroups
 #define LPROF_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64(); const long long t00_ = tq_;
 #define LPROF_T(i) { const long long t_ = clock64(); pt_[i] += t_ - tq_; tq_ = t_; }
 #define NPROF_END if (tid == 0 && (blockIdx.x % 257) == 3) printf("boundprof q %d lists %u postings %u total %lld : table+walk %lld | codes+score %lld | bound %lld | push %lld | sort %lld | tail %lld\n", (int)blockIdx.x, r0, total, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
-#define LPROF_END if (lane == 0 && (wave == 0 || wave == 9) && (blockIdx.x % 997) == 5) printf("lmprof blk %d wave %d queries %u postings %u total %lld : setup+codes %lld | tile0 %lld | score %lld | store %lld | bar %lld | push %lld\n", (int)blockIdx.x, wave, pqn, (unsigned)len, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
+#define LPROF_END if (lane == 0 && (wave == 0 || wave == 9) && (blockIdx.x % 61) == 5) printf("lmprof blk %d wave %d total %lld : codes %lld | wait-first-tile %lld | score %lld | store %lld | bar %lld | push %lld\n", (int)blockIdx.x, wave, clock64() - t00_, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
 #else
 #define LPROF_DECL
 #define LPROF_T(i)
@@ -553,44 +573,72 @@ __global__ __launch_bounds__(LM_NEAR_NT) void adc_bound_kernel(const NearArgs a)
 
 struct LmArgs {
     const float *tables;       // [nq][48 * 256]
-    const uint64_t *list_off;
     const uint32_t *ids;
     const uint8_t *codes;
-    const uint32_t *pair_off;  // [P + 1]
-    const uint32_t *item_off;  // [P + 1]
-    const uint32_t *item_list; // [items] the list of every work item
-    const uint32_t *pairs;     // queries, grouped by list
-    const uint64_t *bound;     // [nq] keys at or under it are candidates (KEY_NONE: no bound)
-    uint32_t P, cand_cap;
+    const LmItem *items;       // the work items (lm_scan_kernel, lm_fill_kernel)
+    const uint32_t *n_items;   // their number
+    uint32_t *work;            // the next item nobody has taken yet, less the grid size (zero at launch)
+    uint32_t cand_cap;
     uint64_t *cand;            // [nq][cand_cap] keys under the bound
     uint32_t *cand_cnt;        // [nq] (may exceed cand_cap: the query is redone)
 };
 
+// Persistent (round 6): one workgroup per CU walks the work items -- the first by its index, the following ones from a shared counter -- and never waits for a
+// descriptor: wave 0 asks for the item after the next (an atomic) and for the next item's record (one 128-byte load) at the top of an item and hands the record
+// to the others through LDS during the item's last query pair, whose second half then stages the NEXT item's first table tile exactly as it would stage the
+// next pair's. Between two items only the chunk's codes are waited for. (One workgroup per item, round 4 / 5: item index -> list -> pair offsets -> queries ->
+// bounds -> tables was a chain of five dependent loads, 9 000 cycles with nothing to overlap them, a quarter of an average item.)
 __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *bql = reinterpret_cast<uint64_t *>(smem + 2 * LM_TILE);                   // [2 * LM_QB] ... and their bounds
-    uint32_t *pql = reinterpret_cast<uint32_t *>(bql + 2 * LM_QB);                       // [2 * LM_QB] this item's queries
+    LmItem *ctl = reinterpret_cast<LmItem *>(smem + 2 * LM_TILE);                       // [2] this item's record, the next one's
+    uint32_t *has_next = reinterpret_cast<uint32_t *>(ctl + 2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t item = blockIdx.x;
-    if (item >= a.item_off[a.P]) return;
+    const uint32_t n_items = *a.n_items;
+    if (blockIdx.x >= n_items) return;
     LPROF_DECL
-    const uint32_t p = a.item_list[item];
-    const uint64_t lo = a.list_off[p], len = a.list_off[p + 1] - lo;      // (> 0: an empty list has no work items)
-    const uint32_t nchunk = (uint32_t)((len + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U));
-    const uint32_t local = item - a.item_off[p], blk = local / nchunk, ch = local - blk * nchunk;
-    const uint32_t pq0 = a.pair_off[p] + blk * 2 * LM_QB;
-    const uint32_t left = a.pair_off[p + 1] - pq0;
-    const uint32_t pqn = left < 2u * LM_QB ? left : 2u * LM_QB;           // queries of this item (>= 1)
-    const uint32_t npair = (pqn + 1) >> 1;
-    if (tid < 2 * LM_QB) {                                                  // an odd block repeats its last query (scored, not pushed twice)
-        const uint32_t q = a.pairs[pq0 + ((uint32_t)tid < pqn ? (uint32_t)tid : pqn - 1)];
-        pql[tid] = q; bql[tid] = a.bound[q];
+    uint32_t nxt = 0, dreg = 0;                                                          // wave 0: the next item, dword `lane` of its record
+    if (wave == 0) {
+        if (lane < 32) reinterpret_cast<uint32_t *>(&ctl[0])[lane] = reinterpret_cast<const uint32_t *>(a.items + blockIdx.x)[lane];
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.work, 1u);
+        nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + gridDim.x;
     }
-    {
-        const uint64_t c0 = lo + len * ch / nchunk;
-        const uint32_t clen = (uint32_t)(lo + len * (ch + 1) / nchunk - c0);       // <= LM_NT * LM_U
+    __syncthreads();
+    f32x4q sa[2], sb[2];
+    // tile (record d, pair j, half t) -> registers: 1536 groups of four entries per query; thread i stages group i and, in waves 0-7, group 1024 + i
+    // (an odd block repeats its last query: scored, not pushed twice)
+    auto tile_load = [&](const LmItem *d, uint32_t j, int t) {
+        const uint32_t last = d->pqn - 1, qa = d->q[2 * j], qb = d->q[2 * j + 1 < last ? 2 * j + 1 : last];
+        const float *ta = a.tables + (size_t)qa * 12288 + t * 6144, *tb = a.tables + (size_t)qb * 12288 + t * 6144;
+        sa[0] = *reinterpret_cast<const f32x4q *>(ta + tid * 4); sb[0] = *reinterpret_cast<const f32x4q *>(tb + tid * 4);
+        if (wave < 8) { sa[1] = *reinterpret_cast<const f32x4q *>(ta + 4096 + tid * 4); sb[1] = *reinterpret_cast<const f32x4q *>(tb + 4096 + tid * 4); }
+    };
+    auto tile_store = [&](int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0 || wave < 8) {
+                f32x4q w0, w1;
+                w0[0] = sa[h][0]; w0[1] = sb[h][0]; w0[2] = sa[h][1]; w0[3] = sb[h][1];
+                w1[0] = sa[h][2]; w1[1] = sb[h][2]; w1[2] = sa[h][3]; w1[3] = sb[h][3];
+                unsigned char *d = smem + slot * LM_TILE + (h * 1024 + tid) * 32;
+                *reinterpret_cast<f32x4q *>(d) = w0; *reinterpret_cast<f32x4q *>(d + 16) = w1;
+            }
+        }
+    };
+    tile_load(&ctl[0], 0, 0);
+    tile_store(0);                                                                       // (visible after the first item's codes are requested: the barrier below)
+    int s = 0;
+    for (;;) {
+        const LmItem *it = &ctl[s];
+        const uint64_t c0 = it->c0;
+        const uint32_t clen = it->clen, pqn = it->pqn, npair = (pqn + 1) >> 1;           // clen <= LM_NT * LM_U, pqn >= 1
         const uint32_t upass = (clen + LM_NT - 1) / LM_NT;
+        uint32_t t2 = 0;
+        if (wave == 0) {
+            if (nxt < n_items && lane < 32) dreg = reinterpret_cast<const uint32_t *>(a.items + nxt)[lane];
+            if (lane == 0) t2 = atomicAdd(a.work, 1u);
+        }
         // the chunk's codes and ids: once, into registers
         uint32_t cw[LM_U][12];
         uint32_t idv[LM_U];
@@ -610,46 +658,38 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
                 idv[u] = a.ids[e];
             }
         }
-        // tile (pair j, half t) -> LDS slot t: 1536 groups of four entries per query; thread i stages group i and, in waves 0-7, group 1024 + i
-        f32x4q sa[2], sb[2];
-        auto tile_load = [&](uint32_t j, int t) {
-            const uint32_t qa = pql[2 * j], qb = pql[2 * j + 1];
-            const float *ta = a.tables + (size_t)qa * 12288 + t * 6144, *tb = a.tables + (size_t)qb * 12288 + t * 6144;
-            sa[0] = *reinterpret_cast<const f32x4q *>(ta + tid * 4); sb[0] = *reinterpret_cast<const f32x4q *>(tb + tid * 4);
-            if (wave < 8) { sa[1] = *reinterpret_cast<const f32x4q *>(ta + 4096 + tid * 4); sb[1] = *reinterpret_cast<const f32x4q *>(tb + 4096 + tid * 4); }
-        };
-        auto tile_store = [&](int slot) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 || wave < 8) {
-                    f32x4q w0, w1;
-                    w0[0] = sa[h][0]; w0[1] = sb[h][0]; w0[2] = sa[h][1]; w0[3] = sb[h][1];
-                    w1[0] = sa[h][2]; w1[1] = sb[h][2]; w1[2] = sa[h][3]; w1[3] = sb[h][3];
-                    unsigned char *d = smem + slot * LM_TILE + (h * 1024 + tid) * 32;
-                    *reinterpret_cast<f32x4q *>(d) = w0; *reinterpret_cast<f32x4q *>(d + 16) = w1;
-                }
-            }
-        };
-        __syncthreads();                                                     // pql / bql visible
         LPROF_T(0)
-        tile_load(0, 0);
-        tile_store(0);
-        __syncthreads();
+        __syncthreads();                                                                 // the first tile of this item is in slot 0 (staged by the prologue or by the item before)
         LPROF_T(1)
+        bool more_items = false;
         for (uint32_t j = 0; j < npair; ++j) {
-            const uint32_t qa = pql[2 * j], qb = pql[2 * j + 1];
+            const uint32_t ia = 2 * j, ib = 2 * j + 1 < pqn ? 2 * j + 1 : pqn - 1;
+            const uint32_t qa = it->q[ia], qb = it->q[ib];
             // keys at or under these bounds are candidates; a posting whose PARTIAL sums already lie above both (every table entry is a sum of squares: the
             // sums only grow) can never become one, and a wave whose 64 postings are all in that state skips the rest of their lookups
-            const uint64_t ba = bql[2 * j], bb = bql[2 * j + 1];
+            const uint64_t ba = it->bound[ia], bb = it->bound[ib];
             const uint32_t da = (uint32_t)(ba >> 32), db = (uint32_t)(bb >> 32);
             const bool two = qb != qa;
+            const bool lastpair = j + 1 == npair;
             f32x2q sum[LM_U];
 #pragma unroll
             for (int u = 0; u < LM_U; ++u) { sum[u][0] = 0.0f; sum[u][1] = 0.0f; }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const bool more = (t == 0) || (j + 1 < npair);
-                if (more) { if (t == 0) tile_load(j, 1); else tile_load(j + 1, 0); }
+                bool more = true;
+                if (t == 0) {
+                    tile_load(it, j, 1);
+                    if (lastpair && wave == 0) {                                         // the next item's record: visible to everybody after this half's barrier
+                        if (nxt < n_items && lane < 32) reinterpret_cast<uint32_t *>(&ctl[s ^ 1])[lane] = dreg;
+                        if (lane == 0) *has_next = nxt < n_items ? 1u : 0u;
+                    }
+                } else if (!lastpair) {
+                    tile_load(it, j + 1, 0);
+                } else {
+                    more_items = *has_next != 0;
+                    more = more_items;
+                    if (more) tile_load(&ctl[s ^ 1], 0, 0);
+                }
                 const unsigned char *tb = smem + t * LM_TILE;
 #pragma unroll
                 for (int u = 0; u < LM_U; ++u) {
@@ -698,6 +738,9 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
             }
             LPROF_T(5)
         }
+        if (!more_items) break;
+        s ^= 1;
+        if (wave == 0) nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t2) + gridDim.x;
     }
     LPROF_END
 }
@@ -843,11 +886,11 @@ static IvfpqLayout ivfpq_layout(const IvfpqState *s, const shodh_index_cfg &cfg,
     L.o_tables = L.o_lm = L.o_pairs = L.o_cand = L.o_items = L.o_redo = L.o_redo_list = L.o_r0 = 0;
     if (L.list_major) {
         L.o_tables = take((size_t)L.lm_chunk * 12288 * 4);
-        L.o_lm = take((size_t)(s->P + 1 + L.lm_chunk) * 4 + (size_t)3 * (s->P + 1) * 4);      // list counts + candidate counts (one memset), pair offsets, fill cursors, item offsets
-        L.o_pairs = take((size_t)L.lm_chunk * L.nprobe * 4);
+        L.o_lm = take((size_t)(s->P + 1 + L.lm_chunk) * 4 + (size_t)3 * (s->P + 1) * 4);      // list counts (+ the scan's work counter) + candidate counts (one memset), pair offsets, fill cursors, item offsets
+        L.o_pairs = 0;
         L.o_cand = take((size_t)L.lm_chunk * LM_CANDS * 8);
         const uint64_t max_chunks = (s->max_list_len + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U);
-        L.o_items = take((((size_t)L.lm_chunk * L.nprobe / (2 * LM_QB) + s->P + 1) * (max_chunks ? max_chunks : 1) + 1) * 4);
+        L.o_items = take((((size_t)L.lm_chunk * L.nprobe / (2 * LM_QB) + s->P + 1) * (max_chunks ? max_chunks : 1) + 1) * sizeof(LmItem));
         L.o_redo = take((size_t)L.lm_chunk * LM_REDO_SPLIT * (k ? k : 1) * 8);
         L.o_redo_list = take((size_t)(L.lm_chunk + 1) * 4);
         L.o_r0 = take((size_t)L.lm_chunk * 8);                         // the bounds
@@ -891,9 +934,8 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
         const uint32_t bound_max = (emax && atoi(emax) > 0 && atoi(emax) < LM_NEAR_NT * LM_NEAR_U) ? (uint32_t)atoi(emax) : (uint32_t)(LM_NEAR_NT * LM_NEAR_U);
         float *tables = (float *)(scratch + L.o_tables);
         uint32_t *lcnt = (uint32_t *)(scratch + L.o_lm), *cand_cnt = lcnt + (s->P + 1), *pair_off = cand_cnt + L.lm_chunk, *cursor = pair_off + (s->P + 1), *item_off = cursor + (s->P + 1);
-        uint32_t *pairs = (uint32_t *)(scratch + L.o_pairs);
         uint64_t *cand = (uint64_t *)(scratch + L.o_cand);
-        uint32_t *item_list = (uint32_t *)(scratch + L.o_items);
+        LmItem *items = (LmItem *)(scratch + L.o_items);
         uint64_t *redo = (uint64_t *)(scratch + L.o_redo);
         uint64_t *bound = (uint64_t *)(scratch + L.o_r0);                 // [m]
         uint32_t *redo_list = (uint32_t *)(scratch + L.o_redo_list);     // [m] + the count
@@ -919,12 +961,13 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             NearArgs na{tables, s->list_off, s->ids, s->codes, pids, pcnt, nprobe, k, cap_near, s->P, bound_max, bound, lcnt};
             hipLaunchKernelGGL(adc_bound_kernel, dim3(m), dim3(LM_NEAR_NT), lds_near, st, na);
             const uint32_t np = m * nprobe;
-            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)lcnt, s->list_off, s->P, pair_off, cursor, item_off, item_list);
-            hipLaunchKernelGGL(lm_fill_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, s->P, cursor, pairs);
-            LmArgs la{tables, s->list_off, s->ids, s->codes, pair_off, item_off, item_list, pairs, bound, s->P, cand_cap, cand, cand_cnt};
-            // work items <= (pairs / (2 LM_QB) + one partly filled block per list) x the chunks of the longest list; workgroups past the count leave at once
+            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)lcnt, s->list_off, s->P, pair_off, cursor, item_off, items);
+            hipLaunchKernelGGL(lm_fill_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, s->P, s->list_off, (const uint32_t *)pair_off, (const uint32_t *)item_off, (const uint64_t *)bound, cursor, items);
+            // one workgroup per CU (96 KiB of LDS each) walks the items; lcnt[P] (zeroed with the list counters, not a list) is the shared work counter
+            LmArgs la{tables, s->ids, s->codes, items, item_off + s->P, lcnt + s->P, cand_cap, cand, cand_cnt};
             const uint64_t max_items = ((uint64_t)np / (2 * LM_QB) + (np < s->P ? np : s->P)) * (max_chunks ? max_chunks : 1);
-            hipLaunchKernelGGL(adc_list_kernel, dim3((uint32_t)(max_items ? max_items : 1)), dim3(LM_NT), LM_LDS, st, la);
+            const uint32_t lm_grid = (uint32_t)std::min<uint64_t>(max_items ? max_items : 1, (uint64_t)s->cus * LM_WG_PER_CU);
+            hipLaunchKernelGGL(adc_list_kernel, dim3(lm_grid), dim3(LM_NT), LM_LDS, st, la);
 #ifdef SHODH_LMPROF
             {
                 std::vector<uint32_t> hc(m);
