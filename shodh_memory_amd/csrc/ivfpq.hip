@@ -344,13 +344,15 @@ constexpr int LM_CANDS = 4096;                                  // candidate key
 #endif
 constexpr int LM_WG_PER_CU = SHODH_LM_WG_PER_CU;               // resident workgroups of the list scan per CU (its LDS admits one)
 // A work item of the list-major scan = (a chunk of <= LM_NT * LM_U postings of one list) x (a block of <= 2 * LM_QB of the queries that probe it), described
-// in one 128-byte record: lm_scan_kernel writes the chunk, lm_fill_kernel the queries and their bounds. The scan reads the record with one 32-lane load.
+// in one 128-byte record written by lm_fill_kernel. The scan reads the record with one 32-lane load.
 struct LmItem { uint64_t c0; uint32_t clen, pqn; uint32_t q[2 * LM_QB]; uint32_t pad[12 - 2 * LM_QB]; uint64_t bound[2 * LM_QB]; uint64_t pad2[8 - 2 * LM_QB]; };
 static_assert(sizeof(LmItem) == 128 && LM_QB <= 4, "one descriptor = 32 dwords");
 constexpr int LM_LDS = 2 * LM_TILE + 2 * (int)sizeof(LmItem) + 16;
 
 constexpr int LM_TQ = 8;      // queries per workgroup of the table kernel (a codebook row is loaded once for all of them)
-__global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict__ q, const float *__restrict__ codebook, uint32_t dim, uint32_t nq, float *__restrict__ tables) {
+__global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict__ q, const float *__restrict__ codebook, uint32_t dim, uint32_t nq, float *__restrict__ tables, uint32_t *__restrict__ zero, uint32_t n_zero) {
+    // (also clears the pass's counters: the first kernel of the pass, a memset would be two launches of its own)
+    { const uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x; if (z < n_zero) zero[z] = 0; }
     // build_distance_table (pq.rs:329-351) for queries blockIdx.x * LM_TQ ..: entry e = m * 256 + c, 8 sequential terms (the arithmetic of adc_scan_kernel's table)
     __shared__ float qs[LM_TQ][32];                              // the four sub-vectors (m = 4 blockIdx.y ..) of each query
     const uint32_t e = blockIdx.y * 1024 + threadIdx.x, m = e >> 8, q0 = blockIdx.x * LM_TQ;
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(1024) void adc_table_kernel(const float *__restrict
     }
 }
 
-// pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (+ the chunk part of every work item's record), fill (+ the query part)
-__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off, LmItem *__restrict__ items) {
+// pairs (query, probed list) grouped by list: counted by adc_bound_kernel; scan (pair and work-item offsets of every list), fill (the work items' records)
+__global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ list_off, uint32_t P, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ item_off) {
     // exclusive scans over the lists: pairs, and work items (a block of <= 2 * LM_QB queries of one list x a chunk of <= LM_NT * LM_U of its postings)
     const uint32_t tid = threadIdx.x, per = (P + 1023) / 1024, b0 = tid * per < P ? tid * per : P, b1 = (b0 + per < P) ? b0 + per : P;
     auto chunks_of = [&](uint32_t p) -> uint32_t { return (uint32_t)((list_off[p + 1] - list_off[p] + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U)); };
@@ -393,18 +395,7 @@ __global__ __launch_bounds__(1024) void lm_scan_kernel(const uint32_t *__restric
     __syncthreads();
     Scan(tmp).ExclusiveSum(it, it, ti);
     if (tid == 0) { pair_off[P] = ta; item_off[P] = ti; }
-    for (uint32_t p = b0; p < b1; ++p) {
-        pair_off[p] = a; cursor[p] = a; item_off[p] = it;
-        const uint64_t lo = list_off[p], len = list_off[p + 1] - lo;
-        const uint32_t nchunk = chunks_of(p), c = cnt[p], ni = ((c + 2 * LM_QB - 1) / (2 * LM_QB)) * nchunk;
-        for (uint32_t i = 0; i < ni; ++i) {                       // item = block * nchunk + chunk
-            const uint32_t blk = i / nchunk, ch = i - blk * nchunk, left = c - blk * 2 * LM_QB;
-            const uint64_t c0 = lo + len * ch / nchunk;
-            LmItem *d = items + it + i;
-            d->c0 = c0; d->clen = (uint32_t)(lo + len * (ch + 1) / nchunk - c0); d->pqn = left < 2u * LM_QB ? left : 2u * LM_QB;
-        }
-        a += c; it += ni;
-    }
+    for (uint32_t p = b0; p < b1; ++p) { pair_off[p] = a; cursor[p] = a; item_off[p] = it; a += cnt[p]; it += items_of(p); }
 }
 __global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32_t *__restrict__ probe_cnt, uint32_t nq, uint32_t nprobe, uint32_t P, const uint64_t *__restrict__ list_off,
                                const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ item_off, const uint64_t *__restrict__ bound, uint32_t *__restrict__ cursor, LmItem *__restrict__ items) {
@@ -417,10 +408,18 @@ __global__ void lm_fill_kernel(const uint32_t *__restrict__ probes, const uint32
     // the query's place among the list's pairs (the order inside a list is arbitrary: every query's result is computed on its own) = a slot of one block:
     // into the record of every chunk of that block
     const uint32_t slot = atomicAdd(&cursor[p], 1u) - pair_off[p], blk = slot / (2 * LM_QB), sl = slot - blk * 2 * LM_QB;
-    const uint32_t nchunk = (uint32_t)((list_off[p + 1] - list_off[p] + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U));
+    const uint64_t lo = list_off[p], len = list_off[p + 1] - lo;
+    const uint32_t nchunk = (uint32_t)((len + (uint64_t)LM_NT * LM_U - 1) / ((uint64_t)LM_NT * LM_U));
     const uint64_t b = bound[q];
     LmItem *d = items + item_off[p] + blk * nchunk;
     for (uint32_t ch = 0; ch < nchunk; ++ch) { d[ch].q[sl] = q; d[ch].bound[sl] = b; }
+    if (sl == 0) {                                                // the block's first query also describes its chunks
+        const uint32_t left = pair_off[p + 1] - pair_off[p] - blk * 2 * LM_QB, pqn = left < 2u * LM_QB ? left : 2u * LM_QB;
+        for (uint32_t ch = 0; ch < nchunk; ++ch) {
+            const uint64_t c0 = lo + len * ch / nchunk;
+            d[ch].c0 = c0; d[ch].clen = (uint32_t)(lo + len * (ch + 1) / nchunk - c0); d[ch].pqn = pqn;
+        }
+    }
 }
 
 #ifdef SHODH_LMPROF      // diagnostic build: phase timers of a few workgroups
@@ -598,10 +597,15 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
     if (blockIdx.x >= n_items) return;
     LPROF_DECL
     uint32_t nxt = 0, dreg = 0;                                                          // wave 0: the next item, dword `lane` of its record
+    // (the counter's offset passes through a VGPR the compiler knows nothing about: with a provably uniform address its atomic optimizer turns the add into a
+    // wave-wide reduction that reads the result back at once -- the one wait this kernel is built to avoid)
+    uint32_t wofs = 0;
+    asm volatile("" : "+v"(wofs));
+    uint32_t *work = a.work + wofs;
     if (wave == 0) {
         if (lane < 32) reinterpret_cast<uint32_t *>(&ctl[0])[lane] = reinterpret_cast<const uint32_t *>(a.items + blockIdx.x)[lane];
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.work, 1u);
+        if (lane == 0) t = atomicAdd(work, 1u);
         nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + gridDim.x;
     }
     __syncthreads();
@@ -626,40 +630,53 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
             }
         }
     };
+    // The chunk's codes (48 bytes per posting, LM_U postings per lane) stay in registers for the whole item. Words 0-5 (sub-quantisers 0-23) are last read in the
+    // first half of the item's last pair, words 6-11 in its second half: the NEXT item's words 0-5 are requested during that second half, its words 6-11 and ids at
+    // its top (first needed half a pair later) -- the same registers, and no item waits for its codes (round 6: that wait was a quarter of the kernel).
+    uint32_t cw[LM_U][12];
+    auto codes_lo = [&](const LmItem *d) {
+        const uint64_t c0 = d->c0; const uint32_t clen = d->clen;
+#pragma unroll
+        for (int u = 0; u < LM_U; ++u) {                                                   // (a lane past the chunk's end reads the last posting again: never scored)
+            const uint32_t g = u * LM_NT + tid;
+            const uint64_t e = c0 + (g < clen ? g : clen - 1);
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.codes + e * 48);
+            const uint2 w = *reinterpret_cast<const uint2 *>(a.codes + e * 48 + 16);
+            cw[u][0] = v.x; cw[u][1] = v.y; cw[u][2] = v.z; cw[u][3] = v.w; cw[u][4] = w.x; cw[u][5] = w.y;
+        }
+    };
     tile_load(&ctl[0], 0, 0);
-    tile_store(0);                                                                       // (visible after the first item's codes are requested: the barrier below)
+    tile_store(0);                                                                       // (visible after the barrier at the first item's top)
+#pragma unroll
+    for (int u = 0; u < LM_U; ++u)
+#pragma unroll
+        for (int w = 0; w < 12; ++w) cw[u][w] = 0;
+    codes_lo(&ctl[0]);
     int s = 0;
+    bool first = true;
     for (;;) {
         const LmItem *it = &ctl[s];
         const uint64_t c0 = it->c0;
         const uint32_t clen = it->clen, pqn = it->pqn, npair = (pqn + 1) >> 1;           // clen <= LM_NT * LM_U, pqn >= 1
-        const uint32_t upass = (clen + LM_NT - 1) / LM_NT;
         uint32_t t2 = 0;
-        if (wave == 0) {
-            if (nxt < n_items && lane < 32) dreg = reinterpret_cast<const uint32_t *>(a.items + nxt)[lane];
-            if (lane == 0) t2 = atomicAdd(a.work, 1u);
+        if (wave == 0) {                                                                  // (unconditional loads: a load under a branch is waited for where the branch ends)
+            dreg = reinterpret_cast<const uint32_t *>(a.items + (nxt < n_items ? nxt : n_items - 1))[lane & 31];
+            if (lane == 0) t2 = atomicAdd(work, 1u);
         }
-        // the chunk's codes and ids: once, into registers
-        uint32_t cw[LM_U][12];
         uint32_t idv[LM_U];
         bool valid[LM_U];
 #pragma unroll
         for (int u = 0; u < LM_U; ++u) {
-            valid[u] = false; idv[u] = 0;
-#pragma unroll
-            for (int w = 0; w < 12; ++w) cw[u][w] = 0;
-            if ((uint32_t)u < upass) {
-                const uint32_t g = u * LM_NT + tid;
-                valid[u] = g < clen;
-                const uint64_t e = c0 + (valid[u] ? g : clen - 1);
-                const uint4 *cp = reinterpret_cast<const uint4 *>(a.codes + e * 48);
-#pragma unroll
-                for (int w = 0; w < 3; ++w) { const uint4 v = cp[w]; cw[u][4 * w] = v.x; cw[u][4 * w + 1] = v.y; cw[u][4 * w + 2] = v.z; cw[u][4 * w + 3] = v.w; }
-                idv[u] = a.ids[e];
-            }
+            const uint32_t g = u * LM_NT + tid;
+            valid[u] = g < clen;
+            const uint64_t e = c0 + (valid[u] ? g : clen - 1);
+            const uint2 w = *reinterpret_cast<const uint2 *>(a.codes + e * 48 + 24);
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.codes + e * 48 + 32);
+            cw[u][6] = w.x; cw[u][7] = w.y; cw[u][8] = v.x; cw[u][9] = v.y; cw[u][10] = v.z; cw[u][11] = v.w;
+            idv[u] = a.ids[e];
         }
         LPROF_T(0)
-        __syncthreads();                                                                 // the first tile of this item is in slot 0 (staged by the prologue or by the item before)
+        if (first) { __syncthreads(); first = false; }                                    // the first item's first tile (the others': staged before the last barrier of the item before)
         LPROF_T(1)
         bool more_items = false;
         for (uint32_t j = 0; j < npair; ++j) {
@@ -679,16 +696,12 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
                 bool more = true;
                 if (t == 0) {
                     tile_load(it, j, 1);
-                    if (lastpair && wave == 0) {                                         // the next item's record: visible to everybody after this half's barrier
-                        if (nxt < n_items && lane < 32) reinterpret_cast<uint32_t *>(&ctl[s ^ 1])[lane] = dreg;
-                        if (lane == 0) *has_next = nxt < n_items ? 1u : 0u;
-                    }
                 } else if (!lastpair) {
                     tile_load(it, j + 1, 0);
                 } else {
                     more_items = *has_next != 0;
                     more = more_items;
-                    if (more) tile_load(&ctl[s ^ 1], 0, 0);
+                    if (more) { tile_load(&ctl[s ^ 1], 0, 0); codes_lo(&ctl[s ^ 1]); }
                 }
                 const unsigned char *tb = smem + t * LM_TILE;
 #pragma unroll
@@ -717,6 +730,10 @@ __global__ __launch_bounds__(LM_NT) void adc_list_kernel(const LmArgs a) {
                 }
                 LPROF_T(2)
                 if (more) tile_store(t ^ 1);
+                if (t == 0 && lastpair && wave == 0) {                                   // the next item's record: visible to everybody after this half's barrier
+                    if (lane < 32) reinterpret_cast<uint32_t *>(&ctl[s ^ 1])[lane] = dreg;    // (here, where the tile's loads are waited for anyway)
+                    if (lane == 0) *has_next = nxt < n_items ? 1u : 0u;
+                }
                 LPROF_T(3)
                 __syncthreads();
                 LPROF_T(4)
@@ -956,12 +973,14 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             const uint32_t m = (nq - b) < L.lm_chunk ? (nq - b) : L.lm_chunk;
             const float *qb = d_q + (size_t)b * s->dim;
             const uint32_t *pids = probe_ids + (size_t)b * nprobe, *pcnt = probe_cnt + b;
-            SHODH_HIP_TRY(hipMemsetAsync(lcnt, 0, (size_t)(s->P + 1 + m) * 4, st));      // list counters + candidate counters (adjacent)
-            hipLaunchKernelGGL(adc_table_kernel, dim3((m + LM_TQ - 1) / LM_TQ, 12), dim3(1024), 0, st, qb, s->codebook, s->dim, m, tables);
+            // tables; list counters + work counter + candidate counters (adjacent) cleared: 12 * ceil(m / 8) * 1024 threads, P + 1 + m words
+            const uint32_t n_zero = s->P + 1 + m, tgx = (m + LM_TQ - 1) / LM_TQ;
+            if ((uint64_t)tgx * 12 * 1024 < n_zero) SHODH_HIP_TRY(hipMemsetAsync(lcnt, 0, (size_t)n_zero * 4, st));      // (few queries, many lists)
+            hipLaunchKernelGGL(adc_table_kernel, dim3(tgx, 12), dim3(1024), 0, st, qb, s->codebook, s->dim, m, tables, lcnt, n_zero);
             NearArgs na{tables, s->list_off, s->ids, s->codes, pids, pcnt, nprobe, k, cap_near, s->P, bound_max, bound, lcnt};
             hipLaunchKernelGGL(adc_bound_kernel, dim3(m), dim3(LM_NEAR_NT), lds_near, st, na);
             const uint32_t np = m * nprobe;
-            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)lcnt, s->list_off, s->P, pair_off, cursor, item_off, items);
+            hipLaunchKernelGGL(lm_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)lcnt, s->list_off, s->P, pair_off, cursor, item_off);
             hipLaunchKernelGGL(lm_fill_kernel, dim3((np + 255) / 256), dim3(256), 0, st, pids, pcnt, m, nprobe, s->P, s->list_off, (const uint32_t *)pair_off, (const uint32_t *)item_off, (const uint64_t *)bound, cursor, items);
             // one workgroup per CU (96 KiB of LDS each) walks the items; lcnt[P] (zeroed with the list counters, not a list) is the shared work counter
             LmArgs la{tables, s->ids, s->codes, items, item_off + s->P, lcnt + s->P, cand_cap, cand, cand_cnt};
