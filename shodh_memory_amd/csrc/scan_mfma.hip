@@ -166,7 +166,11 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const uint32_t q_local = wave * 32 + l31;      // this lane's query within the pass
     // a wave whose 32 queries are all padding (small batches: a single query leaves seven of the eight) multiplies nothing:
     // it only keeps its share of the DMA and the barriers, so a small batch costs the bytes, not the MFMA work of a full one
+#ifdef SHODH_DIAG
+    const bool active = (uint32_t)(pass * MF_BPAD + wave * 32) < a.nq && !(a.ablate & 32u);      // (diagnostics, bit 32: the stream alone -- DMA, waits, barriers -- no multiplication)
+#else
     const bool active = (uint32_t)(pass * MF_BPAD + wave * 32) < a.nq;      // wave-uniform
+#endif
     if (MODE == MF_MODE_EMIT && tid < MF_BPAD) {
         qcount[tid] = 0;
         // this workgroup's private candidate slots of query tid start out empty (nobody else writes them)
@@ -501,7 +505,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PROF_T(5)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+#ifndef SHODH_NO_TILE_BARRIER      // (diagnostic builds: what the per-tile barrier costs; results invalid)
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         PROF_T(6)
         PROF_N(7)
