@@ -80,6 +80,10 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
                          uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext, uint32_t *stats_mirror);
+bool probe_select_supported(uint64_t n_rows, uint32_t dim, uint32_t k, uint32_t order, bool has_deleted, const MfmaPlan &p);
+int launch_probe_select_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const float *d_q, uint32_t nq, uint32_t k, uint32_t id_base,
+                                 float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                                 uint32_t *stats_ext);
 int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
                          uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
@@ -382,7 +386,9 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
     fc->used_mfma = use_mfma(idx, nq, k);
     MfmaPlan p{};
     if (fc->used_mfma) { p = mfma_plan(idx->n, dim, nq, k, idx->cus); p.set_only = idx->probe_set_mode ? 1u : 0u; }
-    fc->solo = fc->used_mfma && solo_supported(nq, k, idx->n, idx->cus, p);
+    // IVF probe selection on the private centroid index: scores of the whole table + one wave per query (scan_mfma.hip, probe_select_kernel)
+    const bool psel = fc->used_mfma && probe_select_supported(idx->n, dim, k, idx->cfg.order, del != nullptr, p);
+    fc->solo = fc->used_mfma && !psel && solo_supported(nq, k, idx->n, idx->cus, p);
     hipEvent_t *rk = w->ring[w->ring_pos % Workspace::RING];
     hipEvent_t rk0 = nullptr, rk1 = nullptr;
     if (kernel_events) {
@@ -399,7 +405,11 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
         fc->sampled_rows = fc->solo ? 0u : p.n_sel_tiles * 64u;
         const size_t part_bytes = exact_partial_bytes(nq, dim, k, fc->gx);
         SHODH_TRY(w->reserve(fc->ws_bytes + part_bytes + 256));
-        if (fc->solo) {     // one query: a single pass over the shadow copy with workgroup-local thresholds
+        if (psel) {
+            fc->sampled_rows = 0;
+            SHODH_TRY(launch_probe_select_pipeline(idx->rows, idx->rows_h, idx->n, dim, d_q, nq, k, idb, idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stats_ext));
+            if (stage_events) { SHODH_HIP_TRY(hipEventRecord(w->ev[1], st)); SHODH_HIP_TRY(hipEventRecord(w->ev[2], st)); }
+        } else if (fc->solo) {     // one query: a single pass over the shadow copy with workgroup-local thresholds
             SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, p, w->buf, fc->offs,
                                            w->solo_cnt, idx->cus, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
                                             stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext, stats_mirror));
@@ -411,7 +421,7 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
         // exact scan of whatever the pre-scan could not settle (device-side list; normally empty). A host-pointer call looks at the
         // statistics after its synchronisation and enqueues it only then, if at all.
         fc->deferred = host_call && stats_ext != nullptr;
-        if (!fc->deferred) SHODH_TRY(enqueue_flat_fallback(idx, w, *fc, d_q, nq, k, d_ids, d_dist, d_counts, st));
+        if (!fc->deferred && !psel) SHODH_TRY(enqueue_flat_fallback(idx, w, *fc, d_q, nq, k, d_ids, d_dist, d_counts, st));      // (probe selection settles every query itself)
     } else {
         const uint32_t gx = exact_grid_x(idx->n, nq, k, idx->cus);
         SHODH_TRY(w->reserve(exact_partial_bytes(nq, dim, k, gx) + 256));

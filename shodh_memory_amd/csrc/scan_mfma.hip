@@ -40,6 +40,7 @@ namespace shodh {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int MF_WQ_CAP = 120;    // LDS emit-queue entries per WAVE (8 private queues per workgroup); 128 until the dynamic threshold needed 3 KiB of LDS
 constexpr int MF_EQ_CAP = 8 * MF_WQ_CAP;
@@ -58,7 +59,10 @@ constexpr int MF_DYN_REP = 4;    // ... and replicas of every query's level coun
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
 constexpr float MF_INV_SCALE2 = 1.0f / 65536.0f;   // acc -> score
 
-enum { MF_MODE_BLOCKMAX = 0, MF_MODE_EMIT = 1 };
+#ifdef SHODH_PROF
+__device__ unsigned long long g_scores_end_ticks = 0;      // when the last workgroup of the score pre-scan finished (s_memrealtime)
+#endif
+enum { MF_MODE_BLOCKMAX = 0, MF_MODE_EMIT = 1, MF_MODE_SCORES = 2 };      // SCORES: every score of the pass is written out (small tables: IVF probe selection, see probe_select_kernel)
 
 // build with SHODH_EXTRA_FLAGS=-DSHODH_PROF to print per-section wave cycles (s_memtime) of the scan kernel
 #ifdef SHODH_PROF
@@ -106,6 +110,10 @@ struct MfmaArgs {
     uint32_t *dpub;           // [passes*256]
     const uint32_t *dpar;     // [passes*256] x {K_B, step}
     uint32_t k;
+    // MF_MODE_SCORES: scores[(pass * 256 + query) * scores_ld + row] = s~ (true score scale), rows of whole tiles (scores_ld = tiles * 64; rows >= n_rows: whatever the
+    // slab's padding holds, the reader ignores them)
+    float *scores;
+    uint32_t scores_ld;
 };
 
 template <int KSTEPS>
@@ -438,6 +446,18 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             have_prev = true;
             prev_sel = sel;
             // (the queue is drained below, after the dynamic threshold's loads have been waited for)
+        } else if (MODE == MF_MODE_SCORES) {
+            // value r of a lane is row (r & 3) + 8 (r >> 2) + 4 hi of its block: four consecutive values are four consecutive rows -- one 16-byte store, and the two
+            // half-waves of a query fill 32 contiguous bytes per instruction
+            float *dst = a.scores + ((size_t)pass * MF_BPAD + q_local) * a.scores_ld + (size_t)sel * a.tile_stride * MF_TR + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4s v0, v1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v0[u] = acc0[4 * j + u] * MF_INV_SCALE2; v1[u] = acc1[4 * j + u] * MF_INV_SCALE2; }
+                *reinterpret_cast<f32x4s *>(dst + 8 * j) = v0;      // (non-temporal stores measured slower: 313 against 306 us per search in tools/psel_probe.py)
+                *reinterpret_cast<f32x4s *>(dst + 32 + 8 * j) = v1;
+            }
         } else {
             // sample pass: the maximum score of this query over the whole 64-row tile
             const uint64_t tile_row0 = (uint64_t)sel * a.tile_stride * MF_TR;
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * 4096);
         }
-        if (MODE != MF_MODE_EMIT && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;   // padding queries: defined values
+        if (MODE == MF_MODE_BLOCKMAX && lane < 32) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;   // padding queries: defined values
       }
         if (DYN && dyn_on && wave >= 6) {
             // (before the drain below: the look issued at the top of this tile is then the only memory operation of this wave in flight, and long landed)
@@ -522,6 +542,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const long long wc2_ = wall_clock64();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the clamped tail DMA before the LDS is released
+#ifdef SHODH_PROF
+    if (MODE == MF_MODE_SCORES && tid == 0) atomicMax(&g_scores_end_ticks, (unsigned long long)wall_clock64());
+#endif
     if (MODE == MF_MODE_EMIT) {
         if (have_prev && active) emit_block(acc1, (uint64_t)prev_sel * a.tile_stride * MF_TR + 32);   // (no maximum was folded for the last tile)
         drain();
@@ -1751,6 +1774,7 @@ template <int MODE>
 // separate hipEventRecord calls are extra packets in the stream and cost 3-5 us each between two kernels)
 static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     if (a.dim > 512) {
+        if constexpr (MODE == MF_MODE_SCORES) { set_error("MFMA scan: score output needs dim <= 512"); return SHODH_ERR_UNSUPPORTED; } else {
         dim3 grid((uint32_t)p.grid_x, p.passes * 2);
         if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
         static const int big_v1 = getenv("SHODH_BIG_SCAN_V1") ? atoi(getenv("SHODH_BIG_SCAN_V1")) : 0;      // diagnostic: 1 = the round-2 kernel (one wave per SIMD)
@@ -1788,6 +1812,7 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
 #undef SHODH_LAUNCH_BIG
         SHODH_HIP_TRY(hipGetLastError());
         return SHODH_OK;
+        }
     }
     const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 <= 160 * 1024) ? 3 : 2;      // == mfma_scan_nbuf<KSTEPS>()
     const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 32;
@@ -2263,6 +2288,284 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     const uint32_t nb_emit = (uint32_t)p.grid_x > (uint32_t)p.n_tiles ? (p.n_tiles ? (uint32_t)p.n_tiles : 1u) : (uint32_t)p.grid_x;   // = launch_scan's grid.x
     SHODH_TRY(launch_final_stage(rows, dim, d_q, nq, k, order, id_base, p, w, nb_emit, w.cand_cnt, nullptr, d_ids, d_dist, d_counts, st));
     if (ev_select_done) SHODH_HIP_TRY(hipEventRecord(ev_select_done, st));
+    return SHODH_OK;
+}
+
+// ---- IVF probe selection on a small table (round 6) ----------------------------------------------------------------------------------------------
+// SpannIndex::search asks the centroid table for the nprobe nearest partitions of every query (spann.rs:595-607) -- thousands of queries against a few
+// thousand rows, k <= 64 -- and only WHICH partitions come back reaches the result (set mode, FinalArgs::set_only). Through the general pipeline that was
+// seven launches and 117 us of configs[3]'s step (sample scan, threshold, emit scan, a 57-us final stage of 1024 four-wave workgroups, two empty fallback
+// launches): built for a corpus that does not fit anywhere, where a table of 4096 rows x 1024 queries is 16 MiB of scores. Here:
+//   1. mfma_scan_kernel<MF_MODE_SCORES>: the same pre-scan (same fp16 shadow, same error bound), every score written out;
+//   2. probe_select_kernel: four waves per query hold the query's scores in registers, find the k-th best, classify every row against
+//      kth +- 2 eps -- above: a sure member (at most k - 1 rows can score above kth + eps exactly); below: out; in between: scored in the reference's order
+//      (spann.rs:562-571: 1 - sum, strictly sequential: the products by everybody, the sum of a row by one thread) -- and write the k ids: the sure ones by approximate score, then the best of the
+//      rest by (distance, id). No overflow paths: an unquantisable query, or fewer rows than k, makes every row "in between" (sixteen rows per round, the k best
+//      kept across rounds), a table of near-equal rows likewise. Same sets as the final stage's set mode (tests/test_probe_select_gpu.py), 30 us.
+struct PselArgs {
+    const float *rows; uint32_t n_rows, dim, id_base;
+    const float *q; uint32_t nq, k;
+    const float *scores; uint32_t ld;
+    const float *qnorm; const uint32_t *unquantisable;
+    float eps_rel_maxnorm, eps_abs_a, maxnorm;
+    uint32_t *ids; float *dist; uint32_t *counts;
+};
+constexpr int PSEL_MAX_K = 64;
+constexpr int PSEL_NT = 256;         // four waves per query: a quarter of the scores each, and four waves per SIMD over the launch to hide one another's latencies
+constexpr int PSEL_LIST = 256;       // keys at or under the first bound ranked by counting (more -- ties -- : bisection)
+#ifndef SHODH_PSEL_RB      // (diagnostic builds time other shapes)
+#define SHODH_PSEL_RB 16
+#endif
+constexpr int PSEL_RB = SHODH_PSEL_RB;          // rows in between scored per sub-round (their products: PSEL_RB x (dim + 4) floats of LDS)
+
+__host__ __device__ inline size_t psel_lds_bytes(uint32_t dim, uint32_t rows_cap) {
+    return (size_t)dim * 4 + (size_t)PSEL_RB * (dim + 4) * 4 + 128 * 8 + 64 * 8 + (size_t)PSEL_LIST * 4 + (size_t)PSEL_NT * 4 + 64 + (((size_t)rows_cap * 2 + 15) & ~(size_t)15);
+}
+
+#ifdef SHODH_PROF      // (wall-clock phase timers: s_memrealtime, 10 ns ticks)
+#define WPROF_DECL long long wp_[5] = {0, 0, 0, 0, 0}, wq_ = wall_clock64(); const long long wt0_ = wq_;
+#define WPROF_T(i) { const long long t_ = wall_clock64(); wp_[i] += t_ - wq_; wq_ = t_; }
+#else
+#define WPROF_DECL
+#define WPROF_T(i)
+#endif
+template <int NV4>      // 16-byte groups of scores per thread: tables of up to 1024 * NV4 rows; row of value (j, tid, u) = 4 (256 j + tid) + u
+__global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);                                 // [dim]
+    float *prod = qs + a.dim;                                                    // [PSEL_RB][dim + 4] products q[i] * row[i] of the rows being scored
+    uint64_t *best = reinterpret_cast<uint64_t *>(prod + (size_t)PSEL_RB * (a.dim + 4));   // [128] exact keys: the best so far, this sub-round's
+    uint64_t *skeys = best + 128;                                                // [64] sure members' keys
+    uint32_t *klist = reinterpret_cast<uint32_t *>(skeys + 64);                  // [PSEL_LIST] keys at or under the first bound
+    uint32_t *mins = klist + PSEL_LIST;                                          // [PSEL_NT] thread minima
+    uint32_t *ctl = mins + PSEL_NT;                                              // [16] counters and hand-over words
+    uint16_t *rlist = reinterpret_cast<uint16_t *>(ctl + 16);                    // [rows] the rows in between
+    const uint32_t tid = threadIdx.x, q = blockIdx.x, n = a.n_rows, k = a.k, dim = a.dim, pitch = dim + 4;
+    WPROF_DECL
+    // the query (for the exact sums), this thread's scores as ascending order keys (a row past the table: 0xFFFFFFFF); everything requested before anything is used
+    uint32_t key[NV4][4];
+    {
+        const f32x4s *sp = reinterpret_cast<const f32x4s *>(a.scores + (size_t)q * a.ld);
+        const uint32_t g_max = a.ld / 4;
+        f32x4s v[NV4];
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) { const uint32_t g = j * PSEL_NT + tid; v[j] = sp[g < g_max ? g : 0]; }
+        for (uint32_t i = tid; i < dim; i += PSEL_NT) qs[i] = a.q[(size_t)q * dim + i];
+        if (tid < 16) ctl[tid] = tid == 1 ? 0xFFFFFFFFu : 0u;                      // [0] list count, [1] T0 / k-th key, [2] sure, [3] in between, [4 + i] bisection counts
+#pragma unroll
+        for (int j = 0; j < NV4; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) key[j][u] = (uint32_t)(4 * (j * PSEL_NT + tid) + u) < n ? order_key(-v[j][u]) : 0xFFFFFFFFu;
+    }
+    uint32_t lmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lmin = key[j][u] < lmin ? key[j][u] : lmin;
+    {   // the minimum of every four neighbouring threads: 64 group minima (ranking all 256 thread minima cost more than everything else together)
+        uint32_t g = lmin;
+        uint32_t o = (uint32_t)__shfl_xor((int)g, 1); g = o < g ? o : g;
+        o = (uint32_t)__shfl_xor((int)g, 2); g = o < g ? o : g;
+        if ((tid & 3u) == 0) mins[tid >> 2] = g;
+    }
+    const float qn = a.qnorm[q];
+    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;      // (threshold_kernel's expression)
+    const bool usual = !a.unquantisable[q] && k >= 1 && k <= n;                  // block-uniform. Otherwise every row is "in between"
+    __syncthreads();
+    WPROF_T(0)
+    float lo = -__builtin_inff(), hi = __builtin_inff();
+    if (usual) {
+        // k-th smallest key. First a bound: the k-th smallest of the 64 group minima (k distinct keys are at or under it: the first k groups hold rows, n >= 16 k; a group without rows holds 0xFFFFFFFF) ...
+        if (tid < 64) {
+            const uint32_t gm = mins[tid];
+            uint32_t rk = 0;
+            for (uint32_t t = 0; t < 64; t += 4) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(mins + t);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rk += (w[u] < gm) || (w[u] == gm && t + u < tid);
+            }
+            if (rk == k - 1) ctl[1] = gm;                                         // exactly one thread
+        }
+        __syncthreads();
+        const uint32_t T0 = ctl[1];
+        // ... then the keys at or under it (a few dozen), ranked by counting -- or bisected when ties make them many
+#pragma unroll
+        for (int j = 0; j < NV4; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (key[j][u] <= T0) { const uint32_t pos = atomicAdd(&ctl[0], 1u); if (pos < (uint32_t)PSEL_LIST) klist[pos] = key[j][u]; }
+        __syncthreads();
+        const uint32_t c = ctl[0];
+        if (c <= (uint32_t)PSEL_LIST) {
+            if (tid < c) {
+                const uint32_t v = klist[tid];
+                uint32_t r = 0;
+                for (uint32_t t = 0; t < c; ++t) { const uint32_t w = klist[t]; r += (w < v) || (w == v && t < tid); }
+                if (r == k - 1) ctl[1] = v;                                       // (one element has rank k - 1; T0 is at least it)
+            }
+            __syncthreads();
+        } else {
+            uint32_t blo = 0, bhi = T0;                  // smallest K with count(key <= K) >= k; block-uniform
+            for (uint32_t it = 0; blo < bhi; ++it) {
+                const uint32_t mid = blo + ((bhi - blo) >> 1);
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int j = 0; j < NV4; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cnt += key[j][u] <= mid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+                uint32_t *slot = &ctl[4 + (it % 3u)];                            // (three slots in turn: the one cleared here is the one read two rounds ago)
+                if ((tid & 63u) == 0) atomicAdd(slot, cnt);
+                if (tid == 0) ctl[4 + ((it + 1) % 3u)] = 0u;
+                __syncthreads();
+                if (*slot >= k) bhi = mid; else blo = mid + 1;
+            }
+            __syncthreads();
+            if (tid == 0) ctl[1] = blo;
+            __syncthreads();
+        }
+        const float kth = -order_key_inv(ctl[1]);
+        const float margin = 2.001f * eps + 1e-7f * __builtin_fabsf(kth);            // (final_stage_kernel's window)
+        lo = kth - margin; hi = kth + margin;
+    }
+    WPROF_T(1)
+    const uint32_t key_hi = order_key(-hi), key_lo = order_key(-lo);                 // score > hi <=> key < key_hi; score >= lo <=> key <= key_lo
+    // sure members -> skeys; rows in between -> rlist (in any order: what follows orders by key)
+#pragma unroll
+    for (int j = 0; j < NV4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t r = 4 * (j * PSEL_NT + tid) + u;
+            if (r < n && key[j][u] <= key_lo) {
+                if (key[j][u] < key_hi) {
+                    const uint32_t pos = atomicAdd(&ctl[2], 1u);
+                    if (pos < 64u) skeys[pos] = make_key(-100.0f + order_key_inv(key[j][u]), a.id_base + r);      // = make_key(-100 - s~, id): under every distance
+                } else {
+                    rlist[atomicAdd(&ctl[3], 1u)] = (uint16_t)r;
+                }
+            }
+        }
+    __syncthreads();
+    uint32_t n_sure = ctl[2];
+    const uint32_t n_amb = ctl[3];
+    if (k && n_sure > k - 1u) n_sure = k - 1u;                                       // (cannot happen: fewer than k rows score above the k-th best)
+    const uint32_t want = k > n_sure ? k - n_sure : 0u;                              // rows to take from the ones in between
+    WPROF_T(2)
+    // The rows in between, PSEL_RB at a time: the workgroup fetches them (whole rows, coalesced, all requested at once), every thread multiplies what it fetched,
+    // thread r then adds row r's products strictly in index order (spann.rs:562-571: one product, one add per element) and forms 1 - sum. The `want` best by
+    // (distance, id) are kept, in order, in best[0 .. have).
+    uint32_t have = 0;
+    const uint32_t d4 = dim / 4;
+    for (uint32_t r0 = 0; r0 < n_amb && want; r0 += PSEL_RB) {
+        const uint32_t nb = n_amb - r0 < (uint32_t)PSEL_RB ? n_amb - r0 : (uint32_t)PSEL_RB;
+        {                                                                            // PSEL_RB * 128 groups of four at most: eight per thread, all in flight
+            f32x4s cv[8];
+            uint32_t er[8], eg[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t e = u * PSEL_NT + tid, ec = e < nb * d4 ? e : nb * d4 - 1;
+                er[u] = ec / d4; eg[u] = ec - er[u] * d4;
+                cv[u] = *reinterpret_cast<const f32x4s *>(a.rows + (size_t)rlist[r0 + er[u]] * dim + 4 * eg[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u * PSEL_NT + tid < nb * d4) {
+                    const f32x4s w = *reinterpret_cast<const f32x4s *>(qs + 4 * eg[u]);
+                    f32x4s pr;
+                    pr[0] = w[0] * cv[u][0]; pr[1] = w[1] * cv[u][1]; pr[2] = w[2] * cv[u][2]; pr[3] = w[3] * cv[u][3];
+                    *reinterpret_cast<f32x4s *>(prod + (size_t)er[u] * pitch + 4 * eg[u]) = pr;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < (uint32_t)PSEL_RB) {
+            uint64_t mine = KEY_NONE;
+            if (tid < nb) {
+                const float *pp = prod + (size_t)tid * pitch;
+                float dot = 0.0f;
+                for (uint32_t g = 0; g < d4; g += 2) {
+                    const f32x4s p0 = *reinterpret_cast<const f32x4s *>(pp + 4 * g), p1 = *reinterpret_cast<const f32x4s *>(pp + 4 * g + 4);      // (dim % 8 == 0)
+                    dot = dot + p0[0]; dot = dot + p0[1]; dot = dot + p0[2]; dot = dot + p0[3];
+                    dot = dot + p1[0]; dot = dot + p1[1]; dot = dot + p1[2]; dot = dot + p1[3];
+                }
+                mine = make_key(1.0f - dot, a.id_base + (uint32_t)rlist[r0 + tid]);
+            }
+            best[64 + tid] = mine;
+        }
+        __syncthreads();
+        // merge: rank every kept key (threads 0 .. 63) and every new one (threads 64 .. 64 + PSEL_RB) among all of them (keys are unique: ids are); the `want` smallest stay
+        uint64_t kx = KEY_NONE;
+        if (tid < have) kx = best[tid];
+        else if (tid >= 64 && tid < 64 + nb) kx = best[tid];
+        uint32_t rkx = 0;
+        if (kx != KEY_NONE) {
+            for (uint32_t t = 0; t < have; ++t) rkx += best[t] < kx;
+            for (uint32_t t = 0; t < nb; ++t) rkx += best[64 + t] < kx;
+        }
+        const bool keep = kx != KEY_NONE && rkx < want;
+        __syncthreads();                                                             // everybody has read what it ranks
+        if (keep) best[rkx] = kx;
+        const uint32_t total = have + nb;
+        have = total < want ? total : want;                                          // (every key is real: the smallest `want` of `total` stay)
+        __syncthreads();
+    }
+    WPROF_T(3)
+    // the sure members in their order (rank by counting), then the kept ones (already in order)
+    if (tid < n_sure) {
+        const uint64_t v = skeys[tid];
+        uint32_t r = 0;
+        for (uint32_t t = 0; t < n_sure; ++t) r += skeys[t] < v;
+        a.ids[(size_t)q * k + r] = (uint32_t)v;
+        a.dist[(size_t)q * k + r] = order_key_inv((uint32_t)(v >> 32));
+    }
+    if (tid < have) {
+        const uint64_t v = best[tid];
+        a.ids[(size_t)q * k + n_sure + tid] = (uint32_t)v;
+        a.dist[(size_t)q * k + n_sure + tid] = order_key_inv((uint32_t)(v >> 32));
+    }
+    const uint32_t m = n_sure + have;
+    if (tid >= m && tid < k) { a.ids[(size_t)q * k + tid] = 0xFFFFFFFFu; a.dist[(size_t)q * k + tid] = __builtin_inff(); }
+    WPROF_T(4)
+#ifdef SHODH_PROF
+    if (tid == 0 && ((q % 97) == 5 || wp_[0] + wp_[1] + wp_[2] + wp_[3] + wp_[4] > 2200)) printf("psel q %u n_sure %u n_amb %u | start %lld after the score kernel's last workgroup, end %lld | load %lld kth %lld classify %lld rescore %lld out %lld (10 ns ticks)\n", q, n_sure, n_amb, wt0_ - (long long)g_scores_end_ticks, (long long)wall_clock64() - (long long)g_scores_end_ticks, wp_[0], wp_[1], wp_[2], wp_[3], wp_[4]);
+#endif
+    if (tid == 0) a.counts[q] = m;      // (no statistics: two same-address atomics per query were 18 of the kernel's 38 us at 1024 queries)
+}
+
+bool probe_select_supported(uint64_t n_rows, uint32_t dim, uint32_t k, uint32_t order, bool has_deleted, const MfmaPlan &p) {
+    const char *ev = getenv("SHODH_PROBE_SELECT");                    // tests / A-B runs (read per call): 0 = the general pipeline (set mode of the final stage)
+    const bool off = ev && atoi(ev) == 0;
+    return !off && p.set_only && order == SHODH_ORDER_SEQ_1M && k >= 1 && k <= (uint32_t)PSEL_MAX_K && n_rows >= 256 && n_rows >= 16ull * k && n_rows <= 8192 && dim <= 512 && (dim % 32) == 0 &&      /* (k groups of sixteen rows each hold a row: the first bound) */
+          
+           !has_deleted && (uint64_t)p.cand_cap * 2 >= ceil_div(n_rows, MF_TR) * MF_TR;      // (the scores live in the overflow lists' room: cand_cap u64 per query)
+}
+
+// convert_queries_kernel, score pre-scan, probe_select_kernel: three launches, nothing left over for the exact scan
+int launch_probe_select_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const float *d_q, uint32_t nq, uint32_t k, uint32_t id_base,
+                                 float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                                 uint32_t *stats_ext) {
+    MfmaWorkspace w;
+    unpack_workspace(w, ws_base, offs);
+    if (stats_ext) w.stats = stats_ext;
+    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
+    hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
+    const uint32_t ld = (uint32_t)(p.n_tiles * MF_TR);
+    float *scores = reinterpret_cast<float *>(w.cand);                             // [n_slots][ld] f32 <= [n_slots][cand_cap] u64
+    MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, nullptr, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, 1u, (uint32_t)p.n_tiles, 0u, nq, nullptr, nullptr, nullptr, nullptr, k, scores, ld};
+    SHODH_TRY(launch_scan<MF_MODE_SCORES>(a, p, (uint32_t)p.n_tiles, st));
+    const EpsCoef c = eps_coefficients(dim, SHODH_ORDER_SEQ_1M);
+    PselArgs s{rows, (uint32_t)n_rows, dim, id_base, d_q, nq, k, scores, ld, w.qnorm, w.fallback, c.rel * maxnorm, c.abs_a, maxnorm, d_ids, d_dist, d_counts};
+    const uint32_t nv4 = (uint32_t)ceil_div(n_rows, 4 * PSEL_NT);
+    const size_t lds = psel_lds_bytes(dim, nv4 * 4 * PSEL_NT);
+#define SHODH_LAUNCH_PSEL(NVV)                                                                                   \
+    do {                                                                                                         \
+        SHODH_TRY(ensure_dynamic_lds((const void *)probe_select_kernel<NVV>, lds));                              \
+        hipLaunchKernelGGL((probe_select_kernel<NVV>), dim3(nq), dim3(PSEL_NT), lds, st, s);                     \
+    } while (0)
+    if (nv4 <= 1) SHODH_LAUNCH_PSEL(1); else if (nv4 <= 2) SHODH_LAUNCH_PSEL(2); else if (nv4 <= 4) SHODH_LAUNCH_PSEL(4); else SHODH_LAUNCH_PSEL(8);
+#undef SHODH_LAUNCH_PSEL
+    SHODH_HIP_TRY(hipGetLastError());
     return SHODH_OK;
 }
 
