@@ -2307,7 +2307,7 @@ struct PselArgs {
     const float *q; uint32_t nq, k;
     const float *scores; uint32_t ld;
     const float *qnorm; const uint32_t *unquantisable;
-    float eps_rel_maxnorm, eps_abs_a, maxnorm;
+    float eps_rel_maxnorm, eps_abs_a, maxnorm, eps2_rel_maxnorm, eps2_abs_a;
     uint32_t *ids; float *dist; uint32_t *counts;
 };
 constexpr int PSEL_MAX_K = 64;
@@ -2318,8 +2318,14 @@ constexpr int PSEL_LIST = 256;       // keys at or under the first bound ranked 
 #endif
 constexpr int PSEL_RB = SHODH_PSEL_RB;          // rows in between scored per sub-round (their products: PSEL_RB x (dim + 4) floats of LDS)
 
+constexpr int PSEL_R2 = 64;          // level 2: rows whose f32 score is formed per sub-round (their partial sums: PSEL_R2 x dim / 4 floats of the same LDS)
+constexpr int PSEL_K2 = 512;         // level 2 takes up to this many rows in between (more: they are all scored exactly)
+__host__ __device__ inline size_t psel_region_floats(uint32_t dim) {
+    const size_t a = (size_t)PSEL_RB * (dim + 4), b = (size_t)PSEL_R2 * (dim / 4);
+    return a > b ? a : b;
+}
 __host__ __device__ inline size_t psel_lds_bytes(uint32_t dim, uint32_t rows_cap) {
-    return (size_t)dim * 4 + (size_t)PSEL_RB * (dim + 4) * 4 + 128 * 8 + 64 * 8 + (size_t)PSEL_LIST * 4 + (size_t)PSEL_NT * 4 + 64 + (((size_t)rows_cap * 2 + 15) & ~(size_t)15);
+    return (size_t)dim * 4 + psel_region_floats(dim) * 4 + 128 * 8 + 64 * 8 + 64 * 8 + (size_t)PSEL_LIST * 4 + 64 * 4 + (size_t)PSEL_K2 * 4 + 64 + (((size_t)rows_cap * 2 + 15) & ~(size_t)15);
 }
 
 #ifdef SHODH_PROF      // (wall-clock phase timers: s_memrealtime, 10 ns ticks)
@@ -2334,13 +2340,16 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);                                 // [dim]
     float *prod = qs + a.dim;                                                    // [PSEL_RB][dim + 4] products q[i] * row[i] of the rows being scored
-    uint64_t *best = reinterpret_cast<uint64_t *>(prod + (size_t)PSEL_RB * (a.dim + 4));   // [128] exact keys: the best so far, this sub-round's
+    uint64_t *best = reinterpret_cast<uint64_t *>(prod + psel_region_floats(a.dim));       // [128] exact keys: the best so far, this sub-round's
     uint64_t *skeys = best + 128;                                                // [64] sure members' keys
-    uint32_t *klist = reinterpret_cast<uint32_t *>(skeys + 64);                  // [PSEL_LIST] keys at or under the first bound
-    uint32_t *mins = klist + PSEL_LIST;                                          // [PSEL_NT] thread minima
-    uint32_t *ctl = mins + PSEL_NT;                                              // [16] counters and hand-over words
+    uint64_t *s2keys = skeys + 64;                                               // [64] level 2: sure by their f32 score
+    uint32_t *klist = reinterpret_cast<uint32_t *>(s2keys + 64);                 // [PSEL_LIST] keys at or under the first bound; level 2: the rows still in between
+    uint32_t *mins = klist + PSEL_LIST;                                          // [64] group minima
+    uint32_t *k2 = mins + 64;                                                    // [PSEL_K2] level 2: order keys of the f32 scores of the rows in between
+    uint32_t *ctl = k2 + PSEL_K2;                                                // [16] counters and hand-over words
     uint16_t *rlist = reinterpret_cast<uint16_t *>(ctl + 16);                    // [rows] the rows in between
     const uint32_t tid = threadIdx.x, q = blockIdx.x, n = a.n_rows, k = a.k, dim = a.dim, pitch = dim + 4;
+    const uint32_t d4inv = ((1u << 20) + dim / 4 - 1) / (dim / 4);                   // e / (dim / 4) = (e * d4inv) >> 20 for e < 2^13
     WPROF_DECL
     // the query (for the exact sums), this thread's scores as ascending order keys (a row past the table: 0xFFFFFFFF); everything requested before anything is used
     uint32_t key[NV4][4];
@@ -2351,7 +2360,7 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
 #pragma unroll
         for (int j = 0; j < NV4; ++j) { const uint32_t g = j * PSEL_NT + tid; v[j] = sp[g < g_max ? g : 0]; }
         for (uint32_t i = tid; i < dim; i += PSEL_NT) qs[i] = a.q[(size_t)q * dim + i];
-        if (tid < 16) ctl[tid] = tid == 1 ? 0xFFFFFFFFu : 0u;                      // [0] list count, [1] T0 / k-th key, [2] sure, [3] in between, [4 + i] bisection counts
+        if (tid < 16) ctl[tid] = tid == 1 ? 0xFFFFFFFFu : 0u;                      // [0] list count, [1] T0 / k-th key, [2] sure, [3] in between, [4 .. 6] bisection counts, [7] level-2 key, [8] sure by it, [9] still in between
 #pragma unroll
         for (int j = 0; j < NV4; ++j)
 #pragma unroll
@@ -2448,15 +2457,86 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
         }
     __syncthreads();
     uint32_t n_sure = ctl[2];
-    const uint32_t n_amb = ctl[3];
+    const uint32_t n_amb0 = ctl[3];
     if (k && n_sure > k - 1u) n_sure = k - 1u;                                       // (cannot happen: fewer than k rows score above the k-th best)
-    const uint32_t want = k > n_sure ? k - n_sure : 0u;                              // rows to take from the ones in between
+    uint32_t want = k > n_sure ? k - n_sure : 0u;                                    // rows to take from the ones in between
+    uint32_t n_amb = n_amb0, n_sure2 = 0;
     WPROF_T(2)
+    // Level 2 (final_stage_kernel's, for the same reason): the band of the fp16 pre-scan is ~1e-3 wide and on a trained table most of the k nearest lie inside
+    // it (configs[3]: 50 - 90 rows in between per query, ten sure) -- and every one of them would cost a 384-step dependent chain. An f32 score s2 (FMA, any
+    // order: |s2 - dot_ref| <= eps2 ~ dim 2^-23 |q| maxnorm, twenty times tighter) of each such row, formed in parallel, settles all but the few within 2 eps2
+    // of the want-th best s2: above -> a member for sure, below -> out, only the rest is summed in the reference's order.
+    const uint32_t d4 = dim / 4;
+    if (want && n_amb > (uint32_t)PSEL_RB && n_amb <= (uint32_t)PSEL_K2) {            // block-uniform
+        float *psum = prod;                                                          // [PSEL_R2][d4] sums of four products
+        for (uint32_t r0 = 0; r0 < n_amb; r0 += PSEL_R2) {
+            const uint32_t nb = n_amb - r0 < (uint32_t)PSEL_R2 ? n_amb - r0 : (uint32_t)PSEL_R2, ng = nb * d4;
+            for (uint32_t e0 = 0; e0 < ng; e0 += 8 * PSEL_NT) {
+                f32x4s cv[8];
+                uint32_t ee[8], eg[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t e = e0 + u * PSEL_NT + tid, ec = e < ng ? e : ng - 1, er = (ec * d4inv) >> 20;      // (= ec / d4: exact for ec < 2^13, d4 <= 128)
+                    ee[u] = ec; eg[u] = ec - er * d4;
+                    cv[u] = *reinterpret_cast<const f32x4s *>(a.rows + (size_t)rlist[r0 + er] * dim + 4 * eg[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (e0 + u * PSEL_NT + tid < ng) {
+                        const f32x4s w = *reinterpret_cast<const f32x4s *>(qs + 4 * eg[u]);
+                        float p = w[0] * cv[u][0];
+                        p = __builtin_fmaf(w[1], cv[u][1], p); p = __builtin_fmaf(w[2], cv[u][2], p); p = __builtin_fmaf(w[3], cv[u][3], p);
+                        psum[ee[u]] = p;                                              // (row er, group eg: index er * d4 + eg = ec)
+                    }
+                }
+            }
+            __syncthreads();
+            {   // four threads per row: a quarter of its group sums each, then the four quarters (a fixed order: the same bits every run)
+                const uint32_t row = tid >> 2, part = tid & 3u, per = d4 / 4;
+                float acc = 0.0f;
+                if (row < nb) { const float *pp = psum + (size_t)row * d4 + part * per; for (uint32_t g = 0; g < per; ++g) acc += pp[g]; }
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (row < nb && part == 0) k2[r0 + row] = order_key(-acc);
+            }
+            __syncthreads();
+        }
+        // the want-th best s2 (rank by counting), the band around it, the rows above / inside it
+        for (uint32_t i = tid; i < n_amb; i += PSEL_NT) {
+            const uint32_t v = k2[i];
+            uint32_t r = 0;
+            for (uint32_t t = 0; t < n_amb; ++t) { const uint32_t w = k2[t]; r += (w < v) || (w == v && t < i); }
+            if (r == want - 1) ctl[7] = v;
+        }
+        __syncthreads();
+        const float t2 = -order_key_inv(ctl[7]);
+        const float eps2 = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f;      // (threshold_kernel's expression)
+        const float m2 = 2.001f * eps2 + 1e-7f * __builtin_fabsf(t2);
+        const uint32_t key_hi2 = order_key(-(t2 + m2)), key_lo2 = order_key(-(t2 - m2));
+        for (uint32_t i = tid; i < n_amb; i += PSEL_NT) {
+            const uint32_t v = k2[i], r = rlist[i];
+            if (v < key_hi2) {
+                const uint32_t pos = atomicAdd(&ctl[8], 1u);
+                if (pos < 64u) s2keys[pos] = make_key(-50.0f + order_key_inv(v), a.id_base + r);      // = make_key(-50 - s2, id): after the sure members, before every distance
+            } else if (v <= key_lo2) {
+                const uint32_t pos = atomicAdd(&ctl[9], 1u);
+                if (pos < (uint32_t)PSEL_LIST) klist[pos] = r;
+            }
+        }
+        __syncthreads();
+        const uint32_t ns2 = ctl[8], nmid = ctl[9];
+        if (nmid <= (uint32_t)PSEL_LIST && ns2 < want) {                             // (otherwise -- hundreds of rows within 2 eps2: ties -- everything in between is summed exactly, as without level 2)
+            n_sure2 = ns2;
+            want -= ns2;
+            if (tid < nmid) rlist[tid] = (uint16_t)klist[tid];
+            n_amb = nmid;
+            __syncthreads();
+        }
+    }
     // The rows in between, PSEL_RB at a time: the workgroup fetches them (whole rows, coalesced, all requested at once), every thread multiplies what it fetched,
     // thread r then adds row r's products strictly in index order (spann.rs:562-571: one product, one add per element) and forms 1 - sum. The `want` best by
     // (distance, id) are kept, in order, in best[0 .. have).
     uint32_t have = 0;
-    const uint32_t d4 = dim / 4;
     for (uint32_t r0 = 0; r0 < n_amb && want; r0 += PSEL_RB) {
         const uint32_t nb = n_amb - r0 < (uint32_t)PSEL_RB ? n_amb - r0 : (uint32_t)PSEL_RB;
         {                                                                            // PSEL_RB * 128 groups of four at most: eight per thread, all in flight
@@ -2465,7 +2545,7 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t e = u * PSEL_NT + tid, ec = e < nb * d4 ? e : nb * d4 - 1;
-                er[u] = ec / d4; eg[u] = ec - er[u] * d4;
+                er[u] = (ec * d4inv) >> 20; eg[u] = ec - er[u] * d4;
                 cv[u] = *reinterpret_cast<const f32x4s *>(a.rows + (size_t)rlist[r0 + er[u]] * dim + 4 * eg[u]);
             }
 #pragma unroll
@@ -2519,16 +2599,23 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
         a.ids[(size_t)q * k + r] = (uint32_t)v;
         a.dist[(size_t)q * k + r] = order_key_inv((uint32_t)(v >> 32));
     }
+    if (tid < n_sure2) {
+        const uint64_t v = s2keys[tid];
+        uint32_t r = 0;
+        for (uint32_t t = 0; t < n_sure2; ++t) r += s2keys[t] < v;
+        a.ids[(size_t)q * k + n_sure + r] = (uint32_t)v;
+        a.dist[(size_t)q * k + n_sure + r] = order_key_inv((uint32_t)(v >> 32));
+    }
     if (tid < have) {
         const uint64_t v = best[tid];
-        a.ids[(size_t)q * k + n_sure + tid] = (uint32_t)v;
-        a.dist[(size_t)q * k + n_sure + tid] = order_key_inv((uint32_t)(v >> 32));
+        a.ids[(size_t)q * k + n_sure + n_sure2 + tid] = (uint32_t)v;
+        a.dist[(size_t)q * k + n_sure + n_sure2 + tid] = order_key_inv((uint32_t)(v >> 32));
     }
-    const uint32_t m = n_sure + have;
+    const uint32_t m = n_sure + n_sure2 + have;
     if (tid >= m && tid < k) { a.ids[(size_t)q * k + tid] = 0xFFFFFFFFu; a.dist[(size_t)q * k + tid] = __builtin_inff(); }
     WPROF_T(4)
 #ifdef SHODH_PROF
-    if (tid == 0 && ((q % 97) == 5 || wp_[0] + wp_[1] + wp_[2] + wp_[3] + wp_[4] > 2200)) printf("psel q %u n_sure %u n_amb %u | start %lld after the score kernel's last workgroup, end %lld | load %lld kth %lld classify %lld rescore %lld out %lld (10 ns ticks)\n", q, n_sure, n_amb, wt0_ - (long long)g_scores_end_ticks, (long long)wall_clock64() - (long long)g_scores_end_ticks, wp_[0], wp_[1], wp_[2], wp_[3], wp_[4]);
+    if (tid == 0 && k > 1 && ((q % 97) == 5 || wp_[0] + wp_[1] + wp_[2] + wp_[3] + wp_[4] > 2200)) printf("psel q %u n_sure %u n_amb %u | start %lld after the score kernel's last workgroup, end %lld | load %lld kth %lld classify %lld rescore %lld out %lld (10 ns ticks)\n", q, n_sure, n_amb0, wt0_ - (long long)g_scores_end_ticks, (long long)wall_clock64() - (long long)g_scores_end_ticks, wp_[0], wp_[1], wp_[2], wp_[3], wp_[4]);
 #endif
     if (tid == 0) a.counts[q] = m;      // (no statistics: two same-address atomics per query were 18 of the kernel's 38 us at 1024 queries)
 }
@@ -2555,7 +2642,7 @@ int launch_probe_select_pipeline(const float *rows, const _Float16 *rows_h, uint
     MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, nullptr, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, 1u, (uint32_t)p.n_tiles, 0u, nq, nullptr, nullptr, nullptr, nullptr, k, scores, ld};
     SHODH_TRY(launch_scan<MF_MODE_SCORES>(a, p, (uint32_t)p.n_tiles, st));
     const EpsCoef c = eps_coefficients(dim, SHODH_ORDER_SEQ_1M);
-    PselArgs s{rows, (uint32_t)n_rows, dim, id_base, d_q, nq, k, scores, ld, w.qnorm, w.fallback, c.rel * maxnorm, c.abs_a, maxnorm, d_ids, d_dist, d_counts};
+    PselArgs s{rows, (uint32_t)n_rows, dim, id_base, d_q, nq, k, scores, ld, w.qnorm, w.fallback, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a, d_ids, d_dist, d_counts};
     const uint32_t nv4 = (uint32_t)ceil_div(n_rows, 4 * PSEL_NT);
     const size_t lds = psel_lds_bytes(dim, nv4 * 4 * PSEL_NT);
 #define SHODH_LAUNCH_PSEL(NVV)                                                                                   \

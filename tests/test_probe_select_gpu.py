@@ -96,3 +96,18 @@ def test_equal_to_the_general_pipeline_and_nearest_centroid(S, oracle, monkeypat
     assign, _ = idx.encode(new)
     for i in range(0, len(new), 7):
         assert assign[i] == oracle.spann_find_nearest_centroid(new[i], c)
+
+
+def test_band_full_of_rows_takes_the_f32_level(S, oracle, monkeypatch):
+    """a trained table's shape: hundreds of rows inside the fp16 band around the k-th best (configs[3]: 50 - 90 per query), a handful inside the f32 band --
+    the rows in between get an f32 score first and only the ones it cannot settle are summed in the reference's order"""
+    monkeypatch.delenv("SHODH_PROBE_SELECT", raising=False)
+    rng = np.random.default_rng(21)
+    base = unit(rng.standard_normal((2, 384)))
+    tab = np.concatenate([unit(base[0] + f32(0.01) * rng.standard_normal((300, 384)).astype(f32)), unit(rng.standard_normal((600, 384))),
+                          unit(base[1] + f32(0.004) * rng.standard_normal((124, 384)).astype(f32))])
+    tab = tab[rng.permutation(len(tab))]
+    st = one_posting_state(tab)
+    q = np.concatenate([base, unit(base + f32(0.02) * rng.standard_normal((2, 384)).astype(f32)), unit(rng.standard_normal((4, 384)))])
+    for nprobe in (1, 10, 32, 64):
+        check(oracle, index_of(S, st, nprobe), st, q, nprobe, nprobe)
