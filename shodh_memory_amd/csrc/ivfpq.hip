@@ -338,7 +338,8 @@ typedef float f32x2q __attribute__((ext_vector_type(2)));
 constexpr int LM_NT = 1024, LM_U = SHODH_LM_U, LM_QB = SHODH_LM_QB, LM_MT = 24;
 constexpr bool LM_PRUNE = SHODH_LM_PRUNE;      // partial-sum pruning (see adc_list_kernel)
 constexpr int LM_TILE = LM_MT * 256 * 8;                       // 48 KiB: 24 sub-quantisers x 256 entries x 2 queries
-constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM)
+constexpr int LM_CANDS = 4096;                                  // candidate keys per query (HBM). (Round 6, 32768 instead: the one query in a thousand with a loose bound --
+                                                                // 29 727 candidates at configs[3] -- then costs the merge kernel 84 us where its redo costs 45 + 10.)
 #ifndef SHODH_LM_WG_PER_CU
 #define SHODH_LM_WG_PER_CU 1
 #endif
@@ -1001,6 +1002,16 @@ int ivfpq_search(IvfpqState *s, const shodh_index_cfg &cfg, const float *d_q, ui
             hipLaunchKernelGGL(lm_overflow_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)cand_cnt, m, cand_cap, redo_list, redo_list + m);
             AdcArgs a2{qb, s->codebook, s->list_off, s->ids, s->codes, pids, pcnt, m, s->dim, s->M, s->ncent, nprobe, k, cap_redo, LM_REDO_SPLIT, redo, redo_list, redo_list + m, tables};
             hipLaunchKernelGGL((adc_scan_kernel<true, ADC_NT, true>), dim3(LM_REDO_COLS, LM_REDO_SPLIT), dim3(ADC_NT), lds_redo, st, a2);
+            {
+                static const bool dbg = getenv("SHODH_ADC_DEBUG") && atoi(getenv("SHODH_ADC_DEBUG")) != 0;      // diagnostics: how many queries were redone, the largest candidate list
+                if (dbg) {
+                    std::vector<uint32_t> hc(m + 1), hr(1);
+                    hipStreamSynchronize(st); hipMemcpy(hc.data(), cand_cnt, (size_t)m * 4, hipMemcpyDeviceToHost); hipMemcpy(hr.data(), redo_list + m, 4, hipMemcpyDeviceToHost);
+                    uint32_t mx = 0, mq = 0; uint64_t sum = 0;
+                    for (uint32_t i = 0; i < m; ++i) { sum += hc[i]; if (hc[i] > mx) { mx = hc[i]; mq = i; } }
+                    fprintf(stderr, "[adc] %u queries: candidates mean %.1f max %u (query %u), cap %u, redone %u\n", m, (double)sum / m, mx, mq, cand_cap, hr[0]);
+                }
+            }
             LmMergeArgs mm{cand, cand_cnt, redo, k, cap, cand_cap, LM_REDO_SPLIT, d_ids + (size_t)b * k, d_dist + (size_t)b * k, d_counts + b};
             hipLaunchKernelGGL(lm_merge_kernel, dim3(m), dim3(256), mlds2, st, mm);
             SHODH_HIP_TRY(hipGetLastError());
