@@ -111,3 +111,21 @@ def test_band_full_of_rows_takes_the_f32_level(S, oracle, monkeypatch):
     q = np.concatenate([base, unit(base + f32(0.02) * rng.standard_normal((2, 384)).astype(f32)), unit(rng.standard_normal((4, 384)))])
     for nprobe in (1, 10, 32, 64):
         check(oracle, index_of(S, st, nprobe), st, q, nprobe, nprobe)
+
+
+@pytest.mark.parametrize("dim", [128, 512])
+def test_other_dimensions(S, oracle, dim, monkeypatch):
+    """the score pre-scan's other instantiations (8 and 32 k-steps)"""
+    monkeypatch.delenv("SHODH_PROBE_SELECT", raising=False)
+    rng = np.random.default_rng(dim)
+    P = 1536
+    c = unit(rng.standard_normal((P, dim)))
+    c[5] = c[3]
+    c[40] = unit((c[41] + f32(1e-4) * rng.standard_normal(dim).astype(f32))[None])[0]
+    st = dict(centroids=c, codebook=(rng.standard_normal((dim // 8, 256, 8)) * 0.05).astype(f32), list_off=np.arange(P + 1, dtype=np.uint64),
+              ids=np.arange(P, dtype=np.uint32), codes=rng.integers(0, 256, (P, dim // 8), dtype=np.uint8))
+    q = np.concatenate([c[3:6], c[40:42], unit(rng.standard_normal((6, dim)))])
+    for nprobe in (1, 20, 64):
+        idx = S.SpannIndex(dim, num_probes=nprobe)
+        idx.set_trained_state(st["centroids"], st["codebook"], st["list_off"], st["ids"], st["codes"])
+        check(oracle, idx, st, q, nprobe, nprobe)
