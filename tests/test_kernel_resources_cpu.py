@@ -65,6 +65,12 @@ def test_scan_kernels_do_not_spill():
             assert res[k].get("spill", 0) == 0, (k, res[k])        # (the final stage keeps a small indexed array in scratch: not a spill)
     for k in find(res, "mfma_scan_big3_kernel"):                   # sixteen queries per wave: two waves per SIMD (that is the point of the shape)
         assert res[k]["vgprs"] <= 256, (k, res[k])
+    # IVF probe selection: four workgroups of four waves per CU (1024 queries in one round) -- 128 registers at most, nothing in scratch; the score pre-scan is
+    # the flat pre-scan's loop with another epilogue and must not spill either
+    for k in find(res, "probe_select_kernel"):
+        assert res[k]["vgprs"] <= 128 and res[k].get("scratch", 0) == 0 and res[k].get("spill", 0) == 0, (k, res[k])
+    for k in find(res, "mfma_scan_kernelILi2ELi24"):
+        assert res[k].get("spill", 0) == 0, (k, res[k])
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
