@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(NT) void final_stage_kernel(FinalArgs a) {
             PROF_T(3)
             // (set mode: the exact keys of the window in ekeys[0 .. nf), the sure members' placeholder keys -- all smaller -- at the end of ekeys)
             auto key_b = [&](uint64_t i) -> uint64_t { return i < nf ? ekeys[i] : ekeys[a.fcap - 1u - (uint32_t)(i - nf)]; };
-            const uint32_t m = block_select_topk<NT>(key_b, nf + n_sure, buf, mins);
+            const uint32_t m = block_select_topk<NT, true>(key_b, nf + n_sure, buf, mins);      // (one key per row of the window: unique)
             PROF_T(4)
 #ifdef SHODH_PROF
             if (tid == 0 && (q % 37) == 0) printf("final q %u n %u nf %u | load-q %lld selectA %lld window %lld rescore %lld selectB %lld\n", q, n, nf, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4]);
