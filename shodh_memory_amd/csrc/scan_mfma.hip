@@ -54,6 +54,19 @@ constexpr int MF_BPAD = 256;     // queries per pass
 #define SHODH_DYN_PERIOD 4
 #endif
 
+// The tile hand-over of mfma_scan_kernel. 0: one s_barrier per tile (rounds 1 - 5). Round 6: per-wave progress words in LDS instead -- the barrier made the eight
+// waves meet once per tile, and the older wave of every SIMD, which the arbiter favours, sat out ~2 200 of a tile's ~5 800 cycles waiting for its partner; a survivor block
+// in ANY wave delayed all eight (k = 120: most of what its survivors cost). What the barrier guaranteed is two facts, and each wave now checks only the one it needs,
+// where it needs it: (a) this tile's data has landed -- every wave, at the top of the tile, against the DMA waves' "landed" words; (b) the buffer the tile's DMA refills
+// is no longer read -- only the DMA waves, and with 2 only in the MIDDLE of the tile (the DMA pieces are issued during the second MFMA chain), against everybody's
+// "finished" words. Waves drift up to a tile apart; a value is only ever read after the fact it stands for (the writer's own counted wait / lgkmcnt(0) precedes the write).
+// Same results (every parity test), emit kernel 211 -> 203 us at k = 10, 231 -> 216 at k = 120 (same box; 1 without the late DMA: 209 / 234; 3, a first look at the
+// words a tile early: no change).
+#ifndef SHODH_MF_POLL
+#define SHODH_MF_POLL 2
+#endif
+constexpr bool MF_POLL = SHODH_MF_POLL != 0;
+constexpr bool MF_POLL_LATE = SHODH_MF_POLL >= 2;      // 2: the DMA of a tile is issued in its second half only, and the DMA waves look at the others' progress there, not at the top
 constexpr int MF_DYN_NB = 16;    // levels of the threshold that tightens DURING the emit scan (see "dynamic threshold" below)
 constexpr int MF_DYN_REP = 4;    // ... and replicas of every query's level counters (workgroup b adds to replica b % 4; the owner sums them): a query's counters are one hot line otherwise
 constexpr float MF_SCALE = 256.0f;                 // rows and queries are stored as fp16(256 x)
@@ -117,7 +130,7 @@ struct MfmaArgs {
 };
 
 template <int KSTEPS>
-__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 <= 160 * 1024) ? 3 : 2; }
+__host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 + 64 <= 160 * 1024) ? 3 : 2; }
 
 // 8 waves per workgroup (2 per SIMD), wave w owns queries [32w, 32w+32) as resident B fragments (dim/16 x 4 VGPRs).
 // Every wave runs ONE software-pipelined instruction stream per 64-row tile: 2*KSTEPS MFMAs (row block 0 into acc0 for all
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     uint32_t *dpar_l = qcount + MF_BPAD;     // [MF_BPAD][2] dynamic threshold: {K_B, step} of every query of the pass (kept for diagnostics; the lanes hold their own)
     uint32_t *pub_l = dpar_l + 2 * MF_BPAD;  // [MF_BPAD] ... and its published bound (MfmaArgs::dpub), refreshed by wave 7 once per tile (LDS-DMA)
     uint32_t *own_l = pub_l + MF_BPAD;       // [64] the counters of the queries this workgroup owns, refreshed by wave 6 once per tile (LDS-DMA)
+    uint32_t *sync_l = own_l + 64;           // [16] MF_POLL: [0 .. 3] tiles whose data waves 0-3 have seen land, [8 .. 15] tiles waves 0-7 have finished reading
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x;
@@ -353,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         }
     };
 
+    if (MF_POLL && tid < 16) sync_l[tid] = tid < 8 ? (uint32_t)PF : 0u;      // the prologue's PF tiles have landed (waited for below); nobody has finished a tile
     // the pipeline is primed: everything issued so far (DMA, query fragments, thresholds) lands before the stream starts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): hipcc's own loads, so that it does not re-wait for them inside the loop
@@ -377,6 +392,29 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         const unsigned char *psrc = uniform_ptr(rows_b + (size_t)psel * tile_bytes_g);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * TILE_BYTES));
 
+      if (MF_POLL) {
+        // Hand-over without a workgroup barrier (see the end of the tile): this tile's data must have landed (every DMA wave has seen its pieces of it land:
+        // sync_l[0 .. 3] > tile_no), and a DMA wave may refill the buffer of the tile before this one only when all eight waves are through with it
+        // (sync_l[8 .. 15] >= tile_no). One read per poll: lane l looks at word l.
+        const uint32_t need = (lane < 4) ? tile_no + 1u : ((!MF_POLL_LATE && lane >= 8 && lane < 16 && wave < 4) ? tile_no : 0u);
+        const uint32_t paddr = smem_lds + (uint32_t)((unsigned char *)sync_l - smem) + (uint32_t)(lane & 15) * 4u;
+        for (;;) {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(paddr) : "memory");
+            if (__builtin_amdgcn_ballot_w64(v >= need) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        PROF_T(8)
+      }
+      auto wait_others = [&]() {      // (MF_POLL_LATE, DMA waves) every wave has finished the tile before this one
+        const uint32_t paddr2 = smem_lds + (uint32_t)((unsigned char *)sync_l - smem) + (8u + (uint32_t)(lane & 7)) * 4u;
+        for (;;) {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(paddr2) : "memory");
+            if (__builtin_amdgcn_ballot_w64(v >= tile_no) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+      };
       if (DYN && dyn_on) {
         // dynamic threshold: the owner's counters (wave 6) and the published bounds of the pass (wave 7) by device-coherent LDS-DMA -- no destination
         // registers for the compiler to move around while the data is in flight -- issued now, waited for at the end of the tile (neither wave issues the
@@ -393,6 +431,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         }
         half8 ring[RING];
         auto rd = [&](int st) {
+#ifdef SHODH_HALF_LDS      // (diagnostic builds, results invalid: every second A fragment is not read -- is the LDS port what the chains wait for?)
+            if (st & 1) return;
+#endif
             const int rb = st / KSTEPS, ks = st % KSTEPS;
             ring[st % RING] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
         };
@@ -408,12 +449,19 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
 #pragma unroll
         for (int st = 0; st < KSTEPS; ++st) {
             rd(st + D);
+#ifdef SHODH_HALF_LDS
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(st & ~1) % RING], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
+#elif defined(SHODH_HALF_MFMA)      // (diagnostic builds, results invalid: every second multiplication left out, its fragment still read)
+            if (st & 1) asm volatile("" ::"v"(ring[st % RING]));
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
+#else
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
+#endif
             if (MODE == MF_MODE_EMIT) {
 #pragma unroll
                 for (int u = 0; u < PER1; ++u) if (st * PER1 + u < 16) m1 = fmaxf(m1, acc1[st * PER1 + u]);
             }
-            if ((st & 3) == 2 && (st >> 2) < NPC) {
+            if (!MF_POLL_LATE && (st & 3) == 2 && (st >> 2) < NPC) {
                 if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -423,17 +471,26 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (have_prev && __builtin_amdgcn_ballot_w64(m1 >= thr_l) != 0) emit_block(acc1, prow1);   // wave-uniform entry
         }
         PROF_T(2)
+        if (MF_POLL_LATE && wave < 4) { wait_others(); PROF_T(9) }      // the buffer this tile's DMA refills: everybody through with the tile before this one?
         // row block 1 -> acc1; in the shadows: maximum of acc0 (from two steps in: its last MFMA has to retire first)
 #pragma unroll
         for (int st = KSTEPS; st < NS; ++st) {
             if (st + D < NS) rd(st + D);
+#ifdef SHODH_HALF_LDS
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(st & ~1) % RING], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+#elif defined(SHODH_HALF_MFMA)
+            if (st & 1) asm volatile("" ::"v"(ring[st % RING]));
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+#else
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[st % RING], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
+#endif
             if (MODE == MF_MODE_EMIT && st >= KSTEPS + 2) {
 #pragma unroll
                 for (int u = 0; u < PER0; ++u) if ((st - KSTEPS - 2) * PER0 + u < 16) m0 = fmaxf(m0, acc0[(st - KSTEPS - 2) * PER0 + u]);
             }
-            if ((st & 3) == 2 && (st >> 2) < NPC) {
-                if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
+            if (MF_POLL_LATE ? ((st & 1) == 0 && ((st - KSTEPS) >> 1) < NPC) : ((st & 3) == 2 && (st >> 2) < NPC)) {
+                constexpr int dummy_ = 0; (void)dummy_;
+                if (wave < 4) { const int pi = MF_POLL_LATE ? ((st - KSTEPS) >> 1) : (st >> 2); glds16(psrc, srcoff[pi], pdst + pi * 4096); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -478,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         }
       } else {
         if (wave < 4) {
+            if (MF_POLL_LATE) wait_others();
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * 4096);
         }
@@ -525,9 +583,19 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PROF_T(5)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        if (MF_POLL) {
+            // this wave is through with the tile (all its LDS reads have returned); a DMA wave has also seen its pieces of the NEXT tile land (the counted wait above)
+            const uint32_t done = tile_no + 1u;
+            if (lane == 0) {
+                const uint32_t a0 = smem_lds + (uint32_t)((unsigned char *)sync_l - smem);
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a0 + (8u + (uint32_t)wave) * 4u), "v"(done) : "memory");
+                if (wave < 4) { const uint32_t ld_ = done + 1u; asm volatile("ds_write_b32 %0, %1" ::"v"(a0 + (uint32_t)wave * 4u), "v"(ld_) : "memory"); }
+            }
+        } else {
 #ifndef SHODH_NO_TILE_BARRIER      // (diagnostic builds: what the per-tile barrier costs; results invalid)
         __builtin_amdgcn_s_barrier();
 #endif
+        }
         __builtin_amdgcn_sched_barrier(0);
         PROF_T(6)
         PROF_N(7)
@@ -535,8 +603,8 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     }
 #ifdef SHODH_PROF
     if (MODE == MF_MODE_EMIT && blockIdx.x == 200 && blockIdx.y == 0 && lane == 0 && pt_[7])
-        printf("wave %d tiles %lld | per tile: top %lld chain0 %lld emit1 %lld chain1 %lld emit0 %lld vmcnt %lld barrier %lld\n", wave, pt_[7],
-               pt_[0] / pt_[7], pt_[1] / pt_[7], pt_[2] / pt_[7], pt_[3] / pt_[7], pt_[4] / pt_[7], pt_[5] / pt_[7], pt_[6] / pt_[7]);
+        printf("wave %d tiles %lld | per tile: landed-wait %lld top %lld chain0 %lld emit1 %lld others-wait %lld chain1 %lld emit0 %lld vmcnt %lld hand-over %lld\n", wave, pt_[7],
+               pt_[8] / pt_[7], pt_[0] / pt_[7], pt_[1] / pt_[7], pt_[2] / pt_[7], pt_[9] / pt_[7], pt_[3] / pt_[7], pt_[4] / pt_[7], pt_[5] / pt_[7], pt_[6] / pt_[7]);
 #endif
 #ifdef SHODH_PROF
     const long long wc2_ = wall_clock64();
@@ -1814,8 +1882,8 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
         return SHODH_OK;
         }
     }
-    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 <= 160 * 1024) ? 3 : 2;      // == mfma_scan_nbuf<KSTEPS>()
-    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 32;
+    const size_t nbuf = (3ull * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 + 64 <= 160 * 1024) ? 3 : 2;      // == mfma_scan_nbuf<KSTEPS>()
+    const size_t lds = nbuf * MF_TR * a.dim * 2 + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + MF_BPAD * 12 + 256 + 64 + 32;
     dim3 grid((uint32_t)p.grid_x, p.passes);
     if ((uint32_t)p.grid_x > n_sel) grid.x = n_sel ? n_sel : 1;
 #define SHODH_LAUNCH_KS(KS)                                                                                        \
