@@ -62,10 +62,29 @@ constexpr int MF_BPAD = 256;     // queries per pass
 // "finished" words. Waves drift up to a tile apart; a value is only ever read after the fact it stands for (the writer's own counted wait / lgkmcnt(0) precedes the write).
 // Same results (every parity test), emit kernel 211 -> 203 us at k = 10, 231 -> 216 at k = 120 (same box; 1 without the late DMA: 209 / 234; 3, a first look at the
 // words a tile early: no change).
+// 4 (the product): with three buffers a DMA wave posts "tile t + 1 has landed" in the MIDDLE of tile t, where it waits for the others anyway: everything it has in
+// flight there is at least a tile old, so vmcnt(0) costs nothing, and nobody finds the words short at the top of the next tile (per tile and wave ~350 cycles of
+// polling instead of ~800). Together with the two knobs below 203 -> 194 us at k = 10, 224 -> 213 at k = 120 (same box, tools/r6_flat_variants.sh).
+// 5 (measured, not kept: 203 / 227): the first A fragments of tile t + 1 requested during the last steps of tile t -- the look at the landed words moves into the
+// second chain and the waves wait there instead.
 #ifndef SHODH_MF_POLL
-#define SHODH_MF_POLL 2
+#define SHODH_MF_POLL 4
 #endif
 constexpr bool MF_POLL = SHODH_MF_POLL != 0;
+// Who issues the corpus DMA, and who wins the SIMD. Per-tile section timers (tools/r6_emit_phases.sh) show the younger wave of every SIMD as the pole: the arbiter
+// serves the older one first, so the younger one's chains stretch (1 000 + 1 860 cycles against 800 + 800 + the DMA's 780), and the older one then sits ~1 200 cycles
+// in the middle of its tile waiting for it. Measured, emit kernel us at k = 10 / 120 on one box: DMA by the older waves 196.8 / 214.8 (+ younger at priority 1: 199 /
+// 221.8, at 3: 198.6 / 222.6); DMA by the YOUNGER waves 204.3 / 228; DMA by the younger waves AND those at priority 1: 193.8 / 213.4 -- the waves that carry the
+// issue stalls of the DMA are the ones that may take the matrix pipe when they are ready. Small effects, each reproduced twice; the structure as a whole sits at
+// ~53 % of the matrix pipe (MI355X_MICROARCH.md "Two waves per SIMD": moving work between the two waves of a SIMD is zero-sum).
+#ifndef SHODH_MF_YPRIO
+#define SHODH_MF_YPRIO 1       // issue priority (s_setprio) of the younger wave of every SIMD, waves 4 - 7; the older wave, which the arbiter favours at equal priority, stays at 0
+#endif
+#ifndef SHODH_MF_DMAY
+#define SHODH_MF_DMAY 1        // 1: the corpus DMA is issued by the younger waves (4 - 7) instead of the older ones
+#endif
+constexpr bool MF_POLL_XPREF = SHODH_MF_POLL >= 5;     // 5: ... and a wave requests the first A fragments of tile t + 1 during the last steps of tile t (no cold start at the top of a tile)
+constexpr bool MF_POLL_EARLY = SHODH_MF_POLL >= 4;     // 4: with three buffers a DMA wave posts "tile t + 1 has landed" in the MIDDLE of tile t (its pieces were issued a tile ago; nothing younger is in flight there), not at its end
 constexpr bool MF_POLL_LATE = SHODH_MF_POLL >= 2;      // 2: the DMA of a tile is issued in its second half only, and the DMA waves look at the others' progress there, not at the top
 constexpr int MF_DYN_NB = 16;    // levels of the threshold that tightens DURING the emit scan (see "dynamic threshold" below)
 constexpr int MF_DYN_REP = 4;    // ... and replicas of every query's level counters (workgroup b adds to replica b % 4; the owner sums them): a query's counters are one hot line otherwise
@@ -182,6 +201,8 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool dma_wave = SHODH_MF_DMAY ? wave >= 4 : wave < 4;      // the four waves that issue the corpus DMA (wave & 3: which quarter of every piece)
+    if (SHODH_MF_YPRIO && wave >= 4) __builtin_amdgcn_s_setprio(SHODH_MF_YPRIO);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
     const uint32_t pass = blockIdx.y;
@@ -237,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     for (int b = 0; b < PF; ++b) {
         const uint32_t tsel = sel + b * step < a.n_sel_tiles ? sel + b * step : (sel < a.n_sel_tiles ? sel : 0u);
         const unsigned char *src = uniform_ptr(rows_b + (size_t)tsel * tile_bytes_g);
-        if (wave < 4) {
+        if (dma_wave) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(src, srcoff[i], wave_lds + b * TILE_BYTES + i * 4096);
         }
@@ -385,18 +406,42 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     const long long wc1_ = wall_clock64();
 #endif
     uint32_t tile_no = 0;                   // tiles this workgroup has done (uniform)
+    constexpr bool XP = MF_POLL_XPREF && PF == 2 && KSTEPS >= 8;      // the first D fragments of a tile are requested during the tile before it
+    half8 ring[RING];
+    auto rd = [&](const unsigned char *buf_, int st) {
+#ifdef SHODH_HALF_LDS      // (diagnostic builds, results invalid: every second A fragment is not read -- is the LDS port what the chains wait for?)
+        if (st & 1) return;
+#endif
+        const int rb = st / KSTEPS, ks = st % KSTEPS;
+        ring[st % RING] = *reinterpret_cast<const half8 *>(buf_ + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
+    };
+    auto wait_landed = [&](uint32_t upto) {      // every DMA wave has seen its pieces of the tiles < upto land
+        const uint32_t need = (lane < 4) ? upto : 0u;
+        const uint32_t paddr = smem_lds + (uint32_t)((unsigned char *)sync_l - smem) + (uint32_t)(lane & 15) * 4u;
+        for (;;) {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(paddr) : "memory");
+            if (__builtin_amdgcn_ballot_w64(v >= need) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    if (XP && active) {
+#pragma unroll
+        for (int st = 0; st < D; ++st) rd(smem, st);
+    }
     for (; sel < a.n_sel_tiles; sel += step, ++tile_no) {
         const unsigned char *buf = smem + cur * TILE_BYTES;
+        const unsigned char *nbuf = smem + (cur + 1 == NBUF ? 0 : cur + 1) * TILE_BYTES;
         const uint32_t pfb = cur + PF >= NBUF ? cur + PF - NBUF : cur + PF;      // buffer the DMA fills during this tile
         const uint32_t psel = sel + PF * step < a.n_sel_tiles ? sel + PF * step : sel;
         const unsigned char *psrc = uniform_ptr(rows_b + (size_t)psel * tile_bytes_g);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * TILE_BYTES));
 
-      if (MF_POLL) {
+      if (MF_POLL && !XP) {
         // Hand-over without a workgroup barrier (see the end of the tile): this tile's data must have landed (every DMA wave has seen its pieces of it land:
         // sync_l[0 .. 3] > tile_no), and a DMA wave may refill the buffer of the tile before this one only when all eight waves are through with it
-        // (sync_l[8 .. 15] >= tile_no). One read per poll: lane l looks at word l.
-        const uint32_t need = (lane < 4) ? tile_no + 1u : ((!MF_POLL_LATE && lane >= 8 && lane < 16 && wave < 4) ? tile_no : 0u);
+        // (sync_l[8 .. 15] >= tile_no). One read per poll: lane l looks at word l. (XP: looked at during the tile before, where its first fragments are requested.)
+        const uint32_t need = (lane < 4) ? tile_no + 1u : ((!MF_POLL_LATE && lane >= 8 && lane < 16 && dma_wave) ? tile_no : 0u);
         const uint32_t paddr = smem_lds + (uint32_t)((unsigned char *)sync_l - smem) + (uint32_t)(lane & 15) * 4u;
         for (;;) {
             uint32_t v;
@@ -414,6 +459,15 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (__builtin_amdgcn_ballot_w64(v >= tile_no) == ~0ull) break;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (MF_POLL_EARLY && PF == 2) {
+            // everything this wave has in flight here is older than the pieces it is about to issue: the pieces of tile t + 1 (issued during tile t - 1) and the
+            // stores of its last drain. Once they are in, tiles <= t + 1 have landed as far as this wave's share goes: nobody waits at the top of the next tile.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const uint32_t ld_ = tile_no + 2u;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(smem_lds + (uint32_t)((unsigned char *)sync_l - smem) + (uint32_t)(wave & 3) * 4u), "v"(ld_) : "memory");
+            }
+        }
       };
       if (DYN && dyn_on) {
         // dynamic threshold: the owner's counters (wave 6) and the published bounds of the pass (wave 7) by device-coherent LDS-DMA -- no destination
@@ -429,16 +483,10 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             const uint32_t w_ = pub_l[q_local];
             if (w_) thr_l = fmaxf(thr_l, __uint_as_float(w_ & ~31u));
         }
-        half8 ring[RING];
-        auto rd = [&](int st) {
-#ifdef SHODH_HALF_LDS      // (diagnostic builds, results invalid: every second A fragment is not read -- is the LDS port what the chains wait for?)
-            if (st & 1) return;
-#endif
-            const int rb = st / KSTEPS, ks = st % KSTEPS;
-            ring[st % RING] = *reinterpret_cast<const half8 *>(buf + rb * 32 * PITCH + aoff[ks & 7] + (ks >> 3) * 256);
-        };
+        if (!XP) {
 #pragma unroll
-        for (int st = 0; st < D; ++st) rd(st);
+            for (int st = 0; st < D; ++st) rd(buf, st);
+        }
         PROF_T(0)
         constexpr int PER1 = (16 + KSTEPS - 1) / KSTEPS;          // accumulator values folded into the maximum per step
         constexpr int PER0 = (16 + KSTEPS - 3) / (KSTEPS - 2);
@@ -448,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         // row block 0 -> acc0; in the shadows: maximum of the previous tile's acc1, DMA issue
 #pragma unroll
         for (int st = 0; st < KSTEPS; ++st) {
-            rd(st + D);
+            rd(buf, st + D);
 #ifdef SHODH_HALF_LDS
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(st & ~1) % RING], bq[st], st == 0 ? zero16 : acc0, 0, 0, 0);
 #elif defined(SHODH_HALF_MFMA)      // (diagnostic builds, results invalid: every second multiplication left out, its fragment still read)
@@ -462,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
                 for (int u = 0; u < PER1; ++u) if (st * PER1 + u < 16) m1 = fmaxf(m1, acc1[st * PER1 + u]);
             }
             if (!MF_POLL_LATE && (st & 3) == 2 && (st >> 2) < NPC) {
-                if (wave < 4) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
+                if (dma_wave) glds16(psrc, srcoff[st >> 2], pdst + (st >> 2) * 4096);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -471,11 +519,17 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (have_prev && __builtin_amdgcn_ballot_w64(m1 >= thr_l) != 0) emit_block(acc1, prow1);   // wave-uniform entry
         }
         PROF_T(2)
-        if (MF_POLL_LATE && wave < 4) { wait_others(); PROF_T(9) }      // the buffer this tile's DMA refills: everybody through with the tile before this one?
+        if (MF_POLL_LATE && dma_wave) { wait_others(); PROF_T(9) }      // the buffer this tile's DMA refills: everybody through with the tile before this one?
         // row block 1 -> acc1; in the shadows: maximum of acc0 (from two steps in: its last MFMA has to retire first)
+        uint32_t fl_ = 0;
 #pragma unroll
         for (int st = KSTEPS; st < NS; ++st) {
-            if (st + D < NS) rd(st + D);
+            if (XP && st == (NS - D - 4 > KSTEPS ? NS - D - 4 : KSTEPS)) fl_ = *reinterpret_cast<volatile uint32_t *>(sync_l + (lane & 3));      // the landed words, on their way while three more steps run
+            if (XP && st == NS - D - 1) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(fl_ >= tile_no + 2u) != ~0ull, 0)) wait_landed(tile_no + 2u);      // (rare: a DMA wave half a tile behind)
+            }
+            if (st + D < NS) rd(buf, st + D);
+            else if (XP) rd(nbuf, st + D - NS);
 #ifdef SHODH_HALF_LDS
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(st & ~1) % RING], bq[st - KSTEPS], st == KSTEPS ? zero16 : acc1, 0, 0, 0);
 #elif defined(SHODH_HALF_MFMA)
@@ -490,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             }
             if (MF_POLL_LATE ? ((st & 1) == 0 && ((st - KSTEPS) >> 1) < NPC) : ((st & 3) == 2 && (st >> 2) < NPC)) {
                 constexpr int dummy_ = 0; (void)dummy_;
-                if (wave < 4) { const int pi = MF_POLL_LATE ? ((st - KSTEPS) >> 1) : (st >> 2); glds16(psrc, srcoff[pi], pdst + pi * 4096); }
+                if (dma_wave) { const int pi = MF_POLL_LATE ? ((st - KSTEPS) >> 1) : (st >> 2); glds16(psrc, srcoff[pi], pdst + pi * 4096); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -534,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (hi == 0) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = m * MF_INV_SCALE2;
         }
       } else {
-        if (wave < 4) {
+        if (dma_wave) {
             if (MF_POLL_LATE) wait_others();
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * 4096);
@@ -579,7 +633,8 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         // hand-over: the tile after this one must have landed (the DMA issued during this tile may stay in flight
         // when there are three buffers); all LDS traffic of this wave done; then the workgroup barrier
         PROF_T(4)
-        if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
+        if (MF_POLL_EARLY && PF == 2) {}       // (the DMA waves wait for their pieces in the middle of the next tile)
+        else if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PROF_T(5)
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -589,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             if (lane == 0) {
                 const uint32_t a0 = smem_lds + (uint32_t)((unsigned char *)sync_l - smem);
                 asm volatile("ds_write_b32 %0, %1" ::"v"(a0 + (8u + (uint32_t)wave) * 4u), "v"(done) : "memory");
-                if (wave < 4) { const uint32_t ld_ = done + 1u; asm volatile("ds_write_b32 %0, %1" ::"v"(a0 + (uint32_t)wave * 4u), "v"(ld_) : "memory"); }
+                if (dma_wave && !(MF_POLL_EARLY && PF == 2)) { const uint32_t ld_ = done + 1u; asm volatile("ds_write_b32 %0, %1" ::"v"(a0 + (uint32_t)(wave & 3) * 4u), "v"(ld_) : "memory"); }
             }
         } else {
 #ifndef SHODH_NO_TILE_BARRIER      // (diagnostic builds: what the per-tile barrier costs; results invalid)
