@@ -2049,6 +2049,9 @@ struct SoloArgs {
     uint32_t ablate;           // diagnostic builds (-DSHODH_DIAG): 1 = no selection / hand-over, 2 = no arithmetic (results invalid)
     uint32_t *skeys;           // global threshold mode: [n_rows] order keys of the scores (0xFFFFFFFF = tombstoned)
     uint32_t *tops;            // global threshold mode: [gridDim.x][SOLO_WAVES] best key of each wave
+    uint32_t ilv;              // 1: workgroup b takes the row blocks b, b + grid, b + 2 grid, ... (one block = the 64 U rows of an iteration) instead of a contiguous slice
+    uint32_t stream;           // 1 (384-d, implies ilv): the rows arrive by LDS-DMA through a ring of 32-row tiles at smem + ring_off, followed by dwl_cap tombstone words and 64 keys
+    uint32_t ring_off, dwl_cap;
 };
 
 template <int DIM, bool GLOBAL_THR = false>
@@ -2095,8 +2098,25 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
         if (tid == 5) { a.eps[0] = eps; a.eps2[0] = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f; a.fallback[0] = bad_q ? 1u : 0u; }
     }
     uint64_t *my_slots = a.slots + (size_t)blockIdx.x * MF_SLOTS;
-    const uint64_t row0 = (uint64_t)blockIdx.x * a.slice;
-    const uint32_t n_loc = row0 >= a.n_rows ? 0u : (a.n_rows - row0 < a.slice ? (uint32_t)(a.n_rows - row0) : a.slice);
+    // Which rows are this workgroup's. Contiguous slices (round 2) make 256 streams megabytes apart; with the blocks of an iteration dealt round-robin
+    // (a.ilv) the workgroups walk the corpus side by side -- at any moment the whole chip reads one ~50 MB window front to back. Measured on the bare stream
+    // (tools/ubench/solo_stream.hip): 6.40 against 6.0 TB/s, whoever issues the loads. Local index i <-> global row grow(i); everything downstream of the
+    // scores (keys in LDS, k-th best, hand-over) works on local indices and only names a row through grow().
+    constexpr bool CAN_STREAM = DIM == 384;
+    const bool stream = CAN_STREAM && a.stream != 0;      // uniform: the rows arrive through an LDS ring (below); implies ilv, in blocks of one 32-row tile
+    const uint32_t ISH = stream ? 5u : (U == 4 ? 8u : (U == 2 ? 7u : 6u)), IBLK = 1u << ISH;      // rows per dealt block
+    const bool ilv = a.ilv != 0;             // uniform
+    const uint64_t row0 = ilv ? 0 : (uint64_t)blockIdx.x * a.slice;
+    uint32_t n_loc;
+    if (ilv) {
+        const uint64_t nblk = (a.n_rows + IBLK - 1) / IBLK;
+        const uint64_t mine = blockIdx.x < nblk ? (nblk - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        n_loc = (uint32_t)(mine * IBLK);
+        if (mine && (nblk - 1) % gridDim.x == blockIdx.x) n_loc -= (uint32_t)(nblk * IBLK - a.n_rows);      // the corpus' last, partial block is this workgroup's last
+    } else {
+        n_loc = row0 >= a.n_rows ? 0u : (a.n_rows - row0 < a.slice ? (uint32_t)(a.n_rows - row0) : a.slice);
+    }
+    auto grow = [&](uint32_t i) -> uint64_t { return ilv ? (((uint64_t)(i >> ISH) * gridDim.x + blockIdx.x) << ISH) + (i & (IBLK - 1u)) : row0 + i; };
     if (bad_q || n_loc == 0) {          // block-uniform
         if (GLOBAL_THR) { if (lane == 0) a.tops[blockIdx.x * SOLO_WAVES + wave] = 0xFFFFFFFFu; }
         else if (tid < (uint32_t)MF_SLOTS) my_slots[tid] = KEY_NONE;
@@ -2104,7 +2124,85 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     }
     uint32_t best = 0xFFFFFFFFu;        // (GLOBAL_THR) smallest key = best score among this lane's rows
     // ---- scores of the slice ------------------------------------------------------------------------------------------
-    const _Float16 *base = a.rows_h + row0 * DIM + (size_t)seg * 8;
+    const _Float16 *base = a.rows_h + (size_t)seg * 8;
+    if (stream) {
+        // ---- the slice as a stream (round 6) ---------------------------------------------------------------------------
+        // Sixteen waves loading their rows straight into registers reach 5.6 - 5.9 TB/s whatever the lane layout (round 2); LDS-DMA of whole tiles, issued by
+        // few waves, with the tiles dealt round-robin over the workgroups reaches 6.4 (tools/ubench/solo_stream.hip, dma_issue.hip: the fewer waves issue, the
+        // better the stream). So: 32-row tiles (24 KiB) into a ring of five, waves 0 and 1 issue nothing else (twelve 1-KiB pieces each per tile, 48 in
+        // flight per wave: vmcnt has six bits), ONE s_barrier per tile, and the other fourteen waves take the tile's eight 4-row groups in rotation -- the
+        // same 16 lanes per row, the same chunks and the same FMA order as below, read from LDS. The tombstone words of the workgroup's tiles (one word per
+        // tile: a tile is 32 aligned rows) are fetched once, up front; in global-threshold mode a tile's 32 keys leave as ONE 128-byte store a tile later.
+        constexpr uint32_t TR = 32, TILE = TR * DIM * 2, NBUF = 5, PER = TILE / 1024 / 2;
+        unsigned char *ring = smem + a.ring_off;
+        uint32_t *dwl = reinterpret_cast<uint32_t *>(ring + NBUF * TILE);      // [dwl_cap] tombstone words of this workgroup's tiles
+        uint32_t *tkeys = dwl + a.dwl_cap;                                      // [2][32] global-threshold mode: the keys of the last two tiles
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
+        const uint32_t n_tiles = (n_loc + TR - 1) / TR;
+        const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(a.rows_h);
+        auto issue = [&](uint32_t j) {      // this wave's half of tile j of the workgroup (global tile j * grid + block) into buffer j % NBUF
+            const unsigned char *src = uniform_ptr(rows_b + ((size_t)j * gridDim.x + blockIdx.x) * TILE);
+            const uint32_t dst = ring_lds + (j % NBUF) * TILE;
+#pragma unroll
+            for (uint32_t i = 0; i < PER; ++i) {
+                const uint32_t n = wave * PER + i;
+                glds16(src, n * 1024u + lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + n * 1024u)));
+            }
+        };
+        if (wave < 2) {
+            for (uint32_t j = 0; j < NBUF - 1 && j < n_tiles; ++j) issue(j);
+        } else {
+            for (uint32_t j = tid - 128; j < n_tiles; j += SOLO_NT - 128) dwl[j] = a.deleted ? a.deleted[(size_t)j * gridDim.x + blockIdx.x] : 0u;
+        }
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            if (wave < 2) {      // tile t has landed: only the pieces of the (up to three) tiles issued after it may still be in flight
+                const uint32_t after = n_tiles - 1 - t < NBUF - 2 ? n_tiles - 1 - t : NBUF - 2;
+                if (after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * PER) : "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PER) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(1 * PER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();      // tile t is there for everybody; everybody is through with tile t - 1 (whose buffer the next issue refills) and its keys
+            if (wave < 2) {
+                if (t + NBUF - 1 < n_tiles) issue(t + NBUF - 1);
+            } else {
+                const uint32_t g = (wave - 2u + 14u - (t * 8u) % 14u) % 14u;      // eight groups of four rows over fourteen waves, in rotation
+                if (g < 8u) {
+                    const uint32_t rt = g * 4 + sr, rl = t * TR + rt;
+                    const unsigned char *rp = ring + (t % NBUF) * TILE + rt * (DIM * 2) + seg * 16;
+                    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < LPL; ++c) {
+                        const u32x4 hc = *reinterpret_cast<const u32x4 *>(rp + c * 256);
+                        const _Float16 *hv = reinterpret_cast<const _Float16 *>(&hc);
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            p0 = __builtin_fmaf(qv[c * 8 + e], (float)hv[e], p0);
+                            p1 = __builtin_fmaf(qv[c * 8 + e + 1], (float)hv[e + 1], p1);
+                        }
+                    }
+                    float pr = p0 + p1;
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) pr += __shfl_xor(pr, off);
+                    const bool del = (dwl[t] >> rt) & 1u;
+                    const uint32_t key = (del || rl >= n_loc) ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
+                    if (GLOBAL_THR) {
+                        best = key < best ? key : best;
+                        if (seg == 0) tkeys[(t & 1u) * TR + rt] = key;
+                    } else if (seg == 0 && rl < n_loc) skey[rl] = key;
+                }
+                if (GLOBAL_THR && wave == 15 && t > 0 && lane < TR) {      // the tile before this one: its keys were complete at the barrier
+                    const uint32_t i = (t - 1) * TR + lane;
+                    if (i < n_loc) a.skeys[grow(i)] = tkeys[((t - 1) & 1u) * TR + lane];
+                }
+            }
+        }
+        __syncthreads();
+        if (GLOBAL_THR && wave == 15 && n_tiles && lane < TR) {
+            const uint32_t i = (n_tiles - 1) * TR + lane;
+            if (i < n_loc) a.skeys[grow(i)] = tkeys[((n_tiles - 1) & 1u) * TR + lane];
+        }
+    } else
     for (uint32_t r0 = 0; r0 < n_loc; r0 += 64 * U) {
         u32x4 h[U][LPL];
         uint32_t dw[U];
@@ -2114,10 +2212,11 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
             // so that their keys leave in one store instruction
             const uint32_t rl = GLOBAL_THR ? r0 + wave * (4 * U) + u * 4 + sr : r0 + u * 64 + wave * 4 + sr;
             const uint32_t rc = rl < n_loc ? rl : n_loc - 1;        // unconditional loads on clamped rows: all of them in flight at once
-            const u32x4 *rp = reinterpret_cast<const u32x4 *>(base + (size_t)rc * DIM);
+            const uint64_t gr = grow(rc);
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(base + (size_t)gr * DIM);
 #pragma unroll
             for (int c = 0; c < LPL; ++c) h[u][c] = rp[c * 16];
-            dw[u] = a.deleted ? a.deleted[(row0 + rc) >> 5] : 0u;
+            dw[u] = a.deleted ? a.deleted[gr >> 5] : 0u;
         }
         uint32_t keyu[U];
 #pragma unroll
@@ -2139,12 +2238,12 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) pr += __shfl_xor(pr, off);
             if (GLOBAL_THR) {           // (the butterfly left the sum in all 16 lanes of the row)
-                const uint32_t row = (uint32_t)(row0 + (rl < n_loc ? rl : n_loc - 1));
+                const uint32_t row = (uint32_t)grow(rl < n_loc ? rl : n_loc - 1);
                 const bool del = (dw[u] >> (row & 31)) & 1u;
                 keyu[u] = (del || rl >= n_loc) ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
                 best = keyu[u] < best ? keyu[u] : best;
             } else if (seg == 0 && rl < n_loc) {
-                const uint32_t row = (uint32_t)(row0 + rl);
+                const uint32_t row = (uint32_t)grow(rl);
                 const bool del = (dw[u] >> (row & 31)) & 1u;
                 skey[rl] = del ? 0xFFFFFFFFu : order_key(-(pr * (1.0f / MF_SCALE)));
             }
@@ -2155,7 +2254,7 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
 #pragma unroll
             for (int u = 1; u < U; ++u) mykey = (int)seg == u ? keyu[u] : mykey;
             const uint32_t rs = r0 + wave * (4 * U) + seg * 4 + sr;
-            if (seg < (uint32_t)U && rs < n_loc) a.skeys[row0 + rs] = mykey;
+            if (seg < (uint32_t)U && rs < n_loc) a.skeys[grow(rs)] = mykey;      // (16 U consecutive rows of one block: still one segment)
         }
     }
     if (GLOBAL_THR) {
@@ -2180,7 +2279,7 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     for (uint32_t i = tid; i < n_loc; i += SOLO_NT) {
         const uint32_t key = skey[i];
         if (key != 0xFFFFFFFFu && key <= klim) {
-            const uint64_t k64 = ((uint64_t)key << 32) | (uint32_t)(row0 + i);
+            const uint64_t k64 = ((uint64_t)key << 32) | (uint32_t)grow(i);
             const uint32_t idx = atomicAdd(&ctl[0], 1u);
             if (idx < (uint32_t)SOLO_EM) em[idx] = k64;
             else {                           // a dense slice: straight to the shared list
@@ -2321,16 +2420,39 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     uint64_t slice = ceil_div(n_rows, nb);
     if (!global_thr && slice > (uint64_t)SOLO_MAX_SLICE) { slice = SOLO_MAX_SLICE; nb = ceil_div(n_rows, slice); }    // (the slice's keys live in LDS)
     if (slice < 1) slice = 1;
+    const uint64_t slice_c = slice;                   // the contiguous partition (solo_emit_kernel walks the keys by it whatever the scan's mapping was)
+    // blocks dealt round-robin (see the kernel) once every workgroup has a few of them; the keys of a workgroup's rows must still fit its LDS
+    static const int ilv_env = getenv("SHODH_SOLO_ILV") ? atoi(getenv("SHODH_SOLO_ILV")) : -1;
+    const uint32_t epl = dim / 16, iblk = 64u * (epl <= 24 ? 4u : (epl <= 32 ? 2u : 1u));      // == the kernel's 64 U
+    uint32_t ilv = (ilv_env >= 0 ? ilv_env != 0 : false) && n_rows >= nb * iblk * 4 ? 1u : 0u;      // (with the direct loads: no gain measured, 184 -> 187 us per call at k = 10; off)
+    // ... and, at 384 dimensions, streamed through LDS (32-row tiles; see the kernel) when a workgroup has enough tiles to fill the ring and its keys leave room for it
+    static const int stream_env = getenv("SHODH_SOLO_STREAM") ? atoi(getenv("SHODH_SOLO_STREAM")) : -1;
+    uint32_t stream = 0, ring_off = 0, dwl_cap = 0;
+    if (dim == 384 && (stream_env >= 0 ? stream_env != 0 : true) && n_rows >= nb * 32 * 8) {
+        const uint64_t per = ceil_div(ceil_div(n_rows, (uint64_t)32), nb) * 32;
+        const size_t head = global_thr ? 0 : ((((size_t)per + (per & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16 + 1023) & ~(size_t)1023);
+        const size_t need = head + 5 * (size_t)(32 * 384 * 2) + (size_t)(per / 32) * 4 + 2 * 32 * 4;
+        if ((global_thr || per <= (uint64_t)SOLO_MAX_SLICE) && need <= 160 * 1024) { stream = 1; ilv = 1; slice = per; ring_off = (uint32_t)head; dwl_cap = (uint32_t)(per / 32); }
+    }
+    static const bool solo_dbg = getenv("SHODH_SOLO_DEBUG") && atoi(getenv("SHODH_SOLO_DEBUG"));
+    if (solo_dbg) fprintf(stderr, "[shodh] single-query scan: %llu rows, %llu workgroups, k %u (%s threshold), %s\n", (unsigned long long)n_rows, (unsigned long long)nb, k,
+                          global_thr ? "global" : "local", stream ? "LDS ring of dealt 32-row tiles" : (ilv ? "direct loads, dealt blocks" : "direct loads, contiguous slices"));
+    if (ilv && !stream) {
+        const uint64_t per = ceil_div(ceil_div(n_rows, (uint64_t)iblk), nb) * iblk;
+        if (!global_thr && per > (uint64_t)SOLO_MAX_SLICE) ilv = 0;
+        else slice = per;
+    }
     if (nb > (uint64_t)p.grid_x * MF_BPAD) { set_error("single-query scan: %llu workgroups do not fit the slot table", (unsigned long long)nb); return SHODH_ERR_UNSUPPORTED; }
     const EpsCoef c = eps_coefficients(dim, order);
     uint32_t *skeys = reinterpret_cast<uint32_t *>(w.cand + p.cand_cap);          // behind query 0's list (solo_global_fits)
     uint32_t *tops = skeys + ((n_rows + 63) & ~(uint64_t)63);
     SoloArgs a{rows_h, n_rows, dim, d_q, deleted, k, (uint32_t)slice, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a,
-               w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u, skeys, tops};
+               w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u, skeys, tops, ilv, stream, ring_off, dwl_cap};
 #ifdef SHODH_DIAG
     a.ablate = getenv("SHODH_SOLO_ABLATE") ? (uint32_t)atoi(getenv("SHODH_SOLO_ABLATE")) : 0u;
 #endif
-    const size_t lds = global_thr ? 0 : ((size_t)slice + (slice & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16;
+    const size_t lds = stream ? (size_t)ring_off + 5 * (size_t)(32 * 384 * 2) + (size_t)dwl_cap * 4 + 2 * 32 * 4
+                              : (global_thr ? 0 : ((size_t)slice + (slice & 1)) * 4 + (size_t)SOLO_EM * 8 + (size_t)KTH_SCRATCH_U32 * 4 + 16);
 #define SHODH_LAUNCH_SOLO_K(KERN)                                                                                     \
         SHODH_TRY(ensure_dynamic_lds((const void *)KERN, lds));                                                       \
         if (ev0 && ev1) hipExtLaunchKernelGGL(KERN, dim3((uint32_t)nb), dim3(SOLO_NT), (uint32_t)lds, st, ev0, ev1, 0u, a);  \
@@ -2352,7 +2474,7 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 #undef SHODH_LAUNCH_SOLO_K
     SHODH_HIP_TRY(hipGetLastError());
     if (global_thr) {
-        SoloEmitArgs e{skeys, tops, (uint32_t)(nb * SOLO_WAVES), n_rows, (uint32_t)slice, k, w.eps, w.fallback, w.slots, w.cand, solo_cnt, p.cand_cap};
+        SoloEmitArgs e{skeys, tops, (uint32_t)(nb * SOLO_WAVES), n_rows, (uint32_t)slice_c, k, w.eps, w.fallback, w.slots, w.cand, solo_cnt, p.cand_cap};
         hipLaunchKernelGGL(solo_emit_kernel, dim3((uint32_t)nb), dim3(256), 0, st, e);
         SHODH_HIP_TRY(hipGetLastError());
     }

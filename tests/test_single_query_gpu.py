@@ -57,6 +57,43 @@ def test_single_query_matches_oracle(S, oracle, dim, order):
     idx.close()
 
 
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("n", [65536, 70001, 131103])
+def test_streamed_scan_matches_oracle(S, oracle, n, order):
+    """From 256 workgroups x 8 tiles on, the 384-d single-query scan reads its rows through an LDS ring of 32-row tiles dealt round-robin over the
+    workgroups (solo_scan_kernel, `stream`): a corpus that ends inside a tile, tombstones in the first and the last tile of the corpus and of single
+    workgroups, local thresholds (k <= 32) and the global one (k = 33, 120, 300), a stored row as the query."""
+    dim = 384
+    q = synth.queries(6, dim, seed=150 + n % 97)
+    rows = synth.corpus(n, dim, seed=160 + n % 89, queries=q)
+    deleted = synth.tombstones(n, 0.05, seed=170)
+    deleted[:40] = True; deleted[n - 45:n - 3] = True; deleted[256 * 32:256 * 32 + 32] = True; deleted[n // 2] = False
+    idx = make_index(S, dim=dim, order=order)
+    idx.build(rows)
+    idx.mark_deleted_many(np.nonzero(deleted)[0].astype(np.uint32))
+    for i, k in enumerate((10, 1, 32, 33, 120, 300)):
+        check_one(oracle, idx, rows, q[i], k, order, deleted)
+        st = idx.scan_stats()
+        assert st["sampled_rows"] == 0 and st["emitted"] >= k and st["overflowed"] == 0, st
+    check_one(oracle, idx, rows, rows[n // 2], 10, order, deleted)
+    check_one(oracle, idx, rows, rows[n - 2], 120, order, deleted)        # the corpus' last rows: the partial tile's keys reach the threshold kernel
+    idx.close()
+
+
+def test_streamed_scan_crowded_cone(S, oracle):
+    """... and a corpus inside a narrow cone at that size: hundreds of hand-overs per workgroup (the staged list overflows into the shared one), level 2."""
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal(384).astype(f32); base /= np.linalg.norm(base)
+    rows = base[None, :] + f32(0.006) * rng.standard_normal((70000, 384)).astype(f32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows = np.ascontiguousarray(rows.astype(f32))
+    idx = make_index(S)
+    idx.build(rows)
+    for qi, k in ((5, 10), (40001, 32), (69999, 120)):
+        check_one(oracle, idx, rows, rows[qi], k, 0)
+    idx.close()
+
+
 def test_negative_scores_few_live_rows_and_ties(S, oracle):
     n = 20000
     rows = synth.corpus(n)

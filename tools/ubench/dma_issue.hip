@@ -17,7 +17,7 @@ __device__ __forceinline__ void glds16(const void *gbase, uint32_t voff, uint32_
 }
 
 // W issuing waves; MATH: every wave runs 48 MFMAs per tile, one ds_read_b128 each (the emit scan's chains); ROT: one wave issues the whole tile, in rotation
-template <int W, bool MATH, bool ROT>
+template <int W, bool MATH, bool ROT, bool CONTIG = false>
 __global__ __launch_bounds__(512) void k(const unsigned char *rows, uint32_t n_tiles, unsigned long long *stall, float *sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512) void k(const unsigned char *rows, uint32_t n_t
         const unsigned char *src = rows + (size_t)t * TILE;
         const uint64_t v = (uint64_t)src;
         const unsigned char *us = (const unsigned char *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-        const int n = ROT ? i : wave + W * i;
+        const int n = ROT ? i : (CONTIG ? wave * PER + i : wave + W * i);
         const long long t0 = clock64();
         glds16(us, (uint32_t)(n * 1024 + lane * 16), (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_lds + b * TILE + n * 1024)));
         st += clock64() - t0; cnt += 1;
@@ -76,16 +76,16 @@ __global__ __launch_bounds__(512) void k(const unsigned char *rows, uint32_t n_t
     if (MATH && acc[0] == 12345.678f) sink[0] = acc[1];
 }
 
-template <int W, bool MATH, bool ROT>
+template <int W, bool MATH, bool ROT, bool CONTIG = false>
 void run(const unsigned char *rows, uint32_t n_tiles, unsigned long long *stall, float *sink, const char *name) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipFuncSetAttribute((const void *)k<W, MATH, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * TILE));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<W, MATH, ROT>), dim3(256), dim3(512), NB * TILE, 0, rows, n_tiles, stall, sink);
+    CK(hipFuncSetAttribute((const void *)k<W, MATH, ROT, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, NB * TILE));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<W, MATH, ROT, CONTIG>), dim3(256), dim3(512), NB * TILE, 0, rows, n_tiles, stall, sink);
     CK(hipDeviceSynchronize());
     CK(hipMemset(stall, 0, 16));
     const int N = 20;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < N; ++i) hipLaunchKernelGGL((k<W, MATH, ROT>), dim3(256), dim3(512), NB * TILE, 0, rows, n_tiles, stall, sink);
+    for (int i = 0; i < N; ++i) hipLaunchKernelGGL((k<W, MATH, ROT, CONTIG>), dim3(256), dim3(512), NB * TILE, 0, rows, n_tiles, stall, sink);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[2]; CK(hipMemcpy(h, stall, 16, hipMemcpyDeviceToHost));
@@ -100,6 +100,10 @@ int main() {
     run<2, false, false>(rows, n_tiles, stall, sink, "stream alone, 2 issuing waves");
     run<4, false, false>(rows, n_tiles, stall, sink, "stream alone, 4 issuing waves");
     run<8, false, false>(rows, n_tiles, stall, sink, "stream alone, 8 issuing waves");
+    run<2, false, false, true>(rows, n_tiles, stall, sink, "stream alone, 2 waves, contiguous halves");
+    run<4, false, false, true>(rows, n_tiles, stall, sink, "stream alone, 4 waves, contiguous quarters");
+    run<8, false, false, true>(rows, n_tiles, stall, sink, "stream alone, 8 waves, contiguous eighths");
+    return 0;
     run<1, true, false>(rows, n_tiles, stall, sink, "with the chains, 1 issuing wave");
     run<2, true, false>(rows, n_tiles, stall, sink, "with the chains, 2 issuing waves");
     run<4, true, false>(rows, n_tiles, stall, sink, "with the chains, 4 issuing waves");
