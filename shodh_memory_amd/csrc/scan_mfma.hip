@@ -302,7 +302,13 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     uint32_t *wq_q = eq_q + wave * MF_WQ_CAP;
     uint32_t wq_n = 0;                       // wave-uniform
     uint64_t *my_slots = a.slots + ((size_t)pass * MF_BPAD * gridDim.x + blockIdx.x) * MF_SLOTS;   // + q * gridDim.x * MF_SLOTS
+#ifdef SHODH_PROF
+    long long ep_[6] = {0, 0, 0, 0, 0, 0};      // emit_block: entries, cycles, survivors; drain: calls, cycles, entries
+#endif
     auto drain = [&]() {
+#ifdef SHODH_PROF
+        const long long d0_ = clock64(); ep_[3] += 1; ep_[5] += wq_n;
+#endif
         const uint32_t n = wq_n < (uint32_t)MF_WQ_CAP ? wq_n : (uint32_t)MF_WQ_CAP;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint64_t key = wq_key[i];
@@ -338,6 +344,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             }
         }
         wq_n = 0;
+#ifdef SHODH_PROF
+        ep_[4] += clock64() - d0_;
+#endif
     };
     // the survivors of one 32-row block (entered BY THE WHOLE WAVE when some lane's maximum reached its threshold: the
     // queue bookkeeping below is wave-uniform). C layout (32x32):
@@ -359,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
         const uint64_t left = a.n_rows > brow0 + 4 * hi ? a.n_rows - (brow0 + 4 * hi) : 0;
         const uint32_t lim = left < 64 ? (uint32_t)left : 64u;      // this lane's values with row offset < lim exist
         const uint32_t wq_n0 = wq_n;
+#ifdef SHODH_PROF
+        const long long e0_ = clock64(); ep_[0] += 1;
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t roff = (r & 3) + 8 * (r >> 2);
@@ -386,6 +398,9 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // these stores / atomics share the VM counter with the DMA (see the loop)
         }
+#ifdef SHODH_PROF
+        ep_[1] += clock64() - e0_; ep_[2] += wq_n - wq_n0;
+#endif
     };
 
     if (MF_POLL && tid < 16) sync_l[tid] = tid < 8 ? (uint32_t)PF : 0u;      // the prologue's PF tiles have landed (waited for below); nobody has finished a tile
@@ -660,6 +675,8 @@ __global__ __launch_bounds__(512, 2) void mfma_scan_kernel(MfmaArgs a) {
     if (MODE == MF_MODE_EMIT && blockIdx.x == 200 && blockIdx.y == 0 && lane == 0 && pt_[7])
         printf("wave %d tiles %lld | per tile: landed-wait %lld top %lld chain0 %lld emit1 %lld others-wait %lld chain1 %lld emit0 %lld vmcnt %lld hand-over %lld\n", wave, pt_[7],
                pt_[8] / pt_[7], pt_[0] / pt_[7], pt_[1] / pt_[7], pt_[2] / pt_[7], pt_[9] / pt_[7], pt_[3] / pt_[7], pt_[4] / pt_[7], pt_[5] / pt_[7], pt_[6] / pt_[7]);
+    if (MODE == MF_MODE_EMIT && blockIdx.x == 200 && blockIdx.y == 0 && lane == 0 && pt_[7] && ep_[0])
+        printf("wave %d emit: %lld blocks entered, %lld cycles each, %lld survivors | %lld drains, %lld cycles each, %lld entries\n", wave, ep_[0], ep_[1] / ep_[0], ep_[2], ep_[3], ep_[3] ? ep_[4] / ep_[3] : 0, ep_[5]);
 #endif
 #ifdef SHODH_PROF
     const long long wc2_ = wall_clock64();
