@@ -920,7 +920,13 @@ __global__ __launch_bounds__(256, 1) void mfma_scan_big_kernel(MfmaArgs a) {
 // C layout (16x16): lane l holds query l & 15 and rows 4 (l >> 4) .. + 3 of the 16-row block.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int KSTEPS>
-__host__ __device__ constexpr int big3_nbuf() { return (3 * MFB_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2; }
+__host__ __device__ constexpr int big3_nbuf() { return (3 * MFB_TR * KSTEPS * 32 + MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 + 64 <= 160 * 1024) ? 3 : 2; }
+// The half-tile hand-over without a workgroup barrier, as in mfma_scan_kernel (see SHODH_MF_POLL there): here all eight waves issue DMA, so there are eight
+// "landed" and eight "finished" words; the pieces of a half tile are issued during the SECOND half of its chain, behind the look at the others' progress, and
+// "landed" is posted there too. Three buffers only (768 dimensions): emit kernel 425 -> 421 us at k = 10, 464 -> 446 at k = 120 (same box). 0: the s_barrier of rounds 4 - 5.
+#ifndef SHODH_BIG3_POLL
+#define SHODH_BIG3_POLL 1
+#endif
 template <int MODE, int KSTEPS>
 __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
     constexpr int NT = 512;
@@ -942,6 +948,8 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
     uint64_t *eq_key = reinterpret_cast<uint64_t *>(smem + NBUF * HALF_BYTES);
     uint32_t *eq_q = reinterpret_cast<uint32_t *>(eq_key + MF_EQ_CAP);
     uint32_t *qcount = eq_q + MF_EQ_CAP;
+    uint32_t *sync_l = qcount + MF_BPAD;       // [16] SHODH_BIG3_POLL: [0 .. 7] half tiles whose pieces wave w has seen land, [8 .. 15] half tiles wave w is through with
+    constexpr bool POLL = SHODH_BIG3_POLL != 0 && PF == 2;      // (two buffers, 1024 dimensions: the late issue leaves the pieces half a tile to land -- 544 -> 603 us; the barrier form stays)
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1054,12 +1062,25 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
         }
     };
 
+    if (POLL && tid < 16) sync_l[tid] = tid < 8 ? (uint32_t)PF : 0u;      // the prologue's PF half tiles have landed (waited for below); nobody has finished one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     float tile_m = -__builtin_inff();
     uint32_t cur = 0;
+    const uint32_t sync_lds = smem_lds + (uint32_t)((unsigned char *)sync_l - smem);
+    auto poll_words = [&](uint32_t first, uint32_t need) {      // words first .. first + 7 >= need (lane l looks at word first + l % 8)
+        const uint32_t paddr = sync_lds + (first + (uint32_t)(lane & 7)) * 4u;
+        for (;;) {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(paddr) : "memory");
+            if (__builtin_amdgcn_ballot_w64(v >= need) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    constexpr int DSTEP = (NS / 2) / NPC;      // late issue: one piece every DSTEP-th step of the chain's second half
+    static_assert(!POLL || DSTEP >= 1, "DMA issue slots in the second half of the chain");
     for (uint32_t u = 0; u < n_half; ++u) {
         const uint32_t sel = blockIdx.x + (u >> 1) * step, h = u & 1;
         const unsigned char *buf = smem + cur * HALF_BYTES;
@@ -1067,6 +1088,14 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
         const unsigned char *psrc = src_of(u + PF);
         const uint32_t pdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + pfb * HALF_BYTES));
         const uint64_t row0 = (uint64_t)sel * a.tile_stride * MF_TR + h * MFB_TR;
+        if (POLL) poll_words(0, u + 1u);      // this half tile's data: every wave has seen its pieces of it land
+        auto before_dma = [&]() {      // the buffer this half tile's DMA refills: everybody through with the half tile before this one
+            poll_words(8, u);
+            if (PF == 2) {      // what this wave has in flight here (the pieces of half tile u + 1, its last stores) is a half tile old: "u + 1 has landed" can be said now
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) { const uint32_t ld_ = u + 2u; asm volatile("ds_write_b32 %0, %1" ::"v"(sync_lds + (uint32_t)wave * 4u), "v"(ld_) : "memory"); }
+            }
+        };
         if (active) {
             floatx4 acc0 = zero4, acc1 = zero4;
             half8 ring[RING];
@@ -1081,7 +1110,10 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
                 if (st + D < NS) rd(st + D);
                 if (st < KS32) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[st % RING], bq[st], acc0, 0, 0, 0);
                 else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[st % RING], bq[st - KS32], acc1, 0, 0, 0);
-                if (st % 6 == 2 && st / 6 < NPC) glds16(psrc, srcoff[st / 6], pdst + (st / 6) * (NT * 16));
+                if (POLL) {
+                    if (st == NS / 2) before_dma();
+                    if (st >= NS / 2 && (st - NS / 2) % DSTEP == 0 && (st - NS / 2) / DSTEP < NPC) glds16(psrc, srcoff[(st - NS / 2) / DSTEP], pdst + ((st - NS / 2) / DSTEP) * (NT * 16));
+                } else if (st % 6 == 2 && st / 6 < NPC) glds16(psrc, srcoff[st / 6], pdst + (st / 6) * (NT * 16));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE == MF_MODE_EMIT) {
@@ -1090,7 +1122,8 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
                 if (__builtin_amdgcn_ballot_w64(m0 >= thr_l) != 0) { emit_block(acc0, row0); emitted = true; }
                 if (__builtin_amdgcn_ballot_w64(m1 >= thr_l) != 0) { emit_block(acc1, row0 + 16); emitted = true; }
                 if (wq_n >= (uint32_t)MF_WQ_CAP / 2) { drain(); emitted = true; }
-                if (emitted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores / atomics share the VM counter with the DMA: nothing of them may be pending at the counted wait
+                if (!POLL && emitted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores / atomics share the VM counter with the DMA: nothing of them may be pending at the counted wait
+                (void)emitted;
             } else {
                 float m = -__builtin_inff();
 #pragma unroll
@@ -1108,16 +1141,27 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
                 }
             }
         } else {
+            if (POLL) before_dma();
 #pragma unroll
             for (int i = 0; i < NPC; ++i) glds16(psrc, srcoff[i], pdst + i * (NT * 16));
             if (MODE != MF_MODE_EMIT && h && lane < 16) a.blockmax[((size_t)pass * a.n_sel_tiles + sel) * MF_BPAD + q_local] = 0.0f;      // padding queries: defined values
         }
         // hand-over: the next half tile must have landed (with three buffers the pieces issued during this half tile may stay in flight)
         // (the sample pass stores its maxima every other half tile: stores and loads share the counter and may return out of order with each other, so it waits for everything)
+        if (POLL) {
+            if (PF != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // two buffers: the pieces issued during this half tile are the next one's
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of the half tile have returned
+            if (lane == 0) {
+                const uint32_t done = u + 1u;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(sync_lds + (8u + (uint32_t)wave) * 4u), "v"(done) : "memory");
+                if (PF != 2) { const uint32_t ld_ = u + 2u; asm volatile("ds_write_b32 %0, %1" ::"v"(sync_lds + (uint32_t)wave * 4u), "v"(ld_) : "memory"); }
+            }
+        } else {
         if (PF == 2 && MODE == MF_MODE_EMIT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
         cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
@@ -1920,8 +1964,8 @@ static int launch_scan(const MfmaArgs &a, const MfmaPlan &p, uint32_t n_sel, hip
         static const int big_v1 = getenv("SHODH_BIG_SCAN_V1") ? atoi(getenv("SHODH_BIG_SCAN_V1")) : 0;      // diagnostic: 1 = the round-2 kernel (one wave per SIMD)
         if (!big_v1) {
             const size_t half = (size_t)MFB_TR * a.dim * 2;
-            const size_t nb = (3 * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 <= 160 * 1024) ? 3 : 2;
-            const size_t lds3 = nb * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 32;
+            const size_t nb = (3 * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 + 64 <= 160 * 1024) ? 3 : 2;      // == big3_nbuf<KSTEPS>()
+            const size_t lds3 = nb * half + (size_t)MF_EQ_CAP * 12 + MF_BPAD * 4 + 64 + 32;
 #define SHODH_LAUNCH_BIG3(KS)                                                                                       \
     case KS:                                                                                                       \
         SHODH_TRY(ensure_dynamic_lds((const void *)mfma_scan_big3_kernel<MODE, KS>, lds3));                         \

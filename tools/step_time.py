@@ -3,10 +3,10 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch, bench
 import shodh_memory_amd as S
 dev = torch.device("cuda", 0)
-n = int(os.environ.get("ROWS", 1_000_000)); k = int(os.environ.get("K", 10)); nq = int(os.environ.get("NQ", 256))
-rows = bench.synth_rows(torch, n, 384, 1, dev)
-q = bench.synth_rows(torch, nq, 384, 2, dev)
-idx = S.VamanaIndex(S.VamanaConfig(dimension=384, scan_mode=2, reserve_rows=n))
+n = int(os.environ.get("ROWS", 1_000_000)); k = int(os.environ.get("K", 10)); nq = int(os.environ.get("NQ", 256)); dim = int(os.environ.get("DIM", 384))
+rows = bench.synth_rows(torch, n, dim, 1, dev)
+q = bench.synth_rows(torch, nq, dim, 2, dev)
+idx = S.VamanaIndex(S.VamanaConfig(dimension=dim, scan_mode=2, reserve_rows=n))
 idx.build(rows)
 for _ in range(3): idx.search_batch_device(q, k)
 torch.cuda.synchronize(); idx.kernel_timing(True)
