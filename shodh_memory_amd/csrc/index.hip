@@ -77,16 +77,16 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
 size_t mfma_workspace_bytes(const MfmaPlan &p, uint32_t dim, size_t *offs);
 bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const MfmaPlan &p);
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
-                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext, uint32_t *stats_mirror);
 bool probe_select_supported(uint64_t n_rows, uint32_t dim, uint32_t k, uint32_t order, bool has_deleted, const MfmaPlan &p);
 int launch_probe_select_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const float *d_q, uint32_t nq, uint32_t k, uint32_t id_base,
-                                 float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                                 float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                                  uint32_t *stats_ext);
 int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
-                         uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t id_base, float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext, uint32_t *stats_mirror);
 int launch_convert_rows(const float *rows, uint64_t first, uint64_t n, uint32_t dim, _Float16 *rows_h, uint32_t *stats, hipStream_t st);
@@ -205,6 +205,7 @@ struct shodh_index {
     std::vector<uint32_t> deleted_host;  // host mirror of the bitmask
     uint64_t n = 0, cap_rows = 0, n_deleted = 0;
     float maxnorm = 0.0f, maxabs = 0.0f;
+    float maxres = 0.0f;                 // the largest |row - its fp16 shadow row| (convert_rows_kernel): the corpus side of the pre-scan's error bound (scan_mfma.hip, eps_coefficients)
     bool quantizable = true;             // fp16 shadow usable (max |x| * 256 < 60000)
     bool shadow = false;                 // shadow copy maintained (dim supported by the MFMA kernel)
     std::mutex ws_mu;
@@ -286,8 +287,8 @@ static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
         SHODH_TRY(launch_convert_rows(idx->rows, first, n, idx->cfg.dim, idx->rows_h, idx->stats, nullptr));
         uint32_t st[4];
         SHODH_HIP_TRY(hipMemcpy(st, idx->stats, sizeof(st), hipMemcpyDeviceToHost));
-        float nsq, ma;
-        memcpy(&nsq, &st[0], 4); memcpy(&ma, &st[1], 4);
+        float nsq, ma, rsq;
+        memcpy(&nsq, &st[0], 4); memcpy(&ma, &st[1], 4); memcpy(&rsq, &st[3], 4);
         if (st[2] != 0) {
             // roll back: the rows are not published (n is not advanced by the caller)
             before[2] = 0;
@@ -296,6 +297,7 @@ static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
             return SHODH_ERR_NONFINITE;
         }
         idx->maxnorm = sqrtf(nsq) * 1.00001f;
+        idx->maxres = sqrtf(rsq) * 1.0001f;
         idx->maxabs = ma;
         idx->quantizable = (ma * 256.0f < 60000.0f);
     } else {
@@ -407,15 +409,15 @@ static int enqueue_flat(shodh_index *idx, Workspace *w, const float *d_q, uint32
         SHODH_TRY(w->reserve(fc->ws_bytes + part_bytes + 256));
         if (psel) {
             fc->sampled_rows = 0;
-            SHODH_TRY(launch_probe_select_pipeline(idx->rows, idx->rows_h, idx->n, dim, d_q, nq, k, idb, idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stats_ext));
+            SHODH_TRY(launch_probe_select_pipeline(idx->rows, idx->rows_h, idx->n, dim, d_q, nq, k, idb, idx->maxnorm, idx->maxres, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stats_ext));
             if (stage_events) { SHODH_HIP_TRY(hipEventRecord(w->ev[1], st)); SHODH_HIP_TRY(hipEventRecord(w->ev[2], st)); }
         } else if (fc->solo) {     // one query: a single pass over the shadow copy with workgroup-local thresholds
-            SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, p, w->buf, fc->offs,
+            SHODH_TRY(launch_solo_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, k, idx->cfg.order, idb, idx->maxnorm, idx->maxres, p, w->buf, fc->offs,
                                            w->solo_cnt, idx->cus, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
                                             stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext, stats_mirror));
         } else {
             SHODH_TRY(launch_mfma_pipeline(idx->rows, idx->rows_h, idx->n, dim, del, d_q, nq, k, idx->cfg.order, idb,
-                                           idx->maxnorm, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
+                                           idx->maxnorm, idx->maxres, p, w->buf, fc->offs, d_ids, d_dist, d_counts, st, stage_events ? w->ev[1] : nullptr,
                                             stage_events ? w->ev[2] : nullptr, rk0, rk1, stats_ext, stats_mirror));
         }
         // exact scan of whatever the pre-scan could not settle (device-side list; normally empty). A host-pointer call looks at the
@@ -623,7 +625,7 @@ static int build_impl(shodh_index *idx, const float *rows, uint64_t n, hipMemcpy
         SHODH_HIP_TRY(hipDeviceSynchronize());
         idx->n = 0;
         idx->n_deleted = 0;
-        idx->maxnorm = 0; idx->maxabs = 0; idx->quantizable = true;
+        idx->maxnorm = 0; idx->maxres = 0; idx->maxabs = 0; idx->quantizable = true;
         if (idx->deleted) SHODH_HIP_TRY(hipMemset(idx->deleted, 0, (idx->cap_rows / 32 + 1) * 4));
         std::fill(idx->deleted_host.begin(), idx->deleted_host.end(), 0u);
         SHODH_HIP_TRY(hipMemset(idx->stats, 0, 16));

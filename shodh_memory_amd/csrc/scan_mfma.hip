@@ -165,8 +165,8 @@ __host__ __device__ constexpr int mfma_scan_nbuf() { return (3 * MF_TR * KSTEPS 
 // ds_read_b128 for the 32x32x16 A fragment). LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE
 // address: the lane that owns LDS chunk (row, p) fetches global chunk (row, p ^ (row&15)) -- a permutation inside one
 // 256-B segment, still whole cache lines per wave.
-// One s_barrier per tile hands the buffers over (raw barrier + lgkmcnt(0): a __syncthreads() would not wait for
-// the DMA anyway, the counted vmcnt before it does).
+// Rounds 1 - 5: one s_barrier per tile handed the buffers over (raw barrier + lgkmcnt(0): a __syncthreads() would not wait for
+// the DMA anyway, the counted vmcnt before it did). Round 6: progress words in LDS instead (SHODH_MF_POLL above).
 // History, cycles per tile at 1M x 384, 256 queries (s_memtime; matrix-pipe floor 2 waves x 48 x 32 = 3072):
 //   register staging, all phases in sequence, waves in lock-step: 5190; two wave groups half a tile out of phase
 //   (one group multiplies while the other stages): 5390 including the profiling reads -- the two groups' MFMA phases
@@ -1172,18 +1172,18 @@ __global__ __launch_bounds__(512, 1) void mfma_scan_big3_kernel(MfmaArgs a) {
 // ---- conversions ------------------------------------------------------------------------------------
 // rows f32 -> fp16(256 x) shadow; also folds max row norm^2, max |x| and a non-finite flag into stats.
 // stats[0] = max norm^2 (float bits, atomicMax on uint works for non-negative floats)
-// stats[1] = max |x| (float bits), stats[2] = non-finite count
+// stats[1] = max |x| (float bits), stats[2] = non-finite count, stats[3] = max |row - shadow row|^2 (float bits)
 __global__ __launch_bounds__(256) void convert_rows_kernel(const float *rows, uint64_t first, uint64_t n, uint32_t dim,
                                                            _Float16 *rows_h, uint32_t *stats) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave_gid = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint64_t wave_cnt = ((uint64_t)gridDim.x * 256) >> 6;
-    float mx_n = 0.0f, mx_a = 0.0f;
+    float mx_n = 0.0f, mx_a = 0.0f, mx_r = 0.0f;
     uint32_t bad = 0;
     for (uint64_t r = first + wave_gid; r < first + n; r += wave_cnt) {
         const float *src = rows + r * dim;
         _Float16 *dst = rows_h + r * dim;
-        float ss = 0.0f;
+        float ss = 0.0f, rs = 0.0f;
         for (uint32_t i = lane * 4; i < dim; i += 256) {   // dim % 4 == 0 on this path
             const float4 v = *reinterpret_cast<const float4 *>(src + i);
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -1195,11 +1195,14 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float *rows, ui
                 mx_a = fmaxf(mx_a, __builtin_fabsf(x));
                 ss = __builtin_fmaf(x, x, ss);
                 h[j] = (_Float16)(x * MF_SCALE);
+                const float d = x - (float)h[j] * (1.0f / MF_SCALE);      // what the rounding to fp16 took away (the difference of two close floats: exact)
+                rs = __builtin_fmaf(d, d, rs);
             }
             *reinterpret_cast<uint2 *>(dst + i) = *reinterpret_cast<const uint2 *>(h);
         }
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); rs += __shfl_xor(rs, off); }
         mx_n = fmaxf(mx_n, ss);
+        mx_r = fmaxf(mx_r, (__builtin_fabsf(rs) <= 3.0e38f) ? rs : 0.0f);      // (a non-finite row is rejected by the caller: keep the maximum finite)
     }
     for (int off = 32; off > 0; off >>= 1) {
         mx_a = fmaxf(mx_a, __shfl_xor(mx_a, off));
@@ -1209,6 +1212,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float *rows, ui
         atomicMax(stats + 0, __float_as_uint(mx_n));
         atomicMax(stats + 1, __float_as_uint(mx_a));
         if (bad) atomicAdd(stats + 2, bad);
+        atomicMax(stats + 3, __float_as_uint(mx_r));      // max over the rows of |row - fp16 copy|^2: the corpus side of the pre-scan's error bound (eps_coefficients)
     }
 }
 
@@ -1246,6 +1250,7 @@ struct QueryPrep {
     uint32_t nq, dim, n_slots;
     _Float16 *q_h;           // [n_slots * dim] fragment-major, see the kernel
     float *qnorm;            // [n_slots]
+    float *qres;             // [n_slots] |q - fp16 copy| (what the query's rounding took away), a hair generous; lives in the workspace's eps array until threshold_kernel replaces it by eps
     uint32_t *cand_cnt;      // [n_slots]
     uint32_t *fallback;      // [n_slots] 1 = must go through the exact scan
     uint32_t *fb_count;      // single counter, zeroed here
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(256) void convert_queries_kernel(QueryPrep p) {
     if (blockIdx.x == 0 && threadIdx.x < 5) p.stats[threadIdx.x] = 0;       // (word 4: arrivals of the final stage, see its end)
     if (blockIdx.x == 0 && threadIdx.x == 4) *p.fb_count = 0;
     if (slot >= p.n_slots) return;
-    float ss = 0.0f, mx = 0.0f;
+    float ss = 0.0f, mx = 0.0f, rs = 0.0f;
     uint32_t bad = 0;
     for (uint32_t i = lane; i < p.dim; i += 64) {
         float x = 0.0f;
@@ -1265,6 +1270,7 @@ __global__ __launch_bounds__(256) void convert_queries_kernel(QueryPrep p) {
         if (!(__builtin_fabsf(x) <= 3.0e38f)) bad++;
         mx = fmaxf(mx, __builtin_fabsf(x));
         ss = __builtin_fmaf(x, x, ss);
+        { const float d = x - (float)(_Float16)(x * MF_SCALE) * (1.0f / MF_SCALE); rs = __builtin_fmaf(d, d, rs); }
         // fragment-major: [pass][wave = q/32][k-step = i/16][lane = ((i%16)/8)*32 + q%32][i%8], so that the scan kernel's
         // 32x32x16 B fragment of one k-step is ONE contiguous 1 KiB wave load (row-major made every load instruction touch 32
         // different 128-B lines for 32 B each: ~9 us of prologue per launch)
@@ -1276,11 +1282,13 @@ __global__ __launch_bounds__(256) void convert_queries_kernel(QueryPrep p) {
     }
     for (int off = 32; off > 0; off >>= 1) {
         ss += __shfl_xor(ss, off);
+        rs += __shfl_xor(rs, off);
         mx = fmaxf(mx, __shfl_xor(mx, off));
         bad += __shfl_xor(bad, off);
     }
     if (lane == 0) {
         p.qnorm[slot] = __builtin_sqrtf(ss) * 1.00001f;
+        p.qres[slot] = (__builtin_fabsf(rs) <= 3.0e38f) ? __builtin_sqrtf(rs) * 1.0001f : 0.0f;      // (an unquantisable / non-finite query goes to the exact scan: its eps is never used)
         p.cand_cnt[slot] = 0;
         // unquantisable query (fp16 range) or non-finite: exact path decides
         p.fallback[slot] = (slot < p.nq && (bad || mx * MF_SCALE > 60000.0f)) ? 1u : 0u;
@@ -1293,11 +1301,12 @@ struct ThrArgs {
     uint32_t J, k, cap, nq;
     const float *qnorm;      // [n_slots]
     const uint32_t *fallback;
-    float eps_rel_maxnorm;   // eps_rel * maxnorm
+    float eps_rel_maxnorm;   // coefficient of |q|: eps_rel * maxnorm + maxres (eps_coefficients)
     float eps_abs_a;         // coefficient of (|q| + maxnorm)
     float maxnorm;
+    float res_mul;           // coefficient of the query's own rounding residual: maxnorm + maxres
     float *thr;              // [n_slots] emit threshold
-    float *eps;              // [n_slots]
+    float *eps;              // [n_slots] in: the query's rounding residual (convert_queries_kernel); out: eps
     float eps2_rel_maxnorm;  // level-2 (f32 FMA re-score) bound: eps2 = eps2_rel_maxnorm * |q| + eps2_abs_a * (|q| + maxnorm) + 1e-9
     float eps2_abs_a;
     float *eps2;             // [n_slots]
@@ -1316,7 +1325,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     const uint32_t slot = blockIdx.x;            // pass*256 + q
     const uint32_t pass = slot / MF_BPAD, ql = slot % MF_BPAD;
     const float qn = a.qnorm[slot];
-    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;
+    const float qres = a.eps[slot];
+    __syncthreads();             // (everybody has read the residual before thread 0 puts eps in its place)
+    const float eps = a.eps_rel_maxnorm * qn + qres * a.res_mul + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;
     if (tid == 0) a.eps2[slot] = a.eps2_rel_maxnorm * qn + a.eps2_abs_a * (qn + a.maxnorm) + 1e-9f;
     if (slot >= a.nq || a.fallback[slot]) {
         if (tid == 0) { a.thr[slot] = __builtin_inff(); a.eps[slot] = eps; }   // never emits
@@ -2152,7 +2163,7 @@ __global__ __launch_bounds__(SOLO_NT) void solo_scan_kernel(SoloArgs a) {
     }
     const float qn = __builtin_sqrtf(ss) * 1.00001f;
     const bool bad_q = badv != 0 || mx * MF_SCALE > 60000.0f;       // the conditions of convert_queries_kernel
-    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;
+    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;      // (the query is not rounded here: no residual term of its own)
     if (blockIdx.x == 0) {
         if (tid < 4) a.stats[tid] = 0;
         if (tid == 4) *a.fb_count = 0;
@@ -2432,12 +2443,21 @@ static void unpack_workspace(MfmaWorkspace &w, unsigned char *ws_base, const siz
     w.dpar = (uint32_t *)(ws_base + offs[14]); w.dpub = w.dpar + (offs[15] - offs[14]) / 12 * 2;
 }
 
-// eps (DESIGN.md "error bound"): fp16 rounding of both operands 2^-10 (1+2^-11), f32 accumulation
-// dim * 2^-23, reference rounding ~1e-5; absolute term for flushed/denormal fp16 after the 2^8 scale
+// eps (DESIGN.md "error bound"). The pre-scan multiplies q~ = fp16(256 q) / 256 by c~ = fp16(256 c) / 256 exactly (fp16 x fp16 products are exact in f32) and adds in f32:
+//   |s~ - dot_ref| <= |(q~ - q) . c~| + |q . (c~ - c)| + accumulation + the reference's own rounding
+//                  <= |q~ - q| (|c| + |c~ - c|) + |q| |c~ - c| + dim 2^-23 1.01 |q||c| + max(1e-5, dim 2^-24 1.01) |q||c|      (Cauchy-Schwarz)
+// Rounds 1 - 5 charged the two rounding terms at their worst case, 2^-11 per element each: 9.7704e-4 |q||c|. Round 6 measures them: convert_rows_kernel keeps the largest
+// |c - c~| over the rows (maxres; index.hip), convert_queries_kernel the query's own |q - q~| -- on unit vectors ~2.5e-4 each, half the worst case, so the window of the
+// final stage and the emit threshold's margin shrink accordingly (k = 120: 25 % fewer rows re-scored). What a flushed / gradually underflowing fp16 denormal adds on top
+// of the stored value stays charged per element in the absolute term, as before. The single-query scan keeps the query in f32: no residual term of its own.
+//   eps = rel maxnorm |q| + maxres |q| + qres (maxnorm + maxres) + abs_a (|q| + maxnorm) + 1e-9        rel = dim 1.1921e-7 1.01 + max(1e-5, dim 5.9605e-8 1.01)
 struct EpsCoef { float rel, abs_a, rel2, abs2_a; };
 static EpsCoef eps_coefficients(uint32_t dim, uint32_t order) {
     EpsCoef c;
-    c.rel = 9.7704e-4f + (float)dim * 1.1921e-7f * 1.01f + 1.0e-5f;
+    // accumulation of the pre-scan (dim terms, charged a whole ulp each: the matrix pipe's internal rounding mode is not documented) + the reference's own sum:
+    // any summation order of dim products is within gamma_dim = dim 2^-24 (1 + ...) of the exact dot (rounds 1 - 5 charged a flat 1e-5 here, short of the
+    // strict worst case from dim = 168 up; with the rounding terms measured there is no slack left elsewhere to lean on)
+    c.rel = (float)dim * 1.1921e-7f * 1.01f + fmaxf(1.0e-5f, (float)dim * 5.9605e-8f * 1.01f);
     c.abs_a = 2.3842e-7f * __builtin_sqrtf((float)dim) * 1.01f + (order == SHODH_ORDER_SEQ_1M ? 1.0e-6f : 0.0f);   // SEQ_1M: + the rounding of `1 - dot` (<= 2^-24 |1 - dot|, |dot| <= qn*maxnorm), charged generously
     // level 2 (final stage, dense corpora only): s2 = f32 FMA dot in any order. Both s2 and the reference's sum are within
     // gamma_dim * |q||c| of the exact dot (gamma_n = n 2^-24 / (1 - n 2^-24)), so |s2 - dot_ref| <= dim * 2^-23 * |q| * maxnorm
@@ -2468,7 +2488,7 @@ bool solo_supported(uint32_t nq, uint32_t k, uint64_t n_rows, int cus, const Mfm
 // The single-query pipeline: solo_scan_kernel [+ solo_emit_kernel] + final stage; like launch_mfma_pipeline it leaves an unresolved query in
 // fb_list / fb_count. `solo_cnt`: one u32 that is zero between calls (allocated zeroed by the caller, handed back zeroed by the final stage).
 int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const uint32_t *deleted, const float *d_q,
-                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t k, uint32_t order, uint32_t id_base, float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *solo_cnt, int cus, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev0, hipEvent_t ev1, uint32_t *stats_ext, uint32_t *stats_mirror) {
     MfmaWorkspace w;
@@ -2507,7 +2527,7 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     const EpsCoef c = eps_coefficients(dim, order);
     uint32_t *skeys = reinterpret_cast<uint32_t *>(w.cand + p.cand_cap);          // behind query 0's list (solo_global_fits)
     uint32_t *tops = skeys + ((n_rows + 63) & ~(uint64_t)63);
-    SoloArgs a{rows_h, n_rows, dim, d_q, deleted, k, (uint32_t)slice, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a,
+    SoloArgs a{rows_h, n_rows, dim, d_q, deleted, k, (uint32_t)slice, c.rel * maxnorm + maxres, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a,
                w.slots, w.cand, solo_cnt, p.cand_cap, w.eps, w.eps2, w.fallback, w.fb_count, w.stats, 0u, skeys, tops, ilv, stream, ring_off, dwl_cap};
 #ifdef SHODH_DIAG
     a.ablate = getenv("SHODH_SOLO_ABLATE") ? (uint32_t)atoi(getenv("SHODH_SOLO_ABLATE")) : 0u;
@@ -2550,7 +2570,7 @@ int launch_solo_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
 // for the exact scan, which the caller enqueues right after (flat_exact.hip, device-side count).
 int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim,
                          const uint32_t *deleted, const float *d_q, uint32_t nq, uint32_t k, uint32_t order,
-                         uint32_t id_base, float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
+                         uint32_t id_base, float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs,
                          uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                          hipEvent_t ev_scan_done, hipEvent_t ev_select_done, hipEvent_t ev_emit0, hipEvent_t ev_emit1, uint32_t *stats_ext, uint32_t *stats_mirror) {
     MfmaWorkspace w;
@@ -2558,7 +2578,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     if (stats_ext) w.stats = stats_ext;      // host-pointer calls: the statistics words of the caller's output block
     w.stats_mirror = stats_mirror;
 
-    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
+    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.eps, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
     SHODH_HIP_TRY(hipGetLastError());
 
@@ -2577,7 +2597,7 @@ int launch_mfma_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_r
     const float eps_rel = c.rel, eps_abs_a = c.abs_a, eps2_rel = c.rel2, eps2_abs_a = c.abs2_a;
     uint32_t r_top = p.tile_stride ? k / p.tile_stride : 0u;
     if (r_top < 1) r_top = 1;
-    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm, eps_abs_a, maxnorm, w.thr, w.eps,
+    ThrArgs t{w.blockmax, p.J, k, p.topk_cap, nq, w.qnorm, w.fallback, eps_rel * maxnorm + maxres, eps_abs_a, maxnorm, maxnorm + maxres, w.thr, w.eps,
               eps2_rel * maxnorm, eps2_abs_a, w.eps2, dyn ? w.dcnt : nullptr, w.dthr, w.dpub, w.dpar, r_top};
     const size_t tlds = (size_t)p.topk_cap * 8 + 512 * 8 + 8 + 4 + 16;
     (void)tlds;
@@ -2613,6 +2633,7 @@ struct PselArgs {
     const float *q; uint32_t nq, k;
     const float *scores; uint32_t ld;
     const float *qnorm; const uint32_t *unquantisable;
+    const float *qres; float res_mul;      // the query's rounding residual (convert_queries_kernel) and its coefficient maxnorm + maxres
     float eps_rel_maxnorm, eps_abs_a, maxnorm, eps2_rel_maxnorm, eps2_abs_a;
     uint32_t *ids; float *dist; uint32_t *counts;
 };
@@ -2684,7 +2705,7 @@ __global__ __launch_bounds__(PSEL_NT) void probe_select_kernel(PselArgs a) {
         if ((tid & 3u) == 0) mins[tid >> 2] = g;
     }
     const float qn = a.qnorm[q];
-    const float eps = a.eps_rel_maxnorm * qn + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;      // (threshold_kernel's expression)
+    const float eps = a.eps_rel_maxnorm * qn + a.qres[q] * a.res_mul + a.eps_abs_a * (qn + a.maxnorm) + 1e-9f;      // (threshold_kernel's expression)
     const bool usual = !a.unquantisable[q] && k >= 1 && k <= n;                  // block-uniform. Otherwise every row is "in between"
     __syncthreads();
     WPROF_T(0)
@@ -2936,19 +2957,19 @@ bool probe_select_supported(uint64_t n_rows, uint32_t dim, uint32_t k, uint32_t 
 
 // convert_queries_kernel, score pre-scan, probe_select_kernel: three launches, nothing left over for the exact scan
 int launch_probe_select_pipeline(const float *rows, const _Float16 *rows_h, uint64_t n_rows, uint32_t dim, const float *d_q, uint32_t nq, uint32_t k, uint32_t id_base,
-                                 float maxnorm, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
+                                 float maxnorm, float maxres, const MfmaPlan &p, unsigned char *ws_base, const size_t *offs, uint32_t *d_ids, float *d_dist, uint32_t *d_counts, hipStream_t st,
                                  uint32_t *stats_ext) {
     MfmaWorkspace w;
     unpack_workspace(w, ws_base, offs);
     if (stats_ext) w.stats = stats_ext;
-    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.cand_cnt, w.fallback, w.fb_count, w.stats};
+    QueryPrep qp{d_q, nq, dim, p.n_slots, w.q_h, w.qnorm, w.eps, w.cand_cnt, w.fallback, w.fb_count, w.stats};
     hipLaunchKernelGGL(convert_queries_kernel, dim3((p.n_slots * 64 + 255) / 256), dim3(256), 0, st, qp);
     const uint32_t ld = (uint32_t)(p.n_tiles * MF_TR);
     float *scores = reinterpret_cast<float *>(w.cand);                             // [n_slots][ld] f32 <= [n_slots][cand_cap] u64
     MfmaArgs a{rows_h, n_rows, dim, w.q_h, w.thr, nullptr, w.slots, w.cand, w.cand_cnt, p.cand_cap, w.blockmax, 1u, (uint32_t)p.n_tiles, 0u, nq, nullptr, nullptr, nullptr, nullptr, k, scores, ld};
     SHODH_TRY(launch_scan<MF_MODE_SCORES>(a, p, (uint32_t)p.n_tiles, st));
     const EpsCoef c = eps_coefficients(dim, SHODH_ORDER_SEQ_1M);
-    PselArgs s{rows, (uint32_t)n_rows, dim, id_base, d_q, nq, k, scores, ld, w.qnorm, w.fallback, c.rel * maxnorm, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a, d_ids, d_dist, d_counts};
+    PselArgs s{rows, (uint32_t)n_rows, dim, id_base, d_q, nq, k, scores, ld, w.qnorm, w.fallback, w.eps, maxnorm + maxres, c.rel * maxnorm + maxres, c.abs_a, maxnorm, c.rel2 * maxnorm, c.abs2_a, d_ids, d_dist, d_counts};
     const uint32_t nv4 = (uint32_t)ceil_div(n_rows, 4 * PSEL_NT);
     const size_t lds = psel_lds_bytes(dim, nv4 * 4 * PSEL_NT);
 #define SHODH_LAUNCH_PSEL(NVV)                                                                                   \

@@ -137,7 +137,7 @@ def test_crowded_corpus_and_interleaved_batches(S, oracle, order):
     hundreds of rows through the shared list; batch calls in between use the same workspace"""
     rng = np.random.default_rng(5)
     base = synth.queries(1)[0]
-    rows = base[None, :] + f32(0.006) * rng.standard_normal((40000, 384)).astype(f32)
+    rows = base[None, :] + f32(0.0045) * rng.standard_normal((40000, 384)).astype(f32)     # (0.006 until round 6: the window follows the measured rounding residuals now)
     rows /= np.linalg.norm(rows, axis=1, keepdims=True)
     rows = np.ascontiguousarray(rows.astype(f32))
     idx = make_index(S, order=order)
