@@ -22,6 +22,7 @@ namespace shodh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int EX_NT = 256;            // threads per block (4 waves)
+constexpr uint32_t FLAT_ARRIVE_WORDS = 1024;   // capacity of the arrival counters of the in-scan merge (index.hip allocates them next to a workspace's single-query counter)
 constexpr uint32_t EX_MAX_GROUPS = 32;  // query groups of one row range in flight at a time (1M rows: 1024 queries 42.7 ms with 128 groups in flight)
 constexpr int EX_CHUNK = 32;          // floats of a row staged per step (one 128-B line)
 constexpr int EX_PITCH = EX_CHUNK + 4;  // LDS row pitch in floats
@@ -43,7 +44,43 @@ struct ExactArgs {
     uint32_t id_base;
     const uint32_t *qlist;     // optional indirection: slot -> query index (device-side fallback list)
     const uint32_t *qcount;    // optional device-side number of slots (overrides nq)
+    // Merge inside the scan (round 6, fallback mode of the pre-scan pipeline only): the workgroup that delivers the LAST partial list of a query group merges the
+    // group's lists itself -- one launch instead of two for a step that nearly always finds its fallback list empty (two empty launches were 9.4 us of a 238 us step).
+    uint32_t *arrive;          // [query groups] arrivals per group, zero between launches (the last arriver hands its counter back zeroed); nullptr = separate merge_topk_kernel
+    uint32_t mcap;             // key buffer capacity of the merge (topk_capacity(k))
+    uint32_t *ids;             // [nq][k] final results (arrive != nullptr)
+    float *dist;
+    uint32_t *counts;
 };
+
+// the merge of one query's partial lists (merge_topk_kernel's body; also run by the last arriver of flat_exact_kernel). LDS: keys[cap] | mins[2 EX_NT] | thr | cnt.
+// Every thread of the block calls; ends with the results written (no trailing barrier).
+__device__ __forceinline__ void merge_query_lists(const uint64_t *lists, uint32_t nlists, uint32_t qb, uint32_t k, uint32_t cap, uint32_t y, uint32_t qi, uint32_t q,
+                                                  uint32_t *ids, float *dist, uint32_t *counts, unsigned char *lds) {
+    uint64_t *keys = reinterpret_cast<uint64_t *>(lds);
+    uint64_t *mins = keys + cap;
+    uint64_t *thr = mins + 2 * EX_NT;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
+    const int tid = threadIdx.x;
+    TopKBuf buf{keys, cnt, thr, cap, k};
+    const uint64_t total = (uint64_t)nlists * k;
+    auto key_at = [&](uint64_t e) -> uint64_t {
+        const uint64_t l = e / k, i = e % k;
+        return lists[((((uint64_t)y * nlists + l) * qb) + qi) * k + i];
+    };
+    const uint32_t m = block_select_topk<EX_NT>(key_at, total, buf, mins);
+    for (uint32_t i = tid; i < k; i += EX_NT) {
+        if (i < m) {
+            const uint64_t key = buf.keys[i];
+            ids[(size_t)q * k + i] = (uint32_t)key;
+            dist[(size_t)q * k + i] = order_key_inv((uint32_t)(key >> 32));
+        } else {
+            ids[(size_t)q * k + i] = 0xFFFFFFFFu;
+            dist[(size_t)q * k + i] = __builtin_inff();
+        }
+    }
+    if (tid == 0) counts[q] = m;
+}
 
 // ---- fast kernel: dim % 32 == 0 -----------------------------------------------------------------
 // One lane = one row (the reference's sums are serial chains per (query, row), so the parallelism is across rows and queries):
@@ -231,6 +268,32 @@ __global__ __launch_bounds__(EX_NT) void flat_exact_kernel(ExactArgs a, const fl
         const uint32_t m = *buf[q].cnt;
         for (uint32_t i = tid; i < a.k; i += EX_NT) out[i] = (i < m) ? buf[q].keys[i] : KEY_NONE;
     }
+    if (a.arrive) {
+        // the group's lists of this row range are out: count the arrival; the last of the gridDim.x row ranges merges the group
+        __threadfence();                       // (each thread: its part of the lists is visible device-wide before the arrival is)
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t old = atomicAdd(&a.arrive[grp], 1u);
+            const bool last = old + 1u == gridDim.x;
+            if (last) a.arrive[grp] = 0u;      // handed back zeroed (nobody else touches this group's counter any more in this launch)
+            cnt[0] = last ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = cnt[0] != 0u;        // block-uniform
+        __syncthreads();
+        if (last) {
+            __threadfence();                   // (acquire: the other workgroups' lists)
+#pragma unroll 1
+            for (int q = 0; q < QB; ++q) {
+                if (q0 + q >= nq_eff) break;
+                const uint32_t s_ = q0 + q;
+                const uint32_t qi = a.qlist ? a.qlist[s_] : s_;
+                __syncthreads();
+                merge_query_lists(a.partial, gridDim.x, QB, a.k, a.mcap, grp, (uint32_t)q, qi, a.ids, a.dist, a.counts, smem);      // (the scan's LDS is free: merge buffers from its base)
+            }
+            __syncthreads();
+        }
+    }
   }
 }
 
@@ -321,34 +384,11 @@ struct MergeArgs {
 
 __global__ __launch_bounds__(EX_NT) void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *mins = keys + a.cap;
-    uint64_t *thr = mins + 2 * EX_NT;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + 1);
-    const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;
     const uint32_t nq_eff = a.qcount ? *a.qcount : a.nq;
     if (slot >= nq_eff) return;
     const uint32_t q = a.qlist ? a.qlist[slot] : slot;
-    TopKBuf buf{keys, cnt, thr, a.cap, a.k};
-    const uint32_t y = slot / a.qb, qi = slot % a.qb;
-    const uint64_t total = (uint64_t)a.nlists * a.k;
-    auto key_at = [&](uint64_t e) -> uint64_t {
-        const uint64_t l = e / a.k, i = e % a.k;
-        return a.lists[((((uint64_t)y * a.nlists + l) * a.qb) + qi) * a.k + i];
-    };
-    const uint32_t m = block_select_topk<EX_NT>(key_at, total, buf, mins);
-    for (uint32_t i = tid; i < a.k; i += EX_NT) {
-        if (i < m) {
-            const uint64_t key = buf.keys[i];
-            a.ids[(size_t)q * a.k + i] = (uint32_t)key;
-            a.dist[(size_t)q * a.k + i] = order_key_inv((uint32_t)(key >> 32));
-        } else {
-            a.ids[(size_t)q * a.k + i] = 0xFFFFFFFFu;
-            a.dist[(size_t)q * a.k + i] = __builtin_inff();
-        }
-    }
-    if (tid == 0) a.counts[q] = m;
+    merge_query_lists(a.lists, a.nlists, a.qb, a.k, a.cap, slot / a.qb, slot % a.qb, q, a.ids, a.dist, a.counts, smem);
 }
 
 // ---- merge of per-shard results (multi-GPU): lists of (id, dist) rows gathered from every rank ----
@@ -465,22 +505,38 @@ static int launch_generic_op(const ExactArgs &a, dim3 grid, size_t lds, hipStrea
 // `partial` must hold exact_partial_bytes(...) bytes. With qlist/qcount (device pointers) the
 // scan runs over the device-side list of query slots instead (fallback of the MFMA path): the
 // grid is sized for `nq` slots at most and blocks beyond *qcount exit at once.
+// `arrive` (optional; FLAT_ARRIVE_WORDS zeroed words that are zero again when the launch is done): the scan merges its own partial lists (ExactArgs::arrive) and no
+// merge kernel is launched -- taken for the fast kernel when the query groups fit the counter array, otherwise the two launches as before.
+int launch_flat_exact_arrive(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
+                             const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                             uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
+                             const uint32_t *qlist, const uint32_t *qcount, uint32_t *arrive, hipStream_t st);
 int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
                       const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
                       uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
                       const uint32_t *qlist, const uint32_t *qcount, hipStream_t st) {
+    return launch_flat_exact_arrive(rows, n_rows, dim, deleted, d_queries, nq, k, order, id_base, partial, grid_x, d_ids, d_dist, d_counts, qlist, qcount, nullptr, st);
+}
+int launch_flat_exact_arrive(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
+                             const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                             uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
+                             const uint32_t *qlist, const uint32_t *qcount, uint32_t *arrive, hipStream_t st) {
     if (nq == 0) return SHODH_OK;
     const uint32_t cap = topk_capacity(k);
-    ExactArgs a{rows, n_rows, dim, deleted, d_queries, nq, k, cap, partial, id_base, qlist, qcount};
+    ExactArgs a{rows, n_rows, dim, deleted, d_queries, nq, k, cap, partial, id_base, qlist, qcount, nullptr, cap, d_ids, d_dist, d_counts};
+    const size_t mlds = (size_t)cap * 8 + 2 * EX_NT * 8 + 8 + 4 + 16;
     int qb = 1;
     if (dim % 32 == 0) {
         qb = exact_pick_qb(nq, dim, k);
         uint32_t gy = (uint32_t)ceil_div(nq, qb);
+        static const bool fuse_ok = !(getenv("SHODH_EXACT_FUSED_MERGE") && atoi(getenv("SHODH_EXACT_FUSED_MERGE")) == 0);
+        if (arrive && fuse_ok && gy <= FLAT_ARRIVE_WORDS) a.arrive = arrive;
         if (qcount && gy > 4) gy = 4;          // fallback mode: few resident groups, they loop
         if (gy > EX_MAX_GROUPS) gy = EX_MAX_GROUPS;   // more groups loop: the rows a round of groups shares stay cache-resident
         dim3 grid(grid_x, gy);
         a.cap = exact_scan_cap(k);
-        const size_t lds = exact_lds_bytes(qb, k);
+        size_t lds = exact_lds_bytes(qb, k);
+        if (a.arrive && mlds > lds) lds = mlds;      // (the last arriver's merge buffers alias the scan's)
         if (lds > 160 * 1024) { set_error("k=%u too large for the exact scan (LDS %zu B)", k, lds); return SHODH_ERR_UNSUPPORTED; }
         switch (qb) {
             case 8: SHODH_TRY(launch_fast<8>(a, order, grid, lds, st)); break;
@@ -501,8 +557,8 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
             default: SHODH_TRY(launch_generic_op<SHODH_ORDER_SCALAR4>(a, grid, lds, st)); break;
         }
     }
+    if (a.arrive) return SHODH_OK;      // merged by the scan itself
     MergeArgs m{partial, grid_x, (uint32_t)qb, k, cap, nq, d_ids, d_dist, d_counts, qlist, qcount};
-    const size_t mlds = (size_t)cap * 8 + 2 * EX_NT * 8 + 8 + 4 + 16;
     SHODH_TRY(ensure_dynamic_lds((const void *)merge_topk_kernel, mlds));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(EX_NT), mlds, st, m);
     SHODH_HIP_TRY(hipGetLastError());

@@ -60,6 +60,10 @@ int launch_flat_exact(const float *rows, uint64_t n_rows, uint32_t dim, const ui
                       const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
                       uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
                       const uint32_t *qlist, const uint32_t *qcount, hipStream_t st);
+int launch_flat_exact_arrive(const float *rows, uint64_t n_rows, uint32_t dim, const uint32_t *deleted,
+                             const float *d_queries, uint32_t nq, uint32_t k, uint32_t order, uint32_t id_base,
+                             uint64_t *partial, uint32_t grid_x, uint32_t *d_ids, float *d_dist, uint32_t *d_counts,
+                             const uint32_t *qlist, const uint32_t *qcount, uint32_t *arrive, hipStream_t st);
 
 int launch_merge_lists(const uint32_t *in_ids, const float *in_dist, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
                        uint32_t *ids, float *dist, uint32_t *counts, hipStream_t st);
@@ -143,11 +147,11 @@ struct Workspace {
         for (auto &e : ev) SHODH_HIP_TRY(hipEventCreate(&e));
         SHODH_HIP_TRY(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
         for (auto &r : ring) { r[0] = nullptr; r[1] = nullptr; }      // created on first use (enqueue_flat): 64 concurrent callers used to mean 64 x 512 events up front
-        SHODH_HIP_TRY(dev_alloc((void **)&solo_cnt, 256));
+        SHODH_HIP_TRY(dev_alloc((void **)&solo_cnt, 256 + 4096));      // + 1024 arrival counters of the exact fallback's in-scan merge (flat_exact.hip, FLAT_ARRIVE_WORDS)
         // hipMemset on device memory is not synchronous with the host and the workspace's stream is non-blocking: without the synchronisation the FIRST search
         // on a new workspace could start before the counter was cleared and have it zeroed under its feet -- survivors lost, a wrong list (seen once in
         // 6400 calls with 64 threads each creating their workspace while the device was busy: bench.py concurrent_callers, round 5)
-        SHODH_HIP_TRY(hipMemsetAsync(solo_cnt, 0, 256, stream));
+        SHODH_HIP_TRY(hipMemsetAsync(solo_cnt, 0, 256 + 4096, stream));
         SHODH_HIP_TRY(hipStreamSynchronize(stream));
         SHODH_HIP_TRY(pin_alloc((void **)&h_q, 4096));
         return SHODH_OK;
@@ -369,8 +373,9 @@ static int enqueue_flat_fallback(shodh_index *idx, Workspace *w, const FlatCall 
     const uint32_t *fb_list = (const uint32_t *)(w->buf + fc.offs[6]);
     const uint32_t *fb_count = (const uint32_t *)(w->buf + fc.offs[7]);
     uint64_t *partial = (uint64_t *)(w->buf + ((fc.ws_bytes + 255) & ~(size_t)255));
-    return launch_flat_exact(idx->rows, idx->n, idx->cfg.dim, idx->n_deleted ? idx->deleted : nullptr, d_q, nq, k, idx->cfg.order, (uint32_t)idx->cfg.id_base,
-                             partial, fc.gx, d_ids, d_dist, d_counts, fb_list, fb_count, st);
+    // (the scan merges its own partial lists -- arrival counters behind the single-query counter, zero between launches: one launch, not two, for a list that is nearly always empty)
+    return launch_flat_exact_arrive(idx->rows, idx->n, idx->cfg.dim, idx->n_deleted ? idx->deleted : nullptr, d_q, nq, k, idx->cfg.order, (uint32_t)idx->cfg.id_base,
+                                    partial, fc.gx, d_ids, d_dist, d_counts, fb_list, fb_count, w->solo_cnt + 64, st);
 }
 
 // enqueue a FLAT search on `st` using workspace w (device in/out pointers). host_call: the caller synchronises the stream and reads

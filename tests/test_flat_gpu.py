@@ -274,6 +274,48 @@ def test_mfma_adversarial_falls_back_to_exact(S, oracle):
     assert idx3.scan_stats()["sampled_rows"] == 0
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_exact_fallback_merges_its_own_lists(S, oracle, order):
+    """Round 6: the exact scan of the queries the pre-scan could not settle merges its partial lists itself (the workgroup that delivers a query group's last
+    list; arrival counters that are zero again afterwards) -- many fallback queries (several groups looping over four resident ones), repeated calls on one
+    workspace (the counters come back zeroed), host and device pointers, k = 10 and 120, next to queries that do not fall back."""
+    import torch
+    rng = np.random.default_rng(77 + order)
+    base = synth.queries(1)[0]
+    same = np.tile(base, (30000, 1)).astype(f32)             # every row identical: every query's window is the corpus
+    idx = make_index(S, order=order, scan_mode=2)
+    idx.build(same)
+    q = np.ascontiguousarray(np.concatenate([np.tile(base, (3, 1)), synth.queries(37), -base[None, :]]).astype(f32))      # 41 queries, all tie on every row
+    for k in (10, 120):
+        e_ids, e_dist = oracle.brute_force_batch(same, q, k, order=order)
+        for rep in range(3):
+            ids, dist, counts = idx.search_batch(q, k)
+            assert idx.scan_stats()["overflowed"] == len(q)
+            assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes() and (counts == k).all()
+            dq = torch.from_numpy(q).cuda()
+            ids, dist, counts = idx.search_batch(dq, k)          # device pointers: the fallback is enqueued unconditionally
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy().view(np.uint32), e_ids) and dist.cpu().numpy().tobytes() == e_dist.tobytes()
+    idx.close()
+    # a corpus where SOME queries fall back: 25k random rows + 5k copies of one row; queries near that row tie on thousands of rows, the others are settled by the pre-scan
+    rows = synth.corpus(30000, queries=q)
+    rows[25000:] = rows[17]
+    qm = np.ascontiguousarray(np.concatenate([rows[[17, 17]], synth.queries(20), rows[[17]]]).astype(f32))
+    idx = make_index(S, order=order, scan_mode=2)
+    idx.build(rows)
+    for k in (10, 120):
+        e_ids, e_dist = oracle.brute_force_batch(rows, qm, k, order=order)
+        for rep in range(2):
+            dq = torch.from_numpy(qm).cuda()
+            ids, dist, counts = idx.search_batch(dq, k)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy().view(np.uint32), e_ids) and dist.cpu().numpy().tobytes() == e_dist.tobytes()
+            ids, dist, counts = idx.search_batch(qm, k)
+            assert np.array_equal(ids, e_ids) and dist.tobytes() == e_dist.tobytes()
+            assert 3 <= idx.scan_stats()["overflowed"] < len(qm)
+    idx.close()
+
+
 def test_mfma_error_bound_holds(S):
     """|s~ - dot_fp64| must stay inside the proven eps for fp16 pre-scan scores: checked indirectly
     through completeness -- for many random queries the exact top-k is never lost (covered above) --
