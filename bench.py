@@ -1133,6 +1133,10 @@ def main():
                                "source": "profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (tools/pmc_traffic.py); NOT measured in this run"}
     except Exception:
         traffic_profile = None
+    # The contract's `traffic` IS the figure of separate --pmc passes (the counters cannot be read inside a timed run): quoted when -- and only when -- the committed
+    # profile carries the hash of the scan source this run was built from and was taken on this workload; null (and "stale" beside it) otherwise.
+    if isinstance(traffic_profile, dict) and not traffic_profile.get("stale") and traffic_profile.get("bytes_per_launch"):
+        traffic = int(traffic_profile["bytes_per_launch"])
     roof = None
     if kern_n:
         ach = alg_bytes / (kern_mean_us * 1e-6) / 1e9

@@ -1324,6 +1324,7 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x;            // pass*256 + q
     const uint32_t pass = slot / MF_BPAD, ql = slot % MF_BPAD;
+    PROF_DECL
     const float qn = a.qnorm[slot];
     const float qres = a.eps[slot];
     __syncthreads();             // (everybody has read the residual before thread 0 puts eps in its place)
@@ -1348,9 +1349,11 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
         for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * 256 + tid; if (j < n_st) staged[j] = kv[u]; }
     }
     __syncthreads();
+    PROF_T(0)
     auto key_at = [&](uint32_t j) -> uint32_t { return j < n_st ? staged[j] : key_glb(j); };
     bool ovf = false;
     const uint32_t kk = a.k ? block_kth_u32<256>(key_at, a.J, a.k, scratch, &ovf) : 0xFFFFFFFFu;
+    PROF_T(1)
     // dynamic threshold: where the levels end. The FINAL k-th best has rank ~ k among all rows = rank ~ k / S among the sampled maxima: the r_top-th
     // largest of them (a second, much smaller selection) is where the bound is expected to end up, so the MF_DYN_NB levels are spread from the
     // k-th maximum (level 0 = the sampled bound) to a little beyond the r_top-th.
@@ -1376,7 +1379,10 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
     }
     __syncthreads();
     const uint32_t ktop = s_ktop;
-    if (tid == 0) {
+    PROF_T(2)
+    {
+        // (every thread holds kk, ktop and eps: the bound and the level parameters are computed by all, thread 0 stores the per-query words and sixteen threads one level
+        // each -- as one thread's loop this tail was 3 600 cycles of every launch, `profiles/r6_threshold_phases_before.txt`)
         float t = -__builtin_inff();
         bool dyn_ok = false;
         if (kk != 0xFFFFFFFFu) {
@@ -1384,8 +1390,10 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
             // a positive k-th tile max is backed by k LIVE rows (tombstoned rows score exactly 0)
             if (kth > 0.0f) { t = kth - (2.001f * eps + 1e-7f * __builtin_fabsf(kth)); dyn_ok = true; }
         }
-        a.thr[slot] = t;   // -inf => emit everything => list overflow => exact fallback
-        a.eps[slot] = eps;
+        if (tid == 0) {
+            a.thr[slot] = t;   // -inf => emit everything => list overflow => exact fallback
+            a.eps[slot] = eps;
+        }
         if (a.dcnt) {
             // level j <=> order key <= K_B - j * step <=> score >= E_j = -order_key_inv(K_B - j * step); E_0 = the sampled k-th maximum
             uint32_t kb = 0u, step = 1u;
@@ -1395,8 +1403,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
                 if (span < 1024u) span = 1024u;
                 step = (uint32_t)(((uint64_t)span + (span >> 3) + MF_DYN_NB - 1) / MF_DYN_NB);      // the levels end 1/8 beyond the expected final bound
             }
-            a.dpar[2 * slot] = kb; a.dpar[2 * slot + 1] = (uint32_t)(0xFFFFFFFFull / step); a.dpub[slot] = 0u;      // (floor((2^32 - 1) / step) <= floor(2^32 / step): never long)
-            for (uint32_t j = 1; j <= (uint32_t)MF_DYN_NB; ++j) {
+            if (tid == 0) { a.dpar[2 * slot] = kb; a.dpar[2 * slot + 1] = 0xFFFFFFFFu / step; a.dpub[slot] = 0u; }      // (floor((2^32 - 1) / step) <= floor(2^32 / step): never long)
+            if (tid < MF_DYN_NB) {
+                const uint32_t j = (uint32_t)tid + 1u;
                 float tj = __builtin_inff();
                 const uint64_t drop = (uint64_t)j * step;
                 // (keys of positive scores are > 0x3F800000-ish: a level whose edge would leave the range of scores <= 2.0 is never offered)
@@ -1410,7 +1419,13 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
             }
         }
     }
+#ifdef SHODH_PROF
+    PROF_T(3)
+    if (tid == 0 && (slot % 37) == 0) printf("thr slot %u J %u k %u | stage %lld kth %lld ktop %lld tail %lld\n", slot, a.J, a.k, pt_[0], pt_[1], pt_[2], pt_[3]);
+#endif
 }
+
+
 
 // ---- final stage: k-th best approximate score, 2-eps window, exact re-score, sort, write -----------------
 struct FinalArgs {

@@ -5,15 +5,16 @@ R=r6; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 50 --warmup 5"
 LIGHT="--no-extra-configs --no-cpu-baseline --no-latency --sustained-s 0"
+# 3. HBM traffic (separate PMC passes)
+for C in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pmc_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python $ROOT/bench.py --steps 10 --warmup 2 --prewarm-ms 0 $LIGHT > /dev/null 2>&1; done
+python $ROOT/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE 1000000 384 256 10 > $OUT/pmc_traffic.json
+cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic.json      # (the bench line below reads it: stamped with the hash of the scan source this run was built from)
 # 1. the driver's command: the bounded contract line (stdout) and the full record (gpurun_out/bench_detail.json)
 $BENCH > $OUT/${R}_bench_line.json 2> $OUT/${R}_bench.err; cp $OUT/bench_detail.json $OUT/${R}_bench_detail.json
 # 2. kernel stats of the contract workload
 rm -rf /tmp/ps; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- $BENCH $LIGHT > /dev/null 2>&1
 cp $(find /tmp/ps -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
 python $ROOT/tools/stats_to_md.py /tmp/ps "round 6 -- rocprofv3 --kernel-trace --stats of \`python bench.py --steps 50 --warmup 5 $LIGHT\` (1M x 384 f32 incl. 5 % tombstones, 256-query batches, top-10, 1 x MI355X)" > $OUT/${R}_bench_kernel_stats.md
-# 3. HBM traffic (separate PMC passes)
-for C in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pmc_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python $ROOT/bench.py --steps 10 --warmup 2 --prewarm-ms 0 $LIGHT > /dev/null 2>&1; done
-python $ROOT/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE 1000000 384 256 10 > $OUT/pmc_traffic.json
 # 4. SQ counters of the same workload: MFMA busy, LDS bank conflicts
 rm -rf /tmp/pmc_sq; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python $ROOT/bench.py --steps 10 --warmup 2 --prewarm-ms 0 $LIGHT > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py /tmp/pmc_sq > $OUT/${R}_bench_pmc_sq.txt 2>&1
