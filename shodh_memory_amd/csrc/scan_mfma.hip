@@ -1368,7 +1368,10 @@ __global__ __launch_bounds__(256) void threshold_kernel(ThrArgs a) {
             if ((uint32_t)tid < a.k) {
                 const uint32_t v = scratch[tid];
                 uint32_t r = 0;
-                for (uint32_t j = 0; j < a.k; ++j) { const uint32_t w = scratch[j]; r += (w < v) || (w == v && j < (uint32_t)tid); }
+                // ((value, index) as ONE 64-bit key: a compare and an add per pair instead of three compares and their mask arithmetic -- the loop is bound by its
+                // instruction chain, not by the LDS reads: 8 000 cycles at k = 120, `profiles/r6_threshold_phases_before.txt`)
+                const uint64_t v64 = ((uint64_t)v << 32) | (uint32_t)tid;
+                for (uint32_t j = 0; j < a.k; ++j) { const uint64_t w64 = ((uint64_t)scratch[j] << 32) | j; r += (uint32_t)(w64 < v64); }
                 if (r == a.r_top - 1u) s_ktop = v;
             }
         } else {

@@ -240,8 +240,15 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
         for (uint32_t i = tid; i < n; i += NT) { const uint32_t key = key_at(i); tmin = key < tmin ? key : tmin; }
         if (tmin != 0xFFFFFFFFu) atomicMin(&gmin[tid % k], tmin);
         __syncthreads();
-        uint32_t m = 0;
-        for (uint32_t j = 0; j < k; ++j) { const uint32_t v = gmin[j]; m = v > m ? v : m; }
+        // the largest of the k group minima, as a reduction (k <= 128 <= NT: the minima sit in the first two waves' lanes). As a k-long loop of dependent LDS reads in
+        // every thread this line was 7 000 of the 14 000 cycles of the call at k = 120 (`profiles/r6_threshold_phases_before.txt`).
+        static_assert(NT >= 128, "block_kth_u32: the group minima are reduced by the first 128 threads");
+        uint32_t m = tid < k ? gmin[tid] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off); m = o > m ? o : m; }
+        if (tid == 0 || tid == 64) sel[tid >> 6] = m;      // (sel: free until the radix passes, which are behind further barriers)
+        __syncthreads();
+        m = sel[0] > sel[1] ? sel[0] : sel[1];
         T = m;      // 0xFFFFFFFF if some group is empty: nothing is filtered, still correct
     }
     for (uint32_t i = tid; i < n; i += NT) {
