@@ -225,11 +225,22 @@ __device__ __forceinline__ uint32_t block_select_topk(KeyFn key_at, uint64_t n, 
 // the first two steps exist. scratch: KTH_SCRATCH_U32 u32 of LDS. Block-uniform arguments; every thread calls.
 constexpr int KTH_BUF = 1024;
 constexpr int KTH_SCRATCH_U32 = 128 + KTH_BUF + 256 + 8;
+// section timers of block_kth_u32 (PROF builds: -DSHODH_PROF; one line from thread 0 of workgroup 37)
+#ifdef SHODH_PROF
+#define KTH_PROF_DECL long long kp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kq_ = clock64();
+#define KTH_PROF_T(i) { const long long t_ = clock64(); kp_[i] += t_ - kq_; kq_ = t_; }
+#define KTH_PROF_PRINT(tag) if (tid == 0 && blockIdx.x == 37) printf("kth %s NT %d n %u k %u c %u | tmin %lld gmin %lld reduce %lld gather %lld rank %lld prep %lld passes %lld\n", tag, NT, n, k, c, kp_[0], kp_[1], kp_[2], kp_[3], kp_[4], kp_[5], kp_[6]);
+#else
+#define KTH_PROF_DECL
+#define KTH_PROF_T(i)
+#define KTH_PROF_PRINT(tag)
+#endif
 template <int NT, class KeyFn>
 __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint32_t k, uint32_t *scratch, bool *overflow) {
     const uint32_t tid = threadIdx.x;
     uint32_t *gmin = scratch, *buf = scratch + 128, *hist = buf + KTH_BUF, *cnt = hist + 256, *res = cnt + 1, *sel = cnt + 2;
     uint32_t T = 0xFFFFFFFFu;
+    KTH_PROF_DECL
     const bool filt = k <= 128 && n >= 4u * k;
     if (tid == 0) { *cnt = 0; *res = 0xFFFFFFFFu; }
     if (filt && tid < k) gmin[tid] = 0xFFFFFFFFu;
@@ -238,18 +249,26 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
         // group g = the keys of the threads with tid % k == g: one LDS atomic per thread, none for empty threads
         uint32_t tmin = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < n; i += NT) { const uint32_t key = key_at(i); tmin = key < tmin ? key : tmin; }
+        KTH_PROF_T(0)
         if (tmin != 0xFFFFFFFFu) atomicMin(&gmin[tid % k], tmin);
         __syncthreads();
-        // the largest of the k group minima, as a reduction (k <= 128 <= NT: the minima sit in the first two waves' lanes). As a k-long loop of dependent LDS reads in
-        // every thread this line was 7 000 of the 14 000 cycles of the call at k = 120 (`profiles/r6_threshold_phases_before.txt`).
+        KTH_PROF_T(1)
+        // the largest of the k group minima: a loop in every thread for a small k; from k = 24 up a reduction over the first two waves (k <= 128 <= NT) -- two barriers and six
+        // shuffles, ~1 000 cycles whatever k is, where the loop's dependent LDS reads cost ~60 cycles per minimum (section timers: `profiles/r6_kth_phases.txt`)
         static_assert(NT >= 128, "block_kth_u32: the group minima are reduced by the first 128 threads");
-        uint32_t m = tid < k ? gmin[tid] : 0u;
+        uint32_t m = 0;
+        if (k < 24u) {
+            for (uint32_t j = 0; j < k; ++j) { const uint32_t v = gmin[j]; m = v > m ? v : m; }
+        } else {
+            m = tid < k ? gmin[tid] : 0u;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off); m = o > m ? o : m; }
-        if (tid == 0 || tid == 64) sel[tid >> 6] = m;      // (sel: free until the radix passes, which are behind further barriers)
-        __syncthreads();
-        m = sel[0] > sel[1] ? sel[0] : sel[1];
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off); m = o > m ? o : m; }
+            if (tid == 0 || tid == 64) sel[tid >> 6] = m;      // (sel: free until the radix passes, which are behind further barriers)
+            __syncthreads();
+            m = sel[0] > sel[1] ? sel[0] : sel[1];
+        }
         T = m;      // 0xFFFFFFFF if some group is empty: nothing is filtered, still correct
+        KTH_PROF_T(2)
     }
     for (uint32_t i = tid; i < n; i += NT) {
         const uint32_t key = key_at(i);
@@ -257,6 +276,7 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
     }
     __syncthreads();
     const uint32_t c = *cnt;
+    KTH_PROF_T(3)
     __syncthreads();              // (see the end of the rank path: nobody may reset the counter before everybody has read it)
     *overflow = false;          // (kept in the signature: an overflowing gather now falls through to the direct radix select)
     if (c < k) return 0xFFFFFFFFu;
@@ -277,12 +297,15 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
         __syncthreads();
         const uint32_t kth = *res;
         __syncthreads();          // a second call in the same kernel resets *res / *cnt: not before everybody has read them
+        KTH_PROF_T(4)
+        KTH_PROF_PRINT("rank")
         return kth;
     }
     // many survivors: radix select over the gathered copy, or -- if even that overflowed (c > KTH_BUF: long runs of
     // near-equal keys, or a large k) -- straight over the source keys that passed the filter
     const bool gathered = c <= (uint32_t)KTH_BUF;
     uint32_t prefix = 0, mask = 0, kk = k;
+    KTH_PROF_T(5)
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
@@ -315,6 +338,8 @@ __device__ __forceinline__ uint32_t block_kth_u32(KeyFn key_at, uint32_t n, uint
         __syncthreads();
         prefix |= sel[0] << shift; mask |= 255u << shift; kk = sel[1];
     }
+    KTH_PROF_T(6)
+    KTH_PROF_PRINT("radix")
     return prefix;
 }
 
