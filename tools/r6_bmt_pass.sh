@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the [query][tile] layout and its -DMF_BM_T switch were removed again after this measurement -- profiles/r6_blockmax_layout_ab.txt, NOTEBOOK 12.18;
+#  to repeat it, re-apply the bm_index() helper of the working tree this script ran on)
 # round 6: sampled tile maxima stored [query][tile] (threshold_kernel reads a query's maxima contiguously) -- parity tests on the new library, threshold_kernel's section
 # timers (libshodh_hip.so.prof), then per-kernel tables of a step with the new layout and the old one (libshodh_hip.so.bmt0, -DMF_BM_T=0) on ONE box
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r6bmt; mkdir -p $OUT
