@@ -1919,7 +1919,10 @@ MfmaPlan mfma_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int c
     // 32nd tile does (k = 10, stride 16 / 24 / 32 / 48 / 64: 264.7 / 261.6 / 260.6 / 260.5 / 261.3 us per step; k = 120 keeps its 9: 345 against 352 at 24).
     static const uint32_t stride_env = getenv("SHODH_SAMPLE_STRIDE") ? (uint32_t)atoi(getenv("SHODH_SAMPLE_STRIDE")) : 0u;
     static const bool dyn_env = !(getenv("SHODH_DYN_THR") && atoi(getenv("SHODH_DYN_THR")) == 0);
-    uint32_t sample_stride = (dyn_env && dim <= 384) ? 32 : 16;
+    // Final library of round 6 (measured error bound, cheaper threshold kernel), k = 40 -- `search_ids` with limit 10 asks for k_index = 4 x limit -- stride 32 / 28 / 24 / 20 / 16:
+    // 0.2585 / 0.2560 / 0.2538 / 0.2538 / 0.2564 ms per step on the contract corpus, 263.9 / - / 259.9 / - / - us on a random one: every 24th tile from k = 17 to 40
+    // (k = 10 keeps 32: 0.2301 against 0.2358 at 24; k = 120 keeps 9: 0.336 against 0.338 - 0.346 at 16 - 24 on the contract corpus, the reverse by 2 % on a clustered one).
+    uint32_t sample_stride = (dyn_env && dim <= 384) ? (k > 16 ? 24 : 32) : 16;
     if (k > 40) {
         sample_stride = (uint32_t)(16.0 * __builtin_sqrt(40.0 / (double)k) + 0.5);
         if (sample_stride < 2) sample_stride = 2;
