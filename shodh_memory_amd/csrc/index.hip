@@ -302,6 +302,9 @@ static int finish_append(shodh_index *idx, uint64_t first, uint64_t n) {
         }
         idx->maxnorm = sqrtf(nsq) * 1.00001f;
         idx->maxres = sqrtf(rsq) * 1.0001f;
+#ifdef SHODH_DIAG_MAXRES0      // (diagnostic builds, results INVALID: the corpus side of the error bound left out -- does a test notice? tools/build_variant.sh with VARIANT_SRC=index)
+        idx->maxres = 0.0f;
+#endif
         idx->maxabs = ma;
         idx->quantizable = (ma * 256.0f < 60000.0f);
     } else {

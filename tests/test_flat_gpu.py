@@ -156,6 +156,97 @@ def test_incremental_growth_and_ids(S, oracle):
     check_against_oracle(oracle, idx, rows[2000:], synth.queries(3, dim), 10, 0)
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_measured_residual_follows_later_adds_and_rejected_batches(S, oracle, order):
+    """Round 6: the corpus side of the pre-scan's error bound is the MEASURED largest |row - its fp16 copy| -- a running maximum over every append. A corpus that
+    starts with rows the shadow holds exactly (multiples of 2^-12: residual 0), then grows by a dense cone of ordinary rows (thousands of scores within the fp16
+    error of each other), must be searched with the bound of the LATER rows; a batch rejected for a NaN in between must leave the maximum as it was; tombstones
+    and their restoration change nothing. Single queries, batches, k = 10 / 40 / 120, bit for bit against the oracle."""
+    rng = np.random.default_rng(91 + order)
+    dim = 384
+    exact_rows = (rng.integers(-400, 401, size=(20000, dim)).astype(f32) * f32(2.0 ** -12)).astype(f32)       # |x| < 0.1, x * 256 = multiples of 1/16: exact in fp16
+    assert np.array_equal((exact_rows * f32(256)).astype(np.float16).astype(f32) / f32(256), exact_rows)
+    axis = synth.queries(1)[0]
+    cone = axis[None, :] + f32(0.0045) * rng.standard_normal((24000, dim)).astype(f32)
+    cone = np.ascontiguousarray((cone / np.linalg.norm(cone, axis=1, keepdims=True)).astype(f32))
+    idx = make_index(S, order=order, scan_mode=2)
+    idx.build(exact_rows)
+    q0 = np.ascontiguousarray(np.stack([axis, exact_rows[7] / np.linalg.norm(exact_rows[7]), synth.queries(2)[1]]).astype(f32))
+    check_against_oracle(oracle, idx, exact_rows, q0, 10, order)                      # (residual 0 on the corpus side: the bound is the query's own rounding + accumulation)
+    bad = cone[:64].copy(); bad[5, 17] = np.nan
+    with pytest.raises(Exception):
+        idx.add_vectors(bad)                                                            # rejected: nothing appended, the running maxima restored
+    assert idx.len() == 20000
+    check_against_oracle(oracle, idx, exact_rows, q0, 10, order)
+    assert idx.add_vectors(cone[:12000]) == 20000
+    assert idx.add_vectors(cone[12000:]) == 32000
+    rows = np.ascontiguousarray(np.concatenate([exact_rows, cone]))
+    far = axis[None, :] + f32(0.022) * rng.standard_normal((3, dim)).astype(f32)
+    far /= np.linalg.norm(far, axis=1, keepdims=True)
+    q = np.ascontiguousarray(np.concatenate([q0, cone[[3, 23999]], far]).astype(f32))
+    for k in (10, 40, 120):
+        check_against_oracle(oracle, idx, rows, q, k, order)                            # batch pipeline (level 2 for the queries on the cone axis)
+        for i in (0, 3, 5):
+            check_against_oracle(oracle, idx, rows, q[i:i + 1], k, order)               # single-query pipeline
+    dele = np.zeros(len(rows), bool)
+    for i in (20003, 20500, 43999):
+        assert idx.mark_deleted(i); dele[i] = True
+    check_against_oracle(oracle, idx, rows, q, 10, order, deleted=dele.astype(np.uint8))
+    idx.close()
+
+
+def _grid_rows(rng, n, dim, msum):
+    """rows whose elements times 256 lie on the fp16 grid of [8, 16) (step 2^-7): m in [0, 1023] with a prescribed sum per row -> (m, values / 256)"""
+    m = rng.integers(200, 824, size=(n, dim)).astype(np.int64)
+    for r in range(n):
+        d = int(msum[r] - m[r].sum())
+        while d != 0:
+            j = int(rng.integers(0, dim))
+            step = max(-m[r, j], min(1023 - m[r, j], d))
+            m[r, j] += step; d -= step
+    return m, ((8.0 + m * 2.0 ** -7) / 256.0).astype(np.float64)
+
+
+@pytest.mark.parametrize("k", [10, 40])
+def test_rounding_errors_all_of_one_sign_need_the_measured_corpus_residual(S, oracle, k):
+    """The case the corpus side of the error bound exists for (round 6: measured, `maxres`): rows whose every element sits just below an fp16 rounding midpoint lose
+    half an ulp in EVERY element, and against a query parallel to that residual (all elements equal, itself exact in fp16) the pre-scan under-scores them by the full
+    |q| |row - shadow| = 3e-4 -- Cauchy-Schwarz with equality. Ten + k such rows truly beat thirty rows the shadow holds exactly by 1e-4, but score 2e-4 BELOW them in
+    fp16: only a window that carries the measured residual still holds them. (A build with that term left out -- -DSHODH_DIAG_MAXRES0 -- returns the wrong rows here,
+    while every other parity test still passes: the bound is a worst-case guarantee, and this is the worst case.)"""
+    rng = np.random.default_rng(2026 + k)
+    dim, n_fill = 384, 24000
+    M = 512 * dim                                            # sum of the grid indices of the thirty best exact rows
+    n_top, n_al = 30, 10 + k
+    fill_drop = rng.integers(1300, 60000, size=n_fill)      # every other row scores >= 2e-3 lower
+    _, top = _grid_rows(rng, n_top, dim, np.full(n_top, M))
+    _, fill = _grid_rows(rng, n_fill, dim, M - fill_drop)
+    mh, _ = _grid_rows(rng, n_al, dim, np.full(n_al, M - 128))
+    al64 = (8.0 + mh * 2.0 ** -7 + 2.0 ** -8) / 256.0      # the midpoint to the next grid value ...
+    al = np.nextafter(al64.astype(f32), f32(-np.inf))       # ... and the float just below it: rounds DOWN, residual ~ +half an ulp in every element
+    assert np.array_equal((al * f32(256)).astype(np.float16).astype(np.float64), 8.0 + mh * 2.0 ** -7)
+    rows = np.concatenate([fill[:9000], top[:15], al[:n_al // 2], fill[9000:], top[15:], al[n_al // 2:]]).astype(f32)
+    rows = np.ascontiguousarray(rows)
+    assert np.array_equal(rows[:9000].astype(np.float64), fill[:9000])                  # (the grid values are exact in f32)
+    al_ids = set(range(9015, 9015 + n_al // 2)) | set(range(len(rows) - (n_al - n_al // 2), len(rows)))
+    q = np.full((1, dim), 13.0 / 256.0, f32)
+    res = np.sqrt(((al.astype(np.float64) - (8.0 + mh * 2.0 ** -7) / 256.0) ** 2).sum(axis=1)).max()
+    assert 2.5e-4 < res < 3.5e-4
+    e_ids, e_dist = oracle.brute_force_search(rows, q[0], k, order=0, select=True)
+    assert set(e_ids.tolist()) <= al_ids                                                  # the truth: aligned rows only
+    sh = ((rows * f32(256)).astype(np.float16).astype(np.float64) / 256.0) @ q[0].astype(np.float64)
+    assert set(np.argsort(-sh, kind="stable")[:n_top].tolist()).isdisjoint(al_ids)      # the shadow's own top thirty: none of them
+    for scan_mode in (2, 0):
+        idx = make_index(S, scan_mode=scan_mode)
+        idx.build(rows)
+        check_against_oracle(oracle, idx, rows, q, k, 0)                                  # single-query pipeline
+        qb = np.ascontiguousarray(np.concatenate([q, synth.queries(5), q]).astype(f32))
+        check_against_oracle(oracle, idx, rows, qb, k, 0)                                 # batch pipeline
+        st = idx.scan_stats()
+        assert st["overflowed"] == 0, st                                                  # settled by the window, not by the exact fallback
+        idx.close()
+
+
 def test_id_base_sharding_offset(S, oracle):
     rows = synth.corpus(3000)
     idx = make_index(S, scan_mode=1, id_base=1_000_000)
