@@ -247,6 +247,54 @@ def test_rounding_errors_all_of_one_sign_need_the_measured_corpus_residual(S, or
         idx.close()
 
 
+def test_query_rounding_errors_all_of_one_sign_need_the_measured_query_residual(S, oracle):
+    """The query side of the same bound (`qres`, measured per query by convert_queries_kernel; batch pipeline only -- the single-query scan keeps the query in f32).
+    A query whose every element sits just below an fp16 rounding midpoint of one binade loses 2^-16 in EVERY element, so a row c is under-scored by 2^-16 sum(c): rows
+    along the all-ones direction lose 2.8e-4, rows whose elements alternate in sign lose nothing. Twenty of the former truly beat thirty of the latter by 4e-5 and score
+    2.4e-4 below them in fp16. At 128 dimensions that is wider than a window without the query's residual (1.9e-4; at 384 the accumulation term alone would cover it),
+    so a build that drops the term returns the wrong rows -- checked once with such a build (NOTEBOOK 12.16)."""
+    rng = np.random.default_rng(5)
+    dim, k = 128, 10
+    mq = np.where(np.arange(dim) % 2 == 0, rng.integers(940, 1000, size=dim), rng.integers(40, 100, size=dim))      # bimodal inside the binade [8, 16) / 256
+    qh = 8.0 + mq * 2.0 ** -7
+    q = np.nextafter(((qh + 2.0 ** -8) / 256.0).astype(f32), f32(-np.inf))
+    assert np.array_equal((q * f32(256)).astype(np.float16).astype(np.float64), qh)
+    q64, qt = q.astype(np.float64), qh / 256.0
+    sign = np.where(np.arange(dim) % 2 == 0, 1.0, -1.0)
+    n_row = 0.5 * sign                                           # exact in fp16, no loss: sum = 0
+    s_n = float(n_row @ q64)
+
+    def tuned(target):                                           # a grid row of [32, 64) / 256 (exact in fp16) whose true score is `target` +- 3e-6
+        m = rng.integers(100, 250, size=dim).astype(np.int64)
+        for _ in range(20000):
+            c = (32.0 + m * 2.0 ** -5) / 256.0
+            d = target - float(c @ q64)
+            if abs(d) < 3e-6:
+                return c
+            j = int(rng.integers(0, dim))
+            step = int(np.clip(round(d / (2.0 ** -5 / 256.0 * q64[j])), -40, 40)) or (1 if d > 0 else -1)
+            if 0 <= m[j] + step <= 1023:
+                m[j] += step
+        raise AssertionError("tuning did not converge")
+    p_rows = np.stack([tuned(s_n + 4e-5) for _ in range(20)])
+    fill = (32.0 + rng.integers(0, 90, size=(20000, dim)) * 2.0 ** -5) / 256.0                      # exact rows scoring ~0.08 lower
+    rows = np.ascontiguousarray(np.concatenate([fill[:7000], np.tile(n_row, (15, 1)), p_rows[:10], fill[7000:], np.tile(n_row, (15, 1)), p_rows[10:]]).astype(f32))
+    assert np.array_equal((rows * f32(256)).astype(np.float16).astype(f32) / f32(256), rows)     # the corpus side is exact: maxres = 0
+    p_ids = set(range(7015, 7025)) | set(range(len(rows) - 10, len(rows)))
+    e_ids, _ = oracle.brute_force_search(rows, q, k, order=0, select=True)
+    assert set(e_ids.tolist()) <= p_ids                                                              # the truth
+    sh = rows.astype(np.float64) @ qt
+    assert set(np.argsort(-sh, kind="stable")[:30].tolist()).isdisjoint(p_ids)                     # the shadow's top thirty: the alternating rows
+    assert 2.0e-4 < float(sh.max() - sh[sorted(p_ids)].max()) < 3.0e-4
+    qb = np.ascontiguousarray(np.concatenate([q[None, :], synth.queries(6, dim), q[None, :]]).astype(f32))
+    idx = make_index(S, dim=dim, scan_mode=2)
+    idx.build(rows)
+    check_against_oracle(oracle, idx, rows, qb, k, 0)
+    assert idx.scan_stats()["overflowed"] == 0 and idx.scan_stats()["sampled_rows"] > 0            # the batch pipeline, settled by the window
+    check_against_oracle(oracle, idx, rows, qb[:1], k, 0)                                            # (single-query scan: the query is not rounded at all)
+    idx.close()
+
+
 def test_id_base_sharding_offset(S, oracle):
     rows = synth.corpus(3000)
     idx = make_index(S, scan_mode=1, id_base=1_000_000)
