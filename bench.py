@@ -111,7 +111,8 @@ def compact_line(full, detail_path=None, max_bytes=CONTRACT_LINE_MAX_BYTES):
     line = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
     line["config"] = {k: (_short(cfg[k]) if isinstance(cfg[k], str) else cfg[k]) for k in
-                      ("workload", "rows_total", "rows_per_gpu", "rows_live_per_gpu", "batch", "k", "scan", "layout", "parallelism") if k in cfg}
+                      ("workload", "rows_total", "rows_per_gpu", "rows_live_per_gpu", "batch", "k", "scan", "layout", "parallelism", "shard_queries_per_s", "weak_scaling_reference")
+                      if k in cfg and cfg[k] is not None}
     r = full.get("roofline")
     if r:
         rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_us_mean", "launch_us_min", "launches_timed",
@@ -1260,6 +1261,9 @@ def main():
                            "layout": "row-sharded + RCCL all-gather of per-shard top-k" if world > 1 else "single device",
                            "parallelism": ("row-shard x%d, one process per GPU, one all-gather of %d B per rank and step" % (world, args.nq * args.k * 8)) if world > 1 else "single device",
                            "value_counts": "answered queries per second over the whole corpus",
+                           # (for a reader who divides by N x the one-GPU value: under weak scaling every rank scans ITS shard for every query, so the work the ranks do
+                           #  per second is world x value shard-queries; `value` itself stays the answered rate a caller sees, BASELINE.json's metric)
+                           "shard_queries_per_s": round(value * world, 1) if world > 1 else None,
                            "weak_scaling_reference": ("per-GPU work is fixed at %d rows: the one-GPU point of this curve is the `flat_10M_b256` entry of the "
                                                       "N = 1 line's `configs`; ideal = the same queries/s while the corpus grows %d-fold" % (rows_local, world))
                                                      if world > 1 and args.scaling == "weak" else None,
