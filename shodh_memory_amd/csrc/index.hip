@@ -821,6 +821,8 @@ static int search_common(shodh_index *idx, const SearchSeg *segs, size_t n_segs,
     } while (0);
     // a single-query call that failed half way may have left its list counter non-zero (the final stage hands it back zeroed)
     if (rc != SHODH_OK && fc.solo) (void)hipMemsetAsync(w->solo_cnt, 0, 4, st);
+    // ... and the arrival counters of the exact fallback's in-scan merge, should an enqueue have failed between its launch and its end (they are zero between complete launches)
+    if (rc != SHODH_OK && fc.used_mfma) (void)hipMemsetAsync(w->solo_cnt + 64, 0, 4096, st);
     w->last_stream = st;
     w->pending = !(sync_host && rc == SHODH_OK);       // successful host-pointer calls end with a stream synchronisation
     ws_release(idx, w);
