@@ -140,8 +140,14 @@ def test_contract_line_is_bounded_whatever_the_record_holds():
     # a line of an N > 1 run (no cpu_baseline, no configs, no latency) goes through as well
     multi = {k: full[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline")}
     multi.update({"n_gpus": 8, "scaling": "weak", "cpu_baseline": None, "latency_single_query": None, "sustained": None})
+    multi["config"] = dict(full["config"], shard_queries_per_s=8 * full["value"], weak_scaling_reference="per-GPU work is fixed at 10000000 rows: " + "w" * 400)
     line = b.compact_line(multi)
     assert line["n_gpus"] == 8 and line["cpu_baseline"] is None and "configs" not in line
+    # ... with the work all ranks do per second next to the answered rate (round 6), its explanation shortened like every string
+    assert line["config"]["shard_queries_per_s"] == 8 * full["value"] and len(line["config"]["weak_scaling_reference"]) <= 120
+    assert len(json.dumps(line)) <= b.CONTRACT_LINE_MAX_BYTES
+    single = b.compact_line(full, None)
+    assert "shard_queries_per_s" not in single["config"] and "weak_scaling_reference" not in single["config"]      # (N = 1: not there)
 
 
 def test_last_stdout_line_is_the_contract_line_whatever_else_is_printed(tmp_path):
